@@ -1,0 +1,303 @@
+"""CPU oracle for the gsum GP hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a CPU restatement of the algorithm that buqeye/gsum runs for
+kernel build -> jittered Cholesky -> multivariate-normal log-likelihood behind
+``ConjugateGaussianProcess`` / ``TruncationGP``.  It issues the same
+numpy / scipy / scikit-learn calls, in the same order, as the reference does
+(each function cites the reference ``file:line`` it follows), so that it can
+stand in for the reference on machines where the reference is absent (the GPU
+box).
+
+Parity status: PINNED.  ``tests/golden/*.json`` hold outputs of the reference
+itself (imported read-only in the build container by
+``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` checks every
+function below against them, and against the one likelihood-grid known answer
+the reference publishes (notebook MAP indices (36, 39)).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module, and there only as the checker /
+reported baseline.  The product package ``gsum_amd`` never imports it.
+"""
+from __future__ import annotations
+
+import numpy as np
+from numpy.linalg import cholesky, solve
+from scipy.linalg import cho_solve, inv
+
+__all__ = [
+    "coefficients", "partials", "geometric_sum",
+    "posterior_center", "posterior_disp", "posterior_df", "posterior_scale_sq",
+    "cov_factor", "cgp_lml", "trunc_lml", "cgp_fit", "cgp_predict", "lml_grid",
+]
+
+
+# --------------------------------------------------------------------------
+# series helpers  (reference: gsum/helpers.py)
+# --------------------------------------------------------------------------
+
+def coefficients(y, ratio, ref=1, orders=None):
+    """y_n -> c_n.  Follows gsum/helpers.py:71-101.
+
+    c_0 = y_0, c_n = y_n - y_{n-1}, then divided by ref * ratio**order.
+    """
+    y = np.asarray(y)
+    if y.ndim != 2:
+        raise ValueError("y must be 2d")                       # helpers.py:86-87
+    if orders is None:
+        orders = np.arange(y.shape[-1])                        # helpers.py:88-89
+    if len(orders) != y.shape[-1]:
+        raise ValueError("partials and orders must have the same length")
+    ref, ratio, orders = np.atleast_1d(ref, ratio, orders)     # helpers.py:93
+    ref = ref[:, None]
+    ratio = ratio[:, None]
+    c = np.diff(y, axis=-1)                                    # helpers.py:98
+    c = np.insert(c, 0, y[..., 0], axis=-1)                    # helpers.py:99
+    return c / (ref * ratio ** orders)                         # helpers.py:100
+
+
+def partials(coeffs, ratio, ref=1, orders=None):
+    """c_n -> partial sums y_k.  Follows gsum/helpers.py:104-146."""
+    coeffs = np.asarray(coeffs)
+    if orders is None:
+        orders = np.arange(coeffs.shape[-1])
+    ratio = np.atleast_1d(ratio)
+    if ratio.ndim == 1:
+        ratio = ratio[:, None]
+    ref = np.atleast_1d(ref)
+    if ref.ndim == 1:
+        ref = ref[:, None]
+    return np.cumsum(ref * coeffs * ratio ** orders, axis=-1)  # helpers.py:145-146
+
+
+def geometric_sum(x, start, end, excluded=None):
+    """sum_{i=start}^{end} x**i minus excluded orders.  helpers.py:149-182."""
+    if end < start:
+        raise ValueError("end must be greater than or equal to start")
+    s = (x ** start - x ** (end + 1)) / (1 - x)                # helpers.py:176
+    if excluded is not None:
+        for n in np.atleast_1d(excluded):
+            if start <= n <= end:
+                s -= x ** n                                    # helpers.py:179-181
+    return s
+
+
+# --------------------------------------------------------------------------
+# conjugate updates  (reference: gsum/models.py:170-503)
+# --------------------------------------------------------------------------
+
+def _num_y(y):                                                 # models.py:601-607
+    return y.shape[1] if y.ndim == 2 else 1
+
+
+def _avg_y(y):                                                 # models.py:609-628
+    if y.ndim == 1:
+        return np.copy(y)
+    if y.ndim == 2:
+        return np.average(y, axis=1)
+    raise ValueError("y must be two-dimensional, not shape={}".format(y.shape))
+
+
+def _rsolve(L, b):
+    """R^{-1} b from the lower Cholesky factor.  models.py:478-479."""
+    return cho_solve((L, True), b)
+
+
+def posterior_disp(y, L, basis, disp0):
+    """V = (V0^-1 + ny B^T R^-1 B)^-1, zero stays zero.  models.py:258-270."""
+    if np.all(disp0 == 0):
+        return np.zeros_like(disp0)
+    ny = _num_y(y)
+    quad = basis.T @ _rsolve(L, basis)                         # models.py:269
+    return inv(inv(disp0) + ny * quad)                         # models.py:270
+
+
+def posterior_center(y, L, basis, center0, disp0):
+    """eta = V (V0^-1 eta0 + ny B^T R^-1 ybar).  models.py:199-220."""
+    if np.all(disp0 == 0):
+        return np.copy(center0)                                # models.py:201-206
+    ybar = _avg_y(y)
+    ny = _num_y(y)
+    invR_ybar = _rsolve(L, ybar)                               # models.py:217
+    disp = posterior_disp(y, L, basis, disp0)                  # models.py:218
+    factor = solve(disp0, center0) + ny * basis.T @ invR_ybar  # models.py:219
+    return disp @ factor                                       # models.py:220
+
+
+def posterior_df(y, df0):
+    return df0 + y.size                                        # models.py:302
+
+
+def posterior_scale_sq(y, L, basis, center0, disp0, df0, scale0):
+    """tau^2 update with the Woodbury mean term.  models.py:419-448."""
+    if df0 == np.inf:
+        return scale0 ** 2                                     # models.py:419-422
+    if y.ndim == 1:
+        y = y[:, None]
+    ybar = _avg_y(y)
+    N = len(ybar)
+    ny = _num_y(y)
+    yc = y - ybar[:, None]                                     # models.py:430
+    quad = np.trace(yc.T @ _rsolve(L, yc))                     # models.py:432-433
+    ybar_c = ybar - basis @ center0                            # models.py:435
+    disp = posterior_disp(y, L, basis, disp0)                  # models.py:436
+    invR_basis = _rsolve(L, basis)                             # models.py:438
+    invR_ybar_c = _rsolve(L, ybar_c)                           # models.py:439
+    mat = np.eye(N) - ny * invR_basis @ disp @ basis.T         # models.py:441
+    mat_v = ny * mat @ invR_ybar_c                             # models.py:442
+    quad2 = ybar_c @ mat_v                                     # models.py:445
+    df = posterior_df(y, df0)
+    return (df0 * scale0 ** 2 + quad + quad2) / df             # models.py:448
+
+
+def cov_factor(scale_sq, df):
+    """sigma^2 = nu tau^2/(nu-2), or tau^2 when nu = inf.  models.py:500-503."""
+    if df != np.inf:
+        return df * scale_sq / (df - 2)
+    return scale_sq
+
+
+def _ones_basis(X):
+    return np.ones((X.shape[0], 1))                            # models.py:150
+
+
+def _priors(center=0, disp=0, df=1, scale=1, sd=None):
+    """Constructor prior bookkeeping.  models.py:113-120."""
+    center0 = np.atleast_1d(center)
+    disp0 = np.atleast_2d(disp)
+    if sd is not None:
+        return center0, disp0, np.inf, sd
+    return center0, disp0, df, scale
+
+
+# --------------------------------------------------------------------------
+# log marginal likelihood  (reference: gsum/models.py:912-1057, 1485-1507)
+# --------------------------------------------------------------------------
+
+def cgp_lml(kernel, theta, X, y, center=0, disp=0, df=1, scale=1, sd=None,
+            nugget=1e-10, return_parts=False):
+    """ConjugateGaussianProcess.log_marginal_likelihood, value path.
+
+    Follows models.py:953-1039 with decomposition='cholesky'.  ``kernel`` is a
+    scikit-learn kernel; ``theta`` its log-hyperparameters (or None to keep
+    the kernel as is).  Returns -inf when the Cholesky fails (models.py:970-972).
+    """
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    if theta is not None:
+        kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))   # :953
+    R = kernel(X)                                              # models.py:960
+    R[np.diag_indices_from(R)] += nugget                       # models.py:963
+    try:
+        L = cholesky(R)                                        # models.py:969
+    except np.linalg.LinAlgError:
+        return -np.inf                                         # models.py:970-972
+    if y.ndim == 1:
+        y = y[:, np.newaxis]                                   # models.py:980-981
+    dfn = posterior_df(y, df0)                                 # models.py:986
+    basis = _ones_basis(X)                                     # models.py:987
+    center_n = posterior_center(y, L, basis, center0, disp0)   # models.py:1001
+    scale2 = posterior_scale_sq(y, L, basis, center0, disp0, df0, scale0)  # :1002
+    mean = basis @ center_n                                    # models.py:1007
+    var = cov_factor(scale2, dfn)                              # models.py:1008
+    Lk = np.sqrt(var) * L                                      # models.py:1014
+    logdet_K = 2 * np.log(np.diag(Lk)).sum()                   # models.py:1015
+    y_train = y - mean[:, None]                                # models.py:1026
+    N = R.shape[0]
+    alpha = cho_solve((Lk, True), y_train)                     # models.py:1032
+    ll = -0.5 * np.einsum("ik,ik->k", y_train, alpha)          # models.py:1035
+    ll -= 0.5 * logdet_K                                       # models.py:1037
+    ll -= N / 2 * np.log(2 * np.pi)                            # models.py:1038
+    out = ll.sum(-1)                                           # models.py:1039
+    if return_parts:
+        return out, dict(L=L, center=center_n, scale_sq=scale2, df=dfn, var=var)
+    return out
+
+
+def trunc_lml(kernel, theta, X, y, orders, ratio=0.5, ref=1, excluded=None,
+              center=0, disp=0, df=1, scale=1, sd=None, nugget=1e-10):
+    """TruncationGP.log_marginal_likelihood.  Follows models.py:1485-1507.
+
+    ``ratio`` / ``ref`` are scalars or (n,) arrays (the reference's default
+    lambdas broadcast a scalar to (n,), models.py:1310,1315).
+    """
+    orders = np.asarray(orders)
+    n = X.shape[0]
+    ref_v = ref * np.ones(n) if np.ndim(ref) == 0 else np.asarray(ref)
+    ratio_v = ratio * np.ones(n) if np.ndim(ratio) == 0 else np.asarray(ratio)
+    mask = ~np.isin(orders, excluded)                          # models.py:1495
+    c = coefficients(y, ratio_v, ref_v, orders)[:, mask]       # models.py:1496
+    c_ll = cgp_lml(kernel, theta, X, c, center, disp, df, scale, sd, nugget)  # :1497
+    orders_in = orders[mask]                                   # models.py:1503
+    n_in = len(orders_in)
+    det = np.sum(n_in * np.log(np.abs(ref_v))
+                 + np.sum(orders_in) * np.log(np.abs(ratio_v)))  # models.py:1505
+    return c_ll - det                                          # models.py:1506
+
+
+def lml_grid(kernel, thetas, ratios, X, y, orders, ref=1, excluded=None, **priors):
+    """The notebook's nested scan: rows = ratio values, columns = thetas.
+
+    docs/notebooks/correlated_EFT_publication.ipynb:1457-1459.
+    """
+    out = np.empty((len(ratios), len(thetas)))
+    for i, q in enumerate(ratios):
+        for j, th in enumerate(thetas):
+            out[i, j] = trunc_lml(kernel, np.atleast_1d(th), X, y, orders,
+                                  ratio=q, ref=ref, excluded=excluded, **priors)
+    return out
+
+
+# --------------------------------------------------------------------------
+# fit / predict  (reference: gsum/models.py:671-738, 753-845)
+# --------------------------------------------------------------------------
+
+def cgp_fit(kernel, X, y, center=0, disp=0, df=1, scale=1, sd=None, nugget=1e-10):
+    """ConjugateGaussianProcess.fit with a fixed kernel (optimizer inactive).
+
+    Follows models.py:705-737.  Returns the fitted attributes as a dict.
+    """
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    basis = _ones_basis(X)                                     # models.py:705
+    lml_value = cgp_lml(kernel, None, X, y, center, disp, df, scale, sd, nugget)  # :668-669
+    corr = kernel(X)                                           # models.py:708
+    L = cholesky(corr + nugget * np.eye(len(X)))               # models.py:711
+    center_n = posterior_center(y, L, basis, center0, disp0)   # models.py:721
+    disp_n = posterior_disp(y, L, basis, disp0)                # models.py:725
+    df_n = posterior_df(y, df0)                                # models.py:729
+    scale_sq = posterior_scale_sq(y, L, basis, center0, disp0, df0, scale0)  # :730
+    return dict(kernel=kernel, X=X, y=y, nugget=nugget, corr=corr, corr_L=L,
+                center=center_n, disp=disp_n, df=df_n, scale=np.sqrt(scale_sq),
+                cov_factor=cov_factor(scale_sq, df_n),         # models.py:735-736
+                lml=lml_value)
+
+
+def cgp_predict(fit, Xnew, return_std=False, return_cov=False, Xc=None, y=None,
+                pred_noise=False):
+    """ConjugateGaussianProcess.predict on a fitted state.  models.py:789-845."""
+    if return_std and return_cov:
+        raise RuntimeError("Only one of return_std or return_cov may be True")
+    kernel, nugget = fit["kernel"], fit["nugget"]
+    if Xc is None:
+        Xc, L = fit["X"], fit["corr_L"]                        # models.py:797-800
+    else:
+        L = cholesky(kernel(Xc) + nugget * np.eye(len(Xc)))    # models.py:807-809
+    if y is None:
+        y = fit["y"]
+    m_old = _ones_basis(Xc) @ fit["center"]                    # models.py:818
+    m_new = _ones_basis(Xnew) @ fit["center"]                  # models.py:819
+    R_on = kernel(Xc, Xnew)                                    # models.py:822
+    R_no = R_on.T
+    R_nn = kernel(Xnew)                                        # models.py:824
+    if y.ndim == 1:
+        y = y[:, None]
+    alpha = _rsolve(L, y - m_old[:, None])                     # models.py:831
+    m_pred = np.squeeze(m_new[:, None] + R_no @ alpha)         # models.py:832
+    if return_std or return_cov:
+        R_pred = R_nn - R_no @ _rsolve(L, R_on)                # models.py:836
+        if pred_noise:
+            R_pred += nugget * np.eye(len(Xnew))               # models.py:837-838
+        var = cov_factor(fit["scale"] ** 2, fit["df"])         # models.py:840
+        K_pred = np.squeeze(var * R_pred)
+        if return_std:
+            return m_pred, np.sqrt(np.diag(K_pred))            # models.py:842-843
+        return m_pred, K_pred
+    return m_pred

@@ -1,0 +1,70 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def make_kernel(spec):
+    """Rebuild a scikit-learn kernel from a golden-fixture kernel spec."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    ls = spec["length_scale"]
+    ls = ls if np.ndim(ls) == 0 else np.asarray(ls, dtype=float)
+    fam = spec["family"]
+    if fam == "rbf":
+        k = RBF(length_scale=ls)
+    elif fam == "matern52":
+        k = Matern(length_scale=ls, nu=2.5)
+    elif fam == "matern32":
+        k = Matern(length_scale=ls, nu=1.5)
+    else:
+        raise ValueError(fam)
+    if spec.get("amplitude") is not None:
+        k = C(spec["amplitude"]) * k
+    if spec.get("white") is not None:
+        k = k + WhiteKernel(spec["white"], noise_level_bounds="fixed")
+    if spec.get("additive") is not None:
+        k = k + C(spec["additive"], constant_value_bounds="fixed")
+    return k
+
+
+def prior_kwargs(p):
+    return {k: v for k, v in p.items() if k != "name"}
+
+
+@pytest.fixture(scope="session")
+def small_cases():
+    return load_golden("small_cases.json")
+
+
+@pytest.fixture(scope="session")
+def notebook_grid():
+    return load_golden("notebook_grid.json")
+
+
+@pytest.fixture(scope="session")
+def large_lml():
+    return load_golden("large_lml.json")
+
+
+def have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

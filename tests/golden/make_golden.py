@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by running the reference (buqeye/gsum) itself.
+
+Runs ONLY in the build container, where /root/reference is mounted read-only.
+The fixtures it writes are data (seeded inputs + the reference's outputs); the
+reference never travels.  Usage:  python tests/golden/make_golden.py
+
+``import gsum`` needs three non-numeric packages that are absent here
+(docrep: docstring templating; seaborn: plotting; statsmodels' MVT class used
+only by gsum.diagnostics).  As SURVEY.md §8(c) records, they are replaced by
+in-memory placeholder modules; no numeric code is stubbed.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("GSUM_REFERENCE", "/root/reference")
+
+
+def _import_reference():
+    d = types.ModuleType("docrep")
+
+    class _DP:
+        def __init__(self, *a, **k):
+            pass
+
+        def get_sectionsf(self, *a, **k):
+            return lambda f: f
+
+        def dedent(self, f):
+            return f
+
+    d.DocstringProcessor = _DP
+    sys.modules["docrep"] = d
+    sys.modules["seaborn"] = types.ModuleType("seaborn")
+    for name in ("statsmodels", "statsmodels.sandbox", "statsmodels.sandbox.distributions",
+                 "statsmodels.sandbox.distributions.mv_normal"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["statsmodels.sandbox.distributions.mv_normal"].MVT = object
+    sys.path.insert(0, REF)
+    import gsum  # noqa
+    return gsum
+
+
+gsum = _import_reference()
+from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C  # noqa: E402
+
+
+def L(a):
+    return np.asarray(a, dtype=float).tolist()
+
+
+# ---------------------------------------------------------------------------
+# kernel zoo: spec -> sklearn kernel (tests rebuild kernels from the spec)
+# ---------------------------------------------------------------------------
+
+def make_kernel(spec):
+    fam = spec["family"]
+    ls = spec["length_scale"]
+    ls = ls if np.ndim(ls) == 0 else np.asarray(ls, dtype=float)
+    if fam == "rbf":
+        k = RBF(length_scale=ls)
+    elif fam == "matern52":
+        k = Matern(length_scale=ls, nu=2.5)
+    elif fam == "matern32":
+        k = Matern(length_scale=ls, nu=1.5)
+    else:
+        raise ValueError(fam)
+    if spec.get("amplitude") is not None:
+        k = C(spec["amplitude"]) * k
+    if spec.get("white") is not None:
+        k = k + WhiteKernel(spec["white"], noise_level_bounds="fixed")
+    if spec.get("additive") is not None:
+        k = k + C(spec["additive"], constant_value_bounds="fixed")
+    return k
+
+
+KERNELS_1D = [
+    dict(name="rbf", family="rbf", length_scale=0.2),
+    dict(name="matern52", family="matern52", length_scale=0.3),
+    dict(name="c_rbf_white", family="rbf", length_scale=0.25, amplitude=1.7, white=1e-3),
+    dict(name="rbf_white_nb", family="rbf", length_scale=0.2, white=1e-10),
+    dict(name="matern32_add", family="matern32", length_scale=0.4, additive=0.5),
+]
+KERNELS_2D = [
+    dict(name="rbf_aniso", family="rbf", length_scale=[0.7, 1.3]),
+    dict(name="matern52_aniso_white", family="matern52", length_scale=[0.7, 1.3], white=1e-6),
+    dict(name="rbf_iso_2d", family="rbf", length_scale=0.9),
+]
+PRIORS = [
+    dict(name="default", center=0, disp=0, df=1, scale=1),
+    dict(name="center_df", center=0.3, disp=0, df=3, scale=1.5),
+    dict(name="disp", center=0.2, disp=2.0, df=1, scale=1),
+    dict(name="disp_sd", center=-0.1, disp=0.7, sd=1.2),
+    dict(name="sd_only", center=-0.4, disp=0, sd=0.8),
+]
+
+
+def prior_kwargs(p):
+    return {k: v for k, v in p.items() if k != "name"}
+
+
+def gen_cgp_cases():
+    """ConjugateGaussianProcess: lml, fit attributes, predict (models.py:671-1039)."""
+    cases = []
+    for dim, kernels in ((1, KERNELS_1D), (2, KERNELS_2D)):
+        rng = np.random.RandomState(100 + dim)
+        n, r = 24, 3
+        if dim == 1:
+            X = np.sort(rng.rand(n))[:, None] * 2.0
+            Xs = np.linspace(-0.1, 2.1, 7)[:, None]
+        else:
+            X = rng.rand(n, 2) * np.array([3.0, 5.0])
+            Xs = rng.rand(6, 2) * np.array([3.0, 5.0])
+        y = rng.randn(n, r) + 0.3
+        Xc = X[::3] + 0.01
+        yc = rng.randn(len(Xc), r)
+        for ks in kernels:
+            for pr in PRIORS:
+                kern = make_kernel(ks)
+                gp = gsum.ConjugateGaussianProcess(kernel=kern, optimizer=None, **prior_kwargs(pr))
+                theta = kern.theta + 0.1          # evaluate away from the spec's own theta
+                lml_theta = gp.log_marginal_likelihood(theta=theta, X=X, y=y)
+                lml_1col = gp.log_marginal_likelihood(theta=theta, X=X, y=y[:, 0])
+                gp.fit(X, y)
+                mean_s, std_s = gp.predict(Xs, return_std=True)
+                _, cov_s = gp.predict(Xs, return_cov=True)
+                _, cov_noise = gp.predict(Xs, return_cov=True, pred_noise=True)
+                mean_c, std_c = gp.predict(Xs, return_std=True, Xc=Xc, y=yc)
+                cases.append(dict(
+                    kernel=ks, prior=pr, X=L(X), y=L(y), Xs=L(Xs), Xc=L(Xc), yc=L(yc),
+                    theta=L(theta), lml_theta=float(lml_theta), lml_1col=float(lml_1col),
+                    fit=dict(lml=float(gp.log_marginal_likelihood_value_), center=L(gp.center_),
+                             disp=L(gp.disp_), df=float(gp.df_), scale=float(gp.scale_),
+                             cov_factor=float(gp.cov_factor_),
+                             corr_row0=L(gp.corr_[0]), corr_L_last=L(gp.corr_L_[-1]),
+                             prior_cov_probe=L(gp.cov(Xs[:3], Xs[3:5]))),
+                    predict=dict(mean=L(mean_s), std=L(std_s), cov=L(cov_s), cov_noise=L(cov_noise),
+                                 mean_c=L(mean_c), std_c=L(std_c)),
+                ))
+    return cases
+
+
+def gen_trunc_cases():
+    """TruncationGP.log_marginal_likelihood / fit (models.py:1367-1387, 1485-1507)."""
+    cases = []
+    rng = np.random.RandomState(7)
+    n = 30
+    X = np.linspace(0, 3, n)[:, None]
+    for orders, excluded in (([0, 1, 2, 3], None), ([0, 2, 3, 4, 5], None), ([0, 1, 2, 3, 4], [1])):
+        orders = np.array(orders)
+        c = rng.randn(n, len(orders))
+        for ref in (1.0, 10.0):
+            y = gsum.partials(c, ratio=0.5, ref=ref, orders=orders)
+            for pr in (PRIORS[0], PRIORS[2], PRIORS[4]):
+                for ks in (KERNELS_1D[0], KERNELS_1D[2]):
+                    kern = make_kernel(ks)
+                    gp = gsum.TruncationGP(kernel=kern, ratio=0.5, ref=ref, excluded=excluded,
+                                           optimizer=None, **prior_kwargs(pr))
+                    gp.fit(X, y, orders=orders)
+                    ratios = [0.3, 0.45, 0.5, 0.62]
+                    theta = kern.theta - 0.2
+                    lmls = [float(gp.log_marginal_likelihood(theta=theta, ratio=q)) for q in ratios]
+                    cases.append(dict(kernel=ks, prior=pr, X=L(X), y=L(y), orders=orders.tolist(),
+                                      excluded=excluded, ref=ref, ratios=ratios, theta=L(theta), lml=lmls,
+                                      coeffs_row0=L(gp.coeffs_[0]),
+                                      fit_cov_factor=float(gp.coeffs_process.cov_factor_),
+                                      fit_lml=float(gp.coeffs_process.log_marginal_likelihood_value_)))
+    # per-point ratio / ref arrays through callables (models.py:1309-1317)
+    orders = np.arange(4)
+    c = rng.randn(n, 4)
+    ratio_arr = 0.3 + 0.2 * X[:, 0] / 3
+    ref_arr = 5.0 + X[:, 0]
+    y = gsum.partials(c, ratio=ratio_arr, ref=ref_arr, orders=orders)
+    kern = make_kernel(KERNELS_1D[0])
+    gp = gsum.TruncationGP(kernel=kern, ratio=lambda X_, scale=1.0: scale * (0.3 + 0.2 * X_[:, 0] / 3),
+                           ref=lambda X_: 5.0 + X_[:, 0], optimizer=None)
+    gp.fit(X, y, orders=orders)
+    scales = [0.8, 1.0, 1.1]
+    lmls = [float(gp.log_marginal_likelihood(theta=kern.theta, scale=s)) for s in scales]
+    arr_case = dict(X=L(X), y=L(y), orders=orders.tolist(), ratio_arr=L(ratio_arr), ref_arr=L(ref_arr),
+                    kernel=KERNELS_1D[0], theta=L(kern.theta), scales=scales, lml=lmls)
+    return cases, arr_case
+
+
+def gen_helpers():
+    """helpers.py:71-182 outputs on seeded inputs."""
+    rng = np.random.RandomState(11)
+    y = rng.randn(5, 4)
+    ratio = rng.rand(5) * 0.5 + 0.2
+    ref = rng.rand(5) + 1.0
+    orders = np.array([0, 2, 3, 5])
+    out = dict(y=L(y), ratio=L(ratio), ref=L(ref), orders=orders.tolist())
+    out["coefficients_arr"] = L(gsum.coefficients(y, ratio, ref, orders))
+    out["coefficients_scalar"] = L(gsum.coefficients(y, 0.4, 2.0))
+    out["partials_arr"] = L(gsum.partials(y, ratio, ref, orders))
+    out["partials_scalar"] = L(gsum.partials(y, 0.4, 2.0))
+    x = rng.rand(3, 2) * 0.8
+    out["geo_x"] = L(x)
+    out["geo_0_inf"] = L(gsum.geometric_sum(x, 0, np.inf))
+    out["geo_2_5"] = L(gsum.geometric_sum(x, 2, 5))
+    out["geo_1_inf_excl"] = L(gsum.geometric_sum(x, 1, np.inf, excluded=[2, 7]))
+    out["geo_3_6_excl"] = L(gsum.geometric_sum(x, 3, 6, excluded=4))
+    return out
+
+
+def gen_notebook_grid():
+    """The published 80x100 (Q, ell) scan; known answer: argmax (36, 39).
+
+    docs/notebooks/correlated_EFT_publication.ipynb:134-171, 978-1005, 1029,
+    1265-1266, 1444-1459, 1611-1612.
+    """
+    x = np.linspace(0, 1, 100)
+    X = x[:, None]
+    orders = np.arange(0, 4)
+    ls, sd, center, ref, ratio, nugget, seed = 0.2, 1, 0, 10, 0.5, 1e-10, 3
+    kernel = RBF(length_scale=ls, length_scale_bounds="fixed") + \
+        WhiteKernel(noise_level=nugget, noise_level_bounds="fixed")
+    gp = gsum.ConjugateGaussianProcess(kernel=kernel, center=center, df=np.inf, scale=sd, nugget=0)
+    coeffs_all = -gp.sample_y(X, n_samples=21, random_state=seed)
+    data_all = gsum.partials(coeffs_all, ratio, ref=ref, orders=np.arange(21))
+    data = data_all[:, :4]
+    mask = np.array([(i - 1) % 24 == 0 for i in range(len(x))])
+    kernel_fit = RBF(length_scale=ls) + WhiteKernel(noise_level=nugget, noise_level_bounds="fixed")
+    gp_trunc = gsum.TruncationGP(kernel=kernel_fit, ref=ref, ratio=ratio, center=0, disp=0, df=1, scale=1,
+                                 optimizer=None)
+    gp_trunc.fit(X[mask], y=data[mask], orders=orders)
+    ls_vals = np.linspace(1e-3, 0.5, 100)
+    ratio_vals = np.linspace(0.3, 0.7, 80)
+    grid = np.array([[gp_trunc.log_marginal_likelihood(theta=[ls_, ], ratio=q) for ls_ in np.log(ls_vals)]
+                     for q in ratio_vals])
+    like = np.exp(grid - np.max(grid))
+    i, j = np.unravel_index(np.argmax(like), like.shape)
+    return dict(X_train=L(X[mask]), y_train=L(data[mask]), orders=orders.tolist(), ref=ref,
+                ls_vals=L(ls_vals), ratio_vals=L(ratio_vals), nugget=nugget,
+                argmax=[int(i), int(j)], best_Q=float(ratio_vals[i]), best_ls=float(ls_vals[j]),
+                n_neg_inf=int(np.isneginf(grid).sum()), grid=L(grid),
+                published=dict(best_Q=0.4822784810126582, best_ls=0.19757575757575757))
+
+
+def gen_large():
+    """S2/S3 known answers: X = 0.1*arange(n), RBF(0.2), nugget 1e-10."""
+    out = []
+    for n, r in ((512, 4), (2048, 4), (8192, 6)):
+        X = 0.1 * np.arange(n)[:, None]
+        c = np.random.RandomState(0).randn(n, r)
+        y = gsum.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+        gp = gsum.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1,
+                               optimizer=None)
+        gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
+        vals = {}
+        for q in (0.5, 0.45):
+            vals[str(q)] = float(gp.log_marginal_likelihood(theta=np.log([0.2]), ratio=q))
+        out.append(dict(n=n, r=r, dx=0.1, length_scale=0.2, nugget=1e-10, seed=0, lml=vals))
+        print("large", n, r, vals, flush=True)
+    return out
+
+
+def gen_nonpd():
+    """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
+    X = np.array([[0.0], [0.5], [0.5], [1.0]])
+    y = np.array([[0.1], [0.2], [0.2], [0.3]])
+    gp = gsum.ConjugateGaussianProcess(kernel=RBF(1.0), nugget=0, optimizer=None)
+    v = gp.log_marginal_likelihood(theta=np.log([1.0]), X=X, y=y)
+    raised = False
+    try:
+        gp.fit(X, y)
+    except np.linalg.LinAlgError:
+        raised = True
+    return dict(X=L(X), y=L(y), lml_is_neg_inf=bool(np.isneginf(v)), fit_raises_linalgerror=raised)
+
+
+def main():
+    out = {}
+    out["helpers"] = gen_helpers()
+    out["cgp"] = gen_cgp_cases()
+    tc, arr = gen_trunc_cases()
+    out["trunc"] = tc
+    out["trunc_arrays"] = arr
+    out["nonpd"] = gen_nonpd()
+    with open(os.path.join(HERE, "small_cases.json"), "w") as f:
+        json.dump(out, f)
+    with open(os.path.join(HERE, "notebook_grid.json"), "w") as f:
+        json.dump(gen_notebook_grid(), f)
+    with open(os.path.join(HERE, "large_lml.json"), "w") as f:
+        json.dump(gen_large(), f, indent=1)
+    import sklearn, scipy
+    with open(os.path.join(HERE, "VERSIONS.json"), "w") as f:
+        json.dump(dict(numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__,
+                       reference="buqeye/gsum v0.3 @ /root/reference"), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""Pin the CPU oracle (oracle/gsum_oracle.py) to outputs of the reference itself.
+
+The golden files were produced by tests/golden/make_golden.py, which imports
+buqeye/gsum read-only in the build container.  CPU-only; no GPU needed.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_kernel, prior_kwargs
+from oracle import gsum_oracle as orc
+
+RTOL = 1e-12
+
+
+def test_helpers_against_reference(small_cases):
+    h = small_cases["helpers"]
+    y, ratio, ref = np.array(h["y"]), np.array(h["ratio"]), np.array(h["ref"])
+    orders = np.array(h["orders"])
+    np.testing.assert_array_equal(orc.coefficients(y, ratio, ref, orders), np.array(h["coefficients_arr"]))
+    np.testing.assert_array_equal(orc.coefficients(y, 0.4, 2.0), np.array(h["coefficients_scalar"]))
+    np.testing.assert_array_equal(orc.partials(y, ratio, ref, orders), np.array(h["partials_arr"]))
+    np.testing.assert_array_equal(orc.partials(y, 0.4, 2.0), np.array(h["partials_scalar"]))
+    x = np.array(h["geo_x"])
+    np.testing.assert_array_equal(orc.geometric_sum(x, 0, np.inf), np.array(h["geo_0_inf"]))
+    np.testing.assert_array_equal(orc.geometric_sum(x, 2, 5), np.array(h["geo_2_5"]))
+    np.testing.assert_array_equal(orc.geometric_sum(x, 1, np.inf, excluded=[2, 7]), np.array(h["geo_1_inf_excl"]))
+    np.testing.assert_array_equal(orc.geometric_sum(x, 3, 6, excluded=4), np.array(h["geo_3_6_excl"]))
+    with pytest.raises(ValueError):
+        orc.geometric_sum(x, 3, 2)
+    with pytest.raises(ValueError):
+        orc.coefficients(y[:, 0], 0.5)
+
+
+def test_cgp_lml_fit_predict_against_reference(small_cases):
+    assert len(small_cases["cgp"]) == 40
+    for case in small_cases["cgp"]:
+        kern = make_kernel(case["kernel"])
+        pk = prior_kwargs(case["prior"])
+        X, y = np.array(case["X"]), np.array(case["y"])
+        theta = np.array(case["theta"])
+        assert orc.cgp_lml(kern, theta, X, y, **pk) == pytest.approx(case["lml_theta"], rel=RTOL)
+        assert orc.cgp_lml(kern, theta, X, y[:, 0], **pk) == pytest.approx(case["lml_1col"], rel=RTOL)
+        fit = orc.cgp_fit(kern, X, y, **pk)
+        g = case["fit"]
+        assert fit["lml"] == pytest.approx(g["lml"], rel=RTOL)
+        np.testing.assert_allclose(fit["center"], g["center"], rtol=RTOL, atol=1e-15)
+        np.testing.assert_allclose(fit["disp"], g["disp"], rtol=RTOL, atol=1e-15)
+        assert fit["df"] == g["df"]
+        assert fit["scale"] == pytest.approx(g["scale"], rel=RTOL)
+        assert fit["cov_factor"] == pytest.approx(g["cov_factor"], rel=RTOL)
+        np.testing.assert_array_equal(fit["corr"][0], g["corr_row0"])
+        np.testing.assert_allclose(fit["corr_L"][-1], g["corr_L_last"], rtol=1e-13, atol=1e-16)
+        Xs, Xc, yc = np.array(case["Xs"]), np.array(case["Xc"]), np.array(case["yc"])
+        p = case["predict"]
+        m, s = orc.cgp_predict(fit, Xs, return_std=True)
+        np.testing.assert_allclose(m, p["mean"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(s, p["std"], rtol=1e-9, atol=1e-12)
+        _, cv = orc.cgp_predict(fit, Xs, return_cov=True)
+        np.testing.assert_allclose(cv, p["cov"], rtol=1e-9, atol=1e-12)
+        _, cvn = orc.cgp_predict(fit, Xs, return_cov=True, pred_noise=True)
+        np.testing.assert_allclose(cvn, p["cov_noise"], rtol=1e-9, atol=1e-12)
+        mc, sc = orc.cgp_predict(fit, Xs, return_std=True, Xc=Xc, y=yc)
+        np.testing.assert_allclose(mc, p["mean_c"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(sc, p["std_c"], rtol=1e-9, atol=1e-12)
+        with pytest.raises(RuntimeError):
+            orc.cgp_predict(fit, Xs, return_std=True, return_cov=True)
+
+
+def test_trunc_lml_against_reference(small_cases):
+    assert len(small_cases["trunc"]) == 36
+    for case in small_cases["trunc"]:
+        kern = make_kernel(case["kernel"])
+        pk = prior_kwargs(case["prior"])
+        X, y = np.array(case["X"]), np.array(case["y"])
+        orders = np.array(case["orders"])
+        for q, want in zip(case["ratios"], case["lml"]):
+            got = orc.trunc_lml(kern, np.array(case["theta"]), X, y, orders, ratio=q, ref=case["ref"],
+                                excluded=case["excluded"], **pk)
+            assert got == pytest.approx(want, rel=RTOL)
+        mask = ~np.isin(orders, case["excluded"])
+        c = orc.coefficients(y, 0.5, case["ref"], orders)[:, mask]
+        np.testing.assert_array_equal(c[0], case["coeffs_row0"])
+        fit = orc.cgp_fit(kern, X, c, **pk)
+        assert fit["cov_factor"] == pytest.approx(case["fit_cov_factor"], rel=RTOL)
+        assert fit["lml"] == pytest.approx(case["fit_lml"], rel=RTOL)
+
+
+def test_trunc_lml_array_ratio_ref(small_cases):
+    a = small_cases["trunc_arrays"]
+    kern = make_kernel(a["kernel"])
+    X, y = np.array(a["X"]), np.array(a["y"])
+    for s, want in zip(a["scales"], a["lml"]):
+        got = orc.trunc_lml(kern, np.array(a["theta"]), X, y, np.array(a["orders"]),
+                            ratio=s * np.array(a["ratio_arr"]), ref=np.array(a["ref_arr"]))
+        assert got == pytest.approx(want, rel=RTOL)
+
+
+def test_nonpd_behaviour(small_cases):
+    c = small_cases["nonpd"]
+    from sklearn.gaussian_process.kernels import RBF
+    X, y = np.array(c["X"]), np.array(c["y"])
+    assert c["lml_is_neg_inf"] and c["fit_raises_linalgerror"]
+    assert orc.cgp_lml(RBF(1.0), np.log([1.0]), X, y, nugget=0) == -np.inf
+    with pytest.raises(np.linalg.LinAlgError):
+        orc.cgp_fit(RBF(1.0), X, y, nugget=0)
+
+
+def test_notebook_grid_known_answer(notebook_grid):
+    """The reference's one published likelihood known answer: MAP indices (36, 39)."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    g = notebook_grid
+    assert g["argmax"] == [36, 39]
+    assert g["best_Q"] == g["published"]["best_Q"] and g["best_ls"] == g["published"]["best_ls"]
+    kern = RBF(0.2) + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+    X, y = np.array(g["X_train"]), np.array(g["y_train"])
+    grid = orc.lml_grid(kern, np.log(g["ls_vals"]), g["ratio_vals"], X, y, np.array(g["orders"]), ref=g["ref"])
+    want = np.array(g["grid"])
+    np.testing.assert_allclose(grid, want, rtol=1e-11)
+    assert list(np.unravel_index(np.argmax(grid), grid.shape)) == [36, 39]
+    assert not np.isneginf(grid).any()
+
+
+def test_large_known_answers(large_lml):
+    """S2-style input (dx = 0.5 ell) at n = 512 and 2048 (n = 8192 is checked on the GPU box)."""
+    from sklearn.gaussian_process.kernels import RBF
+    for case in large_lml:
+        n, r = case["n"], case["r"]
+        if n > 2048:
+            continue
+        X = case["dx"] * np.arange(n)[:, None]
+        c = np.random.RandomState(case["seed"]).randn(n, r)
+        y = orc.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+        for q, want in case["lml"].items():
+            got = orc.trunc_lml(RBF(case["length_scale"]), np.log([case["length_scale"]]), X, y, np.arange(r),
+                                ratio=float(q), ref=1.0, nugget=case["nugget"])
+            assert got == pytest.approx(want, rel=1e-12)
