@@ -1,0 +1,323 @@
+"""ctypes binding of libgsum_hip.so (C ABI: include/gsum_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is
+visible, creating a :class:`HipContext` raises.  Build the library with
+``python -m gsum_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsum_hip.so")
+
+GSUM_MAX_D = 8
+GSUM_MAX_RHS = 16
+FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3}
+
+
+class KernelDesc(C.Structure):
+    """Mirror of ``gsum_kernel_desc``."""
+    _fields_ = [
+        ("family", C.c_int32),
+        ("anisotropic", C.c_int32),
+        ("length_scale", C.c_double * GSUM_MAX_D),
+        ("amplitude", C.c_double),
+        ("additive_const", C.c_double),
+        ("white_noise", C.c_double),
+    ]
+
+    def __repr__(self):
+        ls = list(self.length_scale)[: (GSUM_MAX_D if self.anisotropic else 1)]
+        return (f"KernelDesc(family={self.family}, aniso={self.anisotropic}, ls={ls}, amp={self.amplitude}, "
+                f"add={self.additive_const}, white={self.white_noise})")
+
+
+_p = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_kp = C.POINTER(KernelDesc)
+
+# name -> (restype, argtypes); must list every symbol include/gsum_hip.h declares
+PROTOTYPES = {
+    "gsum_init": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "gsum_destroy": (None, [_p]),
+    "gsum_last_error": (C.c_char_p, [_p]),
+    "gsum_set_option": (C.c_int, [_p, C.c_char_p, C.c_int64]),
+    "gsum_kernel_build": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, C.c_double, _dp]),
+    "gsum_kernel_build_dev": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, C.c_double, C.POINTER(_p)]),
+    "gsum_mat_from_host": (C.c_int, [_p, _dp, C.c_int64, C.POINTER(_p)]),
+    "gsum_potrf_lower": (C.c_int, [_p, _p, _ip]),
+    "gsum_forward_gram": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
+    "gsum_forward_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
+    "gsum_predict_terms": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
+                                     _dp, _dp, _dp]),
+    "gsum_mat_to_host": (C.c_int, [_p, _p, _dp]),
+    "gsum_mat_n": (C.c_int64, [_p]),
+    "gsum_mat_free": (None, [_p, _p]),
+    "gsum_lml_batch": (C.c_int, [_p, _kp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_double,
+                                 _dp, _dp, _ip]),
+    "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
+    "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
+    "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
+    "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, _dp]),
+    "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
+    "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_int32, C.c_double]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: str | None = None):
+    """dlopen libgsum_hip.so and attach prototypes.  Raises if it is absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"{p} not found: the HIP extension is not built. Run `python -m gsum_amd.build` "
+                "(hipcc --offload-arch=gfx950). gsum_amd has no CPU fallback.")
+        lib = C.CDLL(p)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)        # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class DeviceMatrix:
+    """Owner of a ``gsum_mat*`` (device-resident symmetric matrix or Cholesky factor)."""
+
+    def __init__(self, ctx: "HipContext", handle):
+        self._ctx = ctx
+        self._h = handle
+        self.n = int(ctx._lib.gsum_mat_n(handle))
+        self.factored = False
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.n, self.n))
+        self._ctx._check(self._ctx._lib.gsum_mat_to_host(self._ctx._h, self._h, _ptr(out)))
+        return out
+
+    def free(self):
+        if self._h is not None and self._ctx._h is not None:
+            self._ctx._lib.gsum_mat_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipContext:
+    """One GPU, one ``gsum_ctx``.  Not thread-safe (one context per thread)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = _p()
+        rc = self._lib.gsum_init(int(device), C.byref(h))
+        if rc != 0:
+            msg = self._lib.gsum_last_error(None)
+            raise RuntimeError(f"gsum_init(device={device}) failed: {msg.decode() if msg else rc}")
+        self._h = h
+        self.device = int(device)
+
+    # -- plumbing ------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.gsum_last_error(self._h)
+            text = msg.decode() if msg else f"error {rc}"
+            if rc == -2:
+                raise ValueError(text)
+            raise RuntimeError(text)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.gsum_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.gsum_set_option(self._h, name.encode(), int(value)))
+
+    # -- operator level ------------------------------------------------------
+    def kernel_matrix(self, desc: KernelDesc, X, Y=None, diag_add: float = 0.0) -> np.ndarray:
+        X = _f64(X)
+        n, d = X.shape
+        if Y is None:
+            out = np.empty((n, n))
+            self._check(self._lib.gsum_kernel_build(self._h, C.byref(desc), _ptr(X), n, d, None, 0,
+                                                    float(diag_add), _ptr(out)))
+        else:
+            Y = _f64(Y)
+            if Y.shape[1] != d:
+                raise ValueError("X and Y must have the same number of features")
+            out = np.empty((n, Y.shape[0]))
+            self._check(self._lib.gsum_kernel_build(self._h, C.byref(desc), _ptr(X), n, d, _ptr(Y), Y.shape[0],
+                                                    0.0, _ptr(out)))
+        return out
+
+    def kernel_matrix_dev(self, desc: KernelDesc, X, diag_add: float = 0.0) -> DeviceMatrix:
+        X = _f64(X)
+        h = _p()
+        self._check(self._lib.gsum_kernel_build_dev(self._h, C.byref(desc), _ptr(X), X.shape[0], X.shape[1],
+                                                    float(diag_add), C.byref(h)))
+        return DeviceMatrix(self, h)
+
+    def upload(self, A) -> DeviceMatrix:
+        A = _f64(A)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("square matrix expected")
+        h = _p()
+        self._check(self._lib.gsum_mat_from_host(self._h, _ptr(A), A.shape[0], C.byref(h)))
+        return DeviceMatrix(self, h)
+
+    def potrf(self, A: DeviceMatrix) -> int:
+        """In-place lower Cholesky; returns LAPACK ``info`` (0 = success)."""
+        info = C.c_int64(0)
+        self._check(self._lib.gsum_potrf_lower(self._h, A._h, C.byref(info)))
+        A.factored = info.value == 0
+        return int(info.value)
+
+    def forward_gram(self, L: DeviceMatrix, rhs):
+        rhs = _f64(rhs)
+        if rhs.ndim == 1:
+            rhs = rhs[:, None]
+        n, k = rhs.shape
+        G = np.empty((k, k))
+        sld = C.c_double(0.0)
+        self._check(self._lib.gsum_forward_gram(self._h, L._h, _ptr(rhs), n, k, _ptr(G), C.byref(sld)))
+        return G, float(sld.value)
+
+    def forward_solve(self, L: DeviceMatrix, rhs) -> np.ndarray:
+        """W = L^-1 rhs (n x k), k <= 16."""
+        rhs = _f64(rhs)
+        squeeze = rhs.ndim == 1
+        if squeeze:
+            rhs = rhs[:, None]
+        n, k = rhs.shape
+        W = np.empty((n, k))
+        self._check(self._lib.gsum_forward_solve(self._h, L._h, _ptr(rhs), n, k, _ptr(W)))
+        return W[:, 0] if squeeze else W
+
+    def predict_terms(self, L: DeviceMatrix, desc: KernelDesc, X, Xs, rhs=None, want_cov=False):
+        X, Xs = _f64(X), _f64(Xs)
+        n, d = X.shape
+        m = Xs.shape[0]
+        colsumsq = np.empty(m)
+        k = 0
+        VtW = None
+        if rhs is not None:
+            rhs = _f64(rhs)
+            if rhs.ndim == 1:
+                rhs = rhs[:, None]
+            k = rhs.shape[1]
+            VtW = np.empty((m, k))
+        cov = np.empty((m, m)) if want_cov else None
+        self._check(self._lib.gsum_predict_terms(self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m,
+                                                 _ptr(rhs), k, _ptr(colsumsq), _ptr(VtW), _ptr(cov)))
+        return colsumsq, VtW, cov
+
+    # -- fused hot path ------------------------------------------------------
+    @staticmethod
+    def _desc_array(descs):
+        arr = (KernelDesc * len(descs))()
+        for i, dsc in enumerate(descs):
+            C.memmove(C.byref(arr[i]), C.byref(dsc), C.sizeof(KernelDesc))
+        return arr
+
+    def lml_batch(self, descs, X, rhs, nugget: float):
+        """K build + Cholesky + Gram/log-det for each descriptor (host inputs)."""
+        X, rhs = _f64(X), _f64(rhs)
+        n, d = X.shape
+        k = rhs.shape[1]
+        nk = len(descs)
+        G = np.empty((nk, k, k))
+        sld = np.empty(nk)
+        info = np.zeros(nk, dtype=np.int64)
+        arr = self._desc_array(descs)
+        self._check(self._lib.gsum_lml_batch(self._h, arr, nk, _ptr(X), n, d, _ptr(rhs), k, float(nugget),
+                                             _ptr(G), _ptr(sld), info.ctypes.data_as(_ip)))
+        return G, sld, info
+
+    def set_inputs(self, X, rhs):
+        X, rhs = _f64(X), _f64(rhs)
+        self._k = rhs.shape[1]
+        self._check(self._lib.gsum_set_inputs(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(rhs), rhs.shape[1]))
+
+    def lml_resident(self, descs, nugget: float):
+        k = self._k
+        nk = len(descs)
+        G = np.empty((nk, k, k))
+        sld = np.empty(nk)
+        info = np.zeros(nk, dtype=np.int64)
+        arr = self._desc_array(descs)
+        self._check(self._lib.gsum_lml_resident(self._h, arr, nk, float(nugget), _ptr(G), _ptr(sld),
+                                                info.ctypes.data_as(_ip)))
+        return G, sld, info
+
+    # -- measurement ---------------------------------------------------------
+    def timers(self):
+        ms = np.zeros(4)
+        self._check(self._lib.gsum_timers(self._h, _ptr(ms), 4))
+        return dict(build_ms=ms[0], potrf_ms=ms[1], finalize_ms=ms[2], total_ms=ms[3])
+
+    def probe_mfma_f64(self, iters=20000) -> float:
+        v = C.c_double(0)
+        self._check(self._lib.gsum_probe_mfma_f64(self._h, iters, C.byref(v)))
+        return float(v.value)
+
+    def probe_hbm_write(self, nbytes=1 << 30) -> float:
+        v = C.c_double(0)
+        self._check(self._lib.gsum_probe_hbm_write(self._h, nbytes, C.byref(v)))
+        return float(v.value)
+
+    def debug_gemm_nt(self, cfg, Cm, A, B, tri=False, beta=1, sign=-1.0):
+        Cm, A, B = _f64(Cm).copy(), _f64(A), _f64(B)
+        M, K = A.shape
+        N = B.shape[0]
+        self._check(self._lib.gsum_debug_gemm_nt(self._h, cfg, int(tri), _ptr(Cm), _ptr(A), _ptr(B), M, N, K,
+                                                 int(beta), float(sign)))
+        return Cm
+
+
+_default_ctx = {}
+
+
+def default_context(device: int | None = None) -> HipContext:
+    """Process-wide context for ``device`` (default: $LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("GSUM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = HipContext(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,419 @@
+"""ConjugateGaussianProcess on MI355X — host-side mirror of gsum/models.py:31-1057.
+
+The class keeps the reference's constructor, ``fit`` / ``predict`` / ``log_marginal_likelihood``
+/ ``mean`` / ``cov`` surface and fitted attributes, but every O(n^2)/O(n^3) operation is one call
+into libgsum_hip.so:
+
+    kernel(X)                     -> gsum_kernel_build[_dev]      (models.py:708, 958-960)
+    numpy.linalg.cholesky         -> gsum_potrf_lower             (models.py:711, 809, 969)
+    4x cho_solve + traces + N x N
+    Woodbury temporary            -> one Gram matrix G = W^T W, W = L^-1 [Y | B], plus sum(log diag L)
+                                     (models.py:432-445, 1015, 1032-1035)
+
+What is left on the host is O((n_curves+1)^2) scalar algebra on G (``posterior_from_gram``).
+There is no CPU fallback; an unsupported kernel / option raises.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+from scipy.optimize import fmin_l_bfgs_b
+from sklearn.base import clone
+from sklearn.exceptions import ConvergenceWarning
+from sklearn.utils import check_random_state
+
+from ._lib import GSUM_MAX_RHS, default_context
+from .kernels import default_kernel, describe_kernel
+
+__all__ = ["ConjugateGaussianProcess", "posterior_from_gram", "lml_from_gram", "cov_factor"]
+
+
+# ---------------------------------------------------------------------------------------------
+# host algebra on the Gram matrix, p = 1 basis column
+# ---------------------------------------------------------------------------------------------
+
+def cov_factor(scale_sq, df):
+    """sigma^2 = nu tau^2 / (nu - 2); tau^2 when nu = inf (models.py:490-503)."""
+    if df != np.inf:
+        return df * scale_sq / (df - 2)
+    return scale_sq
+
+
+def posterior_from_gram(G, n_points, center0, disp0, df0, scale0):
+    """Conjugate updates from G = [Y | 1]^T R^-1 [Y | 1].
+
+    Restates compute_center / compute_disp / compute_df / compute_scale_sq (models.py:170-457) in
+    terms of the (ny+1) x (ny+1) Gram matrix, so no further solve is needed:
+      q = ybar^T R^-1 ybar, b = 1^T R^-1 ybar, g = 1^T R^-1 1 are bilinear forms of G.
+    Returns dict(center (1,), disp (1,1), df, scale_sq, cov_factor, S) with
+    S = sum_k (y_k - eta)^T R^-1 (y_k - eta).
+    """
+    G = np.asarray(G, dtype=float)
+    ny = G.shape[0] - 1
+    Gyy, gyb, g = G[:ny, :ny], G[:ny, ny], G[ny, ny]
+    center0 = np.atleast_1d(np.asarray(center0, dtype=float))
+    disp0 = np.atleast_2d(np.asarray(disp0, dtype=float))
+    if center0.shape != (1,) or disp0.shape != (1, 1):
+        raise ValueError("center must be a scalar and disp a scalar (single constant basis function)")
+    eta0, V0 = center0[0], disp0[0, 0]
+    w = np.full(ny, 1.0 / ny)
+    q = w @ Gyy @ w
+    b = gyb @ w
+    tr = np.trace(Gyy)
+    if V0 == 0:                                   # models.py:201-206, 260-265
+        V, eta = 0.0, eta0
+    else:
+        V = 1.0 / (1.0 / V0 + ny * g)             # models.py:269-270
+        eta = V * (eta0 / V0 + ny * b)            # models.py:219-220
+    df = df0 + n_points * ny                      # models.py:302
+    if df0 == np.inf:
+        scale_sq = scale0 ** 2                    # models.py:419-422
+    else:
+        quad = tr - ny * q                        # models.py:430-433
+        a = q - 2.0 * eta0 * b + eta0 * eta0 * g  # (ybar - eta0)^T R^-1 (ybar - eta0)
+        v = b - g * eta0
+        quad2 = ny * (a - ny * v * V * v)         # models.py:435-445 (Woodbury term, no N x N matrix)
+        scale_sq = (df0 * scale0 ** 2 + quad + quad2) / df   # models.py:448
+    S = tr - 2.0 * ny * eta * b + ny * eta * eta * g
+    return dict(center=np.array([eta]), disp=np.array([[V]]), df=df, scale_sq=scale_sq,
+                cov_factor=cov_factor(scale_sq, df), S=S)
+
+
+def lml_from_gram(G, sum_log_diag, n_points, center0, disp0, df0, scale0):
+    """log marginal likelihood from (G, sum log diag L).  models.py:1007-1039."""
+    post = posterior_from_gram(G, n_points, center0, disp0, df0, scale0)
+    ny = np.asarray(G).shape[0] - 1
+    var = post["cov_factor"]
+    logdet_K = n_points * np.log(var) + 2.0 * sum_log_diag          # models.py:1014-1015
+    lml = -0.5 * post["S"] / var - 0.5 * ny * logdet_K - ny * n_points / 2.0 * np.log(2.0 * np.pi)
+    return float(lml), post
+
+
+# ---------------------------------------------------------------------------------------------
+# the class
+# ---------------------------------------------------------------------------------------------
+
+class ConjugateGaussianProcess:
+    """Conjugate-prior GP; same constructor and methods as gsum.ConjugateGaussianProcess.
+
+    Parameters are those of gsum/models.py:107-109.  Additive: ``device`` (GPU index; default
+    ``$LOCAL_RANK`` or 0).  ``basis`` other than ``None`` and ``decomposition='eig'`` are not
+    available on the device and raise ``NotImplementedError``.
+    """
+
+    def __init__(self, kernel=None, center=0, disp=0, df=1, scale=1, sd=None, basis=None, nugget=1e-10,
+                 optimizer='fmin_l_bfgs_b', n_restarts_optimizer=0, copy_X_train=True, random_state=None,
+                 decomposition='cholesky', device=None):
+        self.kernel = kernel
+        self._center_0 = np.atleast_1d(center)
+        self._disp_0 = np.atleast_2d(disp)
+        if sd is not None:                      # models.py:115-117
+            self._df_0 = np.inf
+            self._scale_0 = sd
+        else:
+            self._df_0 = df
+            self._scale_0 = scale
+        self._fit = False
+        self.X_train_ = None
+        self.y_train_ = None
+        self.center_ = None
+        self.disp_ = None
+        self.df_ = None
+        self.scale_ = None
+        self.cov_factor_ = self.cbar_sq_mean_ = None
+        self.kernel_ = None
+        self._rng = None
+        self.nugget = nugget
+        self.copy_X_train = copy_X_train
+        self.random_state = random_state
+        self.n_restarts_optimizer = n_restarts_optimizer
+        self.optimizer = optimizer
+        self.decomposition = decomposition
+        self._default_kernel = default_kernel()
+        if basis is not None:
+            # the reference only ever assigns self.basis when basis is None (models.py:149-150)
+            raise NotImplementedError("only the constant basis (basis=None) is supported")
+        self.basis = lambda X: np.ones((np.shape(X)[0], 1))
+        self.basis_train_ = None
+        self.device = device
+        self._ctx = None
+        self._L_dev = None          # device-resident Cholesky factor of kernel_(X_train_) + nugget
+        self._corr = None
+        self._corr_L = None
+        self._gram = None
+
+    # -- priors (models.py:153-167) ------------------------------------------------------------
+    @property
+    def center0(self):
+        return self._center_0
+
+    @property
+    def disp0(self):
+        return self._disp_0
+
+    @property
+    def df0(self):
+        return self._df_0
+
+    @property
+    def scale0(self):
+        return self._scale_0
+
+    # -- device plumbing -----------------------------------------------------------------------
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = default_context(self.device)
+        return self._ctx
+
+    def _check_decomposition(self):
+        if self.decomposition == 'eig':
+            raise NotImplementedError("decomposition='eig' is not built for the device path")
+        if self.decomposition != 'cholesky':
+            raise ValueError('decomposition must be "cholesky" or "eig"')     # models.py:719, 976
+
+    @staticmethod
+    def _rhs(X, y):
+        """[Y | B]: the curves and the constant basis column, the fused kernel's right-hand sides."""
+        y = np.asarray(y, dtype=float)
+        if y.ndim == 1:
+            y = y[:, None]
+        if y.ndim != 2:
+            raise ValueError('y must be two-dimensional, not shape={}'.format(y.shape))
+        if y.shape[1] + 1 > GSUM_MAX_RHS:
+            raise ValueError(f"at most {GSUM_MAX_RHS - 1} curves are supported, got {y.shape[1]}")
+        return np.concatenate([y, np.ones((y.shape[0], 1))], axis=1)
+
+    def _active_kernel(self):
+        if getattr(self, 'kernel_', None) is not None:
+            return self.kernel_
+        return self._default_kernel if self.kernel is None else self.kernel      # models.py:946-952
+
+    # -- lazily materialised n x n attributes (device -> host only on access) -------------------
+    @property
+    def corr_(self):
+        if self._corr is None and self._fit:
+            X = np.asarray(self.X_train_, dtype=float)
+            self._corr = self._context().kernel_matrix(describe_kernel(self.kernel_, X.shape[1]), X)
+        return self._corr
+
+    @property
+    def corr_L_(self):
+        if self._corr_L is None and self._L_dev is not None:
+            self._corr_L = self._L_dev.to_host()
+        return self._corr_L
+
+    corr_sqrt_ = corr_L_
+
+    # -- log marginal likelihood (models.py:912-1039) --------------------------------------------
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False, X=None, y=None):
+        if theta is None and self._fit:
+            if eval_gradient:
+                raise ValueError("Gradient can only be evaluated for theta!=None")   # models.py:940-943
+            return self.log_marginal_likelihood_value_
+        self._check_decomposition()
+        if eval_gradient:
+            raise NotImplementedError("eval_gradient=True (SURVEY.md §8 f-1) is not built yet")
+        kernel = self._active_kernel()
+        if theta is not None:
+            kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))         # models.py:953
+        X = self.X_train_ if X is None else X
+        y = self.y_train_ if y is None else y
+        X = np.asarray(X, dtype=float)
+        Z = self._rhs(X, y)
+        desc = describe_kernel(kernel, X.shape[1])
+        G, sld, info = self._context().lml_batch([desc], X, Z, self.nugget)
+        if info[0] != 0:
+            return -np.inf                                                           # models.py:970-972
+        lml, _ = lml_from_gram(G[0], sld[0], X.shape[0], self.center0, self.disp0, self.df0, self.scale0)
+        return lml
+
+    # -- fit (models.py:630-738) -------------------------------------------------------------------
+    def _constrained_optimization(self, obj_func, initial_theta, bounds):
+        """models.py:884-900; the objective is value-only here, so L-BFGS differentiates numerically."""
+        if self.optimizer == "fmin_l_bfgs_b":
+            theta_opt, func_min, info = fmin_l_bfgs_b(obj_func, initial_theta, bounds=bounds, approx_grad=True)
+            if info["warnflag"] != 0:
+                warnings.warn("fmin_l_bfgs_b terminated abnormally with the  state: %s" % info, ConvergenceWarning)
+        elif callable(self.optimizer):
+            theta_opt, func_min = self.optimizer(obj_func, initial_theta, bounds=bounds)
+        else:
+            raise ValueError("Unknown optimizer %s." % self.optimizer)
+        return theta_opt, func_min
+
+    def _calibrate_kernel(self):
+        """models.py:630-669, with the intended argmin over restarts (the reference's ragged
+        ``np.array(optima)`` at :664 raises on numpy >= 1.24)."""
+        if self.optimizer is not None and self.kernel_.n_dims > 0:
+            def obj_func(theta, eval_gradient=False):
+                return -self.log_marginal_likelihood(theta)
+
+            optima = [self._constrained_optimization(obj_func, self.kernel_.theta, self.kernel_.bounds)]
+            if self.n_restarts_optimizer > 0:
+                if not np.isfinite(self.kernel_.bounds).all():
+                    raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) "
+                                     "requires that all bounds are finite.")
+                bounds = self.kernel_.bounds
+                for _ in range(self.n_restarts_optimizer):
+                    theta_initial = self._rng.uniform(bounds[:, 0], bounds[:, 1])
+                    optima.append(self._constrained_optimization(obj_func, theta_initial, bounds))
+            values = [o[1] for o in optima]
+            best = int(np.argmin(values))
+            self.kernel_.theta = optima[best][0]
+            return -float(values[best])
+        return None
+
+    def fit(self, X, y):
+        self._check_decomposition()
+        self.kernel_ = clone(self._default_kernel if self.kernel is None else self.kernel)   # models.py:685-688
+        self._rng = check_random_state(self.random_state)
+        if self.copy_X_train:
+            self.X_train_ = np.copy(X)
+            self.y_train_ = np.copy(y)
+        else:
+            self.X_train_, self.y_train_ = X, y
+        self.basis_train_ = self.basis(self.X_train_)
+        self._fit = False
+        self._corr = self._corr_L = None
+        Xd = np.asarray(self.X_train_, dtype=float)
+        Z = self._rhs(Xd, self.y_train_)
+
+        lml_opt = self._calibrate_kernel()                                  # models.py:707
+
+        # one build + one factorisation serve both the likelihood value and the posterior updates
+        # (the reference does each twice, models.py:668-669 and :708-711)
+        ctx = self._context()
+        desc = describe_kernel(self.kernel_, Xd.shape[1])
+        if self._L_dev is not None:
+            self._L_dev.free()
+        self._L_dev = ctx.kernel_matrix_dev(desc, Xd, diag_add=self.nugget)
+        info = ctx.potrf(self._L_dev)
+        if info != 0:
+            self._L_dev.free()
+            self._L_dev = None
+            raise np.linalg.LinAlgError("Matrix is not positive definite")    # numpy's message; models.py:711
+        G, sld = ctx.forward_gram(self._L_dev, Z)
+        lml, post = lml_from_gram(G, sld, Xd.shape[0], self.center0, self.disp0, self.df0, self.scale0)
+        self.log_marginal_likelihood_value_ = lml if lml_opt is None else lml_opt
+        self._gram = (G, sld)
+        self.center_ = post["center"]                                        # models.py:721-736
+        self.disp_ = post["disp"]
+        self.df_ = post["df"]
+        self.scale_ = np.sqrt(post["scale_sq"])
+        self.cov_factor_ = self.cbar_sq_mean_ = post["cov_factor"]
+        self._fit = True
+        return self
+
+    # -- accessors that the reference recomputes from the factor (models.py:505-549) --------------
+    def _posterior(self):
+        G, _ = self._gram
+        return posterior_from_gram(G, np.shape(self.X_train_)[0], self.center0, self.disp0, self.df0, self.scale0)
+
+    def center(self):
+        self._check_decomposition()
+        return self._posterior()["center"]
+
+    def disp(self):
+        self._check_decomposition()
+        return self._posterior()["disp"]
+
+    def df(self):
+        return self.df0 + np.asarray(self.y_train_).size
+
+    def scale(self):
+        self._check_decomposition()
+        return np.sqrt(self._posterior()["scale_sq"])
+
+    # -- mean / cov (models.py:551-599) ---------------------------------------------------------------
+    def mean(self, X):
+        center = self.center_ if self._fit else self.center0
+        return self.basis(X) @ center
+
+    def cov(self, X, Xp=None):
+        if not self._fit:
+            if self.df0 <= 2:
+                raise ValueError('df must be greater than 2 for the covariance to exist')
+            factor = cov_factor(self.scale0 ** 2, self.df0)
+            kernel = self._default_kernel if self.kernel is None else self.kernel
+        else:
+            factor = self.cov_factor_
+            kernel = self.kernel_
+        X = np.asarray(X, dtype=float)
+        desc = describe_kernel(kernel, X.shape[1])
+        return factor * self._context().kernel_matrix(desc, X, None if Xp is None else np.asarray(Xp, dtype=float))
+
+    def underlying_properties(self, X, return_std=False, return_cov=False):
+        y_mean = self.mean(X)
+        if return_cov:
+            return y_mean, self.cov(X)
+        if return_std:
+            return y_mean, np.sqrt(np.diag(self.cov(X)))
+        return y_mean
+
+    # -- predict (models.py:753-845) ------------------------------------------------
+    def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):
+        if return_std and return_cov:
+            raise RuntimeError('Only one of return_std or return_cov may be True')
+        if not self._fit:
+            return self.underlying_properties(X=X, return_std=return_std, return_cov=return_cov)
+        self._check_decomposition()
+        ctx = self._context()
+        X = np.asarray(X, dtype=float)
+        desc = describe_kernel(self.kernel_, X.shape[1])
+        own = None
+        if Xc is None:
+            Xc = np.asarray(self.X_train_, dtype=float)
+            L = self._L_dev
+        else:
+            Xc = np.asarray(Xc, dtype=float)
+            own = L = ctx.kernel_matrix_dev(desc, Xc, diag_add=self.nugget)      # models.py:807
+            if ctx.potrf(L) != 0:
+                L.free()
+                raise np.linalg.LinAlgError("Matrix is not positive definite")    # models.py:809
+        try:
+            y = self.y_train_ if y is None else y
+            y = np.asarray(y, dtype=float)
+            if y.ndim == 1:
+                y = y[:, None]
+            m_old = self.mean(Xc)                                                 # models.py:818
+            m_new = self.mean(X)                                                  # models.py:819
+            resid = y - m_old[:, None]
+            m_parts, colsumsq, VtV = [], None, None
+            for lo in range(0, resid.shape[1], GSUM_MAX_RHS):
+                want_cov = return_cov and lo == 0
+                css, VtW, cv = ctx.predict_terms(L, desc, Xc, X, rhs=resid[:, lo:lo + GSUM_MAX_RHS], want_cov=want_cov)
+                m_parts.append(VtW)
+                colsumsq = css
+                VtV = cv if want_cov else VtV
+        finally:
+            if own is not None:
+                own.free()
+        # R_no R^-1 (y - m) = (L^-1 R_on)^T (L^-1 (y - m))                         models.py:831-832
+        m_pred = np.squeeze(m_new[:, None] + np.concatenate(m_parts, axis=1))
+        if return_std or return_cov:
+            var = cov_factor(self.scale_ ** 2, self.df_)                           # models.py:840
+            if return_std:
+                # diag of the one-argument kernel: unit base value, WhiteKernel noise included (:824)
+                diag_nn = desc.amplitude * 1.0 + desc.white_noise + desc.additive_const
+                r_diag = diag_nn - colsumsq                                        # models.py:836
+                if pred_noise:
+                    r_diag = r_diag + self.nugget                                  # models.py:837-838
+                return m_pred, np.sqrt(np.squeeze(var * r_diag))                   # models.py:841-843
+            R_pred = ctx.kernel_matrix(desc, X) - VtV
+            if pred_noise:
+                R_pred += self.nugget * np.eye(len(X))
+            return m_pred, np.squeeze(var * R_pred)
+        return m_pred
+
+    # -- sampling (models.py:847-879) ----------------------------------------------------------------------
+    def sample_y(self, X, n_samples=1, random_state=0, underlying=False):
+        rng = check_random_state(random_state)
+        if underlying:
+            y_mean, y_cov = self.underlying_properties(X=X, return_cov=True)
+        else:
+            y_mean, y_cov = self.predict(X, return_cov=True)
+        if y_mean.ndim == 1:
+            return rng.multivariate_normal(y_mean, y_cov, n_samples).T
+        samples = [rng.multivariate_normal(y_mean[:, i], y_cov, n_samples).T[:, np.newaxis]
+                   for i in range(y_mean.shape[1])]
+        return np.hstack(samples)

@@ -1,0 +1,670 @@
+// libgsum_hip.so — host side of the C ABI declared in include/gsum_hip.h.
+// One context = one GPU = two HIP streams (main + high-priority panel stream for look-ahead).
+#include "gsum_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct gsum_mat {
+    int64_t n = 0, np = 0, ld = 0;
+    int T = 0;                 // np / 128
+    double* A = nullptr;       // (np + 16) x ld augmented matrix
+    double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L
+    double* logdet = nullptr;  // T per-block sums of log L_ii
+    bool factored = false;
+};
+
+struct gsum_ctx {
+    int device = 0;
+    hipStream_t sm = nullptr, sp = nullptr;
+    std::vector<hipEvent_t> evP, evM;
+    hipEvent_t evFork = nullptr;
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    int lookahead = 1;
+    int build_lower_only = 1;
+    // resident inputs of the fused path
+    double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;
+    double* dZ = nullptr; int kZ = 0; size_t dZ_cap = 0;
+    gsum_mat* ws = nullptr;          // workspace matrix of the fused path (reused across calls)
+    double* dres = nullptr; int* dinfo = nullptr;
+    double* hres = nullptr;          // pinned
+    double* scratch = nullptr; size_t scratch_cap = 0;
+    double timers[4] = {0, 0, 0, 0};
+};
+
+static std::string g_init_error;
+
+#define GS_CHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char buf_[512];                                                                        \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            ctx->err = buf_;                                                                       \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+#define GS_FAIL(msg)            \
+    do {                        \
+        ctx->err = (msg);       \
+        return -2;              \
+    } while (0)
+
+static int gs_reserve(gsum_ctx* ctx, double** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return 0;
+    if (*p) GS_CHECK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    GS_CHECK(hipMalloc((void**)p, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+// ---- GEMM launcher ----------------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda,
+                          const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
+    if (M <= 0 || N <= 0) return 0;
+    if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
+    const size_t shmem = 2 * (size_t)(BM + BN) * GS_LSTR * sizeof(double);
+    static bool attr_set = false;     // per instantiation
+    auto kern = k_gemm_nt<WM, WN, WAVES_M, WAVES_N>;
+    if (!attr_set) {
+        GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    int64_t blocks;
+    if (tri) {
+        if (M != N || BM != BN) GS_FAIL("gemm: tri mode needs a square C and square tiles");
+        int64_t T = (M + BM - 1) / BM;
+        blocks = T * (T + 1) / 2;
+    } else {
+        blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
+                       beta, sign);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// cfg 0: 128x128 tile (2x2 waves of 64x64)   — trailing SYRK / big updates
+// cfg 1:  32x128 tile (1x4 waves of 32x32)   — panel TRSM against the explicit block inverse
+// cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
+static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    switch (cfg) {
+        case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        case 1: return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        case 2: return gs_launch_gemm<1, 4, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+    }
+    GS_FAIL("gemm: unknown tile configuration");
+}
+
+// ---- matrices ---------------------------------------------------------------------------------
+static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
+    if (n <= 0 || n > (1 << 20)) GS_FAIL("matrix order out of range");
+    gsum_mat* m = new gsum_mat();
+    m->n = n;
+    m->np = (n + GS_NB - 1) / GS_NB * GS_NB;
+    m->ld = m->np + GS_BORDER;          // row stride 64 KiB + 128 B at n = 8192: no channel aliasing
+    m->T = (int)(m->np / GS_NB);
+    hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->Linv, (size_t)m->T * GS_NB * GS_NB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->logdet, (size_t)m->T * sizeof(double));
+    if (e != hipSuccess) {
+        if (m->A) (void)hipFree(m->A);
+        if (m->Linv) (void)hipFree(m->Linv);
+        if (m->logdet) (void)hipFree(m->logdet);
+        delete m;
+        ctx->err = std::string("hipMalloc(matrix) failed: ") + hipGetErrorString(e);
+        return -1;
+    }
+    if ((int)ctx->evP.size() < m->T + 1) {
+        size_t old = ctx->evP.size();
+        ctx->evP.resize(m->T + 1);
+        ctx->evM.resize(m->T + 1);
+        for (size_t i = old; i < ctx->evP.size(); ++i) {
+            GS_CHECK(hipEventCreateWithFlags(&ctx->evP[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&ctx->evM[i], hipEventDisableTiming));
+        }
+    }
+    *out = m;
+    return 0;
+}
+
+static void gs_mat_release(gsum_mat* m) {
+    if (!m) return;
+    if (m->A) (void)hipFree(m->A);
+    if (m->Linv) (void)hipFree(m->Linv);
+    if (m->logdet) (void)hipFree(m->logdet);
+    delete m;
+}
+
+static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
+    if (!desc) GS_FAIL("kernel descriptor is NULL");
+    if (desc->family < GSUM_RBF || desc->family > GSUM_MATERN12) GS_FAIL("unknown kernel family");
+    if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
+    int nls = desc->anisotropic ? d : 1;
+    for (int i = 0; i < nls; ++i)
+        if (!(desc->length_scale[i] > 0.0)) GS_FAIL("length_scale must be positive");
+    return 0;
+}
+
+// K1 into an augmented matrix (square, symmetric form).  X must already be on the device.
+static int gs_build_into(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const gsum_kernel_desc* desc, const double* dX,
+                         int d, double diag_add, int lower_only) {
+    int64_t T = m->T;
+    int64_t blocks = lower_only ? T * (T + 1) / 2 : T * T;
+    hipLaunchKernelGGL(k_build<false>, dim3((unsigned)blocks), dim3(256), 0, s, m->A, m->ld, dX, (const double*)nullptr,
+                       (int)m->n, (int)m->n, (int)m->np, (int)m->np, d, *desc, diag_add, lower_only);
+    GS_CHECK(hipGetLastError());
+    m->factored = false;
+    return 0;
+}
+
+static int gs_set_border(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const double* dZ, int k) {
+    int64_t cols = m->np + GS_BORDER;
+    hipLaunchKernelGGL(k_set_border, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, m->A, m->ld, (int)m->n,
+                       (int)m->np, dZ, k);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- K2: blocked right-looking Cholesky with look-ahead -----------------------------------------
+// Step k (block column c0 = 128k, rows below r0 = c0 + 128, border included):
+//   diag   : L_kk, L_kk^-1                      (k_potrf_diag, 1 workgroup)
+//   trsm   : P = A[r0:, c0:c0+128] L_kk^-T      (MFMA GEMM against the explicit inverse, in place)
+//   la     : A[r0:, r0:r0+128] -= P P_k+1^T     (next panel's block column only)
+//   bulk   : A[r1:, r1:] -= P P^T (lower tiles), r1 = r0 + 128     (everything else)
+// With look-ahead, diag/trsm/la of step k+1 run on the panel stream while bulk(k) fills the GPU
+// from the main stream.  Both streams are joined on the main stream at the end.
+static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
+    const int T = m->T;
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    GS_CHECK(hipMemsetAsync(ctx->dinfo, 0, sizeof(int), ctx->sm));
+    const bool la = ctx->lookahead != 0;
+    hipStream_t sp = la ? ctx->sp : ctx->sm;
+    if (la) {
+        GS_CHECK(hipEventRecord(ctx->evFork, ctx->sm));
+        GS_CHECK(hipStreamWaitEvent(sp, ctx->evFork, 0));
+    }
+    for (int k = 0; k < T; ++k) {
+        const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
+        const int64_t mrest = naug - r0;     // rows below the diagonal block, border included (>= 16)
+        double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k,
+                           ctx->dinfo, (int)c0);
+        GS_CHECK(hipGetLastError());
+        // panel: rows r0.., columns c0..c0+127  <-  panel * Linv^T   (in place)
+        double* P = A + r0 * ld + c0;
+        if (gs_gemm(ctx, sp, 1, P, ld, P, ld, Linv, GS_NB, mrest, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (!la) {
+            if (gs_gemm(ctx, sp, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
+            continue;
+        }
+        GS_CHECK(hipEventRecord(ctx->evP[k], sp));
+        if (k + 1 < T) {
+            // look-ahead column: needs bulk(k-1) to have finished its tiles of this block column
+            if (k > 0) GS_CHECK(hipStreamWaitEvent(sp, ctx->evM[k - 1], 0));
+            if (gs_gemm(ctx, sp, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            const int64_t r1 = r0 + GS_NB, m1 = naug - r1;
+            double* P1 = A + r1 * ld + c0;
+            GS_CHECK(hipStreamWaitEvent(ctx->sm, ctx->evP[k], 0));
+            if (gs_gemm(ctx, ctx->sm, 0, A + r1 * ld + r1, ld, P1, ld, P1, ld, m1, m1, GS_NB, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(ctx->evM[k], ctx->sm));
+        } else {
+            // last block column: only the 16x16 corner is left
+            GS_CHECK(hipStreamWaitEvent(ctx->sm, ctx->evP[k], 0));
+            if (gs_gemm(ctx, ctx->sm, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
+        }
+    }
+    m->factored = true;
+    return 0;
+}
+
+static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->sm, m->A, m->ld, (int)m->np, m->logdet, m->T, ctx->dinfo,
+                       ctx->dres);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(ctx->hres, ctx->dres, 258 * sizeof(double), hipMemcpyDeviceToHost, ctx->sm));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gsum_init(int device, gsum_ctx** out) {
+    if (!out) return -2;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_init_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+        return -1;
+    }
+    if (device < 0 || device >= count) {
+        g_init_error = "device index out of range";
+        return -2;
+    }
+    gsum_ctx* ctx = new gsum_ctx();
+    ctx->device = device;
+    auto fail = [&](const char* what, hipError_t err) {
+        g_init_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return -1;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    if ((e = hipStreamCreateWithPriority(&ctx->sm, hipStreamNonBlocking, lo)) != hipSuccess) return fail("stream", e);
+    if ((e = hipStreamCreateWithPriority(&ctx->sp, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream", e);
+    if ((e = hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+    for (int i = 0; i < 4; ++i)
+        if ((e = hipEventCreate(&ctx->tev[i])) != hipSuccess) return fail("event", e);
+    if ((e = hipMalloc((void**)&ctx->dres, 258 * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->dinfo, sizeof(int))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->hres, 258 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
+        return fail("hipHostMalloc", e);
+    const char* la = getenv("GSUM_LOOKAHEAD");
+    if (la) ctx->lookahead = atoi(la);
+    *out = ctx;
+    return 0;
+}
+
+void gsum_destroy(gsum_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    gs_mat_release(ctx->ws);
+    if (ctx->dX) (void)hipFree(ctx->dX);
+    if (ctx->dZ) (void)hipFree(ctx->dZ);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->dres) (void)hipFree(ctx->dres);
+    if (ctx->dinfo) (void)hipFree(ctx->dinfo);
+    if (ctx->hres) (void)hipHostFree(ctx->hres);
+    for (auto ev : ctx->evP) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->evM) (void)hipEventDestroy(ev);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
+    if (ctx->sm) (void)hipStreamDestroy(ctx->sm);
+    if (ctx->sp) (void)hipStreamDestroy(ctx->sp);
+    delete ctx;
+}
+
+const char* gsum_last_error(gsum_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return -2;
+    if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
+    else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
+    else GS_FAIL(std::string("unknown option: ") + name);
+    return 0;
+}
+
+static int gs_upload_X(gsum_ctx* ctx, const double* X, int64_t n, int d) {
+    if (!X || n <= 0) GS_FAIL("X is NULL or empty");
+    if (gs_reserve(ctx, &ctx->dX, &ctx->dX_cap, (size_t)n * d * sizeof(double))) return -1;
+    GS_CHECK(hipMemcpyAsync(ctx->dX, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->sm));
+    ctx->nX = n;
+    ctx->dX_d = d;
+    return 0;
+}
+
+static int gs_upload_Z(gsum_ctx* ctx, const double* Z, int64_t n, int k) {
+    if (k < 0 || k > GSUM_MAX_RHS) GS_FAIL("k must be 0..GSUM_MAX_RHS");
+    if (k > 0 && !Z) GS_FAIL("RHS is NULL");
+    if (gs_reserve(ctx, &ctx->dZ, &ctx->dZ_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
+    if (k > 0) GS_CHECK(hipMemcpyAsync(ctx->dZ, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->sm));
+    ctx->kZ = k;
+    return 0;
+}
+
+int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                      const double* Y, int64_t m, double diag_add, double* out) {
+    if (!ctx) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (!X || !out || n <= 0) GS_FAIL("bad argument");
+    const bool cross = Y != nullptr;
+    const int64_t cols = cross ? m : n;
+    if (cols <= 0) GS_FAIL("bad argument");
+    const int64_t ldo = (cols + 1) / 2 * 2;
+    const size_t xb = (size_t)n * d * sizeof(double), yb = cross ? (size_t)m * d * sizeof(double) : 0;
+    const size_t ob = (size_t)n * ldo * sizeof(double);
+    const size_t off_y = (xb + 255) / 256 * 256, off_o = off_y + (yb + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, off_o + ob)) return -1;
+    char* base = (char*)ctx->scratch;
+    double* dXl = (double*)base;
+    double* dYl = (double*)(base + off_y);
+    double* dO = (double*)(base + off_o);
+    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, ctx->sm));
+    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, ctx->sm));
+    const int64_t tr = (n + 127) / 128, tc = (ldo + 127) / 128;
+    if (cross)
+        hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, dO, ldo, dXl, dYl, (int)n, (int)m,
+                           (int)n, (int)ldo, d, *desc, 0.0, 0);
+    else
+        hipLaunchKernelGGL(k_build<false>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, dO, ldo, dXl,
+                           (const double*)nullptr, (int)n, (int)n, (int)n, (int)ldo, d, *desc, diag_add, 0);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dO, (size_t)ldo * sizeof(double),
+                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    return 0;
+}
+
+int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                          double diag_add, gsum_mat** out) {
+    if (!ctx || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (gs_upload_X(ctx, X, n, d)) return -1;
+    gsum_mat* m = nullptr;
+    if (gs_mat_alloc(ctx, n, &m)) return -1;
+    if (gs_build_into(ctx, ctx->sm, m, desc, ctx->dX, d, diag_add, ctx->build_lower_only) ||
+        gs_set_border(ctx, ctx->sm, m, ctx->dZ, 0)) {
+        gs_mat_release(m);
+        return -1;
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    *out = m;
+    return 0;
+}
+
+int gsum_mat_from_host(gsum_ctx* ctx, const double* Ah, int64_t n, gsum_mat** out) {
+    if (!ctx || !out || !Ah) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    gsum_mat* m = nullptr;
+    if (gs_mat_alloc(ctx, n, &m)) return -1;
+    hipError_t e = hipMemcpy2DAsync(m->A, (size_t)m->ld * sizeof(double), Ah, (size_t)n * sizeof(double),
+                                    (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, ctx->sm);
+    if (e == hipSuccess && m->np > n) {
+        hipLaunchKernelGGL(k_pad_identity, dim3((unsigned)((m->np + 255) / 256), (unsigned)(m->np - n)), dim3(256), 0,
+                           ctx->sm, m->A, m->ld, (int)n, (int)m->np);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess || gs_set_border(ctx, ctx->sm, m, ctx->dZ, 0)) {
+        gs_mat_release(m);
+        if (e != hipSuccess) ctx->err = std::string("upload failed: ") + hipGetErrorString(e);
+        return -1;
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    *out = m;
+    return 0;
+}
+
+int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
+    if (!ctx || !A || !info) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (A->factored) GS_FAIL("matrix is already factorised");
+    if (gs_potrf(ctx, A)) return -1;
+    if (gs_finalize(ctx, A)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    *info = (int64_t)ctx->hres[257];
+    if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
+    A->factored = (*info == 0);
+    return 0;
+}
+
+// Forward substitution on the border rows against an existing factor (right-looking, block by block):
+//   W_c = Z_c L_cc^-T ;  Z[:, rest] -= W_c L[rest, c]^T ;  corner accumulates -W W^T.
+static int gs_border_solve(gsum_ctx* ctx, gsum_mat* m) {
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    double* Brow = A + m->np * ld;
+    for (int k = 0; k < m->T; ++k) {
+        const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
+        double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
+        if (gs_gemm(ctx, ctx->sm, 2, Brow + c0, ld, Brow + c0, ld, Linv, GS_NB, GS_BORDER, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->sm, 2, Brow + r0, ld, Brow + c0, ld, A + r0 * ld + c0, ld, GS_BORDER, naug - r0, GS_NB, 0, 1,
+                    -1.0))
+            return -1;
+    }
+    return 0;
+}
+
+int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* G,
+                      double* sum_log_diag) {
+    if (!ctx || !L || !G || !sum_log_diag) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("forward_gram needs a factorised matrix");
+    if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
+    GS_CHECK(hipMemsetAsync(ctx->dinfo, 0, sizeof(int), ctx->sm));
+    if (gs_border_solve(ctx, L)) return -1;
+    if (gs_finalize(ctx, L)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) G[i * k + j] = ctx->hres[i * 16 + j];
+    *sum_log_diag = ctx->hres[256];
+    return 0;
+}
+
+int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* W) {
+    if (!ctx || !L || !W) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("forward_solve needs a factorised matrix");
+    if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
+    if (gs_border_solve(ctx, L)) return -1;
+    std::vector<double> rows((size_t)k * n);
+    GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), L->A + L->np * L->ld, (size_t)L->ld * sizeof(double),
+                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) W[i * k + c] = rows[(size_t)c * n + i];
+    return 0;
+}
+
+// V^T = kernel(Xs, X) L^-T, one row per new point (m x np, row-major): the same right-looking sweep as
+// the factorisation's panel step, with the rows of kernel(Xs, X) in the role of the rows below the panel.
+int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                       int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                       double* colsumsq, double* VtW, double* cov_out) {
+    if (!ctx || !L || !X || !Xs || !colsumsq) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (!L->factored) GS_FAIL("predict_terms needs a factorised matrix");
+    if (n != L->n || m <= 0) GS_FAIL("bad shapes");
+    if (k < 0 || k > GSUM_MAX_RHS || (k > 0 && (!RHS || !VtW))) GS_FAIL("bad RHS / k");
+    const int64_t np = L->np, ld = L->ld, ldb = np + GS_BORDER;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_xs = 0, o_bt = up((size_t)m * d * 8), o_vw = o_bt + up((size_t)m * ldb * 8),
+                 o_ss = o_vw + up((size_t)m * 16 * 8), o_cv = o_ss + up((size_t)m * 8),
+                 total = o_cv + (cov_out ? up((size_t)m * m * 8) : 0);
+    if (gs_upload_X(ctx, X, n, d)) return -1;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, total)) return -1;
+    char* base = (char*)ctx->scratch;
+    double *dXs = (double*)(base + o_xs), *Bt = (double*)(base + o_bt), *dVW = (double*)(base + o_vw),
+           *dSS = (double*)(base + o_ss), *dCov = (double*)(base + o_cv);
+    GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->sm));
+    const int64_t tr = (m + 127) / 128, tc = np / 128;
+    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, Bt, ldb, dXs, ctx->dX, (int)m, (int)n,
+                       (int)m, (int)np, d, *desc, 0.0, 0);
+    GS_CHECK(hipGetLastError());
+    for (int c = 0; c < L->T; ++c) {
+        const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
+        double* Linv = L->Linv + (size_t)c * GS_NB * GS_NB;
+        if (gs_gemm(ctx, ctx->sm, 1, Bt + c0, ldb, Bt + c0, ldb, Linv, GS_NB, m, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->sm, 0, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
+            return -1;
+    }
+    hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->sm, Bt, ldb, (int)m, (int)np, dSS);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->sm));
+    std::vector<double> vw;
+    if (k > 0) {
+        if (gs_upload_Z(ctx, RHS, n, k)) return -1;
+        if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
+        if (gs_border_solve(ctx, L)) return -1;
+        if (gs_gemm(ctx, ctx->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
+        vw.resize((size_t)m * 16);
+        GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->sm));
+    }
+    if (cov_out) {
+        if (gs_gemm(ctx, ctx->sm, 0, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
+        GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->sm));
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    for (int64_t j = 0; j < m && k > 0; ++j)
+        for (int c = 0; c < k; ++c) VtW[j * k + c] = vw[(size_t)j * 16 + c];
+    return 0;
+}
+
+int gsum_mat_to_host(gsum_ctx* ctx, const gsum_mat* A, double* out) {
+    if (!ctx || !A || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = A->n;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)n * n * sizeof(double))) return -1;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->sm, A->A, A->ld, (int)n,
+                       ctx->scratch, A->factored ? 1 : 0);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(out, ctx->scratch, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    return 0;
+}
+
+int64_t gsum_mat_n(const gsum_mat* A) { return A ? A->n : -1; }
+
+void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A) {
+    if (!A) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->sm);
+        (void)hipStreamSynchronize(ctx->sp);
+    }
+    gs_mat_release(A);
+}
+
+int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k) {
+    if (!ctx) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
+    if (gs_upload_X(ctx, X, n, d)) return -1;
+    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
+    if (!ctx->ws || ctx->ws->n != n) {
+        GS_CHECK(hipStreamSynchronize(ctx->sm));
+        gs_mat_release(ctx->ws);
+        ctx->ws = nullptr;
+        if (gs_mat_alloc(ctx, n, &ctx->ws)) return -1;
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    return 0;
+}
+
+int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                      double* G_out, double* sld_out, int64_t* info_out) {
+    if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->ws || !ctx->dX) GS_FAIL("gsum_set_inputs has not been called");
+    gsum_mat* m = ctx->ws;
+    const int k = ctx->kZ;
+    for (int i = 0; i < n_kernels; ++i) {
+        if (gs_check_desc(ctx, &kernels[i], ctx->dX_d)) return -2;
+        GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
+        if (gs_build_into(ctx, ctx->sm, m, &kernels[i], ctx->dX, ctx->dX_d, nugget, ctx->build_lower_only)) return -1;
+        if (gs_set_border(ctx, ctx->sm, m, ctx->dZ, k)) return -1;
+        GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
+        if (gs_potrf(ctx, m)) return -1;
+        GS_CHECK(hipEventRecord(ctx->tev[2], ctx->sm));
+        if (gs_finalize(ctx, m)) return -1;
+        GS_CHECK(hipEventRecord(ctx->tev[3], ctx->sm));
+        GS_CHECK(hipStreamSynchronize(ctx->sm));
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = ctx->hres[a * 16 + b];
+        sld_out[i] = ctx->hres[256];
+        info_out[i] = (int64_t)ctx->hres[257];
+        m->factored = false;           // workspace: always rebuilt by the next evaluation
+        float ms = 0.f;
+        for (int s = 0; s < 3; ++s) {
+            GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[s], ctx->tev[s + 1]));
+            ctx->timers[s] = ms;
+        }
+        GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[3]));
+        ctx->timers[3] = ms;
+    }
+    return 0;
+}
+
+int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
+                   int32_t d, const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out,
+                   int64_t* info_out) {
+    int rc = gsum_set_inputs(ctx, X, n, d, RHS, k);
+    if (rc) return rc;
+    return gsum_lml_resident(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+}
+
+int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
+    if (!ctx || !ms) return -2;
+    for (int i = 0; i < n && i < 4; ++i) ms[i] = ctx->timers[i];
+    return 0;
+}
+
+int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, double* tflops) {
+    if (!ctx || !tflops || iters <= 0) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const int blocks = 256 * 4;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)blocks * 256 * sizeof(double))) return -1;
+    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, 16);   // warm-up
+    GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
+    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, iters);
+    GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    float ms = 0.f;
+    GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[1]));
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return 0;
+}
+
+int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps) {
+    if (!ctx || !gbps || bytes < 4096) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)bytes)) return -1;
+    const int64_t nvec = bytes / 16;
+    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->sm, (gs_d2*)ctx->scratch, nvec);
+    GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
+    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->sm, (gs_d2*)ctx->scratch, nvec);
+    GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    float ms = 0.f;
+    GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[1]));
+    *gbps = (double)(nvec * 16) / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const double* A, const double* B,
+                       int64_t M, int64_t N, int64_t K, int32_t beta, double sign) {
+    if (!ctx || !C || !A || !B) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const size_t cb = (size_t)M * N * 8, ab = (size_t)M * K * 8, bb = (size_t)N * K * 8;
+    const size_t oa = (cb + 255) / 256 * 256, ob = oa + (ab + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, ob + bb)) return -1;
+    char* base = (char*)ctx->scratch;
+    double *dC = (double*)base, *dA = (double*)(base + oa), *dB = (double*)(base + ob);
+    GS_CHECK(hipMemcpyAsync(dC, C, cb, hipMemcpyHostToDevice, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(dA, A, ab, hipMemcpyHostToDevice, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(dB, B, bb, hipMemcpyHostToDevice, ctx->sm));
+    if (gs_gemm(ctx, ctx->sm, cfg, dC, N, dA, K, dB, K, M, N, (int)K, tri, beta, sign)) return -1;
+    GS_CHECK(hipMemcpyAsync(C, dC, cb, hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Sharding of the (ratio, theta) likelihood grid over the GPUs of one node.
+
+Grid points are independent (the reference evaluates them in a nested Python loop,
+docs/notebooks/correlated_EFT_publication.ipynb:1457-1459), so the flattened grid is block-partitioned
+over ranks — one process per GPU — with no data-path collective; the only exchange is one all-gather
+of the fp64 log-likelihood slices (RCCL over xGMI when the process group is "nccl", gloo on CPU).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["shard_range", "gather_flat", "lml_grid_distributed"]
+
+
+def shard_range(total: int, rank: int = 0, world: int = 1):
+    """Contiguous slice [lo, hi) of ``range(total)`` owned by ``rank`` (ceil-sized blocks)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    chunk = -(-total // world)
+    lo = min(total, rank * chunk)
+    return lo, min(total, lo + chunk)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def gather_flat(local: np.ndarray, total: int, group=None) -> np.ndarray:
+    """All-gather the per-rank slices produced with :func:`shard_range` into the full flat array."""
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        if len(local) != total:
+            raise ValueError("single process must hold the whole grid")
+        return np.asarray(local, dtype=np.float64)
+    import torch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    chunk = -(-total // world)
+    lo, hi = shard_range(total, rank, world)
+    if len(local) != hi - lo:
+        raise ValueError(f"rank {rank} holds {len(local)} values, expected {hi - lo}")
+    dev = torch.device("cpu")
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.full((chunk,), float("nan"), dtype=torch.float64)
+    buf[: hi - lo] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    buf = buf.to(dev)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    full = torch.cat(outs).cpu().numpy()
+    pieces = [full[r * chunk: r * chunk + (shard_range(total, r, world)[1] - shard_range(total, r, world)[0])]
+              for r in range(world)]
+    return np.concatenate(pieces)
+
+
+def lml_grid_distributed(evaluate, n_rows: int, n_cols: int, group=None) -> np.ndarray:
+    """Run ``evaluate(shard=(rank, world))`` -> (n_rows, n_cols) array with this rank's entries filled,
+    then gather every rank's slice.  ``evaluate`` is typically
+    ``functools.partial(TruncationGP.log_marginal_likelihood_grid, gp, thetas, ratios, mode=...)``.
+    """
+    dist = _dist()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
+    total = n_rows * n_cols
+    lo, hi = shard_range(total, rank, world)
+    local = np.asarray(evaluate(shard=(rank, world)), dtype=np.float64).reshape(-1)[lo:hi]
+    return gather_flat(local, total, group).reshape(n_rows, n_cols)

@@ -1,0 +1,86 @@
+"""scikit-learn kernel tree -> ``gsum_kernel_desc`` (the POD the HIP kernel-build kernel consumes).
+
+The reference calls ``kernel(X)`` / ``kernel(X, Y)`` on arbitrary scikit-learn kernels
+(gsum/models.py:708, 822-824, 958-960).  The device kernel implements the family the reference's
+own tests, notebooks and defaults use:
+
+    [ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5}))  [+ WhiteKernel] [+ ConstantKernel]
+
+with isotropic or anisotropic ``length_scale``.  Anything else raises ``NotImplementedError`` —
+there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) stays with
+scikit-learn: callers use ``kernel.clone_with_theta(theta)`` and then describe the clone.
+"""
+from __future__ import annotations
+
+import numpy as np
+from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Product, Sum, WhiteKernel)
+
+from ._lib import FAMILY, GSUM_MAX_D, KernelDesc
+
+__all__ = ["describe_kernel", "default_kernel"]
+
+
+def default_kernel():
+    """The reference's default: ConstantKernel(1, fixed) * RBF(1, fixed).  models.py:146-147."""
+    return ConstantKernel(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed")
+
+
+def _sum_terms(k):
+    if isinstance(k, Sum):
+        return _sum_terms(k.k1) + _sum_terms(k.k2)
+    return [k]
+
+
+def _product_factors(k):
+    if isinstance(k, Product):
+        return _product_factors(k.k1) + _product_factors(k.k2)
+    return [k]
+
+
+def describe_kernel(kernel, n_features: int) -> KernelDesc:
+    """Flatten ``kernel`` into a :class:`KernelDesc` for inputs with ``n_features`` columns."""
+    if n_features < 1 or n_features > GSUM_MAX_D:
+        raise ValueError(f"number of features must be 1..{GSUM_MAX_D}, got {n_features}")
+    desc = KernelDesc()
+    desc.amplitude = 1.0
+    desc.additive_const = 0.0
+    desc.white_noise = 0.0
+    base = None
+    for term in _sum_terms(kernel):
+        if isinstance(term, WhiteKernel):
+            desc.white_noise += float(term.noise_level)
+            continue
+        if isinstance(term, ConstantKernel):
+            desc.additive_const += float(term.constant_value)
+            continue
+        if base is not None:
+            raise NotImplementedError(f"sum of two stationary kernels is not supported on the device: {kernel}")
+        amp = 1.0
+        for f in _product_factors(term):
+            if isinstance(f, ConstantKernel):
+                amp *= float(f.constant_value)
+            elif isinstance(f, (RBF, Matern)) and base is None:
+                base = f
+            else:
+                raise NotImplementedError(f"kernel factor {f!r} is not supported on the device (in {kernel})")
+        desc.amplitude = amp
+    if base is None:
+        raise NotImplementedError(f"kernel {kernel} has no RBF/Matern part")
+    if isinstance(base, Matern):        # Matern subclasses RBF: test it first
+        fam = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}.get(float(base.nu))
+        if fam is None:
+            raise NotImplementedError(f"Matern nu={base.nu} is not supported on the device (0.5, 1.5, 2.5 are)")
+    else:
+        fam = "rbf"
+    desc.family = FAMILY[fam]
+    ls = np.atleast_1d(np.asarray(base.length_scale, dtype=float))
+    if ls.size == 1:
+        desc.anisotropic = 0
+        desc.length_scale[0] = float(ls[0])
+    else:
+        if ls.size != n_features:
+            raise ValueError(f"anisotropic kernel has {ls.size} length scales, X has {n_features} features")
+        desc.anisotropic = 1
+        for i, v in enumerate(ls):
+            desc.length_scale[i] = float(v)
+    return desc

@@ -1,0 +1,200 @@
+"""TruncationGP on MI355X — host-side mirror of gsum/models.py:1285-1516.
+
+The truncation layer is thin bookkeeping around the conjugate GP: convert partial sums to
+coefficients, hand them to the coefficient process, subtract the Jacobian term.  The likelihood
+grid scan that the reference spells as a nested Python loop over ``log_marginal_likelihood``
+(docs/notebooks/correlated_EFT_publication.ipynb:1457-1459) is ``log_marginal_likelihood_grid``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .conjugate import ConjugateGaussianProcess, lml_from_gram
+from .kernels import describe_kernel
+from .series import coefficients, geometric_sum
+
+__all__ = ["TruncationGP"]
+
+
+class TruncationGP:
+    """Same constructor and methods as gsum.TruncationGP (models.py:1307-1335, 1510-1516)."""
+
+    def __init__(self, kernel=None, ratio=0.5, ref=1, excluded=None, ratio_kws=None, **kwargs):
+        if not callable(ref):
+            self.ref = lambda X, ref=ref: ref * np.ones(X.shape[0])          # models.py:1309-1312
+        else:
+            self.ref = ref
+        if not callable(ratio):
+            self.ratio = lambda X, ratio=ratio: ratio * np.ones(X.shape[0])  # models.py:1314-1317
+        else:
+            self.ratio = ratio
+        self.coeffs_process = ConjugateGaussianProcess(kernel=kernel, **kwargs)
+        self.kernel = kernel
+        self._log_like = None
+        self.excluded = excluded
+        self.ratio_kws = {} if ratio_kws is None else ratio_kws
+        self._fit = False
+        self.X_train_ = None
+        self.y_train_ = None
+        self.orders_ = None
+        self.dX_ = None
+        self.dy_ = None
+        self.coeffs_ = None
+
+    # -- scaled mean / cov / basis (models.py:1337-1365) -----------------------------------------
+    def mean(self, X, start=0, end=np.inf):
+        coeff_mean = self.coeffs_process.mean(X=X)
+        ratio_sum = geometric_sum(x=self.ratio(X, **self.ratio_kws), start=start, end=end, excluded=self.excluded)
+        return self.ref(X) * ratio_sum * coeff_mean
+
+    def cov(self, X, Xp=None, start=0, end=np.inf):
+        coeff_cov = self.coeffs_process.cov(X=X, Xp=Xp)
+        Xp = X if Xp is None else Xp        # must be reassigned *after* calling cov (WhiteKernel), :1344
+        ratio_mat = self.ratio(X, **self.ratio_kws)[:, None] * self.ratio(Xp, **self.ratio_kws)
+        ratio_sum = geometric_sum(x=ratio_mat, start=start, end=end, excluded=self.excluded)
+        ref_mat = self.ref(X)[:, None] * self.ref(Xp)
+        return ref_mat * ratio_sum * coeff_cov
+
+    def basis(self, X, start=0, end=np.inf):
+        cn_basis = self.coeffs_process.basis(X)
+        ratio = self.ratio(X, **self.ratio_kws)[:, None]
+        ratio_sum = geometric_sum(x=ratio, start=start, end=end, excluded=self.excluded)
+        return self.ref(X)[:, None] * ratio_sum * cn_basis
+
+    def underlying_properties(self, X, order, return_std=False, return_cov=False):
+        y_mean = self.mean(X, start=order + 1)
+        if return_cov:
+            return y_mean, self.cov(X, start=order + 1)
+        if return_std:
+            return y_mean, np.sqrt(np.diag(self.cov(X, start=order + 1)))
+        return y_mean
+
+    # -- fit (models.py:1367-1387) -------------------------------------------------------------------
+    def fit(self, X, y, orders, dX=None, dy=None):
+        self.X_train_ = X
+        self.y_train_ = y
+        self.orders_ = orders
+        orders_mask = ~np.isin(orders, self.excluded)
+        self.dX_ = dX
+        self.dy_ = dy
+        ratio = self.ratio(X, **self.ratio_kws)
+        ref = self.ref(X)
+        if np.atleast_1d(ratio).ndim > 1:
+            raise ValueError('ratio must return a 1d array or a scalar')
+        if np.atleast_1d(ref).ndim > 1:
+            raise ValueError('ref must return a 1d array or a scalar')
+        self.coeffs_ = coefficients(y=y, ratio=ratio, ref=ref, orders=orders)[:, orders_mask]
+        self.coeffs_process.fit(X=X, y=self.coeffs_)
+        self._fit = True
+        return self
+
+    # -- predict (models.py:1389-1483) ----------------------------------------------------------------
+    def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both'):
+        if not self._fit:
+            return self.underlying_properties(X, order, return_cov=return_cov, return_std=return_std)
+        if y is None and order not in self.orders_:
+            raise ValueError('order must be in orders passed to `fit`')            # models.py:1423-1424
+        if kind not in ['both', 'interp', 'trunc']:
+            raise ValueError('kind must be one of "both", "interp" or "trunc"')     # models.py:1430-1431
+        if kind != 'trunc' or self.dX_ is not None:
+            # interpolation / constrained truncation condition with LU on an un-jittered matrix
+            # (models.py:1443-1452, 1464-1473): SURVEY.md §8 row f-2, not built yet.
+            raise NotImplementedError("TruncationGP.predict: only kind='trunc' without dX/dy constraints is built")
+        m_pred = self.mean(X=X, start=order + 1, end=np.inf)                        # models.py:1460, 1475
+        if return_std or return_cov:
+            K_pred = self.cov(X=X, Xp=X, start=order + 1, end=np.inf)               # models.py:1461, 1477
+            if return_cov:
+                return m_pred, K_pred
+            return m_pred, np.sqrt(np.diag(K_pred))
+        return m_pred
+
+    # -- likelihood (models.py:1485-1507) ---------------------------------------------------------------
+    def _coeffs_and_jacobian(self, X, y, orders, ratio_kws):
+        ref = self.ref(X)
+        ratio = self.ratio(X, **ratio_kws)
+        orders = np.asarray(orders)
+        orders_mask = ~np.isin(orders, self.excluded)                              # models.py:1495
+        coeffs = coefficients(y=y, ratio=ratio, ref=ref, orders=orders)[:, orders_mask]
+        orders_in = orders[orders_mask]
+        n = len(orders_in)
+        det_factor = np.sum(n * np.log(np.abs(ref)) + np.sum(orders_in) * np.log(np.abs(ratio)))   # :1505
+        return coeffs, det_factor
+
+    def log_marginal_likelihood(self, theta, eval_gradient=False, X=None, y=None, orders=None, **ratio_kws):
+        X = self.X_train_ if X is None else X
+        y = self.y_train_ if y is None else y
+        orders = self.orders_ if orders is None else orders
+        coeffs, det_factor = self._coeffs_and_jacobian(X, y, orders, ratio_kws)
+        result = self.coeffs_process.log_marginal_likelihood(theta, eval_gradient=eval_gradient, X=X, y=coeffs)
+        # like the reference (:1498-1507) only the value is returned, even when a gradient was requested
+        coeff_log_like = result[0] if eval_gradient else result
+        return coeff_log_like - det_factor
+
+    def log_marginal_likelihood_grid(self, thetas, ratio_kws_list, X=None, y=None, orders=None, mode="full",
+                                     shard=None):
+        """Likelihood surface over (ratio settings) x (thetas): ``out[i, j]`` equals
+        ``self.log_marginal_likelihood(thetas[j], **ratio_kws_list[i])``.
+
+        mode="full"   every grid point runs kernel build + Cholesky + solve, like the reference's
+                      nested loop (notebook :1457-1459) — the throughput-comparable mode;
+        mode="reuse"  one factorisation per theta: all ratio settings share it and only the k-column
+                      forward solve is repeated (never mixed into "full" throughput numbers).
+        ``shard=(rank, world)`` evaluates only this rank's slice of the flattened grid and leaves the
+        rest NaN (see gsum_amd.grid for the torch.distributed gather).
+        """
+        X = self.X_train_ if X is None else X
+        y = self.y_train_ if y is None else y
+        orders = self.orders_ if orders is None else orders
+        Xd = np.asarray(X, dtype=float)
+        gp = self.coeffs_process
+        base = gp._active_kernel()
+        ctx = gp._context()
+        ni, nj = len(ratio_kws_list), len(thetas)
+        out = np.full((ni, nj), np.nan)
+        from .grid import shard_range
+        lo, hi = shard_range(ni * nj, *(shard or (0, 1)))
+        if hi <= lo:
+            return out
+        prep = {}
+
+        def rhs_for(i):
+            if i not in prep:
+                kws = ratio_kws_list[i]
+                kws = kws if isinstance(kws, dict) else {"ratio": kws}
+                coeffs, det = self._coeffs_and_jacobian(Xd, y, orders, kws)
+                prep[i] = (gp._rhs(Xd, coeffs), det)
+            return prep[i]
+
+        def finish(i, j, G, sld, info):
+            if info != 0:
+                return -np.inf
+            lml, _ = lml_from_gram(G, sld, Xd.shape[0], gp.center0, gp.disp0, gp.df0, gp.scale0)
+            return lml - rhs_for(i)[1]
+
+        if mode == "full":
+            for flat in range(lo, hi):
+                i, j = divmod(flat, nj)
+                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
+                G, sld, info = ctx.lml_batch([describe_kernel(kern, Xd.shape[1])], Xd, rhs_for(i)[0], gp.nugget)
+                out[i, j] = finish(i, j, G[0], sld[0], info[0])
+        elif mode == "reuse":
+            by_theta = {}
+            for flat in range(lo, hi):
+                i, j = divmod(flat, nj)
+                by_theta.setdefault(j, []).append(i)
+            for j, rows in by_theta.items():
+                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
+                L = ctx.kernel_matrix_dev(describe_kernel(kern, Xd.shape[1]), Xd, diag_add=gp.nugget)
+                try:
+                    info = ctx.potrf(L)
+                    for i in rows:
+                        if info != 0:
+                            out[i, j] = -np.inf
+                            continue
+                        G, sld = ctx.forward_gram(L, rhs_for(i)[0])
+                        out[i, j] = finish(i, j, G, sld, 0)
+                finally:
+                    L.free()
+        else:
+            raise ValueError('mode must be "full" or "reuse"')
+        return out

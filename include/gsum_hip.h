@@ -1,0 +1,138 @@
+/*
+ * gsum_hip.h — C ABI of libgsum_hip.so: the MI355X (gfx950) replacement for the
+ * compiled third-party routines that buqeye/gsum's GP hot path calls.
+ *
+ * Every entry point names the reference call site(s) it replaces
+ * (paths relative to the reference repository, gsum/models.py unless noted).
+ * The reference is pure Python; its "FFI" for this path is the numpy / scipy /
+ * scikit-learn operator interface:
+ *     kernel(X[, Y])                       models.py:708, 822-824, 958-960
+ *     numpy.linalg.cholesky(A)             models.py:711, 809, 969
+ *     scipy.linalg.cho_solve((L, True), B) models.py:479 (solve_sqrt), 432-439, 831, 836, 1032
+ *     np.log(np.diag(L)).sum(), einsum     models.py:1015, 1035
+ * and this library is bound with ctypes (gsum_amd/_lib.py; INTEGRATION.md shows
+ * the stub a gsum maintainer would add).
+ *
+ * Conventions
+ *   - all matrices are fp64, row-major (numpy C order); host buffers are
+ *     caller-owned and borrowed for the duration of the call only;
+ *   - device objects are opaque handles owned by the library;
+ *   - return value: 0 = success, <0 = API/runtime error (message via
+ *     gsum_last_error).  A non-positive-definite matrix is NOT an error: the
+ *     LAPACK-style *info > 0 (1-based index of the first bad pivot) reports it,
+ *     exactly what numpy.linalg.cholesky turns into LinAlgError;
+ *   - a gsum_ctx is bound to ONE GPU and is not thread-safe; every function is
+ *     synchronous at return (results on the host are valid).
+ */
+#ifndef GSUM_HIP_H
+#define GSUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSUM_MAX_D 8          /* max input dimension of X                      */
+#define GSUM_MAX_RHS 16       /* max right-hand-side columns of the fused path */
+#define GSUM_NB 128           /* Cholesky block size (informational)           */
+
+typedef struct gsum_ctx gsum_ctx;
+typedef struct gsum_mat gsum_mat;   /* device square matrix / Cholesky factor */
+
+enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3 };
+
+/* Flattened scikit-learn kernel tree  amplitude * base(X/length_scale) + additive_const (+ white on the
+ * one-argument diagonal).  Arithmetic follows sklearn/gaussian_process/kernels.py: RBF 1556-1565,
+ * Matern 1711-1738, WhiteKernel 1401-1414, Sum 858-866, Product 956-966. */
+typedef struct {
+    int32_t family;                    /* GSUM_RBF ... */
+    int32_t anisotropic;               /* 0: length_scale[0] for every dimension */
+    double length_scale[GSUM_MAX_D];
+    double amplitude;                  /* ConstantKernel factor (1.0 if absent)  */
+    double additive_const;             /* ConstantKernel summand (0.0 if absent) */
+    double white_noise;                /* WhiteKernel noise_level (0.0 if absent)*/
+} gsum_kernel_desc;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int gsum_init(int device, gsum_ctx** out);
+void gsum_destroy(gsum_ctx* ctx);
+const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
+/* knobs: "lookahead" (0/1), "build_lower_only" (0/1).  Returns <0 for an unknown name. */
+int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
+
+/* ---- operator level (one reference call each) ------------------------------------------------- */
+
+/* kernel(X) / kernel(X, Y) -> host array.   replaces models.py:708 (corr_), 822 (R_on), 824 (R_nn),
+ * 599 (cov).  Y == NULL: one-argument form (n x n, unit diagonal forced, WhiteKernel noise and
+ * diag_add on the diagonal).  Y != NULL: cross form (n x m, no diagonal terms; kernels.py:1413-1414). */
+int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                      const double* Y, int64_t m, double diag_add, double* out);
+
+/* kernel(X) + diag_add*I kept on the device, ready to factorise.   replaces models.py:958-963, 708+711. */
+int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                          double diag_add, gsum_mat** out);
+
+/* upload a caller-built symmetric matrix (only its lower triangle is read). */
+int gsum_mat_from_host(gsum_ctx* ctx, const double* A, int64_t n, gsum_mat** out);
+
+/* numpy.linalg.cholesky(A), in place on the device.   replaces models.py:711, 809, 969.
+ * *info = 0 or the LAPACK dpotrf info (>0: leading minor of that order is not positive definite). */
+int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info);
+
+/* W = L^-1 RHS (forward substitution only), G = W^T W (k x k), sum_log_diag = sum_i log L_ii.
+ * replaces the cho_solve calls at models.py:432, 438, 439, 1032 (+269, 217), the reductions at
+ * :433, :1015, :1035 and the dense N x N Woodbury temporary at :441-442. */
+int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k,
+                      double* G, double* sum_log_diag);
+
+/* W = L^-1 RHS (n x k host, k <= GSUM_MAX_RHS): the forward half of scipy.linalg.cho_solve
+ * (models.py:479); with gsum_predict_terms it replaces the solve at models.py:831. */
+int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* W);
+
+/* Predictive pieces for m new points Xs (models.py:822-836), from the factor of
+ * kernel(X)+nugget:  V = L^-1 kernel(X, Xs);  colsumsq[j] = sum_i V_ij^2;
+ * VtW = V^T Whalf (m x k) with Whalf = L^-1 RHS (RHS n x k host; NULL/k=0 to skip).
+ * If cov_out != NULL it receives V^T V (m x m), the reduction term of models.py:836. */
+int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                       int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                       double* colsumsq, double* VtW, double* cov_out);
+
+/* copy out: the full symmetric matrix (before potrf) or L with a zeroed upper triangle (after). */
+int gsum_mat_to_host(gsum_ctx* ctx, const gsum_mat* A, double* out);
+int64_t gsum_mat_n(const gsum_mat* A);
+void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A);
+
+/* ---- fused hot path: K build -> jittered Cholesky -> Gram / log-det, per kernel --------------- */
+
+/* One full evaluation per kernel descriptor, exactly the work of one
+ * ConjugateGaussianProcess.log_marginal_likelihood call (models.py:958-1039):
+ *   R = kernel_i(X) + nugget*I;  L = chol(R);  W = L^-1 RHS;  G_i = W^T W;  sld_i = sum log diag L.
+ * G_out: n_kernels x k x k, sld_out: n_kernels, info_out: n_kernels (potrf info; G/sld undefined if >0). */
+int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
+                   int32_t d, const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out,
+                   int64_t* info_out);
+
+/* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
+ * gsum_lml_resident evaluates descriptors against them (what bench.py times). */
+int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
+int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                      double* G_out, double* sld_out, int64_t* info_out);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* HIP-event times (ms) of the last fused evaluation on the library's own streams:
+ * ms[0] K build, ms[1] Cholesky (incl. fused forward solve), ms[2] finalize + D2H, ms[3] total. */
+int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
+/* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64, operands in registers): achieved TFLOP/s. */
+int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, double* tflops);
+/* HBM streaming-store probe: achieved GB/s writing `bytes` with 16-B stores. */
+int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps);
+/* debug: C(MxN) = beta*C + sign * A(MxK) B(NxK)^T through the MFMA tile kernel (cfg 0: 128x128 tile,
+ * 1: 32x128 tile, 2: 16x256 tile; tri != 0: lower tiles only, needs M == N). */
+int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const double* A, const double* B,
+                       int64_t M, int64_t N, int64_t K, int32_t beta, double sign);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSUM_HIP_H */

@@ -1,0 +1,85 @@
+"""Multi-process path of the likelihood grid: shard -> evaluate -> all-gather, on CPU with gloo
+(world_size 2 and 3).  The per-point evaluator here is the CPU oracle (test infrastructure); on the GPU
+box the same sharding code wraps the HIP path (tests/test_gpu_parity.py, bench.py)."""
+import functools
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gsum_amd.grid import gather_flat, lml_grid_distributed, shard_range
+
+
+def test_shard_range_partitions_everything():
+    for total in (0, 1, 7, 64, 4096, 8000):
+        for world in (1, 2, 3, 8):
+            got = [shard_range(total, r, world) for r in range(world)]
+            flat = [i for lo, hi in got for i in range(lo, hi)]
+            assert flat == list(range(total))
+            assert max(hi - lo for lo, hi in got) <= -(-total // world) if total else True
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ni, nj, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+        from oracle import gsum_oracle as orc
+        from conftest import load_golden
+        g = load_golden("notebook_grid.json")
+        X, y = np.array(g["X_train"]), np.array(g["y_train"])
+        ls = np.array(g["ls_vals"])[::100 // nj][:nj]
+        qs = np.array(g["ratio_vals"])[::80 // ni][:ni]
+        kern = RBF(0.2) + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+
+        def evaluate(shard):
+            out = np.full((ni, nj), np.nan)
+            lo, hi = shard_range(ni * nj, *shard)
+            for flat in range(lo, hi):
+                i, j = divmod(flat, nj)
+                out[i, j] = orc.trunc_lml(kern, np.log([ls[j]]), X, y, np.array(g["orders"]), ratio=qs[i], ref=g["ref"])
+            return out
+
+        full = lml_grid_distributed(evaluate, ni, nj)
+        want = np.array(g["grid"])[::80 // ni][:ni][:, ::100 // nj][:, :nj]
+        ok = bool(np.allclose(full, want, rtol=1e-11)) and not np.isnan(full).any()
+        q.put((rank, ok, full.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ni,nj", [(2, 4, 5), (3, 5, 4)])
+def test_grid_gather_gloo(world, ni, nj):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ni, nj, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(shape == (ni, nj) for _, _, shape in res)
+
+
+def test_gather_flat_single_process():
+    v = np.arange(5.0)
+    np.testing.assert_array_equal(gather_flat(v, 5), v)
+    with pytest.raises(ValueError):
+        gather_flat(v, 6)

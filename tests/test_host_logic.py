@@ -1,0 +1,157 @@
+"""CPU tests of the host side of gsum_amd: series arithmetic, kernel-tree flattening, the Gram-matrix
+algebra that replaces the reference's cho_solve calls (checked against the golden vectors with a
+numpy-computed Gram matrix), the C-ABI export table, and the option / error behaviour that does not need
+a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy.linalg import solve_triangular
+
+import gsum_amd
+from conftest import ROOT, make_kernel, prior_kwargs
+from gsum_amd.conjugate import lml_from_gram, posterior_from_gram
+
+
+def test_series_helpers_match_reference(small_cases):
+    h = small_cases["helpers"]
+    y, ratio, ref = np.array(h["y"]), np.array(h["ratio"]), np.array(h["ref"])
+    orders = np.array(h["orders"])
+    np.testing.assert_array_equal(gsum_amd.coefficients(y, ratio, ref, orders), np.array(h["coefficients_arr"]))
+    np.testing.assert_array_equal(gsum_amd.coefficients(y, 0.4, 2.0), np.array(h["coefficients_scalar"]))
+    np.testing.assert_array_equal(gsum_amd.partials(y, ratio, ref, orders), np.array(h["partials_arr"]))
+    np.testing.assert_array_equal(gsum_amd.partials(y, 0.4, 2.0), np.array(h["partials_scalar"]))
+    x = np.array(h["geo_x"])
+    np.testing.assert_array_equal(gsum_amd.geometric_sum(x, 0, np.inf), np.array(h["geo_0_inf"]))
+    np.testing.assert_array_equal(gsum_amd.geometric_sum(x, 2, 5), np.array(h["geo_2_5"]))
+    np.testing.assert_array_equal(gsum_amd.geometric_sum(x, 1, np.inf, excluded=[2, 7]), np.array(h["geo_1_inf_excl"]))
+    np.testing.assert_array_equal(gsum_amd.geometric_sum(x, 3, 6, excluded=4), np.array(h["geo_3_6_excl"]))
+    with pytest.raises(ValueError):
+        gsum_amd.geometric_sum(x, 3, 2)
+    with pytest.raises(ValueError):
+        gsum_amd.coefficients(y[:, 0], 0.5)
+    with pytest.raises(ValueError):
+        gsum_amd.coefficients(y, 0.5, orders=[0, 1])
+
+
+def _gram(kern, theta, X, y, nugget=1e-10):
+    k = kern.clone_with_theta(theta) if theta is not None else kern
+    R = k(X)
+    R[np.diag_indices_from(R)] += nugget
+    L = np.linalg.cholesky(R)
+    if y.ndim == 1:
+        y = y[:, None]
+    Z = np.concatenate([y, np.ones((len(X), 1))], axis=1)
+    W = solve_triangular(L, Z, lower=True)
+    return W.T @ W, np.log(np.diag(L)).sum()
+
+
+def test_gram_algebra_reproduces_reference_lml_and_posterior(small_cases):
+    """lml_from_gram / posterior_from_gram against reference outputs, all prior regimes."""
+    for case in small_cases["cgp"]:
+        kern = make_kernel(case["kernel"])
+        pk = prior_kwargs(case["prior"])
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pk)
+        X, y = np.array(case["X"]), np.array(case["y"])
+        G, sld = _gram(kern, np.array(case["theta"]), X, y)
+        lml, _ = lml_from_gram(G, sld, len(X), gp.center0, gp.disp0, gp.df0, gp.scale0)
+        assert lml == pytest.approx(case["lml_theta"], rel=1e-11)
+        G1, sld1 = _gram(kern, np.array(case["theta"]), X, y[:, 0])
+        lml1, _ = lml_from_gram(G1, sld1, len(X), gp.center0, gp.disp0, gp.df0, gp.scale0)
+        assert lml1 == pytest.approx(case["lml_1col"], rel=1e-11)
+        G, sld = _gram(kern, None, X, y)
+        lml, post = lml_from_gram(G, sld, len(X), gp.center0, gp.disp0, gp.df0, gp.scale0)
+        g = case["fit"]
+        assert lml == pytest.approx(g["lml"], rel=1e-11)
+        # center/disp are ratios of R^-1 bilinear forms: on the randomly spaced (ill-conditioned) golden
+        # inputs two valid evaluation orders differ at ~cond * eps
+        np.testing.assert_allclose(post["center"], g["center"], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(post["disp"], g["disp"], rtol=1e-7, atol=1e-15)
+        assert post["df"] == g["df"]
+        assert np.sqrt(post["scale_sq"]) == pytest.approx(g["scale"], rel=1e-11)
+        assert post["cov_factor"] == pytest.approx(g["cov_factor"], rel=1e-11)
+
+
+def test_posterior_rejects_vector_priors():
+    with pytest.raises(ValueError):
+        posterior_from_gram(np.eye(3), 10, [0.0, 1.0], 0, 1, 1)
+
+
+def test_describe_kernel_flattening():
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C, RationalQuadratic
+    d = gsum_amd.describe_kernel(C(1.7) * RBF([0.3, 0.4]) + WhiteKernel(1e-3) + C(0.5), 2)
+    assert (d.family, d.anisotropic, d.amplitude, d.additive_const, d.white_noise) == (0, 1, 1.7, 0.5, 1e-3)
+    assert list(d.length_scale)[:2] == [0.3, 0.4]
+    d = gsum_amd.describe_kernel(Matern(0.3, nu=2.5), 3)
+    assert (d.family, d.anisotropic, d.length_scale[0], d.amplitude) == (1, 0, 0.3, 1.0)
+    assert gsum_amd.describe_kernel(Matern(0.3, nu=1.5), 1).family == 2
+    assert gsum_amd.describe_kernel(Matern(0.3, nu=0.5), 1).family == 3
+    d = gsum_amd.describe_kernel(C(2.0) * (C(3.0) * RBF(1.0)), 1)
+    assert d.amplitude == 6.0
+    # theta ordering / log-parameters stay with scikit-learn
+    k = (C(1.0) * RBF(1.0) + WhiteKernel(1e-2, noise_level_bounds="fixed")).clone_with_theta(np.log([2.0, 0.5]))
+    d = gsum_amd.describe_kernel(k, 1)
+    assert d.amplitude == pytest.approx(2.0) and d.length_scale[0] == pytest.approx(0.5)
+    for bad in (RBF(1.0) + RBF(2.0), RationalQuadratic(), Matern(1.0, nu=3.5), RBF(1.0) * RBF(2.0), WhiteKernel(1.0)):
+        with pytest.raises(NotImplementedError):
+            gsum_amd.describe_kernel(bad, 1)
+    with pytest.raises(ValueError):
+        gsum_amd.describe_kernel(RBF([1.0, 2.0]), 3)
+    with pytest.raises(ValueError):
+        gsum_amd.describe_kernel(RBF(1.0), 9)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/gsum_hip.h is the contract: every function it declares must be exported and bound."""
+    from gsum_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gsum_hip.h")).read()
+    declared = set(re.findall(r"\b(gsum_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = _lib.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in gsum_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    import ctypes
+    assert ctypes.sizeof(_lib.KernelDesc) == 8 + 8 * _lib.GSUM_MAX_D + 24
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gsum_amd import _lib
+    with pytest.raises(RuntimeError, match="gsum_init"):
+        _lib.HipContext(0)
+    from sklearn.gaussian_process.kernels import RBF
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(1.0), optimizer=None)
+    with pytest.raises(RuntimeError):
+        gp.fit(np.arange(5.0)[:, None], np.arange(5.0))
+
+
+def test_missing_library_is_reported(tmp_path):
+    from gsum_amd import _lib
+    with pytest.raises(RuntimeError, match="not built"):
+        _lib.load_library(str(tmp_path / "nope.so"))
+
+
+def test_constructor_and_argument_errors():
+    from sklearn.gaussian_process.kernels import RBF
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(1.0), sd=2.0)
+    assert gp.df0 == np.inf and gp.scale0 == 2.0
+    assert gp.center0.shape == (1,) and gp.disp0.shape == (1, 1)
+    with pytest.raises(NotImplementedError):
+        gsum_amd.ConjugateGaussianProcess(basis=lambda X: X)
+    with pytest.raises(RuntimeError):
+        gp._fit = True
+        gp.predict(np.zeros((2, 1)), return_std=True, return_cov=True)
+    gp._fit = False
+    with pytest.raises(ValueError):
+        gsum_amd.ConjugateGaussianProcess(decomposition="lu").log_marginal_likelihood(np.array([0.0]), X=np.zeros((2, 1)), y=np.zeros(2))
+    with pytest.raises(NotImplementedError):
+        gsum_amd.ConjugateGaussianProcess(decomposition="eig").log_marginal_likelihood(np.array([0.0]), X=np.zeros((2, 1)), y=np.zeros(2))
+    with pytest.raises(ValueError):
+        gsum_amd.ConjugateGaussianProcess().cov(np.zeros((2, 1)))     # df0 = 1 <= 2: covariance does not exist
+    t = gsum_amd.TruncationGP(kernel=RBF(1.0), ratio=lambda X: np.ones((len(X), 1, 1)))
+    with pytest.raises(ValueError):
+        t.fit(np.zeros((3, 1)), np.zeros((3, 2)), orders=np.arange(2))
