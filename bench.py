@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — log-marginal-likelihood throughput of the gsum GP hot path on MI355X.
+
+One "step" = one FULL-RECOMPUTE evaluation, the work of one
+``TruncationGP.log_marginal_likelihood(theta, ratio=...)`` call in the reference
+(gsum/models.py:958-1039, 1485-1507): RBF kernel-matrix build, jittered Cholesky, forward solve,
+Gram / log-det reduction, host scalar algebra.  Workload (BASELINE.json configs[2], SURVEY.md §8d "S3"):
+n = 8192 1-D points at dx = 0.5 ell, RBF(ell ~ 0.2), nugget 1e-10, 6 EFT orders, synthetic
+coefficients; X and the right-hand sides are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; every rank evaluates its own K grid points (weak scaling, no data-path
+collective) and the fp64 likelihood slices are all-gathered over RCCL inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (AMD spec; vector fp64 is the same rate)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_workload(n, r, seed=0):
+    import gsum_amd
+    X = 0.1 * np.arange(n)[:, None]
+    c = np.random.RandomState(seed).randn(n, r)
+    y = gsum_amd.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+    return X, y
+
+
+def cpu_baseline(n, r, evals):
+    """The CPU oracle (same numpy/scipy/sklearn calls as the reference) on this host's cores."""
+    from sklearn.gaussian_process.kernels import RBF
+    from oracle import gsum_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    X, y = make_workload(n, r)
+    t = []
+    val = None
+    for i in range(evals):
+        t0 = time.perf_counter()
+        val = orc.trunc_lml(RBF(0.2), np.log([0.2]), X, y, np.arange(r), ratio=0.5, ref=1.0)
+        t.append(time.perf_counter() - t0)
+    best = min(t)
+    return dict(value=1.0 / best, unit="evals/s", cores=int(threads), kind="port",
+                sample=f"{evals} full evaluations of oracle.trunc_lml at n={n}, {r} orders (best of {evals}: {best:.2f} s each)",
+                lml=float(val))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--orders", type=int, default=6)
+    ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+
+    import gsum_amd
+    from sklearn.gaussian_process.kernels import RBF
+    from gsum_amd.conjugate import lml_from_gram
+    from gsum_amd.grid import gather_flat
+
+    n, r, K, W = args.n, args.orders, args.steps, args.warmup
+    ctx = gsum_amd.default_context(local_rank)
+    X, y = make_workload(n, r)
+    c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
+    Z = np.concatenate([c, np.ones((n, 1))], axis=1)
+    jac = float(np.sum(r * np.log(np.abs(np.ones(n))) + np.sum(np.arange(r)) * np.log(np.abs(0.5 * np.ones(n)))))
+    ctx.set_inputs(X, Z)                     # X, RHS resident in HBM from here on
+
+    # this rank's grid points: length scales around 0.2 (every point is a distinct evaluation)
+    total = world * K
+    ells = np.linspace(0.19, 0.21, total) if total > 1 else np.array([0.2])
+    mine = ells[rank * K:(rank + 1) * K]
+    descs = [gsum_amd.describe_kernel(RBF(float(e)), 1) for e in mine]
+
+    def evaluate(desc):
+        G, sld, info = ctx.lml_resident([desc], 1e-10)
+        if info[0] != 0:
+            return -np.inf
+        return lml_from_gram(G[0], sld[0], n, 0.0, 0.0, 1, 1)[0] - jac
+
+    for i in range(W):
+        evaluate(descs[i % len(descs)])
+    ctx.set_option("profile_gemm", 1)
+    ctx.gemm_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vals = np.empty(K)
+    stage = np.zeros(4)
+    for i in range(K):
+        vals[i] = evaluate(descs[i])
+        tm = ctx.timers()
+        stage += [tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]]
+    allvals = gather_flat(vals, total) if world > 1 else vals
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gemm_ms, gemm_flops, gemm_launches = ctx.gemm_profile()
+    ctx.set_option("profile_gemm", 0)
+    stage /= K
+
+    if rank == 0:
+        potrf_flops = n ** 3 / 3.0
+        chol_tflops = potrf_flops / (stage[1] * 1e-3) / 1e12
+        syrk_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "lml_evals_per_sec", "value": total / elapsed, "unit": "evals/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, "
+                                   f"{r} orders (BASELINE configs[2], S3)", "n": n, "orders": r,
+                       "evals_per_gpu": K, "mode": "full-recompute"},
+            "stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1], "finalize_d2h": stage[2],
+                         "gpu_total": stage[3]},
+            "cholesky": {"gflops": chol_tflops * 1e3, "frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,
+                         "flops": "n^3/3", "ms": stage[1]},
+            "kernel_build": {"gbps_algorithmic_8n2": 8.0 * n * n / (stage[0] * 1e-3) / 1e9,
+                             "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128)"},
+            "roofline": {"kernel": "k_gemm_nt<4,4,2,2> (128x128-tile fp64 MFMA: trailing SYRK + look-ahead column)",
+                         "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
+                         "flops_per_launch": "SYRK: M(M+1)K, look-ahead column: 2MNK, K=128 (algorithmic)"},
+            "lml_sample": float(allvals[0]),
+        }
+        if world == 1 and args.cpu_evals > 0:
+            out["cpu_baseline"] = cpu_baseline(n, r, args.cpu_evals)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
+    "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
     "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
@@ -289,6 +290,12 @@ class HipContext:
         ms = np.zeros(4)
         self._check(self._lib.gsum_timers(self._h, _ptr(ms), 4))
         return dict(build_ms=ms[0], potrf_ms=ms[1], finalize_ms=ms[2], total_ms=ms[3])
+
+    def gemm_profile(self):
+        """(total ms, total algorithmic flops, launches) of the profiled big-tile GEMM launches; resets."""
+        ms, fl, cnt = C.c_double(0), C.c_double(0), C.c_int64(0)
+        self._check(self._lib.gsum_gemm_profile(self._h, C.byref(ms), C.byref(fl), C.byref(cnt)))
+        return float(ms.value), float(fl.value), int(cnt.value)
 
     def probe_mfma_f64(self, iters=20000) -> float:
         v = C.c_double(0)

@@ -36,6 +36,12 @@ struct gsum_ctx {
     double* hres = nullptr;          // pinned
     double* scratch = nullptr; size_t scratch_cap = 0;
     double timers[4] = {0, 0, 0, 0};
+    // optional per-launch HIP-event profile of the big-tile (cfg 0) GEMM launches
+    int profile_gemm = 0;
+    std::vector<hipEvent_t> prof_pool;
+    struct ProfRec { int e0, e1; double flops; };
+    std::vector<ProfRec> prof_recs;
+    size_t prof_next = 0;
 };
 
 static std::string g_init_error;
@@ -100,6 +106,22 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
 // cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
 static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                    const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    if (cfg == 0 && ctx->profile_gemm && M > 0 && N > 0) {
+        while (ctx->prof_pool.size() < ctx->prof_next + 2) {
+            hipEvent_t ev;
+            GS_CHECK(hipEventCreate(&ev));
+            ctx->prof_pool.push_back(ev);
+        }
+        const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
+        ctx->prof_next += 2;
+        GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
+        int rc = gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
+        // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
+        const double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
+        ctx->prof_recs.push_back({e0, e1, fl});
+        return rc;
+    }
     switch (cfg) {
         case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 1: return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
@@ -298,6 +320,7 @@ void gsum_destroy(gsum_ctx* ctx) {
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     for (int i = 0; i < 4; ++i)
         if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
+    for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
     if (ctx->sm) (void)hipStreamDestroy(ctx->sm);
     if (ctx->sp) (void)hipStreamDestroy(ctx->sp);
     delete ctx;
@@ -309,6 +332,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return -2;
     if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
     else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
+    else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
 }
@@ -613,6 +637,26 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
     if (!ctx || !ms) return -2;
     for (int i = 0; i < n && i < 4; ++i) ms[i] = ctx->timers[i];
+    return 0;
+}
+
+int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
+    if (!ctx || !total_ms || !total_flops || !launches) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->sp));
+    double ms_sum = 0.0, fl_sum = 0.0;
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        GS_CHECK(hipEventElapsedTime(&ms, ctx->prof_pool[r.e0], ctx->prof_pool[r.e1]));
+        ms_sum += ms;
+        fl_sum += r.flops;
+    }
+    *total_ms = ms_sum;
+    *total_flops = fl_sum;
+    *launches = (int64_t)ctx->prof_recs.size();
+    ctx->prof_recs.clear();
+    ctx->prof_next = 0;
     return 0;
 }
 

@@ -58,7 +58,7 @@ typedef struct {
 int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
-/* knobs: "lookahead" (0/1), "build_lower_only" (0/1).  Returns <0 for an unknown name. */
+/* knobs: "lookahead" (0/1), "build_lower_only" (0/1), "profile_gemm" (0/1).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
@@ -123,6 +123,11 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
 /* HIP-event times (ms) of the last fused evaluation on the library's own streams:
  * ms[0] K build, ms[1] Cholesky (incl. fused forward solve), ms[2] finalize + D2H, ms[3] total. */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
+/* With option "profile_gemm" = 1 every launch of the 128x128-tile MFMA GEMM (the trailing SYRK and the
+ * look-ahead column of the Cholesky) is bracketed by HIP events on the stream it is launched on.  This
+ * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
+ * call, and resets the record. */
+int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
 /* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64, operands in registers): achieved TFLOP/s. */
 int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, double* tflops);
 /* HBM streaming-store probe: achieved GB/s writing `bytes` with 16-B stores. */

@@ -1,0 +1,383 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every call goes through the C ABI of
+libgsum_hip.so and is compared with the CPU oracle / the golden vectors generated from the reference.
+
+Tolerances.  Log-likelihoods: 1e-10 relative on conditioned inputs (BASELINE north_star).  Where the
+input itself is ill-conditioned (the randomly spaced golden cases, cond(R) up to 7e10) any two valid fp64
+factorisations differ by ~cond * eps (measured 3e-7 between LAPACK and a re-blocked
+numpy Cholesky), so the bound there is max(1e-10, 1e-16 * cond(R)).  Kernel-matrix entries: 4 ulp
+(different exp implementations).  Indices (argmax, potrf info): exact.
+"""
+import numpy as np
+import pytest
+from scipy.linalg import solve_triangular
+from scipy.linalg.lapack import dpotrf
+
+from conftest import make_kernel, prior_kwargs
+
+pytestmark = pytest.mark.gpu
+
+import gsum_amd  # noqa: E402
+from oracle import gsum_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return gsum_amd.default_context(0)
+
+
+def lml_tol(R):
+    return max(1e-10, 1e-16 * np.linalg.cond(R))
+
+
+# ---------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg,M,N,K", [(0, 128, 128, 128), (0, 300, 300, 128), (0, 144, 128, 256), (0, 130, 70, 64),
+                                       (1, 32, 128, 128), (1, 700, 128, 128), (1, 50, 16, 384),
+                                       (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32)])
+def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
+    """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
+    swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
+    rng = np.random.RandomState(cfg * 1000 + M + N)
+    A, B, C = rng.randn(M, K), rng.randn(N, K), rng.randn(M, N)
+    got = ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=1, sign=-1.0)
+    np.testing.assert_allclose(got, C - A @ B.T, rtol=1e-12, atol=1e-12 * K)
+    got = ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=0, sign=1.0)
+    np.testing.assert_allclose(got, A @ B.T, rtol=1e-12, atol=1e-12 * K)
+
+
+@pytest.mark.parametrize("M", [128, 272, 400])
+def test_mfma_gemm_lower_tiles(ctx, M):
+    rng = np.random.RandomState(M)
+    A, C = rng.randn(M, 128), rng.randn(M, M)
+    got = ctx.debug_gemm_nt(0, C, A, A, tri=True, beta=1, sign=-1.0)
+    want = C - A @ A.T
+    # tiles on/below the diagonal are updated, tiles strictly above are untouched
+    T = -(-M // 128)
+    for bi in range(T):
+        for bj in range(T):
+            sl = (slice(bi * 128, min(M, (bi + 1) * 128)), slice(bj * 128, min(M, (bj + 1) * 128)))
+            ref = want[sl] if bj <= bi else C[sl]
+            np.testing.assert_allclose(got[sl], ref, rtol=1e-12, atol=1e-10)
+
+
+KERNEL_SPECS = [
+    dict(family="rbf", length_scale=0.2),
+    dict(family="matern52", length_scale=0.3),
+    dict(family="matern32", length_scale=0.4, additive=0.5),
+    dict(family="rbf", length_scale=0.25, amplitude=1.7, white=1e-3),
+    dict(family="rbf", length_scale=[0.7, 1.3]),
+    dict(family="matern52", length_scale=[0.7, 1.3, 0.4], white=1e-6, amplitude=0.3),
+]
+
+
+def ulp_close(a, b, ulps=4):
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
+
+
+@pytest.mark.parametrize("spec", KERNEL_SPECS)
+@pytest.mark.parametrize("n", [7, 128, 333])
+def test_kernel_matrix_matches_sklearn(ctx, spec, n):
+    kern = make_kernel(spec)
+    d = 1 if np.ndim(spec["length_scale"]) == 0 else len(spec["length_scale"])
+    rng = np.random.RandomState(n)
+    X, Y = rng.rand(n, d) * 3, rng.rand(n // 2 + 1, d) * 3
+    desc = gsum_amd.describe_kernel(kern, d)
+    K = ctx.kernel_matrix(desc, X)
+    want = kern(X)
+    assert ulp_close(K, want), np.abs(K - want).max()
+    np.testing.assert_array_equal(np.diag(K), np.diag(want))          # diagonal: exact
+    np.testing.assert_array_equal(K, K.T)
+    Kd = ctx.kernel_matrix(desc, X, diag_add=1e-10)
+    np.testing.assert_array_equal(np.diag(Kd), np.diag(want) + 1e-10)
+    Kc = ctx.kernel_matrix(desc, X, Y)
+    assert Kc.shape == (n, len(Y))
+    assert ulp_close(Kc, kern(X, Y))
+    # device-resident build (lower tiles only + mirror on export) gives the same matrix
+    for lower in (1, 0):
+        ctx.set_option("build_lower_only", lower)
+        M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+        np.testing.assert_array_equal(M.to_host(), Kd)
+        M.free()
+    ctx.set_option("build_lower_only", 1)
+
+
+def spd(n, seed, cond=1e4):
+    rng = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    w = np.geomspace(1.0, 1.0 / cond, n)
+    return (Q * w) @ Q.T
+
+
+@pytest.mark.parametrize("n", [1, 5, 128, 129, 200, 384, 1000])
+@pytest.mark.parametrize("lookahead", [1, 0])
+def test_potrf_matches_lapack(ctx, n, lookahead):
+    ctx.set_option("lookahead", lookahead)
+    A = spd(n, n)
+    M = ctx.upload(A)
+    np.testing.assert_array_equal(M.to_host(), np.tril(A) + np.tril(A, -1).T)
+    assert ctx.potrf(M) == 0
+    L = M.to_host()
+    want = np.linalg.cholesky(A)
+    np.testing.assert_array_equal(np.triu(L, 1), 0.0)                 # numpy zeroes the upper triangle
+    np.testing.assert_allclose(L, want, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(L @ L.T, A, rtol=1e-12, atol=1e-13)
+    Z = np.random.RandomState(n + 1).randn(n, 5)
+    G, sld = ctx.forward_gram(M, Z)
+    W = solve_triangular(want, Z, lower=True)
+    np.testing.assert_allclose(G, W.T @ W, rtol=1e-9, atol=1e-9 * np.abs(W.T @ W).max())
+    assert sld == pytest.approx(np.log(np.diag(want)).sum(), rel=1e-12, abs=1e-12)
+    np.testing.assert_allclose(ctx.forward_solve(M, Z), W, rtol=1e-8, atol=1e-10 * np.abs(W).max())
+    M.free()
+    ctx.set_option("lookahead", 1)
+
+
+@pytest.mark.parametrize("n,bad", [(6, 3), (200, 0), (200, 130), (300, 299), (384, 255)])
+def test_potrf_info_matches_lapack(ctx, n, bad):
+    """Not positive definite -> LAPACK-style info (index exact), as numpy.linalg.cholesky's LinAlgError."""
+    A = spd(n, 7, cond=10.0)
+    A[bad, bad] = -1.0
+    _, info = dpotrf(A, lower=1)
+    assert info == bad + 1
+    M = ctx.upload(A)
+    assert ctx.potrf(M) == info
+    M.free()
+    A[bad, bad] = np.nan
+    M = ctx.upload(A)
+    assert ctx.potrf(M) == bad + 1
+    M.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors from the reference, through the drop-in classes
+# ---------------------------------------------------------------------------------------------
+
+def test_cgp_lml_fit_predict_golden(small_cases):
+    for case in small_cases["cgp"]:
+        kern = make_kernel(case["kernel"])
+        pk = prior_kwargs(case["prior"])
+        X, y = np.array(case["X"]), np.array(case["y"])
+        theta = np.array(case["theta"])
+        R = kern.clone_with_theta(theta)(X)
+        tol = lml_tol(R + 1e-10 * np.eye(len(X)))
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pk)
+        assert gp.log_marginal_likelihood(theta=theta, X=X, y=y) == pytest.approx(case["lml_theta"], rel=tol)
+        assert gp.log_marginal_likelihood(theta=theta, X=X, y=y[:, 0]) == pytest.approx(case["lml_1col"], rel=tol)
+        gp.fit(X, y)
+        g = case["fit"]
+        tol = lml_tol(kern(X) + 1e-10 * np.eye(len(X)))
+        ptol = max(1e-9, 100 * tol)
+        assert gp.log_marginal_likelihood_value_ == pytest.approx(g["lml"], rel=tol)
+        assert gp.log_marginal_likelihood() == gp.log_marginal_likelihood_value_
+        np.testing.assert_allclose(gp.center_, g["center"], rtol=ptol, atol=1e-12)
+        np.testing.assert_allclose(gp.disp_, g["disp"], rtol=ptol, atol=1e-15)
+        assert gp.df_ == g["df"]
+        assert gp.scale_ == pytest.approx(g["scale"], rel=ptol)
+        assert gp.cov_factor_ == pytest.approx(g["cov_factor"], rel=ptol)
+        assert gp.cbar_sq_mean_ == gp.cov_factor_
+        np.testing.assert_allclose(gp.center(), gp.center_)
+        np.testing.assert_allclose(gp.scale(), gp.scale_)
+        assert gp.df() == gp.df_
+        assert ulp_close(gp.corr_[0], np.array(g["corr_row0"]))
+        np.testing.assert_allclose(gp.corr_L_[-1], g["corr_L_last"], rtol=ptol, atol=1e-9)
+        assert gp.corr_sqrt_ is gp.corr_L_
+        Xs, Xc, yc = np.array(case["Xs"]), np.array(case["Xc"]), np.array(case["yc"])
+        np.testing.assert_allclose(gp.cov(Xs[:3], Xs[3:5]), g["prior_cov_probe"], rtol=max(1e-12, ptol))
+        p = case["predict"]
+        scale = np.abs(np.array(p["mean"])).max()
+        vs = gp.cov_factor_
+        m, s = gp.predict(Xs, return_std=True)
+        np.testing.assert_allclose(m, p["mean"], rtol=ptol, atol=ptol * scale)
+        # variances: absolute tolerance in units of cov_factor (cancellation 1 - sum V^2)
+        np.testing.assert_allclose(s ** 2, np.array(p["std"]) ** 2, rtol=ptol, atol=max(1e-10, ptol) * vs)
+        m2, cv = gp.predict(Xs, return_cov=True)
+        np.testing.assert_allclose(m2, m, rtol=1e-12, atol=1e-12 * scale)
+        np.testing.assert_allclose(cv, p["cov"], rtol=ptol, atol=max(1e-10, ptol) * vs)
+        _, cvn = gp.predict(Xs, return_cov=True, pred_noise=True)
+        np.testing.assert_allclose(cvn, p["cov_noise"], rtol=ptol, atol=max(1e-10, ptol) * vs)
+        mc, sc = gp.predict(Xs, return_std=True, Xc=Xc, y=yc)
+        np.testing.assert_allclose(mc, p["mean_c"], rtol=ptol, atol=ptol * np.abs(np.array(p["mean_c"])).max())
+        np.testing.assert_allclose(sc ** 2, np.array(p["std_c"]) ** 2, rtol=ptol, atol=max(1e-10, ptol) * vs)
+        assert gp.predict(Xs).shape == np.array(p["mean"]).shape
+
+
+def test_trunc_lml_golden(small_cases):
+    for case in small_cases["trunc"]:
+        kern = make_kernel(case["kernel"])
+        pk = prior_kwargs(case["prior"])
+        X, y = np.array(case["X"]), np.array(case["y"])
+        orders = np.array(case["orders"])
+        theta = np.array(case["theta"])
+        tol = lml_tol(kern.clone_with_theta(theta)(X) + 1e-10 * np.eye(len(X)))
+        gp = gsum_amd.TruncationGP(kernel=kern, ratio=0.5, ref=case["ref"], excluded=case["excluded"],
+                                   optimizer=None, **pk)
+        gp.fit(X, y, orders=orders)
+        np.testing.assert_array_equal(gp.coeffs_[0], case["coeffs_row0"])
+        ftol = lml_tol(kern(X) + 1e-10 * np.eye(len(X)))
+        assert gp.coeffs_process.cov_factor_ == pytest.approx(case["fit_cov_factor"], rel=max(1e-9, 100 * ftol))
+        assert gp.coeffs_process.log_marginal_likelihood_value_ == pytest.approx(case["fit_lml"], rel=ftol)
+        got = [gp.log_marginal_likelihood(theta=theta, ratio=q) for q in case["ratios"]]
+        np.testing.assert_allclose(got, case["lml"], rtol=tol)
+        # the batched grid entry reproduces the loop, in both modes
+        for mode in ("full", "reuse"):
+            grid = gp.log_marginal_likelihood_grid([theta], case["ratios"], mode=mode)
+            np.testing.assert_allclose(grid[:, 0], case["lml"], rtol=tol)
+
+
+def test_trunc_lml_array_ratio_ref(small_cases):
+    a = small_cases["trunc_arrays"]
+    kern = make_kernel(a["kernel"])
+    X, y = np.array(a["X"]), np.array(a["y"])
+    gp = gsum_amd.TruncationGP(kernel=kern, ratio=lambda X_, scale=1.0: scale * (0.3 + 0.2 * X_[:, 0] / 3),
+                               ref=lambda X_: 5.0 + X_[:, 0], optimizer=None)
+    gp.fit(X, y, orders=np.array(a["orders"]))
+    tol = lml_tol(kern(X) + 1e-10 * np.eye(len(X)))
+    got = [gp.log_marginal_likelihood(theta=np.array(a["theta"]), scale=s) for s in a["scales"]]
+    np.testing.assert_allclose(got, a["lml"], rtol=tol)
+    grid = gp.log_marginal_likelihood_grid([np.array(a["theta"])], [dict(scale=s) for s in a["scales"]], mode="reuse")
+    np.testing.assert_allclose(grid[:, 0], a["lml"], rtol=tol)
+
+
+def test_nonpd_behaviour(small_cases):
+    from sklearn.gaussian_process.kernels import RBF
+    c = small_cases["nonpd"]
+    X, y = np.array(c["X"]), np.array(c["y"])
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(1.0), nugget=0, optimizer=None)
+    assert gp.log_marginal_likelihood(theta=np.log([1.0]), X=X, y=y) == -np.inf      # models.py:970-972
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.fit(X, y)                                                                 # models.py:711
+
+
+def test_interpolation_property():
+    """The reference's own hot-path test (gsum/tests/test.py:63-72): nugget=0, predict(X_train) == y_train."""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C
+    X = np.atleast_2d([1., 3., 5., 6., 7., 8.]).T
+    y = (X * np.sin(X)).ravel()
+    for kernel in (RBF(length_scale=1.0, length_scale_bounds="fixed"),
+                   C(1.0, "fixed") * RBF(1.0, "fixed")):
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kernel, nugget=0).fit(X, y)
+        y_pred, y_cov = gp.predict(X, return_cov=True)
+        np.testing.assert_almost_equal(y_pred, y, decimal=7)
+        np.testing.assert_almost_equal(np.diag(y_cov), 0.0, decimal=10)
+
+
+def test_fit_with_optimizer_reaches_the_grid_optimum(notebook_grid):
+    """fit() with the default L-BFGS optimiser (numerical gradient until SURVEY §8 f-1 lands) finds the
+    length scale the reference reports (RBF(length_scale=0.199), notebook :1115)."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    g = notebook_grid
+    X, y = np.array(g["X_train"]), np.array(g["y_train"])
+    c = gsum_amd.coefficients(y, 0.5, g["ref"], np.array(g["orders"]))
+    kern = RBF(0.2) + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, n_restarts_optimizer=2,
+                                           random_state=32)
+    gp.fit(X, c)
+    ls = gp.kernel_.k1.length_scale
+    best = max(np.log(np.linspace(0.15, 0.25, 41)), key=lambda t: gp.log_marginal_likelihood(theta=[t]))
+    assert abs(np.log(ls) - best) < 0.02
+    assert np.sqrt(gp.cov_factor_) == pytest.approx(0.9775259008799535, rel=2e-3)
+
+
+def test_notebook_grid_known_answer(notebook_grid):
+    """The published MAP of the 80 x 100 (Q, ell) scan: indices (36, 39), bit-exact."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    g = notebook_grid
+    X, y = np.array(g["X_train"]), np.array(g["y_train"])
+    kern = RBF(0.2) + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+    gp = gsum_amd.TruncationGP(kernel=kern, ref=g["ref"], ratio=0.5, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y, orders=np.array(g["orders"]))
+    thetas = [[t] for t in np.log(g["ls_vals"])]
+    want = np.array(g["grid"])
+    for mode in ("full", "reuse"):
+        grid = gp.log_marginal_likelihood_grid(thetas, g["ratio_vals"], mode=mode)
+        assert list(np.unravel_index(np.argmax(grid), grid.shape)) == [36, 39]
+        assert not np.isneginf(grid).any() and not np.isnan(grid).any()
+        # 5 training points 0.24 apart: columns with ell >~ 0.3 are ill-conditioned by construction
+        np.testing.assert_allclose(grid, want, rtol=1e-6)
+        np.testing.assert_allclose(grid[:, :45], want[:, :45], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE-sized inputs
+# ---------------------------------------------------------------------------------------------
+
+def s_inputs(n, r, seed=0):
+    X = 0.1 * np.arange(n)[:, None]
+    c = np.random.RandomState(seed).randn(n, r)
+    return X, gsum_amd.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_large_known_answers(large_lml, idx):
+    """S2/S3 inputs (dx = 0.5 ell): lml within 1e-10 relative of the reference's value, n up to 8192."""
+    from sklearn.gaussian_process.kernels import RBF
+    case = large_lml[idx]
+    n, r = case["n"], case["r"]
+    X, y = s_inputs(n, r, case["seed"])
+    gp = gsum_amd.TruncationGP(kernel=RBF(case["length_scale"]), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1,
+                               optimizer=None)
+    gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
+    for q, want in case["lml"].items():
+        got = gp.log_marginal_likelihood(theta=np.log([case["length_scale"]]), ratio=float(q))
+        assert got == pytest.approx(want, rel=1e-10), (n, q, got, want)
+
+
+def test_lml_vs_oracle_n2048_matern_2d():
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    n, r = 2048, 8
+    rng = np.random.RandomState(0)
+    X = rng.rand(n, 2) * np.array([0.7, 1.3]) * np.sqrt(n) * 0.5
+    kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    y = rng.randn(n, r)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, center=0.1, disp=1.5, df=2, scale=0.7)
+    got = gp.log_marginal_likelihood(theta=kern.theta, X=X, y=y)
+    want = orc.cgp_lml(kern, kern.theta, X, y, center=0.1, disp=1.5, df=2, scale=0.7)
+    assert got == pytest.approx(want, rel=1e-10)
+    # predictive std at 512 new points: variance tolerance 1e-10 * cov_factor (SURVEY.md §8 d)
+    gp.fit(X, y)
+    fit = orc.cgp_fit(kern, X, y, center=0.1, disp=1.5, df=2, scale=0.7)
+    Xs = rng.rand(512, 2) * X.max(axis=0)
+    m, s = gp.predict(Xs, return_std=True)
+    mo, so = orc.cgp_predict(fit, Xs, return_std=True)
+    np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-9 * np.abs(mo).max())
+    np.testing.assert_allclose(s ** 2, so ** 2, rtol=1e-9, atol=1e-10 * fit["cov_factor"])
+
+
+def test_full_size_properties_n8192():
+    """Size-independent properties at the BASELINE size: look-ahead on/off and lower-only/full kernel
+    build are bit-identical (same arithmetic, different scheduling); the ratio rescaling identity
+    G(rho) = D G(rho0) D holds; L L^T reproduces K on sampled rows."""
+    from sklearn.gaussian_process.kernels import RBF
+    n, r = 8192, 6
+    X, y = s_inputs(n, r)
+    ctx = gsum_amd.default_context(0)
+    desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+    c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
+    Z = np.concatenate([c, np.ones((n, 1))], axis=1)
+    out = {}
+    for la in (1, 0):
+        for lower in (1, 0):
+            ctx.set_option("lookahead", la)
+            ctx.set_option("build_lower_only", lower)
+            out[(la, lower)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    ctx.set_option("lookahead", 1)
+    ctx.set_option("build_lower_only", 1)
+    G0, s0, i0 = out[(1, 1)]
+    assert i0[0] == 0
+    for key, (G, s, i) in out.items():
+        np.testing.assert_array_equal(G, G0)
+        np.testing.assert_array_equal(s, s0)
+    rho = 0.45
+    c2 = gsum_amd.coefficients(y, rho, 1.0, np.arange(r))
+    G2, _, _ = ctx.lml_batch([desc], X, np.concatenate([c2, np.ones((n, 1))], axis=1), 1e-10)
+    D = np.append((0.5 / rho) ** np.arange(r), 1.0)
+    np.testing.assert_allclose(G2[0], D[:, None] * G0[0] * D[None, :], rtol=1e-7)
+    M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+    assert ctx.potrf(M) == 0
+    L = M.to_host()
+    M.free()
+    rows = np.array([0, 1, 127, 128, 129, 4095, 4096, 8000, 8191])
+    K = RBF(0.2)(X[rows], X)
+    K[np.arange(len(rows)), rows] += 1e-10
+    np.testing.assert_allclose(L[rows] @ L.T, K, rtol=0, atol=1e-13)
