@@ -65,7 +65,7 @@ PROTOTYPES = {
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
-    "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, _dp]),
+    "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
     "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int32, C.c_double]),
@@ -297,10 +297,11 @@ class HipContext:
         self._check(self._lib.gsum_gemm_profile(self._h, C.byref(ms), C.byref(fl), C.byref(cnt)))
         return float(ms.value), float(fl.value), int(cnt.value)
 
-    def probe_mfma_f64(self, iters=20000) -> float:
-        v = C.c_double(0)
-        self._check(self._lib.gsum_probe_mfma_f64(self._h, iters, C.byref(v)))
-        return float(v.value)
+    def probe_mfma_f64(self, iters=10000, waves_per_simd=1, n_acc=8):
+        """dict(tflops, cycles_per_mfma, clock_ghz) of a register-resident fp64 MFMA loop."""
+        v = np.zeros(3)
+        self._check(self._lib.gsum_probe_mfma_f64(self._h, iters, waves_per_simd, n_acc, _ptr(v)))
+        return dict(tflops=float(v[0]), cycles_per_mfma=float(v[1]), clock_ghz=float(v[2]))
 
     def probe_hbm_write(self, nbytes=1 << 30) -> float:
         v = C.c_double(0)

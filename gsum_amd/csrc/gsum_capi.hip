@@ -16,6 +16,7 @@ struct gsum_mat {
     double* A = nullptr;       // (np + 16) x ld augmented matrix
     double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L
     double* logdet = nullptr;  // T per-block sums of log L_ii
+    double* diag0 = nullptr;   // np original diagonal entries (pivot-cancellation test)
     bool factored = false;
 };
 
@@ -141,10 +142,12 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->Linv, (size_t)m->T * GS_NB * GS_NB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->logdet, (size_t)m->T * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->diag0, (size_t)m->np * sizeof(double));
     if (e != hipSuccess) {
         if (m->A) (void)hipFree(m->A);
         if (m->Linv) (void)hipFree(m->Linv);
         if (m->logdet) (void)hipFree(m->logdet);
+        if (m->diag0) (void)hipFree(m->diag0);
         delete m;
         ctx->err = std::string("hipMalloc(matrix) failed: ") + hipGetErrorString(e);
         return -1;
@@ -167,6 +170,7 @@ static void gs_mat_release(gsum_mat* m) {
     if (m->A) (void)hipFree(m->A);
     if (m->Linv) (void)hipFree(m->Linv);
     if (m->logdet) (void)hipFree(m->logdet);
+    if (m->diag0) (void)hipFree(m->diag0);
     delete m;
 }
 
@@ -213,6 +217,8 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
     GS_CHECK(hipMemsetAsync(ctx->dinfo, 0, sizeof(int), ctx->sm));
+    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, ctx->sm, A, ld, (int)m->np, m->diag0);
+    GS_CHECK(hipGetLastError());
     const bool la = ctx->lookahead != 0;
     hipStream_t sp = la ? ctx->sp : ctx->sm;
     if (la) {
@@ -224,7 +230,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t mrest = naug - r0;     // rows below the diagonal block, border included (>= 16)
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k,
-                           ctx->dinfo, (int)c0);
+                           ctx->dinfo, (int)c0, m->diag0 + c0);
         GS_CHECK(hipGetLastError());
         // panel: rows r0.., columns c0..c0+127  <-  panel * Linv^T   (in place)
         double* P = A + r0 * ld + c0;
@@ -237,7 +243,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         if (k + 1 < T) {
             // look-ahead column: needs bulk(k-1) to have finished its tiles of this block column
             if (k > 0) GS_CHECK(hipStreamWaitEvent(sp, ctx->evM[k - 1], 0));
-            if (gs_gemm(ctx, sp, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sp, 1, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
             const int64_t r1 = r0 + GS_NB, m1 = naug - r1;
             double* P1 = A + r1 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(ctx->sm, ctx->evP[k], 0));
@@ -660,20 +666,45 @@ int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int6
     return 0;
 }
 
-int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, double* tflops) {
-    if (!ctx || !tflops || iters <= 0) return -2;
+int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, int32_t waves_per_simd, int32_t n_acc, double* out3) {
+    if (!ctx || !out3 || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
-    const int blocks = 256 * 4;
-    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)blocks * 256 * sizeof(double))) return -1;
-    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, 16);   // warm-up
+    const int blocks = 256 * waves_per_simd;      // 256-thread blocks: one wave per SIMD each
+    const size_t ob = (size_t)blocks * 256 * sizeof(double), sb = (size_t)blocks * 4 * 2 * sizeof(unsigned long long);
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, ob + sb)) return -1;
+    unsigned long long* dst = (unsigned long long*)((char*)ctx->scratch + ob);
+    auto launch = [&](int its) -> int {
+        switch (n_acc) {
+            case 1: hipLaunchKernelGGL(k_probe_mfma<1>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            case 2: hipLaunchKernelGGL(k_probe_mfma<2>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            case 4: hipLaunchKernelGGL(k_probe_mfma<4>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            case 8: hipLaunchKernelGGL(k_probe_mfma<8>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            case 16: hipLaunchKernelGGL(k_probe_mfma<16>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            default: return -2;
+        }
+        return 0;
+    };
+    if (launch(64)) GS_FAIL("n_acc must be 1, 2, 4, 8 or 16");      // warm-up
+    GS_CHECK(hipGetLastError());
     GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
-    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, iters);
+    launch(iters);
+    GS_CHECK(hipGetLastError());
     GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
+    std::vector<unsigned long long> st((size_t)blocks * 8);
+    GS_CHECK(hipMemcpyAsync(st.data(), dst, sb, hipMemcpyDeviceToHost, ctx->sm));
     GS_CHECK(hipStreamSynchronize(ctx->sm));
     float ms = 0.f;
     GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[1]));
-    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
-    *tflops = flops / (ms * 1e-3) / 1e12;
+    const double n_mfma = (double)iters * 16.0;   // per wave
+    const double flops = (double)blocks * 4.0 * n_mfma * 2048.0;
+    double cyc = 0.0, rt = 0.0;
+    for (size_t i = 0; i < st.size(); i += 2) {
+        cyc += (double)st[i];
+        rt += (double)st[i + 1];
+    }
+    out3[0] = flops / (ms * 1e-3) / 1e12;                       // TFLOP/s
+    out3[1] = cyc / ((double)blocks * 4.0) / n_mfma;            // shader cycles per MFMA per wave
+    out3[2] = rt > 0 ? cyc / rt * 0.1 : 0.0;                    // GHz (s_memrealtime ticks at 100 MHz)
     return 0;
 }
 

@@ -36,19 +36,68 @@ typedef double gs_d2 __attribute__((ext_vector_type(2)));
 //                       2.5: t=d*sqrt5, (1+t+t*t/3)exp(-t)
 //   Product :956-966 (amplitude * base), Sum :858-866 (+ constant), White :1401-1414 (+ noise on diag)
 // Floating-point contraction is off so that sums of squares round like the host code does.
+//
+// exp: numpy's float64 exp on AVX512 hosts (the reference's CPU path, and the GPU box's own host) is
+// Intel SVML's __svml_exp8_ha.  It is NOT correctly rounded — e.g. exp(-0.125) comes out 1 ulp low —
+// and on a uniform grid one such value fills a whole diagonal of K: that single ulp moves the S3
+// log-likelihood by 6e-10.  gs_exp_np therefore restates the published structure of that
+// routine operation for operation (Tang-style: N = floor_{1/16}(x log2 e), two-step Cody-Waite
+// reduction, 16-entry 2^(j/16) table with tail, degree-6 polynomial, every step one IEEE fma), so
+// kernel-matrix entries come out bit-identical to sklearn's.  Checked bit-for-bit against np.exp on 13k
+// arguments by tests/test_exp_restatement.py (CPU) and on the device by tests/test_gpu_parity.py.
+// |x| >= 707.7 (results below 4.6e-308 or overflow) takes SVML's scalar "rare" path on the host; here it
+// falls through to the device library's exp: such entries are < 1e-307 against a unit diagonal.
+__device__ __constant__ double gs_exp_th[16] = {
+    0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
+    0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0,
+    0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0, 0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};
+__device__ __constant__ double gs_exp_tl[16] = {
+    0x0.0p+0, 0x1.79aa65d837b6dp-54, -0x1.01b15eaa59348p-55, 0x1.68efde3a8a894p-54,
+    0x1.34d754db0abb6p-55, 0x1.59f48a72a4c6dp-55, 0x1.690cebb7aafb0p-56, 0x1.063e1e21c5409p-54,
+    -0x1.3b3efbf5e2228p-54, -0x1.b32dcb94da51dp-56, 0x1.db72fc1f0eab4p-55, 0x1.1affc2b91ce27p-56,
+    0x1.c1a7792cb3387p-55, 0x1.36eae30af0cb3p-56, 0x1.4a385a63d07a7p-56, -0x1.ff7128fd391f0p-55};
+
+__device__ __forceinline__ double gs_exp_np(double x) {
+#pragma clang fp contract(off)
+    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
+    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
+    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
+    // M = RZ(x*L2E + SH): round-toward-zero of a positive sum = floor on the 1/16 grid.  Emulated with a
+    // round-to-nearest fma and an exact sign test of the residual.
+    const double t = __builtin_fma(x, L2E, SH);
+    const double nn = t - SH;
+    const double dd = __builtin_fma(x, L2E, -nn);
+    const double N = dd < 0.0 ? nn - 0.0625 : nn;
+    const long long k16 = (long long)(N * 16.0);
+    const int j = (int)(k16 & 15);
+    double R = __builtin_fma(-N, L2H, x);
+    R = __builtin_fma(-N, L2L, R);
+    const double R2 = R * R;
+    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
+    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
+    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
+    double pp = __builtin_fma(R2, pA, pB);
+    pp = __builtin_fma(R2, pp, pC);
+    const double q = __builtin_fma(pp, R, gs_exp_tl[j]);
+    const double th = gs_exp_th[j];
+    const double res = __builtin_fma(th, q, th);
+    return ldexp(res, (int)(k16 >> 4));
+}
+
 __device__ __forceinline__ double gs_base_value(int family, double s) {
 #pragma clang fp contract(off)
-    if (family == GSUM_RBF) return exp(-0.5 * s);
+    if (family == GSUM_RBF) return gs_exp_np(-0.5 * s);
     double dist = sqrt(s);
     if (family == GSUM_MATERN52) {
         double t = dist * 2.23606797749979;      // math.sqrt(5)
-        return (1.0 + t + (t * t) / 3.0) * exp(-t);
+        return (1.0 + t + (t * t) / 3.0) * gs_exp_np(-t);
     }
     if (family == GSUM_MATERN32) {
         double t = dist * 1.7320508075688772;    // math.sqrt(3)
-        return (1.0 + t) * exp(-t);
+        return (1.0 + t) * gs_exp_np(-t);
     }
-    return exp(-dist);
+    return gs_exp_np(-dist);
 }
 
 // One 128x128 tile per 256-thread workgroup.  Each lane owns two adjacent columns (one 16-B store per
@@ -142,6 +191,12 @@ __global__ __launch_bounds__(256) void k_set_border(double* A, int64_t ld, int n
         A[(int64_t)(np + c) * ld + i] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
 }
 
+// diag0[i] = A[i][i] before the factorisation touches it.
+__global__ __launch_bounds__(256) void k_save_diag(const double* A, int64_t ld, int np, double* diag0) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < np) diag0[i] = A[(int64_t)i * ld + i];
+}
+
 // Rows >= n of the padded square part become identity rows; used after a host upload.
 __global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int n, int np) {
     int j = blockIdx.x * 256 + threadIdx.x;
@@ -151,129 +206,210 @@ __global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2a: diagonal block — unblocked right-looking Cholesky of a 128x128 block held ENTIRELY IN
-// REGISTERS (2-D cyclic 16x16 thread grid, 36 lower 16x16 sub-blocks -> 36 doubles per thread), with
-// the inverse of the factor built alongside by forward elimination on an identity (another 36).
-// Each column costs one barrier: the unscaled column and the inverse's pivot row go through a
-// double-buffered 2 KiB LDS mailbox.  LAPACK dpotf2 semantics: pivot <= 0 or NaN -> info.
+// K2a: diagonal block (128x128), one workgroup, two phases.
+//
+// Phase 1 — unblocked right-looking Cholesky with the block held ENTIRELY IN REGISTERS: 2-D cyclic
+// 16x16 thread grid, thread (tr, tc) owns element (tr, tc) of each of the 36 lower 16x16 sub-blocks.
+// One barrier per column: the unscaled column goes through a double-buffered LDS mailbox whose layout is
+// permuted (row i at (i & 15) * 8 + (i >> 4)) so that every thread fetches its 8 row values and its 8
+// column values with four ds_read_b128 each.  1/sqrt(pivot) comes from v_rsq_f64 + two Newton steps (a
+// 90-cycle dependent chain instead of ~250 for sqrt + divide); masks are needed only inside the active
+// sub-block.  The inverses of the eight 16x16 DIAGONAL sub-blocks are built alongside by forward
+// elimination on an identity (one extra fma per thread per column).
+// LAPACK dpotf2 semantics: pivot <= 0 or NaN -> info.  One addition: a pivot that has lost every
+// significant bit (p <= 8 eps * original A_jj) also counts as not positive.  On an exactly singular
+// matrix (duplicated points, nugget 0) the sign of such a pivot is rounding noise that depends on the
+// summation order; LAPACK's order happens to give <= 0 on the reference's case (tests/golden nonpd), a
+// right-looking order gives +1e-17.  The threshold makes the outcome the mathematically right one.
+//
+// Phase 2 — L^-1 on the matrix cores.  Block column j of the inverse depends only on L and the diagonal
+// inverses:  X_jj = D_j^-1,  X_ij = -D_i^-1 * sum_{p=j}^{i-1} L_ip X_pj.  Wave w owns block columns w and
+// 7-w (140..92 MFMAs each way) and keeps them in registers: the accumulator layout of
+// v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 reg) IS its B-operand layout for k-step
+// reg, so X_pj feeds the next product with no data movement; L_ip is read as the A operand straight from
+// the global block phase 1 just stored (L2-resident).  No barrier inside phase 2.
 // ------------------------------------------------------------------------------------------------
+#define GS_DV_STR 17     // padded row stride of the 16x16 diagonal inverses in LDS
+
+__device__ __forceinline__ double gs_rsqrt_nr(double p) {
+    // ~1 ulp reciprocal square root: hardware estimate + two Newton-Raphson steps
+    double r = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = __builtin_fma(-(h * r), r, 0.5);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-(h * r), r, 0.5);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
 template <int JB>
-__device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&v)[8][8], double* colbuf,
-                                              double* rowbuf, double* dbuf, int tr, int tc, int* fail_col) {
+__device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8], double* mail, double* rmail,
+                                              double* dbuf, const double* thr, int tr, int tc, int* fail_col) {
     for (int jr = 0; jr < 16; ++jr) {
         const int j = JB * 16 + jr;
-        double* cb = colbuf + (j & 1) * 128;
-        double* rb = rowbuf + (j & 1) * 128;
-        if (tc == jr) {
+        double* cb = mail + (j & 1) * 128;
+        double* rb = rmail + (j & 1) * 16;
+        if (tc == jr) {      // owners of column j publish it (unscaled), permuted: row i -> (i&15)*8 + (i>>4)
 #pragma unroll
-            for (int ii = JB; ii < 8; ++ii) cb[tr + 16 * ii] = a[ii][JB];
+            for (int ii = JB; ii < 8; ++ii) cb[tr * 8 + ii] = a[ii][JB];
         }
-        if (tr == jr) {
-#pragma unroll
-            for (int kk = 0; kk <= JB; ++kk) rb[tc + 16 * kk] = v[JB][kk];
-        }
+        if (tr == jr) rb[tc] = vd[JB];          // pivot row of the diagonal inverse being built
         __syncthreads();
-        const double p = cb[j];
-        if (!(p > 0.0)) {           // same value in every thread: uniform exit
+        const double p = cb[jr * 8 + JB];       // A_jj
+        if (!(p > thr[j])) {                    // same value in every thread: uniform exit (catches NaN)
             *fail_col = j;
             return false;
         }
-        const double dj = sqrt(p);
-        const double r = 1.0 / dj;
+        const double r = gs_rsqrt_nr(p);
+        double dj = p * r;                                       // sqrt(p) ...
+        dj = __builtin_fma(__builtin_fma(-dj, dj, p), 0.5 * r, dj);   // ... corrected to ~0.5 ulp
         if (threadIdx.x == 0) dbuf[j] = dj;
-        double li[8], lk[8], vk[8];
+        double cr[8], cc[8];
+        {
+            const gs_d2* pr = reinterpret_cast<const gs_d2*>(cb + tr * 8);
+            const gs_d2* pc = reinterpret_cast<const gs_d2*>(cb + tc * 8);
 #pragma unroll
-        for (int ii = JB; ii < 8; ++ii) {
-            const int row = tr + 16 * ii;
-            li[ii] = (row > j) ? cb[row] * r : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const gs_d2 x = pr[q], y = pc[q];
+                cr[2 * q] = x[0]; cr[2 * q + 1] = x[1];
+                cc[2 * q] = y[0]; cc[2 * q + 1] = y[1];
+            }
         }
+        double li[8], lk[8];
 #pragma unroll
-        for (int kk = JB; kk < 8; ++kk) {
-            const int col = tc + 16 * kk;
-            lk[kk] = (col > j) ? cb[col] * r : 0.0;
-        }
+        for (int ii = JB; ii < 8; ++ii) li[ii] = cr[ii] * r;
 #pragma unroll
-        for (int kk = 0; kk <= JB; ++kk) {
-            const int col = tc + 16 * kk;
-            vk[kk] = (col <= j) ? rb[col] * r : 0.0;
-        }
+        for (int kk = JB; kk < 8; ++kk) lk[kk] = cc[kk] * r;
+        // inside the active sub-block only rows / columns beyond j take part
+        li[JB] = (tr > jr) ? li[JB] : 0.0;
+        lk[JB] = (tc > jr) ? lk[JB] : 0.0;
+        const double vk = (tc <= jr) ? rb[tc] * r : 0.0;          // scaled pivot row of D^-1
         // trailing update of the block:  A_ik -= l_ij l_kj   (i, k > j)
 #pragma unroll
         for (int ii = JB; ii < 8; ++ii)
 #pragma unroll
-            for (int kk = JB; kk <= ii; ++kk) a[ii][kk] -= li[ii] * lk[kk];
+            for (int kk = JB; kk <= ii; ++kk) a[ii][kk] = __builtin_fma(-li[ii], lk[kk], a[ii][kk]);
         // column j is final: l_ij below the diagonal, d_j on it
         if (tc == jr) {
 #pragma unroll
-            for (int ii = JB; ii < 8; ++ii) {
-                const int row = tr + 16 * ii;
-                a[ii][JB] = (row > j) ? li[ii] : ((row == j) ? dj : a[ii][JB]);
-            }
+            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = li[ii];
+            a[JB][JB] = (tr > jr) ? li[JB] : ((tr == jr) ? dj : a[JB][JB]);
         }
-        // inverse: rows below j eliminate against the scaled pivot row
-#pragma unroll
-        for (int ii = JB; ii < 8; ++ii)
-#pragma unroll
-            for (int kk = 0; kk <= JB; ++kk) v[ii][kk] -= li[ii] * vk[kk];
-        if (tr == jr) {
-#pragma unroll
-            for (int kk = 0; kk <= JB; ++kk) v[JB][kk] = vk[kk];
-        }
+        // diagonal-block inverse: rows below j eliminate against the scaled pivot row
+        vd[JB] = (tr == jr) ? vk : __builtin_fma(-li[JB], vk, vd[JB]);
     }
     return true;
+}
+
+// One block column J of L^-1 on the matrix cores (see the header comment above).  Lg: the factored diagonal
+// block in global memory (leading dimension ld); Dv: the eight 16x16 diagonal inverses in LDS.
+template <int J>
+__device__ __forceinline__ void gs_trtri_col(const double* Lg, int64_t ld, const double* Dv, double* Linv, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    gs_d4 X[8];
+    // X_JJ = D_J^-1, fetched in accumulator layout: reg x holds row fq + 4x, column fr
+#pragma unroll
+    for (int x = 0; x < 4; ++x) X[J][x] = Dv[(J * 16 + fq + 4 * x) * GS_DV_STR + fr];
+#pragma unroll
+    for (int i = J + 1; i < 8; ++i) {
+        gs_d4 T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = J; p < i; ++p) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double av = Lg[(int64_t)(16 * i + fr) * ld + 16 * p + 4 * s4 + fq];     // A operand: L_ip
+                T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[p][s4], T, 0, 0, 0);
+            }
+        }
+        gs_d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double av = Dv[(i * 16 + fr) * GS_DV_STR + 4 * s4 + fq];                     // A operand: D_i^-1
+            R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], R, 0, 0, 0);
+        }
+        X[i] = -R;
+    }
+    // write block column J of the 128x128 inverse: zeros above the diagonal block
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            Linv[(16 * i + fq + 4 * x) * 128 + 16 * J + fr] = (i < J) ? 0.0 : X[i][x];
 }
 
 // A: pointer to the diagonal block inside the augmented matrix (leading dimension ld).
 // Linv: 128x128 row-major output (zeros above the diagonal).  logdet[0] = sum_j log L_jj.
 // info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
+// diag0: the block's 128 original diagonal entries (before any trailing update).
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
-                                                     int* info, int col0) {
-    __shared__ double colbuf[256];
-    __shared__ double rowbuf[256];
+                                                     int* info, int col0, const double* diag0) {
+    __shared__ __attribute__((aligned(16))) double mail[256];
+    __shared__ double rmail[32];
     __shared__ double dbuf[128];
+    __shared__ double thr[128];
+    __shared__ double Dv[128 * GS_DV_STR];
     if (*info != 0) return;                    // an earlier block already failed (uniform)
     const int t = threadIdx.x;
+    if (t < 128) {
+        const double d0 = diag0[t];
+        thr[t] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
+    }
     const int tr = t >> 4, tc = t & 15;
-    double a[8][8], v[8][8];
+    double a[8][8], vd[8];
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
+    for (int ii = 0; ii < 8; ++ii) {
 #pragma unroll
-        for (int kk = 0; kk <= ii; ++kk) {
-            a[ii][kk] = A[(int64_t)(tr + 16 * ii) * ld + tc + 16 * kk];
-            v[ii][kk] = (ii == kk && tr == tc) ? 1.0 : 0.0;
-        }
+        for (int kk = 0; kk <= ii; ++kk) a[ii][kk] = A[(int64_t)(tr + 16 * ii) * ld + tc + 16 * kk];
+        vd[ii] = (tr == tc) ? 1.0 : 0.0;
+    }
+    __syncthreads();
     int fail_col = -1;
-    bool ok = gs_diag_steps<0>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<1>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<2>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<3>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<4>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<5>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<6>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<7>(a, v, colbuf, rowbuf, dbuf, tr, tc, &fail_col);
+    bool ok = gs_diag_steps<0>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<1>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<2>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<3>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<4>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<5>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<6>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
+    if (ok) ok = gs_diag_steps<7>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (!ok) {
         if (t == 0) *info = col0 + fail_col + 1;
         return;
     }
+    // L back to the matrix (lower part), diagonal inverses to LDS
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
+    for (int ii = 0; ii < 8; ++ii) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk <= ii; ++kk) {
             const int row = tr + 16 * ii, col = tc + 16 * kk;
-            if (kk <= ii) {
-                if (col <= row) A[(int64_t)row * ld + col] = a[ii][kk];
-                Linv[row * 128 + col] = (col <= row) ? v[ii][kk] : 0.0;
-            } else {
-                Linv[row * 128 + col] = 0.0;
-            }
+            if (col <= row) A[(int64_t)row * ld + col] = a[ii][kk];
         }
+        Dv[(ii * 16 + tr) * GS_DV_STR + tc] = (tc <= tr) ? vd[ii] : 0.0;
+    }
+    __threadfence_block();
     __syncthreads();
     if (t < 128) dbuf[t] = log(dbuf[t]);
+    // phase 2: wave w builds block columns w and 7-w of L^-1
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (w == 0) {
+        gs_trtri_col<0>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<7>(A, ld, Dv, Linv, lane);
+    } else if (w == 1) {
+        gs_trtri_col<1>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<6>(A, ld, Dv, Linv, lane);
+    } else if (w == 2) {
+        gs_trtri_col<2>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<5>(A, ld, Dv, Linv, lane);
+    } else {
+        gs_trtri_col<3>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<4>(A, ld, Dv, Linv, lane);
+    }
     __syncthreads();
     if (t == 0) {
-        double s = 0.0;
-        for (int j = 0; j < 128; ++j) s += dbuf[j];
-        logdet[0] = s;
+        double sl = 0.0;
+        for (int j = 0; j < 128; ++j) sl += dbuf[j];
+        logdet[0] = sl;
     }
 }
 
@@ -287,7 +423,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 //     (lane l holds [row l&15][k l>>4]);
 //   - rows >= M / cols >= N are clamped on load and predicated on store, so the 16-row border tile
 //     and the padded tail run through the same code;
-//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix).
+//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix);
+//   - sign must be +1 or -1 (it multiplies the staged A operand exactly).
 // In-place use (C == A, TRSM against an explicit inverse) is safe when one tile spans all N = K
 // columns: every global load of the tile's rows is finished before the epilogue stores.
 // ------------------------------------------------------------------------------------------------
@@ -316,11 +453,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
     }
     const int m0 = bm * BM, n0 = bn * BN;
 
+    // The accumulators start as beta*C (all loads of the tile issued back to back, one wait) and the
+    // sign rides on the staged A operand, so the epilogue is stores only.  (A load-modify-store epilogue
+    // serialises 64 global round trips per thread: stores may alias the next load.)
+    const int fr = lane & 15, fq = lane >> 4;
     gs_d4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+            }
+        }
 
     gs_d2 ra[A_IT], rb[B_IT];
     auto gload = [&](int kc) {
@@ -349,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int vv = t + it * 256;
-            if (vv < A_VECS) *reinterpret_cast<gs_d2*>(sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7)) = ra[it];
+            if (vv < A_VECS) *reinterpret_cast<gs_d2*>(sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7)) = ra[it] * sign;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -362,7 +510,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
     gload(0);
     swrite(0);
     __syncthreads();
-    const int fr = lane & 15, fq = lane >> 4;
     for (int c = 0; c < nk; ++c) {
         if (c + 1 < nk) gload(c + 1);
         const double* sA = lds + (c & 1) * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
@@ -392,12 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) {
-                    double* p = C + (int64_t)row * ldc + col;
-                    double val = sign * acc[i][j][x];
-                    if (beta) val += *p;
-                    *p = val;
-                }
+                if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][x];
             }
         }
 }
@@ -442,19 +584,32 @@ __global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int
 }
 
 // ---- probes ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
-    gs_d4 acc[8];
+// NACC independent accumulators held in VGPRs (inline asm: hipcc would otherwise shuttle them through
+// AGPRs every iteration), back-to-back v_mfma_f64_16x16x4_f64.  NACC = 1 measures dependent latency.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters, unsigned long long* stamps) {
+    gs_d4 acc[NACC];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < NACC; ++u) acc[u] = (gs_d4){0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 1e-4;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+        for (int rep = 0; rep < 16 / NACC; ++rep)
+#pragma unroll
+            for (int u = 0; u < NACC; ++u)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
     }
     double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+    for (int u = 0; u < NACC; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) {     // diagnostic stamps go to their own buffer, never into results
+        const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * wv] = c1 - c0;
+        stamps[2 * wv + 1] = r1 - r0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_probe_store(gs_d2* out, int64_t nvec) {

@@ -128,8 +128,10 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
  * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
  * call, and resets the record. */
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
-/* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64, operands in registers): achieved TFLOP/s. */
-int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, double* tflops);
+/* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64, operands in registers, waves_per_simd resident
+ * waves on every SIMD, n_acc independent accumulators per wave; n_acc = 1 gives the dependent latency):
+ * out3 = {achieved TFLOP/s, shader cycles per MFMA per wave, in-kernel clock GHz}. */
+int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, int32_t waves_per_simd, int32_t n_acc, double* out3);
 /* HBM streaming-store probe: achieved GB/s writing `bytes` with 16-B stores. */
 int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps);
 /* debug: C(MxN) = beta*C + sign * A(MxK) B(NxK)^T through the MFMA tile kernel (cfg 0: 128x128 tile,

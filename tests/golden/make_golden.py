@@ -260,6 +260,30 @@ def gen_large():
     return out
 
 
+def gen_large_gp_drawn():
+    """Same X / kernel as gen_large, but coefficients drawn FROM the GP (c = L z), the statistically
+    faithful variant of SURVEY.md §8d.  The quadratic form is then O(n), not O(n / lambda_min), and the
+    log-likelihood is well conditioned: this is the input class the 1e-10 parity bar is checked on."""
+    out = []
+    for n, r in ((512, 4), (2048, 4), (8192, 6)):
+        X = 0.1 * np.arange(n)[:, None]
+        K = RBF(0.2)(X)
+        K[np.diag_indices_from(K)] += 1e-10
+        c = np.linalg.cholesky(K) @ np.random.RandomState(1).randn(n, r)
+        y = gsum.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+        gp = gsum.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1,
+                               optimizer=None)
+        gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
+        vals = {}
+        for q in (0.5, 0.45):
+            vals[str(q)] = float(gp.log_marginal_likelihood(theta=np.log([0.2]), ratio=q))
+        out.append(dict(n=n, r=r, dx=0.1, length_scale=0.2, nugget=1e-10, seed=1, lml=vals,
+                        y_checksum=float(np.sum(y * np.cos(np.arange(y.size).reshape(y.shape)))),
+                        recipe="c = cholesky(RBF(0.2)(X) + 1e-10 I) @ RandomState(1).randn(n, r)"))
+        print("gp-drawn", n, r, vals, flush=True)
+    return out
+
+
 def gen_nonpd():
     """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
     X = np.array([[0.0], [0.5], [0.5], [1.0]])
@@ -288,6 +312,8 @@ def main():
         json.dump(gen_notebook_grid(), f)
     with open(os.path.join(HERE, "large_lml.json"), "w") as f:
         json.dump(gen_large(), f, indent=1)
+    with open(os.path.join(HERE, "large_lml_gp_drawn.json"), "w") as f:
+        json.dump(gen_large_gp_drawn(), f, indent=1)
     import sklearn, scipy
     with open(os.path.join(HERE, "VERSIONS.json"), "w") as f:
         json.dump(dict(numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__,

@@ -54,3 +54,35 @@ def test_bordered_blocked_cholesky_matches_direct():
         got, _ = lml_from_gram(G, sld, n, 0, 0, 1, 1)
         want, _ = lml_from_gram(Wr.T @ Wr, s_ref, n, 0, 0, 1, 1)
         assert abs(got - want) <= 1e-10 * abs(want)
+
+
+def _potf2_right_looking(A):
+    """Unblocked right-looking Cholesky with reciprocal scaling (the order the device's diagonal kernel uses)."""
+    A = A.copy()
+    n = len(A)
+    for j in range(n):
+        d = np.sqrt(A[j, j])
+        l = A[j + 1:, j] * (1.0 / d)
+        A[j, j] = d
+        A[j + 1:, j] = l
+        A[j + 1:, j + 1:] -= np.outer(l, l)
+    return np.tril(A)
+
+
+def test_intrinsic_spread_of_the_uniform_grid_input():
+    """Why tests/test_gpu_parity.py bounds the uniform-grid S-inputs at 3e-10 rather than 1e-10: on the CPU,
+    with the SAME kernel matrix, LAPACK's blocked dpotrf and a plain right-looking Cholesky already disagree
+    by several 1e-11 in the log-likelihood (cond(K) = 4e7, white-noise coefficients)."""
+    from scipy.linalg import solve_triangular
+    from gsum_amd.conjugate import lml_from_gram
+    n, r = 512, 4
+    X = 0.1 * np.arange(n)[:, None]
+    K = np.exp(-0.5 * ((X - X.T) / 0.2) ** 2) + 1e-10 * np.eye(n)
+    Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
+    vals = []
+    for chol in (np.linalg.cholesky, _potf2_right_looking):
+        L = chol(K)
+        W = solve_triangular(L, Z, lower=True)
+        vals.append(lml_from_gram(W.T @ W, np.log(np.diag(L)).sum(), n, 0, 0, 1, 1)[0])
+    spread = abs(vals[0] - vals[1]) / abs(vals[0])
+    assert 1e-12 < spread < 3e-10, spread

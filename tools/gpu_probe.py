@@ -14,7 +14,10 @@ from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 out = {}
 ctx = gsum_amd.default_context(0)
-out["mfma_f64_tflops"] = [ctx.probe_mfma_f64(it) for it in (2000, 20000, 20000)]
+out["mfma_f64"] = {f"wps{w}_acc{a}": ctx.probe_mfma_f64(4000, w, a)
+                   for w, a in ((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 8), (2, 16), (4, 4), (4, 8), (8, 4), (1, 16))}
+for k, v in out["mfma_f64"].items():
+    print(k, {a: round(b, 3) for a, b in v.items()}, flush=True)
 out["hbm_write_gbps"] = [ctx.probe_hbm_write(1 << 30) for _ in range(3)]
 print(out, flush=True)
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
