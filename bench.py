@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
     ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
+    ap.add_argument("--slots", type=int, default=4, help="independent evaluations kept in flight per GPU")
     args = ap.parse_args()
 
     import torch
@@ -101,26 +102,25 @@ def main():
     mine = ells[rank * K:(rank + 1) * K]
     descs = [gsum_amd.describe_kernel(RBF(float(e)), 1) for e in mine]
 
-    def evaluate(desc):
-        G, sld, info = ctx.lml_resident([desc], 1e-10)
-        if info[0] != 0:
-            return -np.inf
-        return lml_from_gram(G[0], sld[0], n, 0.0, 0.0, 1, 1)[0] - jac
+    def evaluate(batch):
+        """K build + Cholesky + fused solve for every descriptor (the library keeps `slots` independent
+        evaluations in flight), then the O(k^2) host algebra per evaluation."""
+        G, sld, info = ctx.lml_resident(batch, 1e-10)
+        out = np.empty(len(batch))
+        for i in range(len(batch)):
+            out[i] = -np.inf if info[i] != 0 else lml_from_gram(G[i], sld[i], n, 0.0, 0.0, 1, 1)[0] - jac
+        return out
 
-    for i in range(W):
-        evaluate(descs[i % len(descs)])
+    ctx.set_option("batch_slots", args.slots)
+    if W > 0:
+        evaluate([descs[i % len(descs)] for i in range(W)])
     ctx.set_option("profile_gemm", 1)
     ctx.gemm_profile()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    vals = np.empty(K)
-    stage = np.zeros(4)
-    for i in range(K):
-        vals[i] = evaluate(descs[i])
-        tm = ctx.timers()
-        stage += [tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]]
+    vals = evaluate(descs)
     allvals = gather_flat(vals, total) if world > 1 else vals
     torch.cuda.synchronize()
     if world > 1:
@@ -132,7 +132,15 @@ def main():
         elapsed = float(tt.item())
     gemm_ms, gemm_flops, gemm_launches = ctx.gemm_profile()
     ctx.set_option("profile_gemm", 0)
-    stage /= K
+    # single-evaluation stage times (one evaluation alone on the GPU), outside the timed region
+    ctx.set_option("batch_slots", 1)
+    stage = np.zeros(4)
+    for i in range(3):
+        ctx.lml_resident([descs[0]], 1e-10)
+        tm = ctx.timers()
+        stage = np.maximum(stage, 0) if i == 0 else stage
+        cur = np.array([tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]])
+        stage = cur if i == 0 else np.minimum(stage, cur)
 
     if rank == 0:
         potrf_flops = n ** 3 / 3.0
@@ -145,11 +153,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, "
                                    f"{r} orders (BASELINE configs[2], S3)", "n": n, "orders": r,
-                       "evals_per_gpu": K, "mode": "full-recompute"},
-            "stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1], "finalize_d2h": stage[2],
-                         "gpu_total": stage[3]},
-            "cholesky": {"gflops": chol_tflops * 1e3, "frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,
-                         "flops": "n^3/3", "ms": stage[1]},
+                       "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": args.slots},
+            "single_eval_stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1],
+                                     "finalize_d2h": stage[2], "gpu_total": stage[3]},
+            "cholesky": {"single_eval_gflops": chol_tflops * 1e3,
+                         "single_eval_frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,
+                         "pipelined_gflops_per_gpu": potrf_flops * K / elapsed / 1e9,
+                         "pipelined_frac_of_fp64_mfma_peak": potrf_flops * K / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "flops": "n^3/3", "single_eval_ms": stage[1]},
             "kernel_build": {"gbps_algorithmic_8n2": 8.0 * n * n / (stage[0] * 1e-3) / 1e9,
                              "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128)"},
             "roofline": {"kernel": "k_gemm_nt<4,4,2,2> (128x128-tile fp64 MFMA: trailing SYRK + look-ahead column)",

@@ -291,6 +291,14 @@ class HipContext:
         self._check(self._lib.gsum_timers(self._h, _ptr(ms), 4))
         return dict(build_ms=ms[0], potrf_ms=ms[1], finalize_ms=ms[2], total_ms=ms[3])
 
+    def diag_stamps(self):
+        """Shader-cycle stamps of the last diagonal-block kernel (needs option diag_stamps=1)."""
+        v = np.zeros(9)
+        self._check(self._lib.gsum_timers(self._h, _ptr(v), 9))
+        tot, ticks = v[7], v[8]
+        return dict(prologue_cyc=v[4], loop_cyc=v[5], inverse_cyc=v[6], total_cyc=tot,
+                    total_us=ticks * 0.01, clock_ghz=(tot / ticks * 0.1) if ticks else 0.0)
+
     def gemm_profile(self):
         """(total ms, total algorithmic flops, launches) of the profiled big-tile GEMM launches; resets."""
         ms, fl, cnt = C.c_double(0), C.c_double(0), C.c_int64(0)

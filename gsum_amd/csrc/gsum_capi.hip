@@ -20,23 +20,39 @@ struct gsum_mat {
     bool factored = false;
 };
 
-struct gsum_ctx {
-    int device = 0;
+// One evaluation pipeline: a main + a high-priority panel stream, the events that tie them together, a
+// result buffer and a workspace matrix.  Independent evaluations of a batch run on different slots, so
+// the latency-bound panel chain of one overlaps the bulk GEMMs of the others.
+struct gs_slot {
     hipStream_t sm = nullptr, sp = nullptr;
     std::vector<hipEvent_t> evP, evM;
     hipEvent_t evFork = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* dres = nullptr; int* dinfo = nullptr;
+    double* hres = nullptr;          // pinned
+    gsum_mat* ws = nullptr;          // workspace matrix of the fused path (reused across calls)
+    int pending = -1;                // index of the evaluation in flight on this slot
+};
+
+#define GS_MAX_SLOTS 8
+
+struct gsum_ctx {
+    int device = 0;
+    gs_slot slots[GS_MAX_SLOTS];
+    int n_slots_ready = 0;
+    gs_slot* cur = nullptr;          // slot the helpers below enqueue on
+    int batch_slots = 4;             // evaluations kept in flight by gsum_lml_resident
+    int prio_lo = 0, prio_hi = 0;
     std::string err;
     int lookahead = 1;
     int build_lower_only = 1;
     // resident inputs of the fused path
     double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;
     double* dZ = nullptr; int kZ = 0; size_t dZ_cap = 0;
-    gsum_mat* ws = nullptr;          // workspace matrix of the fused path (reused across calls)
-    double* dres = nullptr; int* dinfo = nullptr;
-    double* hres = nullptr;          // pinned
     double* scratch = nullptr; size_t scratch_cap = 0;
     double timers[4] = {0, 0, 0, 0};
+    unsigned long long* dstamps = nullptr;   // 8 u64: phase stamps of the last diagonal-block kernel
+    int diag_stamps = 0;
     // optional per-launch HIP-event profile of the big-tile (cfg 0) GEMM launches
     int profile_gemm = 0;
     std::vector<hipEvent_t> prof_pool;
@@ -152,15 +168,6 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
         ctx->err = std::string("hipMalloc(matrix) failed: ") + hipGetErrorString(e);
         return -1;
     }
-    if ((int)ctx->evP.size() < m->T + 1) {
-        size_t old = ctx->evP.size();
-        ctx->evP.resize(m->T + 1);
-        ctx->evM.resize(m->T + 1);
-        for (size_t i = old; i < ctx->evP.size(); ++i) {
-            GS_CHECK(hipEventCreateWithFlags(&ctx->evP[i], hipEventDisableTiming));
-            GS_CHECK(hipEventCreateWithFlags(&ctx->evM[i], hipEventDisableTiming));
-        }
-    }
     *out = m;
     return 0;
 }
@@ -214,23 +221,32 @@ static int gs_set_border(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const double
 // from the main stream.  Both streams are joined on the main stream at the end.
 static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int T = m->T;
+    if ((int)ctx->cur->evP.size() < T + 1) {
+        size_t old = ctx->cur->evP.size();
+        ctx->cur->evP.resize(T + 1);
+        ctx->cur->evM.resize(T + 1);
+        for (size_t i = old; i < ctx->cur->evP.size(); ++i) {
+            GS_CHECK(hipEventCreateWithFlags(&ctx->cur->evP[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&ctx->cur->evM[i], hipEventDisableTiming));
+        }
+    }
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
-    GS_CHECK(hipMemsetAsync(ctx->dinfo, 0, sizeof(int), ctx->sm));
-    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, ctx->sm, A, ld, (int)m->np, m->diag0);
+    GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
+    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, ctx->cur->sm, A, ld, (int)m->np, m->diag0);
     GS_CHECK(hipGetLastError());
     const bool la = ctx->lookahead != 0;
-    hipStream_t sp = la ? ctx->sp : ctx->sm;
+    hipStream_t sp = la ? ctx->cur->sp : ctx->cur->sm;
     if (la) {
-        GS_CHECK(hipEventRecord(ctx->evFork, ctx->sm));
-        GS_CHECK(hipStreamWaitEvent(sp, ctx->evFork, 0));
+        GS_CHECK(hipEventRecord(ctx->cur->evFork, ctx->cur->sm));
+        GS_CHECK(hipStreamWaitEvent(sp, ctx->cur->evFork, 0));
     }
     for (int k = 0; k < T; ++k) {
         const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
         const int64_t mrest = naug - r0;     // rows below the diagonal block, border included (>= 16)
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k,
-                           ctx->dinfo, (int)c0, m->diag0 + c0);
+                           ctx->cur->dinfo, (int)c0, m->diag0 + c0, ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
         GS_CHECK(hipGetLastError());
         // panel: rows r0.., columns c0..c0+127  <-  panel * Linv^T   (in place)
         double* P = A + r0 * ld + c0;
@@ -239,20 +255,20 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             if (gs_gemm(ctx, sp, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
             continue;
         }
-        GS_CHECK(hipEventRecord(ctx->evP[k], sp));
+        GS_CHECK(hipEventRecord(ctx->cur->evP[k], sp));
         if (k + 1 < T) {
             // look-ahead column: needs bulk(k-1) to have finished its tiles of this block column
-            if (k > 0) GS_CHECK(hipStreamWaitEvent(sp, ctx->evM[k - 1], 0));
+            if (k > 0) GS_CHECK(hipStreamWaitEvent(sp, ctx->cur->evM[k - 1], 0));
             if (gs_gemm(ctx, sp, 1, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
             const int64_t r1 = r0 + GS_NB, m1 = naug - r1;
             double* P1 = A + r1 * ld + c0;
-            GS_CHECK(hipStreamWaitEvent(ctx->sm, ctx->evP[k], 0));
-            if (gs_gemm(ctx, ctx->sm, 0, A + r1 * ld + r1, ld, P1, ld, P1, ld, m1, m1, GS_NB, 1, 1, -1.0)) return -1;
-            GS_CHECK(hipEventRecord(ctx->evM[k], ctx->sm));
+            GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evP[k], 0));
+            if (gs_gemm(ctx, ctx->cur->sm, 0, A + r1 * ld + r1, ld, P1, ld, P1, ld, m1, m1, GS_NB, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(ctx->cur->evM[k], ctx->cur->sm));
         } else {
             // last block column: only the 16x16 corner is left
-            GS_CHECK(hipStreamWaitEvent(ctx->sm, ctx->evP[k], 0));
-            if (gs_gemm(ctx, ctx->sm, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evP[k], 0));
+            if (gs_gemm(ctx, ctx->cur->sm, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
         }
     }
     m->factored = true;
@@ -260,10 +276,10 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
 }
 
 static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->sm, m->A, m->ld, (int)m->np, m->logdet, m->T, ctx->dinfo,
-                       ctx->dres);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->cur->sm, m->A, m->ld, (int)m->np, m->logdet, m->T, ctx->cur->dinfo,
+                       ctx->cur->dres);
     GS_CHECK(hipGetLastError());
-    GS_CHECK(hipMemcpyAsync(ctx->hres, ctx->dres, 258 * sizeof(double), hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(ctx->cur->hres, ctx->cur->dres, 258 * sizeof(double), hipMemcpyDeviceToHost, ctx->cur->sm));
     return 0;
 }
 
@@ -271,6 +287,26 @@ static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+static int gs_slot_init(gsum_ctx* ctx, gs_slot* sl) {
+    GS_CHECK(hipStreamCreateWithPriority(&sl->sm, hipStreamNonBlocking, ctx->prio_lo));
+    GS_CHECK(hipStreamCreateWithPriority(&sl->sp, hipStreamNonBlocking, ctx->prio_hi));
+    GS_CHECK(hipEventCreateWithFlags(&sl->evFork, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) GS_CHECK(hipEventCreate(&sl->tev[i]));
+    GS_CHECK(hipMalloc((void**)&sl->dres, 258 * sizeof(double)));
+    GS_CHECK(hipMalloc((void**)&sl->dinfo, sizeof(int)));
+    GS_CHECK(hipHostMalloc((void**)&sl->hres, 258 * sizeof(double), hipHostMallocDefault));
+    return 0;
+}
+
+static int gs_need_slots(gsum_ctx* ctx, int n) {
+    if (n > GS_MAX_SLOTS) n = GS_MAX_SLOTS;
+    while (ctx->n_slots_ready < n) {
+        if (gs_slot_init(ctx, &ctx->slots[ctx->n_slots_ready])) return -1;
+        ++ctx->n_slots_ready;
+    }
+    return 0;
+}
 
 int gsum_init(int device, gsum_ctx** out) {
     if (!out) return -2;
@@ -293,19 +329,19 @@ int gsum_init(int device, gsum_ctx** out) {
         return -1;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-    if ((e = hipStreamCreateWithPriority(&ctx->sm, hipStreamNonBlocking, lo)) != hipSuccess) return fail("stream", e);
-    if ((e = hipStreamCreateWithPriority(&ctx->sp, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream", e);
-    if ((e = hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
-    for (int i = 0; i < 4; ++i)
-        if ((e = hipEventCreate(&ctx->tev[i])) != hipSuccess) return fail("event", e);
-    if ((e = hipMalloc((void**)&ctx->dres, 258 * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipMalloc((void**)&ctx->dinfo, sizeof(int))) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&ctx->hres, 258 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
-        return fail("hipHostMalloc", e);
+    (void)hipDeviceGetStreamPriorityRange(&ctx->prio_lo, &ctx->prio_hi);   // hi = numerically lowest
+    if (gs_need_slots(ctx, 1)) {
+        g_init_error = ctx->err;
+        delete ctx;
+        return -1;
+    }
+    ctx->cur = &ctx->slots[0];
+    if ((e = hipMalloc((void**)&ctx->dstamps, 8 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
+    (void)hipMemset(ctx->dstamps, 0, 8 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
+    const char* bs = getenv("GSUM_BATCH_SLOTS");
+    if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;
     return 0;
 }
@@ -314,21 +350,25 @@ void gsum_destroy(gsum_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    gs_mat_release(ctx->ws);
+    for (int i = 0; i < ctx->n_slots_ready; ++i) {
+        gs_slot* sl = &ctx->slots[i];
+        gs_mat_release(sl->ws);
+        if (sl->dres) (void)hipFree(sl->dres);
+        if (sl->dinfo) (void)hipFree(sl->dinfo);
+        if (sl->hres) (void)hipHostFree(sl->hres);
+        for (auto ev : sl->evP) (void)hipEventDestroy(ev);
+        for (auto ev : sl->evM) (void)hipEventDestroy(ev);
+        if (sl->evFork) (void)hipEventDestroy(sl->evFork);
+        for (int k = 0; k < 4; ++k)
+            if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
+        if (sl->sm) (void)hipStreamDestroy(sl->sm);
+        if (sl->sp) (void)hipStreamDestroy(sl->sp);
+    }
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dZ) (void)hipFree(ctx->dZ);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->dres) (void)hipFree(ctx->dres);
-    if (ctx->dinfo) (void)hipFree(ctx->dinfo);
-    if (ctx->hres) (void)hipHostFree(ctx->hres);
-    for (auto ev : ctx->evP) (void)hipEventDestroy(ev);
-    for (auto ev : ctx->evM) (void)hipEventDestroy(ev);
-    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
-    for (int i = 0; i < 4; ++i)
-        if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
+    if (ctx->dstamps) (void)hipFree(ctx->dstamps);
     for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
-    if (ctx->sm) (void)hipStreamDestroy(ctx->sm);
-    if (ctx->sp) (void)hipStreamDestroy(ctx->sp);
     delete ctx;
 }
 
@@ -339,6 +379,8 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
     else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
     else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
+    else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
+    else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
 }
@@ -346,7 +388,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
 static int gs_upload_X(gsum_ctx* ctx, const double* X, int64_t n, int d) {
     if (!X || n <= 0) GS_FAIL("X is NULL or empty");
     if (gs_reserve(ctx, &ctx->dX, &ctx->dX_cap, (size_t)n * d * sizeof(double))) return -1;
-    GS_CHECK(hipMemcpyAsync(ctx->dX, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(ctx->dX, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
     ctx->nX = n;
     ctx->dX_d = d;
     return 0;
@@ -356,7 +398,7 @@ static int gs_upload_Z(gsum_ctx* ctx, const double* Z, int64_t n, int k) {
     if (k < 0 || k > GSUM_MAX_RHS) GS_FAIL("k must be 0..GSUM_MAX_RHS");
     if (k > 0 && !Z) GS_FAIL("RHS is NULL");
     if (gs_reserve(ctx, &ctx->dZ, &ctx->dZ_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
-    if (k > 0) GS_CHECK(hipMemcpyAsync(ctx->dZ, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->sm));
+    if (k > 0) GS_CHECK(hipMemcpyAsync(ctx->dZ, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
     ctx->kZ = k;
     return 0;
 }
@@ -379,19 +421,19 @@ int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double*
     double* dXl = (double*)base;
     double* dYl = (double*)(base + off_y);
     double* dO = (double*)(base + off_o);
-    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, ctx->sm));
-    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, ctx->cur->sm));
+    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, ctx->cur->sm));
     const int64_t tr = (n + 127) / 128, tc = (ldo + 127) / 128;
     if (cross)
-        hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, dO, ldo, dXl, dYl, (int)n, (int)m,
+        hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, dO, ldo, dXl, dYl, (int)n, (int)m,
                            (int)n, (int)ldo, d, *desc, 0.0, 0);
     else
-        hipLaunchKernelGGL(k_build<false>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, dO, ldo, dXl,
+        hipLaunchKernelGGL(k_build<false>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, dO, ldo, dXl,
                            (const double*)nullptr, (int)n, (int)n, (int)n, (int)ldo, d, *desc, diag_add, 0);
     GS_CHECK(hipGetLastError());
     GS_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dO, (size_t)ldo * sizeof(double),
-                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
 }
 
@@ -403,12 +445,12 @@ int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const dou
     if (gs_upload_X(ctx, X, n, d)) return -1;
     gsum_mat* m = nullptr;
     if (gs_mat_alloc(ctx, n, &m)) return -1;
-    if (gs_build_into(ctx, ctx->sm, m, desc, ctx->dX, d, diag_add, ctx->build_lower_only) ||
-        gs_set_border(ctx, ctx->sm, m, ctx->dZ, 0)) {
+    if (gs_build_into(ctx, ctx->cur->sm, m, desc, ctx->dX, d, diag_add, ctx->build_lower_only) ||
+        gs_set_border(ctx, ctx->cur->sm, m, ctx->dZ, 0)) {
         gs_mat_release(m);
         return -1;
     }
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     *out = m;
     return 0;
 }
@@ -419,18 +461,18 @@ int gsum_mat_from_host(gsum_ctx* ctx, const double* Ah, int64_t n, gsum_mat** ou
     gsum_mat* m = nullptr;
     if (gs_mat_alloc(ctx, n, &m)) return -1;
     hipError_t e = hipMemcpy2DAsync(m->A, (size_t)m->ld * sizeof(double), Ah, (size_t)n * sizeof(double),
-                                    (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, ctx->sm);
+                                    (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, ctx->cur->sm);
     if (e == hipSuccess && m->np > n) {
         hipLaunchKernelGGL(k_pad_identity, dim3((unsigned)((m->np + 255) / 256), (unsigned)(m->np - n)), dim3(256), 0,
-                           ctx->sm, m->A, m->ld, (int)n, (int)m->np);
+                           ctx->cur->sm, m->A, m->ld, (int)n, (int)m->np);
         e = hipGetLastError();
     }
-    if (e != hipSuccess || gs_set_border(ctx, ctx->sm, m, ctx->dZ, 0)) {
+    if (e != hipSuccess || gs_set_border(ctx, ctx->cur->sm, m, ctx->dZ, 0)) {
         gs_mat_release(m);
         if (e != hipSuccess) ctx->err = std::string("upload failed: ") + hipGetErrorString(e);
         return -1;
     }
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     *out = m;
     return 0;
 }
@@ -441,8 +483,8 @@ int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
     if (A->factored) GS_FAIL("matrix is already factorised");
     if (gs_potrf(ctx, A)) return -1;
     if (gs_finalize(ctx, A)) return -1;
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
-    *info = (int64_t)ctx->hres[257];
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    *info = (int64_t)ctx->cur->hres[257];
     if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
     A->factored = (*info == 0);
     return 0;
@@ -457,8 +499,8 @@ static int gs_border_solve(gsum_ctx* ctx, gsum_mat* m) {
     for (int k = 0; k < m->T; ++k) {
         const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
-        if (gs_gemm(ctx, ctx->sm, 2, Brow + c0, ld, Brow + c0, ld, Linv, GS_NB, GS_BORDER, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
-        if (gs_gemm(ctx, ctx->sm, 2, Brow + r0, ld, Brow + c0, ld, A + r0 * ld + c0, ld, GS_BORDER, naug - r0, GS_NB, 0, 1,
+        if (gs_gemm(ctx, ctx->cur->sm, 2, Brow + c0, ld, Brow + c0, ld, Linv, GS_NB, GS_BORDER, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->cur->sm, 2, Brow + r0, ld, Brow + c0, ld, A + r0 * ld + c0, ld, GS_BORDER, naug - r0, GS_NB, 0, 1,
                     -1.0))
             return -1;
     }
@@ -473,14 +515,14 @@ int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, 
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
     if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
-    GS_CHECK(hipMemsetAsync(ctx->dinfo, 0, sizeof(int), ctx->sm));
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
+    GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
     if (gs_border_solve(ctx, L)) return -1;
     if (gs_finalize(ctx, L)) return -1;
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j) G[i * k + j] = ctx->hres[i * 16 + j];
-    *sum_log_diag = ctx->hres[256];
+        for (int j = 0; j < k; ++j) G[i * k + j] = ctx->cur->hres[i * 16 + j];
+    *sum_log_diag = ctx->cur->hres[256];
     return 0;
 }
 
@@ -491,12 +533,12 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
     if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
     if (gs_border_solve(ctx, L)) return -1;
     std::vector<double> rows((size_t)k * n);
     GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), L->A + L->np * L->ld, (size_t)L->ld * sizeof(double),
-                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     for (int64_t i = 0; i < n; ++i)
         for (int c = 0; c < k; ++c) W[i * k + c] = rows[(size_t)c * n + i];
     return 0;
@@ -523,35 +565,35 @@ int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc,
     char* base = (char*)ctx->scratch;
     double *dXs = (double*)(base + o_xs), *Bt = (double*)(base + o_bt), *dVW = (double*)(base + o_vw),
            *dSS = (double*)(base + o_ss), *dCov = (double*)(base + o_cv);
-    GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->cur->sm));
     const int64_t tr = (m + 127) / 128, tc = np / 128;
-    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->sm, Bt, ldb, dXs, ctx->dX, (int)m, (int)n,
+    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, Bt, ldb, dXs, ctx->dX, (int)m, (int)n,
                        (int)m, (int)np, d, *desc, 0.0, 0);
     GS_CHECK(hipGetLastError());
     for (int c = 0; c < L->T; ++c) {
         const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
         double* Linv = L->Linv + (size_t)c * GS_NB * GS_NB;
-        if (gs_gemm(ctx, ctx->sm, 1, Bt + c0, ldb, Bt + c0, ldb, Linv, GS_NB, m, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
-        if (gs_gemm(ctx, ctx->sm, 0, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
+        if (gs_gemm(ctx, ctx->cur->sm, 1, Bt + c0, ldb, Bt + c0, ldb, Linv, GS_NB, m, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->cur->sm, 0, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
             return -1;
     }
-    hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->sm, Bt, ldb, (int)m, (int)np, dSS);
+    hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
     GS_CHECK(hipGetLastError());
-    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->sm));
+    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     std::vector<double> vw;
     if (k > 0) {
         if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-        if (gs_set_border(ctx, ctx->sm, L, ctx->dZ, k)) return -1;
+        if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
         if (gs_border_solve(ctx, L)) return -1;
-        if (gs_gemm(ctx, ctx->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->cur->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
         vw.resize((size_t)m * 16);
-        GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->sm));
+        GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
     if (cov_out) {
-        if (gs_gemm(ctx, ctx->sm, 0, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
-        GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->sm));
+        if (gs_gemm(ctx, ctx->cur->sm, 0, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
+        GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     for (int64_t j = 0; j < m && k > 0; ++j)
         for (int c = 0; c < k; ++c) VtW[j * k + c] = vw[(size_t)j * 16 + c];
     return 0;
@@ -562,11 +604,11 @@ int gsum_mat_to_host(gsum_ctx* ctx, const gsum_mat* A, double* out) {
     GS_CHECK(hipSetDevice(ctx->device));
     const int64_t n = A->n;
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)n * n * sizeof(double))) return -1;
-    hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->sm, A->A, A->ld, (int)n,
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->cur->sm, A->A, A->ld, (int)n,
                        ctx->scratch, A->factored ? 1 : 0);
     GS_CHECK(hipGetLastError());
-    GS_CHECK(hipMemcpyAsync(out, ctx->scratch, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipMemcpyAsync(out, ctx->scratch, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
 }
 
@@ -576,8 +618,8 @@ void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A) {
     if (!A) return;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->sm);
-        (void)hipStreamSynchronize(ctx->sp);
+        (void)hipStreamSynchronize(ctx->cur->sm);
+        (void)hipStreamSynchronize(ctx->cur->sp);
     }
     gs_mat_release(A);
 }
@@ -585,16 +627,53 @@ void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A) {
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k) {
     if (!ctx) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
+    ctx->cur = &ctx->slots[0];
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
     if (gs_upload_X(ctx, X, n, d)) return -1;
     if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-    if (!ctx->ws || ctx->ws->n != n) {
-        GS_CHECK(hipStreamSynchronize(ctx->sm));
-        gs_mat_release(ctx->ws);
-        ctx->ws = nullptr;
-        if (gs_mat_alloc(ctx, n, &ctx->ws)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    return 0;
+}
+
+// enqueue one evaluation on the current slot (asynchronous: nothing waits on the host)
+static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double nugget) {
+    gs_slot* sl = ctx->cur;
+    if (!sl->ws || sl->ws->n != ctx->nX) {
+        GS_CHECK(hipStreamSynchronize(sl->sm));
+        gs_mat_release(sl->ws);
+        sl->ws = nullptr;
+        if (gs_mat_alloc(ctx, ctx->nX, &sl->ws)) return -1;
     }
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    gsum_mat* m = sl->ws;
+    GS_CHECK(hipEventRecord(sl->tev[0], sl->sm));
+    if (gs_build_into(ctx, sl->sm, m, desc, ctx->dX, ctx->dX_d, nugget, ctx->build_lower_only)) return -1;
+    if (gs_set_border(ctx, sl->sm, m, ctx->dZ, ctx->kZ)) return -1;
+    GS_CHECK(hipEventRecord(sl->tev[1], sl->sm));
+    if (gs_potrf(ctx, m)) return -1;
+    GS_CHECK(hipEventRecord(sl->tev[2], sl->sm));
+    if (gs_finalize(ctx, m)) return -1;
+    GS_CHECK(hipEventRecord(sl->tev[3], sl->sm));
+    m->factored = false;               // workspace: always rebuilt by the next evaluation
+    return 0;
+}
+
+// wait for the evaluation pending on a slot and copy its results out
+static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sld_out, int64_t* info_out) {
+    const int i = sl->pending, k = ctx->kZ;
+    if (i < 0) return 0;
+    GS_CHECK(hipStreamSynchronize(sl->sm));
+    for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = sl->hres[a * 16 + b];
+    sld_out[i] = sl->hres[256];
+    info_out[i] = (int64_t)sl->hres[257];
+    float ms = 0.f;
+    for (int s = 0; s < 3; ++s) {
+        GS_CHECK(hipEventElapsedTime(&ms, sl->tev[s], sl->tev[s + 1]));
+        ctx->timers[s] = ms;
+    }
+    GS_CHECK(hipEventElapsedTime(&ms, sl->tev[0], sl->tev[3]));
+    ctx->timers[3] = ms;
+    sl->pending = -1;
     return 0;
 }
 
@@ -602,34 +681,26 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
                       double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
-    if (!ctx->ws || !ctx->dX) GS_FAIL("gsum_set_inputs has not been called");
-    gsum_mat* m = ctx->ws;
-    const int k = ctx->kZ;
-    for (int i = 0; i < n_kernels; ++i) {
+    if (!ctx->dX) GS_FAIL("gsum_set_inputs has not been called");
+    for (int i = 0; i < n_kernels; ++i)
         if (gs_check_desc(ctx, &kernels[i], ctx->dX_d)) return -2;
-        GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
-        if (gs_build_into(ctx, ctx->sm, m, &kernels[i], ctx->dX, ctx->dX_d, nugget, ctx->build_lower_only)) return -1;
-        if (gs_set_border(ctx, ctx->sm, m, ctx->dZ, k)) return -1;
-        GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
-        if (gs_potrf(ctx, m)) return -1;
-        GS_CHECK(hipEventRecord(ctx->tev[2], ctx->sm));
-        if (gs_finalize(ctx, m)) return -1;
-        GS_CHECK(hipEventRecord(ctx->tev[3], ctx->sm));
-        GS_CHECK(hipStreamSynchronize(ctx->sm));
-        for (int a = 0; a < k; ++a)
-            for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = ctx->hres[a * 16 + b];
-        sld_out[i] = ctx->hres[256];
-        info_out[i] = (int64_t)ctx->hres[257];
-        m->factored = false;           // workspace: always rebuilt by the next evaluation
-        float ms = 0.f;
-        for (int s = 0; s < 3; ++s) {
-            GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[s], ctx->tev[s + 1]));
-            ctx->timers[s] = ms;
-        }
-        GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[3]));
-        ctx->timers[3] = ms;
+    const int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
+    if (gs_need_slots(ctx, S)) return -1;
+    int rc = 0;
+    for (int i = 0; i < n_kernels && !rc; ++i) {
+        gs_slot* sl = &ctx->slots[i % S];
+        ctx->cur = sl;
+        rc = gs_eval_harvest(ctx, sl, G_out, sld_out, info_out);     // frees the slot (evaluation i - S)
+        if (!rc) rc = gs_eval_enqueue(ctx, &kernels[i], nugget);
+        if (!rc) sl->pending = i;
     }
-    return 0;
+    for (int s = 0; s < S; ++s) {
+        ctx->cur = &ctx->slots[s];
+        int r2 = gs_eval_harvest(ctx, ctx->cur, G_out, sld_out, info_out);
+        if (!rc) rc = r2;
+    }
+    ctx->cur = &ctx->slots[0];
+    return rc;
 }
 
 int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
@@ -643,14 +714,19 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
     if (!ctx || !ms) return -2;
     for (int i = 0; i < n && i < 4; ++i) ms[i] = ctx->timers[i];
+    if (n > 4) {
+        GS_CHECK(hipSetDevice(ctx->device));
+        unsigned long long st[8] = {0};
+        GS_CHECK(hipMemcpy(st, ctx->dstamps, sizeof st, hipMemcpyDeviceToHost));
+        for (int i = 4; i < n && i < 9; ++i) ms[i] = (double)st[i - 4];
+    }
     return 0;
 }
 
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
     if (!ctx || !total_ms || !total_flops || !launches) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sp));
+    GS_CHECK(hipDeviceSynchronize());
     double ms_sum = 0.0, fl_sum = 0.0;
     for (auto& r : ctx->prof_recs) {
         float ms = 0.f;
@@ -675,26 +751,26 @@ int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, int32_t waves_per_simd, in
     unsigned long long* dst = (unsigned long long*)((char*)ctx->scratch + ob);
     auto launch = [&](int its) -> int {
         switch (n_acc) {
-            case 1: hipLaunchKernelGGL(k_probe_mfma<1>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
-            case 2: hipLaunchKernelGGL(k_probe_mfma<2>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
-            case 4: hipLaunchKernelGGL(k_probe_mfma<4>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
-            case 8: hipLaunchKernelGGL(k_probe_mfma<8>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
-            case 16: hipLaunchKernelGGL(k_probe_mfma<16>, dim3(blocks), dim3(256), 0, ctx->sm, ctx->scratch, its, dst); break;
+            case 1: hipLaunchKernelGGL(k_probe_mfma<1>, dim3(blocks), dim3(256), 0, ctx->cur->sm, ctx->scratch, its, dst); break;
+            case 2: hipLaunchKernelGGL(k_probe_mfma<2>, dim3(blocks), dim3(256), 0, ctx->cur->sm, ctx->scratch, its, dst); break;
+            case 4: hipLaunchKernelGGL(k_probe_mfma<4>, dim3(blocks), dim3(256), 0, ctx->cur->sm, ctx->scratch, its, dst); break;
+            case 8: hipLaunchKernelGGL(k_probe_mfma<8>, dim3(blocks), dim3(256), 0, ctx->cur->sm, ctx->scratch, its, dst); break;
+            case 16: hipLaunchKernelGGL(k_probe_mfma<16>, dim3(blocks), dim3(256), 0, ctx->cur->sm, ctx->scratch, its, dst); break;
             default: return -2;
         }
         return 0;
     };
     if (launch(64)) GS_FAIL("n_acc must be 1, 2, 4, 8 or 16");      // warm-up
     GS_CHECK(hipGetLastError());
-    GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
+    GS_CHECK(hipEventRecord(ctx->cur->tev[0], ctx->cur->sm));
     launch(iters);
     GS_CHECK(hipGetLastError());
-    GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
+    GS_CHECK(hipEventRecord(ctx->cur->tev[1], ctx->cur->sm));
     std::vector<unsigned long long> st((size_t)blocks * 8);
-    GS_CHECK(hipMemcpyAsync(st.data(), dst, sb, hipMemcpyDeviceToHost, ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipMemcpyAsync(st.data(), dst, sb, hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     float ms = 0.f;
-    GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[1]));
+    GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
     const double n_mfma = (double)iters * 16.0;   // per wave
     const double flops = (double)blocks * 4.0 * n_mfma * 2048.0;
     double cyc = 0.0, rt = 0.0;
@@ -713,13 +789,13 @@ int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps) {
     GS_CHECK(hipSetDevice(ctx->device));
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)bytes)) return -1;
     const int64_t nvec = bytes / 16;
-    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->sm, (gs_d2*)ctx->scratch, nvec);
-    GS_CHECK(hipEventRecord(ctx->tev[0], ctx->sm));
-    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->sm, (gs_d2*)ctx->scratch, nvec);
-    GS_CHECK(hipEventRecord(ctx->tev[1], ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->cur->sm, (gs_d2*)ctx->scratch, nvec);
+    GS_CHECK(hipEventRecord(ctx->cur->tev[0], ctx->cur->sm));
+    hipLaunchKernelGGL(k_probe_store, dim3(2048), dim3(256), 0, ctx->cur->sm, (gs_d2*)ctx->scratch, nvec);
+    GS_CHECK(hipEventRecord(ctx->cur->tev[1], ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     float ms = 0.f;
-    GS_CHECK(hipEventElapsedTime(&ms, ctx->tev[0], ctx->tev[1]));
+    GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
     *gbps = (double)(nvec * 16) / (ms * 1e-3) / 1e9;
     return 0;
 }
@@ -733,12 +809,12 @@ int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, ob + bb)) return -1;
     char* base = (char*)ctx->scratch;
     double *dC = (double*)base, *dA = (double*)(base + oa), *dB = (double*)(base + ob);
-    GS_CHECK(hipMemcpyAsync(dC, C, cb, hipMemcpyHostToDevice, ctx->sm));
-    GS_CHECK(hipMemcpyAsync(dA, A, ab, hipMemcpyHostToDevice, ctx->sm));
-    GS_CHECK(hipMemcpyAsync(dB, B, bb, hipMemcpyHostToDevice, ctx->sm));
-    if (gs_gemm(ctx, ctx->sm, cfg, dC, N, dA, K, dB, K, M, N, (int)K, tri, beta, sign)) return -1;
-    GS_CHECK(hipMemcpyAsync(C, dC, cb, hipMemcpyDeviceToHost, ctx->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->sm));
+    GS_CHECK(hipMemcpyAsync(dC, C, cb, hipMemcpyHostToDevice, ctx->cur->sm));
+    GS_CHECK(hipMemcpyAsync(dA, A, ab, hipMemcpyHostToDevice, ctx->cur->sm));
+    GS_CHECK(hipMemcpyAsync(dB, B, bb, hipMemcpyHostToDevice, ctx->cur->sm));
+    if (gs_gemm(ctx, ctx->cur->sm, cfg, dC, N, dA, K, dB, K, M, N, (int)K, tri, beta, sign)) return -1;
+    GS_CHECK(hipMemcpyAsync(C, dC, cb, hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
 }
 

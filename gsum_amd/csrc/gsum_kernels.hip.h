@@ -255,15 +255,10 @@ __device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8]
         }
         if (tr == jr) rb[tc] = vd[JB];          // pivot row of the diagonal inverse being built
         __syncthreads();
+        // every LDS read of the step is issued before the pivot's dependent rsqrt chain starts
         const double p = cb[jr * 8 + JB];       // A_jj
-        if (!(p > thr[j])) {                    // same value in every thread: uniform exit (catches NaN)
-            *fail_col = j;
-            return false;
-        }
-        const double r = gs_rsqrt_nr(p);
-        double dj = p * r;                                       // sqrt(p) ...
-        dj = __builtin_fma(__builtin_fma(-dj, dj, p), 0.5 * r, dj);   // ... corrected to ~0.5 ulp
-        if (threadIdx.x == 0) dbuf[j] = dj;
+        const double tj = thr[j];
+        const double rbv = rb[tc];
         double cr[8], cc[8];
         {
             const gs_d2* pr = reinterpret_cast<const gs_d2*>(cb + tr * 8);
@@ -275,6 +270,14 @@ __device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8]
                 cc[2 * q] = y[0]; cc[2 * q + 1] = y[1];
             }
         }
+        if (!(p > tj)) {                        // same value in every thread: uniform exit (catches NaN)
+            *fail_col = j;
+            return false;
+        }
+        const double r = gs_rsqrt_nr(p);
+        double dj = p * r;                                       // sqrt(p) ...
+        dj = __builtin_fma(__builtin_fma(-dj, dj, p), 0.5 * r, dj);   // ... corrected to ~0.5 ulp
+        if (threadIdx.x == 0) dbuf[j] = dj;
         double li[8], lk[8];
 #pragma unroll
         for (int ii = JB; ii < 8; ++ii) li[ii] = cr[ii] * r;
@@ -283,7 +286,7 @@ __device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8]
         // inside the active sub-block only rows / columns beyond j take part
         li[JB] = (tr > jr) ? li[JB] : 0.0;
         lk[JB] = (tc > jr) ? lk[JB] : 0.0;
-        const double vk = (tc <= jr) ? rb[tc] * r : 0.0;          // scaled pivot row of D^-1
+        const double vk = (tc <= jr) ? rbv * r : 0.0;             // scaled pivot row of D^-1
         // trailing update of the block:  A_ik -= l_ij l_kj   (i, k > j)
 #pragma unroll
         for (int ii = JB; ii < 8; ++ii)
@@ -342,7 +345,8 @@ __device__ __forceinline__ void gs_trtri_col(const double* Lg, int64_t ld, const
 // info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
 // diag0: the block's 128 original diagonal entries (before any trailing update).
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
-                                                     int* info, int col0, const double* diag0) {
+                                                     int* info, int col0, const double* diag0,
+                                                     unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) double mail[256];
     __shared__ double rmail[32];
     __shared__ double dbuf[128];
@@ -350,6 +354,12 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
     __shared__ double Dv[128 * GS_DV_STR];
     if (*info != 0) return;                    // an earlier block already failed (uniform)
     const int t = threadIdx.x;
+    // optional phase stamps (diagnostics only: own buffer, never feeds a result)
+    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
+    if (stamps) {
+        st0 = __builtin_amdgcn_s_memtime();
+        sr0 = __builtin_amdgcn_s_memrealtime();
+    }
     if (t < 128) {
         const double d0 = diag0[t];
         thr[t] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
         vd[ii] = (tr == tc) ? 1.0 : 0.0;
     }
     __syncthreads();
+    if (stamps) st1 = __builtin_amdgcn_s_memtime();
     int fail_col = -1;
     bool ok = gs_diag_steps<0>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (ok) ok = gs_diag_steps<1>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
     }
     __threadfence_block();
     __syncthreads();
+    if (stamps) st2 = __builtin_amdgcn_s_memtime();
     if (t < 128) dbuf[t] = log(dbuf[t]);
     // phase 2: wave w builds block columns w and 7-w of L^-1
     const int lane = t & 63;
@@ -410,6 +422,14 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
         double sl = 0.0;
         for (int j = 0; j < 128; ++j) sl += dbuf[j];
         logdet[0] = sl;
+        if (stamps) {
+            const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
+            stamps[0] = st1 - st0;      // prologue (loads)
+            stamps[1] = st2 - st1;      // phase 1 (column loop + store)
+            stamps[2] = st3 - st2;      // phase 2 (block inverse)
+            stamps[3] = st3 - st0;      // total shader cycles
+            stamps[4] = sr3 - sr0;      // total 100 MHz ticks
+        }
     }
 }
 

@@ -58,7 +58,7 @@ typedef struct {
 int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
-/* knobs: "lookahead" (0/1), "build_lower_only" (0/1), "profile_gemm" (0/1).  <0 for an unknown name. */
+/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
@@ -114,14 +114,19 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
                    int64_t* info_out);
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
- * gsum_lml_resident evaluates descriptors against them (what bench.py times). */
+ * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one
+ * call are independent, so up to "batch_slots" of them are kept in flight on separate stream pairs and
+ * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
+ * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs. */
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event times (ms) of the last fused evaluation on the library's own streams:
- * ms[0] K build, ms[1] Cholesky (incl. fused forward solve), ms[2] finalize + D2H, ms[3] total. */
+ * ms[0] K build, ms[1] Cholesky (incl. fused forward solve), ms[2] finalize + D2H, ms[3] total.
+ * With option "diag_stamps" = 1 and n > 4: ms[4..8] = shader-cycle stamps of the last diagonal-block
+ * kernel {prologue, column loop, block inverse, total} and its total in 100 MHz ticks. */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
 /* With option "profile_gemm" = 1 every launch of the 128x128-tile MFMA GEMM (the trailing SYRK and the
  * look-ahead column of the Cholesky) is bracketed by HIP events on the stream it is launched on.  This

@@ -21,6 +21,7 @@ for k, v in out["mfma_f64"].items():
 out["hbm_write_gbps"] = [ctx.probe_hbm_write(1 << 30) for _ in range(3)]
 print(out, flush=True)
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+ctx.set_option("diag_stamps", 1)
 for n, r in ((128, 4), (2048, 4), (4096, 6), (8192, 6)):
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
@@ -38,12 +39,33 @@ for n, r in ((128, 4), (2048, 4), (4096, 6), (8192, 6)):
                 tm["wall_ms"] = wall
                 ts.append(tm)
             best = min(ts, key=lambda t: t["total_ms"])
+            if n == 128:
+                print("diag stamps", ctx.diag_stamps(), flush=True)
             best["chol_tflops"] = n ** 3 / 3 / (best["potrf_ms"] * 1e-3) / 1e12
             best["build_gbps_8n2"] = 8.0 * n * n / (best["build_ms"] * 1e-3) / 1e9
             out[f"n{n}_la{la}_lower{lower}"] = best
             print(n, la, lower, {k: round(v, 4) for k, v in best.items()}, int(info[0]), flush=True)
 ctx.set_option("lookahead", 1)
 ctx.set_option("build_lower_only", 1)
+# batched evaluations, several in flight
+n, r = 8192, 6
+X = 0.1 * np.arange(n)[:, None]
+Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
+ctx.set_inputs(X, Z)
+for la in (1, 0):
+    ctx.set_option("lookahead", la)
+    for slots in (1, 2, 3, 4, 6, 8):
+        ctx.set_option("batch_slots", slots)
+        ctx.lml_resident([desc] * slots, 1e-10)
+        nb = 16
+        t0 = time.perf_counter()
+        G, sld, info = ctx.lml_resident([desc] * nb, 1e-10)
+        dt = time.perf_counter() - t0
+        out[f"batch_la{la}_slots{slots}"] = dict(ms_per_eval=dt / nb * 1e3, evals_per_s=nb / dt,
+                                                 chol_tflops_aggregate=n ** 3 / 3 * nb / dt / 1e12)
+        print("batch", la, slots, out[f"batch_la{la}_slots{slots}"], bool((G == G[0]).all()), flush=True)
+ctx.set_option("lookahead", 1)
+ctx.set_option("batch_slots", 4)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "probe.json"), "w") as f:
     json.dump(out, f, indent=1)
