@@ -67,6 +67,8 @@ PROTOTYPES = {
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
+    "gsum_bench_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp]),
+    "gsum_debug_gemm_phases": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int32, C.c_double]),
 }
@@ -291,6 +293,12 @@ class HipContext:
         self._check(self._lib.gsum_timers(self._h, _ptr(ms), 4))
         return dict(build_ms=ms[0], potrf_ms=ms[1], finalize_ms=ms[2], total_ms=ms[3])
 
+    def host_enqueue_ms(self) -> float:
+        """Host wall time spent enqueuing the most recent evaluation (launch-overhead diagnostics)."""
+        v = np.zeros(10)
+        self._check(self._lib.gsum_timers(self._h, _ptr(v), 10))
+        return float(v[9])
+
     def diag_stamps(self):
         """Shader-cycle stamps of the last diagonal-block kernel (needs option diag_stamps=1)."""
         v = np.zeros(9)
@@ -315,6 +323,17 @@ class HipContext:
         v = C.c_double(0)
         self._check(self._lib.gsum_probe_hbm_write(self._h, nbytes, C.byref(v)))
         return float(v.value)
+
+    def bench_gemm_nt(self, cfg, M, N, K, tri=False, lda=None, reps=5):
+        """(TFLOP/s, us per launch) of the MFMA tile kernel on device-resident random operands."""
+        v = np.zeros(2)
+        self._check(self._lib.gsum_bench_gemm_nt(self._h, cfg, int(tri), M, N, K, lda or K, reps, _ptr(v)))
+        return float(v[0]), float(v[1])
+
+    def debug_gemm_phases(self, M, K, lda=None):
+        v = np.zeros(5)
+        self._check(self._lib.gsum_debug_gemm_phases(self._h, M, K, lda or K, _ptr(v)))
+        return dict(zip(("prologue", "load_issue", "mfma", "wait_store", "barrier"), v.tolist()))
 
     def debug_gemm_nt(self, cfg, Cm, A, B, tri=False, beta=1, sign=-1.0):
         Cm, A, B = _f64(Cm).copy(), _f64(A), _f64(B)

@@ -3,6 +3,7 @@
 #include "gsum_kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,12 @@ struct gsum_ctx {
     struct ProfRec { int e0, e1; double flops; };
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
+    // XCD-aware tile orders of the lower-triangular SYRK, one per number of tile rows (device arrays)
+    std::vector<int*> tile_maps;
+    std::vector<int> tile_map_blocks;
+    int xcd_swizzle = 1;
+    int bulk_cfg = 0;                // tile configuration of the bulk trailing update (0 or 3; 0 measured faster)
+    double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
 };
 
 static std::string g_init_error;
@@ -90,6 +97,53 @@ static int gs_reserve(gsum_ctx* ctx, double** p, size_t* cap, size_t bytes) {
     return 0;
 }
 
+// ---- XCD-aware tile order for the lower-triangular update ------------------------------------------
+// Tiles (bm >= bn) of a Tt x Tt tile triangle are listed patch by patch (4x4 tiles, patches row-major along
+// super-rows) and the list is cut into 8 contiguous, equally long segments.  Workgroup b takes entry
+// (b >> 3) of segment (b & 7): the hardware deals consecutive workgroups round-robin over the 8 XCDs, so
+// each XCD walks one segment and the ~64 tiles it has in flight share 4 + 16 panel blocks through its L2
+// (6.4x reuse instead of ~1x for row-major order).  Placement only affects speed, never results.
+static int gs_tile_map(gsum_ctx* ctx, int M, int BM, int BN, const int** map, int* blocks) {
+    // tiles are BM x BN; a tile belongs to the update if it touches the lower triangle (incl. diagonal)
+    const int Tm = (M + BM - 1) / BM, Tn = (M + BN - 1) / BN;
+    const int key = Tn * 2 + (BM == BN ? 0 : 1);     // Tn (128-wide tile columns) fixes Tm for either shape
+    if ((int)ctx->tile_maps.size() <= key) {
+        ctx->tile_maps.resize(key + 1, nullptr);
+        ctx->tile_map_blocks.resize(key + 1, 0);
+    }
+    if (!ctx->tile_maps[key]) {
+        std::vector<int> tiles;      // (bm, bn) pairs in patch order
+        const int PM = 512 / BM, PN = 512 / BN;          // one patch covers a 512 x 512 region
+        for (int I = 0; I * PM < Tm; ++I)
+            for (int J = 0; J * PN < Tn; ++J)
+                for (int bm = I * PM; bm < std::min(Tm, (I + 1) * PM); ++bm)
+                    for (int bn = J * PN; bn < std::min(Tn, (J + 1) * PN); ++bn)
+                        if ((int64_t)bn * BN <= (int64_t)bm * BM + BM - 1) {
+                            tiles.push_back(bm);
+                            tiles.push_back(bn);
+                        }
+        const int nt = (int)tiles.size() / 2;
+        const int L = (nt + 7) / 8;
+        std::vector<int> h((size_t)L * 8 * 2, -1);
+        for (int x = 0; x < 8; ++x) {
+            const int lo = (int)((int64_t)nt * x / 8), hi = (int)((int64_t)nt * (x + 1) / 8);
+            for (int i = lo; i < hi; ++i) {
+                const int bb = (i - lo) * 8 + x;
+                h[2 * bb] = tiles[2 * i];
+                h[2 * bb + 1] = tiles[2 * i + 1];
+            }
+        }
+        int* d = nullptr;
+        GS_CHECK(hipMalloc((void**)&d, h.size() * sizeof(int)));
+        GS_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        ctx->tile_maps[key] = d;
+        ctx->tile_map_blocks[key] = L * 8;
+    }
+    *map = ctx->tile_maps[key];
+    *blocks = ctx->tile_map_blocks[key];
+    return 0;
+}
+
 // ---- GEMM launcher ----------------------------------------------------------------------------
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda,
@@ -105,15 +159,21 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
         attr_set = true;
     }
     int64_t blocks;
+    const int* tmap = nullptr;
     if (tri) {
-        if (M != N || BM != BN) GS_FAIL("gemm: tri mode needs a square C and square tiles");
+        if (M != N) GS_FAIL("gemm: tri mode needs a square C");
         int64_t T = (M + BM - 1) / BM;
         blocks = T * (T + 1) / 2;
+        if (BM != BN || (ctx->xcd_swizzle && T >= 8)) {
+            int nb = 0;
+            if (gs_tile_map(ctx, (int)M, BM, BN, &tmap, &nb)) return -1;
+            blocks = nb;
+        }
     } else {
         blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                       beta, sign);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), shmem, s, C, ldc, A, lda, B, ldb, (int)M,
+                       (int)N, K, tri, beta, sign, tmap, (unsigned long long*)nullptr);
     GS_CHECK(hipGetLastError());
     return 0;
 }
@@ -121,9 +181,10 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
 // cfg 0: 128x128 tile (2x2 waves of 64x64)   — trailing SYRK / big updates
 // cfg 1:  32x128 tile (1x4 waves of 32x32)   — panel TRSM against the explicit block inverse
 // cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
+// cfg 3: 256x128 tile (4x2 waves of 64x64, 512 threads, one workgroup per CU) — bulk trailing update
 static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                    const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
-    if (cfg == 0 && ctx->profile_gemm && M > 0 && N > 0) {
+    if ((cfg == 0 || cfg == 3) && ctx->profile_gemm && M > 0 && N > 0) {
         while (ctx->prof_pool.size() < ctx->prof_next + 2) {
             hipEvent_t ev;
             GS_CHECK(hipEventCreate(&ev));
@@ -132,7 +193,8 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
         const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
         ctx->prof_next += 2;
         GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
-        int rc = gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        int rc = cfg == 0 ? gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign)
+                          : gs_launch_gemm<4, 4, 4, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
         // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
         const double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
@@ -143,6 +205,7 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
         case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 1: return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 2: return gs_launch_gemm<1, 4, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        case 3: return gs_launch_gemm<4, 4, 4, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
     }
     GS_FAIL("gemm: unknown tile configuration");
 }
@@ -211,64 +274,89 @@ static int gs_set_border(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const double
     return 0;
 }
 
-// ---- K2: blocked right-looking Cholesky with look-ahead -----------------------------------------
-// Step k (block column c0 = 128k, rows below r0 = c0 + 128, border included):
-//   diag   : L_kk, L_kk^-1                      (k_potrf_diag, 1 workgroup)
-//   trsm   : P = A[r0:, c0:c0+128] L_kk^-T      (MFMA GEMM against the explicit inverse, in place)
-//   la     : A[r0:, r0:r0+128] -= P P_k+1^T     (next panel's block column only)
-//   bulk   : A[r1:, r1:] -= P P^T (lower tiles), r1 = r0 + 128     (everything else)
-// With look-ahead, diag/trsm/la of step k+1 run on the panel stream while bulk(k) fills the GPU
-// from the main stream.  Both streams are joined on the main stream at the end.
+// ---- K2: two-level blocked right-looking Cholesky with look-ahead --------------------------------
+// Outer step = a 256-column panel made of two 128-column sub-steps (block columns b, b+1):
+//   diag(b)   : L_bb, L_bb^-1                                  (k_potrf_diag, one workgroup)
+//   trsm(b)   : rows below  <-  rows * L_bb^-T                 (MFMA GEMM against the explicit inverse)
+//   col(b+1)  : block column b+1 -= P_b P_b[b+1]^T             (K = 128, only 128 columns wide)
+//   diag(b+1), trsm(b+1)
+//   la        : next panel's 256 columns -= P P[next]^T        (K = 256)   } P = both sub-panels,
+//   bulk      : everything right of it  -= P P^T, lower tiles  (K = 256)   } 256 contiguous columns
+// The trailing matrix is read and written once per 256 eliminated columns: K = 256 doubles the flops
+// per byte of C traffic over a plain nb = 128 sweep (the K = 128 update was memory-side bound).  With
+// look-ahead, everything but `bulk` runs on the high-priority panel stream, so the panel chain of step
+// s+1 overlaps bulk(s).  Both streams are joined on the main stream at the end.
 static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int T = m->T;
-    if ((int)ctx->cur->evP.size() < T + 1) {
-        size_t old = ctx->cur->evP.size();
-        ctx->cur->evP.resize(T + 1);
-        ctx->cur->evM.resize(T + 1);
-        for (size_t i = old; i < ctx->cur->evP.size(); ++i) {
-            GS_CHECK(hipEventCreateWithFlags(&ctx->cur->evP[i], hipEventDisableTiming));
-            GS_CHECK(hipEventCreateWithFlags(&ctx->cur->evM[i], hipEventDisableTiming));
+    gs_slot* sl = ctx->cur;
+    if ((int)sl->evP.size() < T + 1) {
+        size_t old = sl->evP.size();
+        sl->evP.resize(T + 1);
+        sl->evM.resize(T + 1);
+        for (size_t i = old; i < sl->evP.size(); ++i) {
+            GS_CHECK(hipEventCreateWithFlags(&sl->evP[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evM[i], hipEventDisableTiming));
         }
     }
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
-    GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
-    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, ctx->cur->sm, A, ld, (int)m->np, m->diag0);
+    GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
+    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, sl->sm, A, ld, (int)m->np, m->diag0);
     GS_CHECK(hipGetLastError());
     const bool la = ctx->lookahead != 0;
-    hipStream_t sp = la ? ctx->cur->sp : ctx->cur->sm;
+    hipStream_t sp = la ? sl->sp : sl->sm;
+    hipStream_t sm = sl->sm;
     if (la) {
-        GS_CHECK(hipEventRecord(ctx->cur->evFork, ctx->cur->sm));
-        GS_CHECK(hipStreamWaitEvent(sp, ctx->cur->evFork, 0));
+        GS_CHECK(hipEventRecord(sl->evFork, sm));
+        GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
     }
-    for (int k = 0; k < T; ++k) {
-        const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
-        const int64_t mrest = naug - r0;     // rows below the diagonal block, border included (>= 16)
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    int prev = -1;                                   // outer step whose bulk update is still in flight
+    for (int k = 0; k < T; k += 2) {
+        const bool two = k + 1 < T;
+        const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
+        const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
+        const int Kp = two ? 2 * GS_NB : GS_NB;
+        // ---- sub-step a
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k,
-                           ctx->cur->dinfo, (int)c0, m->diag0 + c0, ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k, sl->dinfo,
+                           (int)c0, m->diag0 + c0, stamps);
         GS_CHECK(hipGetLastError());
-        // panel: rows r0.., columns c0..c0+127  <-  panel * Linv^T   (in place)
-        double* P = A + r0 * ld + c0;
-        if (gs_gemm(ctx, sp, 1, P, ld, P, ld, Linv, GS_NB, mrest, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
+        if (gs_gemm(ctx, sp, 1, Pa, ld, Pa, ld, Linv, GS_NB, naug - c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (two) {
+            // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
+            if (gs_gemm(ctx, sp, 1, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            double* Linv1 = Linv + GS_NB * GS_NB;
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c1 * ld + c1, ld, Linv1, m->logdet + k + 1,
+                               sl->dinfo, (int)c1, m->diag0 + c1, stamps);
+            GS_CHECK(hipGetLastError());
+            double* Pb = A + r2 * ld + c1;
+            if (gs_gemm(ctx, sp, 1, Pb, ld, Pb, ld, Linv1, GS_NB, naug - r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        }
+        // ---- trailing update with the whole panel: rows r2.., columns c0..c0+Kp-1
+        double* P = A + r2 * ld + c0;
+        const int64_t mrest = naug - r2;            // >= 16 (the border)
         if (!la) {
-            if (gs_gemm(ctx, sp, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, ctx->bulk_cfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
             continue;
         }
-        GS_CHECK(hipEventRecord(ctx->cur->evP[k], sp));
-        if (k + 1 < T) {
-            // look-ahead column: needs bulk(k-1) to have finished its tiles of this block column
-            if (k > 0) GS_CHECK(hipStreamWaitEvent(sp, ctx->cur->evM[k - 1], 0));
-            if (gs_gemm(ctx, sp, 1, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            const int64_t r1 = r0 + GS_NB, m1 = naug - r1;
-            double* P1 = A + r1 * ld + c0;
-            GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evP[k], 0));
-            if (gs_gemm(ctx, ctx->cur->sm, 0, A + r1 * ld + r1, ld, P1, ld, P1, ld, m1, m1, GS_NB, 1, 1, -1.0)) return -1;
-            GS_CHECK(hipEventRecord(ctx->cur->evM[k], ctx->cur->sm));
+        GS_CHECK(hipEventRecord(sl->evP[k], sp));
+        if (r2 < m->np) {
+            const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
+            // look-ahead columns: need the previous bulk update to have finished with them
+            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evM[prev], 0));
+            if (gs_gemm(ctx, sp, 1, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+            const int64_t r3 = r2 + wn, m3 = naug - r3;
+            double* P3 = A + r3 * ld + c0;
+            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
+            if (gs_gemm(ctx, sm, ctx->bulk_cfg, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(sl->evM[k], sm));
+            prev = k;
         } else {
-            // last block column: only the 16x16 corner is left
-            GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evP[k], 0));
-            if (gs_gemm(ctx, ctx->cur->sm, 0, A + r0 * ld + r0, ld, P, ld, P, ld, mrest, mrest, GS_NB, 1, 1, -1.0)) return -1;
+            // last panel: only the 16x16 corner (the Gram matrix) is left
+            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
+            if (gs_gemm(ctx, sm, 0, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
         }
     }
     m->factored = true;
@@ -369,6 +457,8 @@ void gsum_destroy(gsum_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
     for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
+    for (auto d : ctx->tile_maps)
+        if (d) (void)hipFree(d);
     delete ctx;
 }
 
@@ -380,6 +470,8 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
     else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
+    else if (!strcmp(name, "xcd_swizzle")) ctx->xcd_swizzle = (int)value;
+    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 3) ? 3 : 0;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
@@ -638,6 +730,11 @@ int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const 
 // enqueue one evaluation on the current slot (asynchronous: nothing waits on the host)
 static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double nugget) {
     gs_slot* sl = ctx->cur;
+    const auto h0 = std::chrono::steady_clock::now();
+    struct HostTimer {
+        gsum_ctx* c; std::chrono::steady_clock::time_point t0;
+        ~HostTimer() { c->host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    } host_timer{ctx, h0};
     if (!sl->ws || sl->ws->n != ctx->nX) {
         GS_CHECK(hipStreamSynchronize(sl->sm));
         gs_mat_release(sl->ws);
@@ -719,6 +816,7 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
         unsigned long long st[8] = {0};
         GS_CHECK(hipMemcpy(st, ctx->dstamps, sizeof st, hipMemcpyDeviceToHost));
         for (int i = 4; i < n && i < 9; ++i) ms[i] = (double)st[i - 4];
+        if (n > 9) ms[9] = ctx->host_enqueue_ms;
     }
     return 0;
 }
@@ -797,6 +895,66 @@ int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps) {
     float ms = 0.f;
     GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
     *gbps = (double)(nvec * 16) / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// diagnostic: phase stamps of the 128x128-tile kernel on a square SYRK launch; out5 = mean shader cycles per
+// wave spent in {prologue, load issue, MFMA+fragment reads, vmcnt wait + LDS stores, barrier}
+int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, double* out5) {
+    if (!ctx || !out5 || M <= 0 || K <= 0 || lda < K) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const int64_t T = (M + 127) / 128, blocks = T * (T + 1) / 2;
+    const size_t cb = (size_t)M * M * 8, ab = (size_t)M * lda * 8, sb = (size_t)blocks * 4 * 5 * 8;
+    const size_t oa = (cb + 255) / 256 * 256, os = oa + (ab + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, os + sb)) return -1;
+    char* base = (char*)ctx->scratch;
+    double *dC = (double*)base, *dA = (double*)(base + oa);
+    unsigned long long* dS = (unsigned long long*)(base + os);
+    hipStream_t s = ctx->cur->sm;
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dC, (int64_t)(cb / 8), 1u);
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dA, (int64_t)(ab / 8), 2u);
+    auto kern = k_gemm_nt<4, 4, 2, 2, true>;
+    const size_t shmem = 2 * (size_t)256 * GS_LSTR * sizeof(double);
+    GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    for (int rep = 0; rep < 2; ++rep)
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, s, dC, M, dA, lda, dA, lda, (int)M, (int)M, (int)K, 1, 1,
+                           -1.0, (const int*)nullptr, dS);
+    GS_CHECK(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)blocks * 20);
+    GS_CHECK(hipMemcpyAsync(h.data(), dS, sb, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < 5; ++i) out5[i] = 0.0;
+    for (size_t wv = 0; wv < (size_t)blocks * 4; ++wv)
+        for (int i = 0; i < 5; ++i) out5[i] += (double)h[wv * 5 + i];
+    for (int i = 0; i < 5; ++i) out5[i] /= (double)(blocks * 4);
+    return 0;
+}
+
+int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int32_t reps, double* out2) {
+    if (!ctx || !out2 || M <= 0 || N <= 0 || K <= 0 || reps <= 0 || lda < K) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const size_t cb = (size_t)M * N * 8, ab = (size_t)M * lda * 8, bb = (size_t)N * lda * 8;
+    const size_t oa = (cb + 255) / 256 * 256, ob = oa + (ab + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, ob + bb)) return -1;
+    char* base = (char*)ctx->scratch;
+    double *dC = (double*)base, *dA = (double*)(base + oa), *dB = (double*)(base + ob);
+    hipStream_t s = ctx->cur->sm;
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dC, (int64_t)(cb / 8), 1u);
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dA, (int64_t)(ab / 8), 2u);
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dB, (int64_t)(bb / 8), 3u);
+    const double* Bop = tri ? dA : dB;       // SYRK: both operands are the same panel
+    if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, 1, -1.0)) return -1;   // warm-up
+    GS_CHECK(hipEventRecord(ctx->cur->tev[0], s));
+    for (int r = 0; r < reps; ++r)
+        if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, 1, -1.0)) return -1;
+    GS_CHECK(hipEventRecord(ctx->cur->tev[1], s));
+    GS_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
+    const double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
+    out2[0] = fl * reps / (ms * 1e-3) / 1e12;
+    out2[1] = ms * 1e3 / reps;
     return 0;
 }
 

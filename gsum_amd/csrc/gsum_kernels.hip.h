@@ -22,7 +22,8 @@
 #define GS_NB 128
 #define GS_BORDER 16
 #define GS_KC 16                  // K chunk staged through LDS (16 doubles = one 128-B line per row)
-#define GS_LSTR (GS_KC + 2)       // padded LDS row stride: conflict-free ds_read_b64 fragment reads
+#define GS_LSTR (GS_KC + 1)       // odd LDS row stride (17 doubles): the compiler pairs fragment reads into
+                                  // ds_read2_b64, which banks mod 32 dwords -> rows 2 dwords apart, no conflicts
 
 typedef double gs_d4 __attribute__((ext_vector_type(4)));
 typedef double gs_d2 __attribute__((ext_vector_type(2)));
@@ -436,31 +437,39 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // ------------------------------------------------------------------------------------------------
 // K2b: C (+)= sign * A * B^T  on fp64 MFMA.   A: M x K, B: N x K (both row-major, K contiguous — the
 // shape every step of a row-major lower Cholesky produces), C: M x N.
-//   - 4 waves per workgroup, wave tile (WM*16) x (WN*16) of v_mfma_f64_16x16x4_f64 accumulators;
+//   - 4 or 8 waves per workgroup, wave tile (WM*16) x (WN*16) of v_mfma_f64_16x16x4_f64 accumulators;
 //   - K is staged 16 doubles (one 128-B line per row) at a time: global -> registers -> LDS, two LDS
 //     stages, one barrier per chunk; the next chunk's global loads are in flight during the MFMAs;
-//   - fragment reads are ds_read_b64 at row stride 18 doubles: conflict-free for the A/B lane map
-//     (lane l holds [row l&15][k l>>4]);
+//   - fragment reads at row stride 17 doubles: conflict-free for the A/B lane map (lane l holds
+//     [row l&15][k l>>4]) under ds_read2_b64's 32-bank mapping (stride 18 measured 40% conflict cycles);
 //   - rows >= M / cols >= N are clamped on load and predicated on store, so the 16-row border tile
 //     and the padded tail run through the same code;
-//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix);
+//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix), optionally in the
+//     XCD-aware order of a host-built tile map;
 //   - sign must be +1 or -1 (it multiplies the staged A operand exactly).
 // In-place use (C == A, TRSM against an explicit inverse) is safe when one tile spans all N = K
 // columns: every global load of the tile's rows is finished before the epilogue stores.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
                                                      const double* B, int64_t ldb, int M, int N, int K,
-                                                     int tri, int beta, double sign) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+                                                     int tri, int beta, double sign, const int* tile_map,
+                                                     unsigned long long* stamps = nullptr) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;          // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
     constexpr int A_VECS = BM * (GS_KC / 2), B_VECS = BN * (GS_KC / 2);
-    constexpr int A_IT = (A_VECS + 255) / 256, B_IT = (B_VECS + 255) / 256;
+    constexpr int A_IT = (A_VECS + NT - 1) / NT, B_IT = (B_VECS + NT - 1) / NT;
     extern __shared__ double lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
-    if (tri) {
+    if (tile_map) {
+        // XCD-aware order (host-built, gs_tile_map): workgroups b, b+8, b+16 ... land on one XCD and walk
+        // a contiguous run of 4x4-tile patches, so the panel blocks they share are served by that XCD's L2
+        bm = tile_map[2 * blockIdx.x];
+        bn = tile_map[2 * blockIdx.x + 1];
+        if (bm < 0) return;               // padding entry: the whole workgroup leaves before any barrier
+    } else if (tri) {
         const int bid = blockIdx.x;
         bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
         while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
@@ -491,47 +500,75 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
         }
 
     gs_d2 ra[A_IT], rb[B_IT];
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int vv = t + it * 256;
+    // one 16-B global load of the staging set: i < A_IT -> A tile, else B tile
+    auto gload_one = [&](int kc, int i) {
+        if (i < A_IT) {
+            const int vv = t + i * NT;
             if (vv < A_VECS) {
                 int row = m0 + (vv >> 3);
                 row = row < M ? row : M - 1;
-                ra[it] = *reinterpret_cast<const gs_d2*>(A + (int64_t)row * lda + kc * GS_KC + 2 * (vv & 7));
+                ra[i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)row * lda + kc * GS_KC + 2 * (vv & 7));
             }
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int vv = t + it * 256;
+        } else {
+            const int vv = t + (i - A_IT) * NT;
             if (vv < B_VECS) {
                 int row = n0 + (vv >> 3);
                 row = row < N ? row : N - 1;
-                rb[it] = *reinterpret_cast<const gs_d2*>(B + (int64_t)row * ldb + kc * GS_KC + 2 * (vv & 7));
+                rb[i - A_IT] = *reinterpret_cast<const gs_d2*>(B + (int64_t)row * ldb + kc * GS_KC + 2 * (vv & 7));
             }
         }
+    };
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < A_IT + B_IT; ++i) gload_one(kc, i);
     };
     auto swrite = [&](int stage) {
         double* sA = lds + stage * (BM + BN) * GS_LSTR;
         double* sB = sA + BM * GS_LSTR;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int vv = t + it * 256;
-            if (vv < A_VECS) *reinterpret_cast<gs_d2*>(sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7)) = ra[it] * sign;
+            const int vv = t + it * NT;
+            if (vv < A_VECS) {          // rows are only 8-B aligned at an odd stride: two 8-byte stores
+                double* q = sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
+                q[0] = ra[it][0] * sign;
+                q[1] = ra[it][1] * sign;
+            }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int vv = t + it * 256;
-            if (vv < B_VECS) *reinterpret_cast<gs_d2*>(sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7)) = rb[it];
+            const int vv = t + it * NT;
+            if (vv < B_VECS) {
+                double* q = sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
+                q[0] = rb[it][0];
+                q[1] = rb[it][1];
+            }
         }
     };
 
     const int nk = K / GS_KC;
+    // STAMP build only (diagnostics, separate instantiation): shader-cycle sums of the loop phases
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
+    auto stamp = [&](int i) {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long now;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (i >= 0) ph[i] += now - tq;
+            tq = now;
+        }
+    };
+    stamp(-1);
     gload(0);
     swrite(0);
     __syncthreads();
+    stamp(0);                                   // prologue: C loads issued, first chunk staged
     for (int c = 0; c < nk; ++c) {
+        // Next chunk's operands: issued in one burst ahead of the MFMAs.  (Spreading them over the k-steps
+        // was measured and is no better: under load each load instruction blocks in-order issue for ~300
+        // cycles wherever it sits; the CU's vector-memory path, ~7-10 B/clk, is the ceiling for this tile.)
         if (c + 1 < nk) gload(c + 1);
+        stamp(1);                               // global load issue
         const double* sA = lds + (c & 1) * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
         const double* sB = lds + (c & 1) * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
 #pragma unroll
@@ -547,8 +584,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* C, int64_t ldc, cons
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        stamp(2);                               // fragment reads + MFMAs
         if (c + 1 < nk) swrite((c + 1) & 1);
+        stamp(3);                               // wait for the global loads, LDS stores
         __syncthreads();
+        stamp(4);                               // barrier
+    }
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((int64_t)blockIdx.x * (NT / 64) + w) * 5;
+        for (int i = 0; i < 5; ++i) o[i] = ph[i];
     }
     // accumulator map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
@@ -604,6 +648,18 @@ __global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int
 }
 
 // ---- probes ------------------------------------------------------------------------------------
+// pseudo-random fill in [-1, 1) (integer hash), so benchmark operands are not zeros (DVFS reads high on zeros)
+__global__ __launch_bounds__(256) void k_fill_random(double* p, int64_t n, unsigned seed) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    }
+}
+
 // NACC independent accumulators held in VGPRs (inline asm: hipcc would otherwise shuttle them through
 // AGPRs every iteration), back-to-back v_mfma_f64_16x16x4_f64.  NACC = 1 measures dependent latency.
 template <int NACC>

@@ -35,7 +35,8 @@ def lml_tol(R):
 
 @pytest.mark.parametrize("cfg,M,N,K", [(0, 128, 128, 128), (0, 300, 300, 128), (0, 144, 128, 256), (0, 130, 70, 64),
                                        (1, 32, 128, 128), (1, 700, 128, 128), (1, 50, 16, 384),
-                                       (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32)])
+                                       (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32),
+                                       (3, 256, 128, 128), (3, 600, 300, 256), (3, 272, 144, 64), (3, 100, 50, 32)])
 def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
     """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
     swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
@@ -47,19 +48,22 @@ def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
     np.testing.assert_allclose(got, A @ B.T, rtol=1e-12, atol=1e-12 * K)
 
 
-@pytest.mark.parametrize("M", [128, 272, 400])
-def test_mfma_gemm_lower_tiles(ctx, M):
+@pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552])
+@pytest.mark.parametrize("cfg,BM", [(0, 128), (3, 256)])
+def test_mfma_gemm_lower_tiles(ctx, M, cfg, BM):
+    """SYRK mode: every element of the lower triangle is updated exactly once (also through the XCD-aware
+    tile map, M >= 1024), and tiles that lie wholly above the diagonal are never touched."""
     rng = np.random.RandomState(M)
     A, C = rng.randn(M, 128), rng.randn(M, M)
-    got = ctx.debug_gemm_nt(0, C, A, A, tri=True, beta=1, sign=-1.0)
+    got = ctx.debug_gemm_nt(cfg, C, A, A, tri=True, beta=1, sign=-1.0)
     want = C - A @ A.T
-    # tiles on/below the diagonal are updated, tiles strictly above are untouched
-    T = -(-M // 128)
-    for bi in range(T):
-        for bj in range(T):
-            sl = (slice(bi * 128, min(M, (bi + 1) * 128)), slice(bj * 128, min(M, (bj + 1) * 128)))
-            ref = want[sl] if bj <= bi else C[sl]
-            np.testing.assert_allclose(got[sl], ref, rtol=1e-12, atol=1e-10)
+    low = np.tril(np.ones((M, M), dtype=bool))
+    np.testing.assert_allclose(got[low], want[low], rtol=1e-12, atol=1e-10)
+    for bi in range(-(-M // BM)):
+        for bj in range(-(-M // 128)):
+            if bj * 128 > bi * BM + BM - 1:          # tile entirely above the diagonal
+                sl = (slice(bi * BM, min(M, (bi + 1) * BM)), slice(bj * 128, min(M, (bj + 1) * 128)))
+                np.testing.assert_array_equal(got[sl], C[sl])
 
 
 KERNEL_SPECS = [
