@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
     ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
-    ap.add_argument("--slots", type=int, default=4, help="independent evaluations kept in flight per GPU")
+    ap.add_argument("--slots", type=int, default=3, help="independent evaluations kept in flight per GPU")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -97,9 +99,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = local_rank if args.device is None else args.device
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
     elif args.gpus != 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
 
@@ -109,7 +115,7 @@ def main():
     from gsum_amd.grid import gather_flat
 
     n, r, K, W = args.n, args.orders, args.steps, args.warmup
-    ctx = gsum_amd.default_context(local_rank)
+    ctx = gsum_amd.default_context(dev)
     X, y = make_workload(n, r)
     c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
     Z = np.concatenate([c, np.ones((n, 1))], axis=1)
@@ -147,7 +153,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     gemm_ms, gemm_flops, gemm_launches = ctx.gemm_profile()

@@ -42,7 +42,8 @@ struct gsum_ctx {
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
-    int batch_slots = 4;             // evaluations kept in flight by gsum_lml_resident
+    int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident (3 measured best)
+    int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
     int lookahead = 1;
@@ -60,11 +61,7 @@ struct gsum_ctx {
     struct ProfRec { int e0, e1; double flops; };
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
-    // XCD-aware tile orders of the lower-triangular SYRK, one per number of tile rows (device arrays)
-    std::vector<int*> tile_maps;
-    std::vector<int> tile_map_blocks;
-    int xcd_swizzle = 1;
-    int bulk_cfg = 0;                // tile configuration of the bulk trailing update (0 or 3; 0 measured faster)
+    int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
 };
 
@@ -97,53 +94,6 @@ static int gs_reserve(gsum_ctx* ctx, double** p, size_t* cap, size_t bytes) {
     return 0;
 }
 
-// ---- XCD-aware tile order for the lower-triangular update ------------------------------------------
-// Tiles (bm >= bn) of a Tt x Tt tile triangle are listed patch by patch (4x4 tiles, patches row-major along
-// super-rows) and the list is cut into 8 contiguous, equally long segments.  Workgroup b takes entry
-// (b >> 3) of segment (b & 7): the hardware deals consecutive workgroups round-robin over the 8 XCDs, so
-// each XCD walks one segment and the ~64 tiles it has in flight share 4 + 16 panel blocks through its L2
-// (6.4x reuse instead of ~1x for row-major order).  Placement only affects speed, never results.
-static int gs_tile_map(gsum_ctx* ctx, int M, int BM, int BN, const int** map, int* blocks) {
-    // tiles are BM x BN; a tile belongs to the update if it touches the lower triangle (incl. diagonal)
-    const int Tm = (M + BM - 1) / BM, Tn = (M + BN - 1) / BN;
-    const int key = Tn * 2 + (BM == BN ? 0 : 1);     // Tn (128-wide tile columns) fixes Tm for either shape
-    if ((int)ctx->tile_maps.size() <= key) {
-        ctx->tile_maps.resize(key + 1, nullptr);
-        ctx->tile_map_blocks.resize(key + 1, 0);
-    }
-    if (!ctx->tile_maps[key]) {
-        std::vector<int> tiles;      // (bm, bn) pairs in patch order
-        const int PM = 512 / BM, PN = 512 / BN;          // one patch covers a 512 x 512 region
-        for (int I = 0; I * PM < Tm; ++I)
-            for (int J = 0; J * PN < Tn; ++J)
-                for (int bm = I * PM; bm < std::min(Tm, (I + 1) * PM); ++bm)
-                    for (int bn = J * PN; bn < std::min(Tn, (J + 1) * PN); ++bn)
-                        if ((int64_t)bn * BN <= (int64_t)bm * BM + BM - 1) {
-                            tiles.push_back(bm);
-                            tiles.push_back(bn);
-                        }
-        const int nt = (int)tiles.size() / 2;
-        const int L = (nt + 7) / 8;
-        std::vector<int> h((size_t)L * 8 * 2, -1);
-        for (int x = 0; x < 8; ++x) {
-            const int lo = (int)((int64_t)nt * x / 8), hi = (int)((int64_t)nt * (x + 1) / 8);
-            for (int i = lo; i < hi; ++i) {
-                const int bb = (i - lo) * 8 + x;
-                h[2 * bb] = tiles[2 * i];
-                h[2 * bb + 1] = tiles[2 * i + 1];
-            }
-        }
-        int* d = nullptr;
-        GS_CHECK(hipMalloc((void**)&d, h.size() * sizeof(int)));
-        GS_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
-        ctx->tile_maps[key] = d;
-        ctx->tile_map_blocks[key] = L * 8;
-    }
-    *map = ctx->tile_maps[key];
-    *blocks = ctx->tile_map_blocks[key];
-    return 0;
-}
-
 // ---- GEMM launcher ----------------------------------------------------------------------------
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda,
@@ -159,21 +109,16 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
         attr_set = true;
     }
     int64_t blocks;
-    const int* tmap = nullptr;
     if (tri) {
-        if (M != N) GS_FAIL("gemm: tri mode needs a square C");
+        if (M != N || BM != BN) GS_FAIL("gemm: tri mode needs a square C and square tiles");
         int64_t T = (M + BM - 1) / BM;
         blocks = T * (T + 1) / 2;
-        if (BM != BN || (ctx->xcd_swizzle && T >= 8)) {
-            int nb = 0;
-            if (gs_tile_map(ctx, (int)M, BM, BN, &tmap, &nb)) return -1;
-            blocks = nb;
-        }
     } else {
         blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), shmem, s, C, ldc, A, lda, B, ldb, (int)M,
-                       (int)N, K, tri, beta, sign, tmap, (unsigned long long*)nullptr);
+                       (int)N, K, tri, beta, sign, (unsigned long long*)nullptr,
+                       (BM == 128 && BN == 128) ? (ctx->stagger < 0 ? K / 16 : ctx->stagger) : 0);
     GS_CHECK(hipGetLastError());
     return 0;
 }
@@ -181,10 +126,9 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
 // cfg 0: 128x128 tile (2x2 waves of 64x64)   — trailing SYRK / big updates
 // cfg 1:  32x128 tile (1x4 waves of 32x32)   — panel TRSM against the explicit block inverse
 // cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
-// cfg 3: 256x128 tile (4x2 waves of 64x64, 512 threads, one workgroup per CU) — bulk trailing update
 static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                    const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
-    if ((cfg == 0 || cfg == 3) && ctx->profile_gemm && M > 0 && N > 0) {
+    if (cfg == 0 && ctx->profile_gemm && M > 0 && N > 0) {
         while (ctx->prof_pool.size() < ctx->prof_next + 2) {
             hipEvent_t ev;
             GS_CHECK(hipEventCreate(&ev));
@@ -193,8 +137,7 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
         const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
         ctx->prof_next += 2;
         GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
-        int rc = cfg == 0 ? gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign)
-                          : gs_launch_gemm<4, 4, 4, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        int rc = gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
         // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
         const double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
@@ -205,7 +148,6 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
         case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 1: return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 2: return gs_launch_gemm<1, 4, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
-        case 3: return gs_launch_gemm<4, 4, 4, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
     }
     GS_FAIL("gemm: unknown tile configuration");
 }
@@ -303,7 +245,9 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
     hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, sl->sm, A, ld, (int)m->np, m->diag0);
     GS_CHECK(hipGetLastError());
-    const bool la = ctx->lookahead != 0;
+    // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
+    // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
+    const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm;
     if (la) {
@@ -338,7 +282,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         double* P = A + r2 * ld + c0;
         const int64_t mrest = naug - r2;            // >= 16 (the border)
         if (!la) {
-            if (gs_gemm(ctx, sm, ctx->bulk_cfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, 0, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
             continue;
         }
         GS_CHECK(hipEventRecord(sl->evP[k], sp));
@@ -350,7 +294,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
-            if (gs_gemm(ctx, sm, ctx->bulk_cfg, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, 0, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
             GS_CHECK(hipEventRecord(sl->evM[k], sm));
             prev = k;
         } else {
@@ -457,8 +401,6 @@ void gsum_destroy(gsum_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
     for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
-    for (auto d : ctx->tile_maps)
-        if (d) (void)hipFree(d);
     delete ctx;
 }
 
@@ -470,8 +412,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
     else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
-    else if (!strcmp(name, "xcd_swizzle")) ctx->xcd_swizzle = (int)value;
-    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 3) ? 3 : 0;
+    else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
@@ -783,6 +724,7 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
         if (gs_check_desc(ctx, &kernels[i], ctx->dX_d)) return -2;
     const int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
     if (gs_need_slots(ctx, S)) return -1;
+    ctx->batch_active = S;
     int rc = 0;
     for (int i = 0; i < n_kernels && !rc; ++i) {
         gs_slot* sl = &ctx->slots[i % S];
@@ -797,6 +739,7 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
         if (!rc) rc = r2;
     }
     ctx->cur = &ctx->slots[0];
+    ctx->batch_active = 1;
     return rc;
 }
 
@@ -918,7 +861,7 @@ int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, dou
     GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     for (int rep = 0; rep < 2; ++rep)
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, s, dC, M, dA, lda, dA, lda, (int)M, (int)M, (int)K, 1, 1,
-                           -1.0, (const int*)nullptr, dS);
+                           -1.0, dS, 0);
     GS_CHECK(hipGetLastError());
     std::vector<unsigned long long> h((size_t)blocks * 20);
     GS_CHECK(hipMemcpyAsync(h.data(), dS, sb, hipMemcpyDeviceToHost, s));

@@ -437,15 +437,14 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // ------------------------------------------------------------------------------------------------
 // K2b: C (+)= sign * A * B^T  on fp64 MFMA.   A: M x K, B: N x K (both row-major, K contiguous — the
 // shape every step of a row-major lower Cholesky produces), C: M x N.
-//   - 4 or 8 waves per workgroup, wave tile (WM*16) x (WN*16) of v_mfma_f64_16x16x4_f64 accumulators;
+//   - 4 waves per workgroup, wave tile (WM*16) x (WN*16) of v_mfma_f64_16x16x4_f64 accumulators;
 //   - K is staged 16 doubles (one 128-B line per row) at a time: global -> registers -> LDS, two LDS
 //     stages, one barrier per chunk; the next chunk's global loads are in flight during the MFMAs;
 //   - fragment reads at row stride 17 doubles: conflict-free for the A/B lane map (lane l holds
 //     [row l&15][k l>>4]) under ds_read2_b64's 32-bank mapping (stride 18 measured 40% conflict cycles);
 //   - rows >= M / cols >= N are clamped on load and predicated on store, so the 16-row border tile
 //     and the padded tail run through the same code;
-//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix), optionally in the
-//     XCD-aware order of a host-built tile map;
+//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix);
 //   - sign must be +1 or -1 (it multiplies the staged A operand exactly).
 // In-place use (C == A, TRSM against an explicit inverse) is safe when one tile spans all N = K
 // columns: every global load of the tile's rows is finished before the epilogue stores.
@@ -453,9 +452,9 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
                                                      const double* B, int64_t ldb, int M, int N, int K,
-                                                     int tri, int beta, double sign, const int* tile_map,
-                                                     unsigned long long* stamps = nullptr) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N;          // 4 waves (256 threads) or 8 waves (512 threads)
+                                                     int tri, int beta, double sign,
+                                                     unsigned long long* stamps = nullptr, int stagger = 0) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;          // 256 threads
     constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
     constexpr int A_VECS = BM * (GS_KC / 2), B_VECS = BN * (GS_KC / 2);
     constexpr int A_IT = (A_VECS + NT - 1) / NT, B_IT = (B_VECS + NT - 1) / NT;
@@ -463,13 +462,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_nt(double* C
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
-    if (tile_map) {
-        // XCD-aware order (host-built, gs_tile_map): workgroups b, b+8, b+16 ... land on one XCD and walk
-        // a contiguous run of 4x4-tile patches, so the panel blocks they share are served by that XCD's L2
-        bm = tile_map[2 * blockIdx.x];
-        bn = tile_map[2 * blockIdx.x + 1];
-        if (bm < 0) return;               // padding entry: the whole workgroup leaves before any barrier
-    } else if (tri) {
+    if (tri) {
         const int bid = blockIdx.x;
         bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
         while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
@@ -481,6 +474,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_nt(double* C
         bn = blockIdx.x / tm;
     }
     const int m0 = bm * BM, n0 = bn * BN;
+    // De-phase the two workgroups that share a CU.  All workgroups of a launch take the same time, so the
+    // pair that starts together stays in lockstep: both wait on their C-tile loads, both fight for the
+    // matrix pipe, both store.  The dispatcher fills every CU once before placing second workgroups, so
+    // blocks 256..511 are the late partners of blocks 0..255 (observed; speed only): they sleep `stagger` x
+    // 2048 cycles once, and every later workgroup inherits the offset of the slot it replaces.
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);       // 32 x 64 cycles
+    }
 
     // The accumulators start as beta*C (all loads of the tile issued back to back, one wait) and the
     // sign rides on the staged A operand, so the epilogue is stores only.  (A load-modify-store epilogue

@@ -58,8 +58,8 @@ typedef struct {
 int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
-/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps", "xcd_swizzle" (0/1), "batch_slots" (1..8),
- * "bulk_cfg" (0: 128x128 tiles, 3: 256x128 tiles for the trailing update).  <0 for an unknown name. */
+/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8),
+ * "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
@@ -150,7 +150,7 @@ int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64
  * MFMAs, vmcnt wait + LDS stores, barrier} for one SYRK launch of order M, depth K. */
 int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, double* out5);
 /* debug: C(MxN) = beta*C + sign * A(MxK) B(NxK)^T through the MFMA tile kernel (cfg 0: 128x128 tile,
- * 1: 32x128 tile, 2: 16x256 tile, 3: 256x128 tile; tri != 0: lower tiles only, needs M == N). */
+ * 1: 32x128 tile, 2: 16x256 tile; tri != 0: lower tiles only, needs M == N). */
 int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const double* A, const double* B,
                        int64_t M, int64_t N, int64_t K, int32_t beta, double sign);
 

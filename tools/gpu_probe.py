@@ -52,23 +52,23 @@ n, r = 8192, 6
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
 ctx.set_inputs(X, Z)
-for la, swz in ((1, 3), (1, 0), (0, 3), (0, 0)):       # "swz" column now = bulk tile configuration
+G_ref = None
+for la in (1, 0):
     ctx.set_option("lookahead", la)
-    ctx.set_option("bulk_cfg", swz)
-    for slots in (1, 3, 4, 8):
+    for slots in (1, 2, 3, 4, 6):
         ctx.set_option("batch_slots", slots)
         ctx.lml_resident([desc] * slots, 1e-10)
-        nb = 16
+        nb = 18
         t0 = time.perf_counter()
         G, sld, info = ctx.lml_resident([desc] * nb, 1e-10)
         dt = time.perf_counter() - t0
-        out[f"batch_la{la}_swz{swz}_slots{slots}"] = dict(ms_per_eval=dt / nb * 1e3, evals_per_s=nb / dt,
-                                                 chol_tflops_aggregate=n ** 3 / 3 * nb / dt / 1e12)
-        print("batch la", la, "swz", swz, "slots", slots, out[f"batch_la{la}_swz{swz}_slots{slots}"],
-              bool((G == G[0]).all()), flush=True)
+        G_ref = G[0] if G_ref is None else G_ref
+        key = f"batch_la{la}_slots{slots}"
+        out[key] = dict(ms_per_eval=dt / nb * 1e3, evals_per_s=nb / dt, chol_tflops_aggregate=n ** 3 / 3 * nb / dt / 1e12,
+                        bit_identical=bool((G == G_ref).all()))
+        print(key, out[key], flush=True)
 ctx.set_option("lookahead", 1)
-ctx.set_option("bulk_cfg", 3)
-ctx.set_option("batch_slots", 4)
+ctx.set_option("batch_slots", 3)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "probe.json"), "w") as f:
     json.dump(out, f, indent=1)
