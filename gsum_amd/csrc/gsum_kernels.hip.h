@@ -211,9 +211,9 @@ __global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int
 //
 // Phase 1 — unblocked right-looking Cholesky with the block held ENTIRELY IN REGISTERS: 2-D cyclic
 // 16x16 thread grid, thread (tr, tc) owns element (tr, tc) of each of the 36 lower 16x16 sub-blocks.
-// One barrier per column: the unscaled column goes through a double-buffered LDS mailbox whose layout is
-// permuted (row i at (i & 15) * 8 + (i >> 4)) so that every thread fetches its 8 row values and its 8
-// column values with four ds_read_b128 each.  1/sqrt(pivot) comes from v_rsq_f64 + two Newton steps (a
+// One barrier per TWO columns: the unscaled columns go through a double-buffered LDS mailbox whose layout
+// is permuted (row i at (i & 15) * 10 + (i >> 4)) so that every thread fetches its 8 row values and its 8
+// column values with four conflict-free ds_read_b128 each.  1/sqrt(pivot) comes from v_rsq_f64 + two Newton steps (a
 // 90-cycle dependent chain instead of ~250 for sqrt + divide); masks are needed only inside the active
 // sub-block.  The inverses of the eight 16x16 DIAGONAL sub-blocks are built alongside by forward
 // elimination on an identity (one extra fma per thread per column).
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int
 // inverses:  X_jj = D_j^-1,  X_ij = -D_i^-1 * sum_{p=j}^{i-1} L_ip X_pj.  Wave w owns block columns w and
 // 7-w (140..92 MFMAs each way) and keeps them in registers: the accumulator layout of
 // v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 reg) IS its B-operand layout for k-step
-// reg, so X_pj feeds the next product with no data movement; L_ip is read as the A operand straight from
-// the global block phase 1 just stored (L2-resident).  No barrier inside phase 2.
+// reg, so X_pj feeds the next product with no data movement; L_ip is read as the A operand from an LDS copy
+// of the factor that phase 1 leaves behind.  No barrier inside phase 2.
 // ------------------------------------------------------------------------------------------------
 #define GS_DV_STR 17     // padded row stride of the 16x16 diagonal inverses in LDS
 
@@ -243,72 +243,126 @@ __device__ __forceinline__ double gs_rsqrt_nr(double p) {
     return r;
 }
 
+#define GS_MB_STR 10     // mailbox: row i of a column lives at (i & 15) * 10 + (i >> 4): 16-B aligned groups of 8,
+                         // 80-B group stride -> the four ds_read_b128 of a thread are bank-conflict free
+#define GS_MB_SIZE (16 * GS_MB_STR)
+
+// Columns j0 = 16 JB + jr and j0 + 1 per barrier.  Every thread receives both (unscaled) columns, scales
+// column j0, applies it to column j0 + 1 itself (8 + 8 extra fmas), scales that, and performs the rank-2
+// update of its 36 sub-block entries.  One LDS round trip and one barrier per TWO columns.
 template <int JB>
 __device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8], double* mail, double* rmail,
                                               double* dbuf, const double* thr, int tr, int tc, int* fail_col) {
-    for (int jr = 0; jr < 16; ++jr) {
-        const int j = JB * 16 + jr;
-        double* cb = mail + (j & 1) * 128;
-        double* rb = rmail + (j & 1) * 16;
-        if (tc == jr) {      // owners of column j publish it (unscaled), permuted: row i -> (i&15)*8 + (i>>4)
+    for (int jr = 0; jr < 16; jr += 2) {
+        const int j0 = JB * 16 + jr, j1 = j0 + 1;
+        const int buf = (jr >> 1) & 1;
+        double* cA = mail + buf * 2 * GS_MB_SIZE;
+        double* cB = cA + GS_MB_SIZE;
+        double* rA = rmail + buf * 32;
+        double* rB = rA + 16;
+        if (tc == jr) {
 #pragma unroll
-            for (int ii = JB; ii < 8; ++ii) cb[tr * 8 + ii] = a[ii][JB];
+            for (int ii = JB; ii < 8; ++ii) cA[tr * GS_MB_STR + ii] = a[ii][JB];
         }
-        if (tr == jr) rb[tc] = vd[JB];          // pivot row of the diagonal inverse being built
+        if (tc == jr + 1) {
+#pragma unroll
+            for (int ii = JB; ii < 8; ++ii) cB[tr * GS_MB_STR + ii] = a[ii][JB];
+        }
+        if (tr == jr) rA[tc] = vd[JB];
+        if (tr == jr + 1) rB[tc] = vd[JB];
         __syncthreads();
-        // every LDS read of the step is issued before the pivot's dependent rsqrt chain starts
-        const double p = cb[jr * 8 + JB];       // A_jj
-        const double tj = thr[j];
-        const double rbv = rb[tc];
-        double cr[8], cc[8];
+        // every LDS read of the step is issued before the dependent rsqrt chains start
+        const double p0 = cA[jr * GS_MB_STR + JB];               // A[j0][j0]
+        const double a10 = cA[(jr + 1) * GS_MB_STR + JB];        // A[j1][j0]
+        const double p1raw = cB[(jr + 1) * GS_MB_STR + JB];      // A[j1][j1], before column j0 is applied
+        const double t0 = thr[j0], t1 = thr[j1];
+        const double rAv = rA[tc], rBv = rB[tc];
+        double ar[8], ac[8], br[8], bc[8];
         {
-            const gs_d2* pr = reinterpret_cast<const gs_d2*>(cb + tr * 8);
-            const gs_d2* pc = reinterpret_cast<const gs_d2*>(cb + tc * 8);
+            const gs_d2* q0 = reinterpret_cast<const gs_d2*>(cA + tr * GS_MB_STR);
+            const gs_d2* q1 = reinterpret_cast<const gs_d2*>(cA + tc * GS_MB_STR);
+            const gs_d2* q2 = reinterpret_cast<const gs_d2*>(cB + tr * GS_MB_STR);
+            const gs_d2* q3 = reinterpret_cast<const gs_d2*>(cB + tc * GS_MB_STR);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const gs_d2 x = pr[q], y = pc[q];
-                cr[2 * q] = x[0]; cr[2 * q + 1] = x[1];
-                cc[2 * q] = y[0]; cc[2 * q + 1] = y[1];
+                const gs_d2 x0 = q0[q], x1 = q1[q], x2 = q2[q], x3 = q3[q];
+                ar[2 * q] = x0[0]; ar[2 * q + 1] = x0[1];
+                ac[2 * q] = x1[0]; ac[2 * q + 1] = x1[1];
+                br[2 * q] = x2[0]; br[2 * q + 1] = x2[1];
+                bc[2 * q] = x3[0]; bc[2 * q + 1] = x3[1];
             }
         }
-        if (!(p > tj)) {                        // same value in every thread: uniform exit (catches NaN)
-            *fail_col = j;
+        if (!(p0 > t0)) {                       // same value in every thread: uniform exit (catches NaN)
+            *fail_col = j0;
             return false;
         }
-        const double r = gs_rsqrt_nr(p);
-        double dj = p * r;                                       // sqrt(p) ...
-        dj = __builtin_fma(__builtin_fma(-dj, dj, p), 0.5 * r, dj);   // ... corrected to ~0.5 ulp
-        if (threadIdx.x == 0) dbuf[j] = dj;
-        double li[8], lk[8];
+        const double r0 = gs_rsqrt_nr(p0);
+        double d0 = p0 * r0;                                            // sqrt(p0) ...
+        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);   // ... corrected to ~0.5 ulp
+        const double l10 = a10 * r0;                                    // L[j1][j0]
+        const double p1 = __builtin_fma(-l10, l10, p1raw);
+        if (!(p1 > t1)) {
+            *fail_col = j1;
+            return false;
+        }
+        const double r1 = gs_rsqrt_nr(p1);
+        double d1 = p1 * r1;
+        d1 = __builtin_fma(__builtin_fma(-d1, d1, p1), 0.5 * r1, d1);
+        if (threadIdx.x == 0) {
+            dbuf[j0] = d0;
+            dbuf[j1] = d1;
+        }
+        double l0r[8], l0c[8], l1r[8], l1c[8];
 #pragma unroll
-        for (int ii = JB; ii < 8; ++ii) li[ii] = cr[ii] * r;
+        for (int ii = JB; ii < 8; ++ii) {
+            l0r[ii] = ar[ii] * r0;
+            l1r[ii] = __builtin_fma(-l0r[ii], l10, br[ii]) * r1;       // column j1 after column j0, scaled
+        }
 #pragma unroll
-        for (int kk = JB; kk < 8; ++kk) lk[kk] = cc[kk] * r;
-        // inside the active sub-block only rows / columns beyond j take part
-        li[JB] = (tr > jr) ? li[JB] : 0.0;
-        lk[JB] = (tc > jr) ? lk[JB] : 0.0;
-        const double vk = (tc <= jr) ? rbv * r : 0.0;             // scaled pivot row of D^-1
-        // trailing update of the block:  A_ik -= l_ij l_kj   (i, k > j)
+        for (int kk = JB; kk < 8; ++kk) {
+            l0c[kk] = ac[kk] * r0;
+            l1c[kk] = __builtin_fma(-l0c[kk], l10, bc[kk]) * r1;
+        }
+        // inside the active sub-block only rows / columns beyond the pivots take part
+        l0r[JB] = (tr > jr) ? l0r[JB] : 0.0;
+        l1r[JB] = (tr > jr + 1) ? l1r[JB] : 0.0;
+        l0c[JB] = (tc > jr) ? l0c[JB] : 0.0;
+        l1c[JB] = (tc > jr + 1) ? l1c[JB] : 0.0;
+        // scaled pivot rows of the diagonal-block inverse
+        const double vk0 = (tc <= jr) ? rAv * r0 : 0.0;
+        const double vk1 = (tc <= jr + 1) ? __builtin_fma(-l10, vk0, rBv) * r1 : 0.0;
+        // rank-2 trailing update:  A_ik -= l0_i l0_k + l1_i l1_k
 #pragma unroll
         for (int ii = JB; ii < 8; ++ii)
 #pragma unroll
-            for (int kk = JB; kk <= ii; ++kk) a[ii][kk] = __builtin_fma(-li[ii], lk[kk], a[ii][kk]);
-        // column j is final: l_ij below the diagonal, d_j on it
+            for (int kk = JB; kk <= ii; ++kk)
+                a[ii][kk] = __builtin_fma(-l1r[ii], l1c[kk], __builtin_fma(-l0r[ii], l0c[kk], a[ii][kk]));
+        // columns j0 and j1 are final
         if (tc == jr) {
 #pragma unroll
-            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = li[ii];
-            a[JB][JB] = (tr > jr) ? li[JB] : ((tr == jr) ? dj : a[JB][JB]);
+            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = l0r[ii];
+            a[JB][JB] = (tr > jr) ? l0r[JB] : ((tr == jr) ? d0 : a[JB][JB]);
         }
-        // diagonal-block inverse: rows below j eliminate against the scaled pivot row
-        vd[JB] = (tr == jr) ? vk : __builtin_fma(-li[JB], vk, vd[JB]);
+        if (tc == jr + 1) {
+#pragma unroll
+            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = l1r[ii];
+            a[JB][JB] = (tr > jr + 1) ? l1r[JB] : ((tr == jr + 1) ? d1 : a[JB][JB]);
+        }
+        // diagonal-block inverse: eliminate against both scaled pivot rows
+        vd[JB] = (tr == jr) ? vk0
+               : (tr == jr + 1) ? vk1
+                                : __builtin_fma(-l1r[JB], vk1, __builtin_fma(-l0r[JB], vk0, vd[JB]));
     }
     return true;
 }
 
-// One block column J of L^-1 on the matrix cores (see the header comment above).  Lg: the factored diagonal
-// block in global memory (leading dimension ld); Dv: the eight 16x16 diagonal inverses in LDS.
+#define GS_LS_BLK (16 * 17)   // LDS copy of L for phase 2: the 28 strictly lower 16x16 blocks, block (i, p) at
+                              // index i (i - 1) / 2 + p, rows padded to 17 doubles (61 KB)
+
+// One block column J of L^-1 on the matrix cores (see the header comment above).  Ls: LDS copy of the factored
+// block's strictly lower 16x16 blocks; Dv: the eight 16x16 diagonal inverses in LDS.
 template <int J>
-__device__ __forceinline__ void gs_trtri_col(const double* Lg, int64_t ld, const double* Dv, double* Linv, int lane) {
+__device__ __forceinline__ void gs_trtri_col(const double* Ls, const double* Dv, double* Linv, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     gs_d4 X[8];
     // X_JJ = D_J^-1, fetched in accumulator layout: reg x holds row fq + 4x, column fr
@@ -321,7 +375,7 @@ __device__ __forceinline__ void gs_trtri_col(const double* Lg, int64_t ld, const
         for (int p = J; p < i; ++p) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double av = Lg[(int64_t)(16 * i + fr) * ld + 16 * p + 4 * s4 + fq];     // A operand: L_ip
+                const double av = Ls[(i * (i - 1) / 2 + p) * GS_LS_BLK + fr * 17 + 4 * s4 + fq];   // A operand: L_ip
                 T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[p][s4], T, 0, 0, 0);
             }
         }
@@ -348,8 +402,10 @@ __device__ __forceinline__ void gs_trtri_col(const double* Lg, int64_t ld, const
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
                                                      int* info, int col0, const double* diag0,
                                                      unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double mail[256];
-    __shared__ double rmail[32];
+    __shared__ __attribute__((aligned(16))) double mail[4 * GS_MB_SIZE];
+    __shared__ double rmail[64];
+    __shared__ double Ls[28 * GS_LS_BLK];           // 61 KB; with Dv and the mailboxes 85 KB: one 73-KB bulk
+                                                    // workgroup still fits on the CU beside this kernel
     __shared__ double dbuf[128];
     __shared__ double thr[128];
     __shared__ double Dv[128 * GS_DV_STR];
@@ -395,6 +451,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
         for (int kk = 0; kk <= ii; ++kk) {
             const int row = tr + 16 * ii, col = tc + 16 * kk;
             if (col <= row) A[(int64_t)row * ld + col] = a[ii][kk];
+            if (kk < ii) Ls[(ii * (ii - 1) / 2 + kk) * GS_LS_BLK + tr * 17 + tc] = a[ii][kk];   // for phase 2
         }
         Dv[(ii * 16 + tr) * GS_DV_STR + tc] = (tc <= tr) ? vd[ii] : 0.0;
     }
@@ -406,17 +463,17 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     if (w == 0) {
-        gs_trtri_col<0>(A, ld, Dv, Linv, lane);
-        gs_trtri_col<7>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<0>(Ls, Dv, Linv, lane);
+        gs_trtri_col<7>(Ls, Dv, Linv, lane);
     } else if (w == 1) {
-        gs_trtri_col<1>(A, ld, Dv, Linv, lane);
-        gs_trtri_col<6>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<1>(Ls, Dv, Linv, lane);
+        gs_trtri_col<6>(Ls, Dv, Linv, lane);
     } else if (w == 2) {
-        gs_trtri_col<2>(A, ld, Dv, Linv, lane);
-        gs_trtri_col<5>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<2>(Ls, Dv, Linv, lane);
+        gs_trtri_col<5>(Ls, Dv, Linv, lane);
     } else {
-        gs_trtri_col<3>(A, ld, Dv, Linv, lane);
-        gs_trtri_col<4>(A, ld, Dv, Linv, lane);
+        gs_trtri_col<3>(Ls, Dv, Linv, lane);
+        gs_trtri_col<4>(Ls, Dv, Linv, lane);
     }
     __syncthreads();
     if (t == 0) {
