@@ -4,7 +4,8 @@ multivariate-normal log-likelihood) behind gsum's ConjugateGaussianProcess / Tru
 Compute runs in libgsum_hip.so (hand-written HIP for gfx950, bound with ctypes); there is no CPU path.
 """
 from .series import coefficients, partials, geometric_sum
-from .conjugate import ConjugateGaussianProcess, posterior_from_gram, lml_from_gram, cov_factor
+from .conjugate import (ConjugateGaussianProcess, posterior_from_gram, lml_from_gram, lml_from_gram_batch,
+                        cov_factor)
 from .truncation import TruncationGP
 from .kernels import describe_kernel
 from .grid import shard_range, gather_flat, lml_grid_distributed
@@ -13,6 +14,6 @@ from ._lib import HipContext, KernelDesc, default_context, load_library
 __version__ = "0.1.0"
 __all__ = [
     "coefficients", "partials", "geometric_sum", "ConjugateGaussianProcess", "TruncationGP",
-    "posterior_from_gram", "lml_from_gram", "cov_factor", "describe_kernel", "shard_range", "gather_flat",
+    "posterior_from_gram", "lml_from_gram", "lml_from_gram_batch", "cov_factor", "describe_kernel", "shard_range", "gather_flat",
     "lml_grid_distributed", "HipContext", "KernelDesc", "default_context", "load_library",
 ]

@@ -61,6 +61,7 @@ struct gsum_ctx {
     struct ProfRec { int e0, e1; double flops; };
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
+    int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
 };
@@ -413,6 +414,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
     else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
+    else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
@@ -715,6 +717,35 @@ static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sl
     return 0;
 }
 
+// n <= 128: one fused workgroup per evaluation (k_lml_small), up to 512 evaluations per launch
+static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
+                        double* sld_out, int64_t* info_out) {
+    const int k = ctx->kZ, CH = 512;
+    hipStream_t s = ctx->cur->sm;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * GS_SMALL_SCRATCH * 8)) return -1;
+    char* base = (char*)ctx->scratch;
+    std::vector<double> hres((size_t)CH * 258);
+    for (int lo = 0; lo < n_kernels; lo += CH) {
+        const int cnt = std::min(CH, n_kernels - lo);
+        GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lml_small, dim3(cnt), dim3(256), 0, s, ctx->dX, (int)ctx->nX, ctx->dX_d, ctx->dZ, k,
+                           (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), (double*)(base + o_res));
+        GS_CHECK(hipGetLastError());
+        GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipStreamSynchronize(s));
+        for (int e = 0; e < cnt; ++e) {
+            const double* r = hres.data() + (size_t)e * 258;
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) G_out[(size_t)(lo + e) * k * k + a * k + b] = r[a * 16 + b];
+            sld_out[lo + e] = r[256];
+            info_out[lo + e] = (int64_t)r[257];
+        }
+    }
+    return 0;
+}
+
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
@@ -722,6 +753,10 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
     if (!ctx->dX) GS_FAIL("gsum_set_inputs has not been called");
     for (int i = 0; i < n_kernels; ++i)
         if (gs_check_desc(ctx, &kernels[i], ctx->dX_d)) return -2;
+    if (ctx->nX <= GS_NB && ctx->small_path) {
+        ctx->cur = &ctx->slots[0];
+        return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    }
     const int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
     if (gs_need_slots(ctx, S)) return -1;
     ctx->batch_active = S;

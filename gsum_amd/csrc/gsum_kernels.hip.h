@@ -395,21 +395,20 @@ __device__ __forceinline__ void gs_trtri_col(const double* Ls, const double* Dv,
             Linv[(16 * i + fq + 4 * x) * 128 + 16 * J + fr] = (i < J) ? 0.0 : X[i][x];
 }
 
-// A: pointer to the diagonal block inside the augmented matrix (leading dimension ld).
-// Linv: 128x128 row-major output (zeros above the diagonal).  logdet[0] = sum_j log L_jj.
-// info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
-// diag0: the block's 128 original diagonal entries (before any trailing update).
-__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
-                                                     int* info, int col0, const double* diag0,
-                                                     unsigned long long* stamps) {
+// The whole diagonal-block routine as a device function, so the fused small-n kernel can share it.
+// A: the 128x128 block (leading dimension ld), factored in place (lower part).  Linv: 128x128 row-major
+// output (zeros above the diagonal).  diag0: the block's 128 original diagonal entries.
+// Returns 0 or the 1-based local column of the first bad pivot (uniform over the workgroup); *logdet_out
+// (written by thread 0 only) = sum_j log L_jj.  Ends with a workgroup barrier after the Linv stores.
+__device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* logdet_out,
+                                             const double* diag0, unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) double mail[4 * GS_MB_SIZE];
     __shared__ double rmail[64];
-    __shared__ double Ls[28 * GS_LS_BLK];           // 61 KB; with Dv and the mailboxes 85 KB: one 73-KB bulk
-                                                    // workgroup still fits on the CU beside this kernel
     __shared__ double dbuf[128];
     __shared__ double thr[128];
     __shared__ double Dv[128 * GS_DV_STR];
-    if (*info != 0) return;                    // an earlier block already failed (uniform)
+    __shared__ double Ls[28 * GS_LS_BLK];           // 61 KB; with Dv and the mailboxes 85 KB: one 73-KB bulk
+                                                    // workgroup still fits on the CU beside this kernel
     const int t = threadIdx.x;
     // optional phase stamps (diagnostics only: own buffer, never feeds a result)
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -440,11 +439,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
     if (ok) ok = gs_diag_steps<5>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (ok) ok = gs_diag_steps<6>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (ok) ok = gs_diag_steps<7>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (!ok) {
-        if (t == 0) *info = col0 + fail_col + 1;
-        return;
-    }
-    // L back to the matrix (lower part), diagonal inverses to LDS
+    if (!ok) return fail_col + 1;
+    // L back to the matrix (lower part), strictly lower blocks and diagonal inverses to LDS
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
 #pragma unroll
@@ -475,11 +471,12 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
         gs_trtri_col<3>(Ls, Dv, Linv, lane);
         gs_trtri_col<4>(Ls, Dv, Linv, lane);
     }
+    __threadfence_block();
     __syncthreads();
     if (t == 0) {
         double sl = 0.0;
         for (int j = 0; j < 128; ++j) sl += dbuf[j];
-        logdet[0] = sl;
+        *logdet_out = sl;
         if (stamps) {
             const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
             stamps[0] = st1 - st0;      // prologue (loads)
@@ -487,6 +484,138 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
             stamps[2] = st3 - st2;      // phase 2 (block inverse)
             stamps[3] = st3 - st0;      // total shader cycles
             stamps[4] = sr3 - sr0;      // total 100 MHz ticks
+        }
+    }
+    return 0;
+}
+
+// info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
+__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
+                                                     int* info, int col0, const double* diag0,
+                                                     unsigned long long* stamps) {
+    if (*info != 0) return;                    // an earlier block already failed (uniform)
+    const int bad = gs_diag_block(A, ld, Linv, logdet, diag0, stamps);
+    if (bad && threadIdx.x == 0) *info = col0 + bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused path for n <= 128 (the reference's own problem sizes: 5-100 points, thousands of grid points):
+// ONE workgroup per evaluation builds K, factors it, solves for the right-hand sides and reduces the Gram
+// matrix; a launch evaluates a whole row of a likelihood grid.  Same arithmetic as the general path
+// (k_build's kernel functions, gs_diag_block), per-evaluation scratch in global memory (L2-resident).
+//   scratch per evaluation: A (128x128) | Linv (128x128);   res per evaluation: 258 doubles as k_finalize.
+// ------------------------------------------------------------------------------------------------
+#define GS_SMALL_SCRATCH (2 * 128 * 128)
+
+__global__ __launch_bounds__(256) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
+                                                    const gsum_kernel_desc* descs, double nugget, double* scratch,
+                                                    double* res) {
+#pragma clang fp contract(off)
+    __shared__ double us[128 * GSUM_MAX_D];
+    __shared__ double dg0[128];
+    __shared__ double Wt[16 * 129];
+    __shared__ double ldet;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const gsum_kernel_desc desc = descs[blockIdx.x];
+    double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
+    double* Linv = A + 128 * 128;
+    double* out = res + (int64_t)blockIdx.x * 258;
+    // ---- kernel matrix (full symmetric 128x128 tile, identity padding beyond n)
+    for (int idx = t; idx < 128 * d; idx += 256) {
+        const int r = idx / d, dd = idx - r * d;
+        const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
+        us[idx] = r < n ? X[(int64_t)r * d + dd] / ls : 0.0;
+    }
+    __syncthreads();
+    {
+        double vj0[GSUM_MAX_D], vj1[GSUM_MAX_D];
+#pragma unroll
+        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+            vj0[dd] = dd < d ? us[(2 * lane) * d + dd] : 0.0;
+            vj1[dd] = dd < d ? us[(2 * lane + 1) * d + dd] : 0.0;
+        }
+        for (int gi = w; gi < 128; gi += 4) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+                if (dd < d) {
+                    const double xi = us[gi * d + dd];
+                    const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
+                    s0 = s0 + e0 * e0;
+                    s1 = s1 + e1 * e1;
+                }
+            }
+            const double ss[2] = {s0, s1};
+            double v[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int gj = 2 * lane + c;
+                double val;
+                if (gi >= n || gj >= n) {
+                    val = (gi == gj) ? 1.0 : 0.0;
+                } else {
+                    const bool dg = gi == gj;
+                    const double bse = dg ? 1.0 : gs_base_value(desc.family, ss[c]);
+                    val = desc.amplitude * bse;
+                    if (dg) val = val + desc.white_noise;
+                    val = val + desc.additive_const;
+                    if (dg) val = val + nugget;
+                }
+                if (gi == gj) dg0[gi] = val;
+                v[c] = val;
+            }
+            gs_d2 o = {v[0], v[1]};
+            *reinterpret_cast<gs_d2*>(A + gi * 128 + 2 * lane) = o;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- Cholesky + inverse of the block
+    const int bad = gs_diag_block(A, 128, Linv, &ldet, dg0, nullptr);
+    if (bad) {
+        if (t == 0) {
+            out[256] = 0.0;
+            out[257] = (double)bad;
+        }
+        return;
+    }
+    // ---- W^T = Z^T L^-T on the matrix cores: wave w owns column blocks 2w, 2w+1 of the 16 x 128 result.
+    // A operand: Z^T (row r = right-hand side, k = point), B operand: rows of L^-1 (lower triangular: only
+    // K blocks up to the column block contribute)
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int jb = 2 * w + h;
+        gs_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb <= jb; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kk = 16 * kb + 4 * s4 + fq;
+                const double av = (fr < k && kk < n) ? Z[(int64_t)kk * k + fr] : 0.0;
+                const double bv = Linv[(16 * jb + fr) * 128 + kk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) Wt[(fq + 4 * x) * 129 + 16 * jb + fr] = acc[x];
+    }
+    __syncthreads();
+    // ---- Gram matrix G = W^T W (16 x 16, K = 128) by wave 0
+    if (w == 0) {
+        gs_d4 g = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double wv = Wt[fr * 129 + 16 * kb + 4 * s4 + fq];
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) out[(fq + 4 * x) * 16 + fr] = g[x];
+        if (lane == 0) {
+            out[256] = ldet;
+            out[257] = 0.0;
         }
     }
 }

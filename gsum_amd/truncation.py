@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .conjugate import ConjugateGaussianProcess, lml_from_gram
+from .conjugate import ConjugateGaussianProcess, lml_from_gram, lml_from_gram_batch
 from .kernels import describe_kernel
 from .series import coefficients, geometric_sum
 
@@ -172,11 +172,27 @@ class TruncationGP:
             return lml - rhs_for(i)[1]
 
         if mode == "full":
+            # group this rank's points by ratio setting: they share the right-hand sides, so X and Z go to the
+            # device once per row and the thetas of the row run as ONE pipelined batch (several evaluations
+            # in flight on the GPU); every point still does its own kernel build + Cholesky + solve
+            rows = {}
             for flat in range(lo, hi):
                 i, j = divmod(flat, nj)
-                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
-                G, sld, info = ctx.lml_batch([describe_kernel(kern, Xd.shape[1])], Xd, rhs_for(i)[0], gp.nugget)
-                out[i, j] = finish(i, j, G[0], sld[0], info[0])
+                rows.setdefault(i, []).append(j)
+            desc_of = {}                # one descriptor per theta (clone_with_theta is the slow host step)
+
+            def desc_for(j):
+                if j not in desc_of:
+                    kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
+                    desc_of[j] = describe_kernel(kern, Xd.shape[1])
+                return desc_of[j]
+
+            for i, js in rows.items():
+                Zi, det = rhs_for(i)
+                ctx.set_inputs(Xd, Zi)
+                G, sld, info = ctx.lml_resident([desc_for(j) for j in js], gp.nugget)
+                vals = lml_from_gram_batch(G, sld, Xd.shape[0], gp.center0, gp.disp0, gp.df0, gp.scale0) - det
+                out[i, js] = np.where(info != 0, -np.inf, vals)
         elif mode == "reuse":
             by_theta = {}
             for flat in range(lo, hi):

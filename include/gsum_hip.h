@@ -59,7 +59,7 @@ int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8),
- * "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles).  <0 for an unknown name. */
+ * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
@@ -118,7 +118,9 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one
  * call are independent, so up to "batch_slots" of them are kept in flight on separate stream pairs and
  * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
- * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs. */
+ * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs.
+ * n <= 128 (the reference's own problem sizes) takes a fused path: one workgroup per evaluation builds K,
+ * factors it, solves and reduces, hundreds of evaluations per launch. */
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out);

@@ -294,6 +294,37 @@ def test_fit_with_optimizer_reaches_the_grid_optimum(notebook_grid):
     assert np.sqrt(gp.cov_factor_) == pytest.approx(0.9775259008799535, rel=2e-3)
 
 
+@pytest.mark.parametrize("n,d,spec", [(5, 1, KERNEL_SPECS[0]), (100, 1, KERNEL_SPECS[3]), (128, 3, KERNEL_SPECS[5]),
+                                      (77, 2, KERNEL_SPECS[4])])
+def test_small_fused_path_matches_general_path(ctx, n, d, spec):
+    """n <= 128 runs in one fused workgroup per evaluation; it must agree with the multi-kernel path."""
+    rng = np.random.RandomState(n)
+    X = rng.rand(n, d) * 3
+    Z = np.concatenate([rng.randn(n, 5), np.ones((n, 1))], axis=1)
+    kern = make_kernel(spec)
+    descs = [gsum_amd.describe_kernel(kern.clone_with_theta(kern.theta + dt), d) for dt in (0.0, 0.1, -0.2)]
+    ctx.set_inputs(X, Z)
+    got = ctx.lml_resident(descs, 1e-8)
+    ctx.set_option("small_path", 0)
+    want = ctx.lml_resident(descs, 1e-8)
+    ctx.set_option("small_path", 1)
+    tol = lml_tol(kern(X) + 1e-8 * np.eye(n)) * 100
+    np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got[0], want[0], rtol=max(1e-11, tol), atol=1e-11 * np.abs(want[0]).max())
+    # not positive definite -> same info on both paths
+    Xd = X.copy()
+    if n > 3:
+        Xd[3] = Xd[1]
+        ctx.set_inputs(Xd, Z)
+        i_small = ctx.lml_resident(descs[:1], 0.0)[2]
+        ctx.set_option("small_path", 0)
+        i_gen = ctx.lml_resident(descs[:1], 0.0)[2]
+        ctx.set_option("small_path", 1)
+        assert i_small[0] == i_gen[0]
+        assert (i_small[0] > 0) == (spec.get("white") is None)      # WhiteKernel noise keeps duplicates regular
+
+
 def test_notebook_grid_known_answer(notebook_grid):
     """The published MAP of the 80 x 100 (Q, ell) scan: indices (36, 39), bit-exact."""
     from sklearn.gaussian_process.kernels import RBF, WhiteKernel

@@ -73,6 +73,21 @@ def test_gram_algebra_reproduces_reference_lml_and_posterior(small_cases):
         assert post["cov_factor"] == pytest.approx(g["cov_factor"], rel=1e-11)
 
 
+def test_batched_gram_algebra_equals_scalar_version():
+    from gsum_amd.conjugate import lml_from_gram_batch
+    rng = np.random.RandomState(3)
+    Gs, ss = [], []
+    for _ in range(7):
+        W = rng.randn(40, 5)
+        W[:, -1] = np.abs(W[:, -1])
+        Gs.append(W.T @ W)
+        ss.append(rng.randn())
+    for pri in ((0, 0, 1, 1), (0.3, 0, 3, 1.5), (0.2, 2.0, 1, 1), (-0.1, 0.7, np.inf, 1.2), (-0.4, 0, np.inf, 0.8)):
+        want = [lml_from_gram(G, s_, 40, *pri)[0] for G, s_ in zip(Gs, ss)]
+        got = lml_from_gram_batch(np.array(Gs), np.array(ss), 40, *pri)
+        np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
 def test_posterior_rejects_vector_priors():
     with pytest.raises(ValueError):
         posterior_from_gram(np.eye(3), 10, [0.0, 1.0], 0, 1, 1)
