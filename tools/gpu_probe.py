@@ -39,7 +39,7 @@ for n, r in ((128, 4), (2048, 4), (4096, 6), (8192, 6)):
                 tm["wall_ms"] = wall
                 ts.append(tm)
             best = min(ts, key=lambda t: t["total_ms"])
-            if n == 128:
+            if n == 2048:
                 print("diag stamps", ctx.diag_stamps(), flush=True)
             best["chol_tflops"] = n ** 3 / 3 / (best["potrf_ms"] * 1e-3) / 1e12
             best["build_gbps_8n2"] = 8.0 * n * n / (best["build_ms"] * 1e-3) / 1e9
