@@ -28,6 +28,7 @@ __all__ = [
     "coefficients", "partials", "geometric_sum",
     "posterior_center", "posterior_disp", "posterior_df", "posterior_scale_sq",
     "cov_factor", "cgp_lml", "trunc_lml", "cgp_fit", "cgp_predict", "lml_grid",
+    "trunc_mean", "trunc_cov", "trunc_basis", "trunc_predict_trunc", "cgp_prior_predict",
 ]
 
 
@@ -301,3 +302,58 @@ def cgp_predict(fit, Xnew, return_std=False, return_cov=False, Xc=None, y=None,
             return m_pred, np.sqrt(np.diag(K_pred))            # models.py:842-843
         return m_pred, K_pred
     return m_pred
+
+
+# --------------------------------------------------------------------------
+# truncation-layer mean / cov / predict(kind='trunc')  (reference: gsum/models.py:1337-1365, 1456-1477)
+# --------------------------------------------------------------------------
+
+def _vec(v, n):
+    return v * np.ones(n) if np.ndim(v) == 0 else np.asarray(v)
+
+
+def trunc_mean(center, X, ratio, ref, start=0, end=np.inf, excluded=None):
+    """ref(X) * geometric_sum(ratio(X)) * (basis @ center).  models.py:1337-1340."""
+    n = X.shape[0]
+    coeff_mean = _ones_basis(X) @ np.atleast_1d(center)
+    return _vec(ref, n) * geometric_sum(_vec(ratio, n), start, end, excluded) * coeff_mean
+
+
+def trunc_cov(factor, kernel, X, Xp=None, ratio=0.5, ref=1, start=0, end=np.inf, excluded=None):
+    """ref_mat * geometric_sum(ratio_mat) * cov_factor * kernel(X, Xp).  models.py:1342-1348, 599."""
+    coeff_cov = factor * kernel(X, Xp)
+    Xp = X if Xp is None else Xp                    # reassigned after the kernel call (models.py:1344)
+    ratio_mat = _vec(ratio, X.shape[0])[:, None] * _vec(ratio, Xp.shape[0])
+    ref_mat = _vec(ref, X.shape[0])[:, None] * _vec(ref, Xp.shape[0])
+    return ref_mat * geometric_sum(ratio_mat, start, end, excluded) * coeff_cov
+
+
+def trunc_basis(X, ratio, ref, start=0, end=np.inf, excluded=None):
+    """models.py:1350-1354."""
+    n = X.shape[0]
+    return _vec(ref, n)[:, None] * geometric_sum(_vec(ratio, n)[:, None], start, end, excluded) * _ones_basis(X)
+
+
+def trunc_predict_trunc(center, factor, kernel, X, order, ratio, ref, excluded=None, fitted=True,
+                        return_std=False, return_cov=False):
+    """TruncationProcess.predict(kind='trunc') without constraints (fitted=True: models.py:1460-1461,
+    1474-1483, covariance built with Xp = X given explicitly, so no WhiteKernel term) and the unfitted path
+    underlying_properties (fitted=False: models.py:1356-1365, one-argument covariance)."""
+    m = trunc_mean(center, X, ratio, ref, start=order + 1, end=np.inf, excluded=excluded)
+    if not (return_std or return_cov):
+        return m
+    K = trunc_cov(factor, kernel, X, X if fitted else None, ratio, ref, start=order + 1, end=np.inf,
+                  excluded=excluded)
+    return (m, K) if return_cov else (m, np.sqrt(np.diag(K)))
+
+
+def cgp_prior_predict(kernel, Xnew, center=0, df=1, scale=1, sd=None, return_std=False, return_cov=False):
+    """Unfitted ConjugateGaussianProcess.predict = underlying_properties.  models.py:740-749, 792-793, 587-599."""
+    center0, _, df0, scale0 = _priors(center, 0, df, scale, sd)
+    mean = _ones_basis(Xnew) @ center0
+    if not (return_std or return_cov):
+        return mean
+    if df0 <= 2:
+        raise ValueError("df must be greater than 2 for the covariance to exist")
+    cov = cov_factor(scale0 ** 2, df0) * kernel(Xnew)
+    return (mean, cov) if return_cov else (mean, np.sqrt(np.diag(cov)))

@@ -284,6 +284,37 @@ def gen_large_gp_drawn():
     return out
 
 
+def gen_trunc_predict():
+    """TruncationGP.predict(kind='trunc'), mean/cov/basis scaling and the unfitted (prior) paths
+    (models.py:1337-1365, 1389-1483) plus ConjugateGaussianProcess prior predict (:792-793)."""
+    rng = np.random.RandomState(21)
+    n = 20
+    X = np.linspace(0, 2, n)[:, None]
+    Xs = np.linspace(0.05, 1.95, 6)[:, None]
+    out = []
+    for orders, excluded in (([0, 1, 2, 3], None), ([0, 2, 3, 4, 5], [3])):
+        orders = np.array(orders)
+        c = rng.randn(n, len(orders))
+        y = gsum.partials(c, ratio=0.4, ref=3.0, orders=orders)
+        kern = C(1.3) * RBF(0.35) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+        gp = gsum.TruncationGP(kernel=kern, ratio=0.4, ref=3.0, excluded=excluded, center=0.1, disp=0, df=4, scale=1.2,
+                               optimizer=None)
+        prior_mean = gp.predict(Xs, order=2)                      # unfitted: underlying_properties
+        _, prior_std = gp.predict(Xs, order=2, return_std=True)
+        gp.fit(X, y, orders=orders)
+        order = int(orders[2])
+        m, sd = gp.predict(Xs, order=order, return_std=True, kind="trunc")
+        _, cv = gp.predict(Xs, order=order, return_cov=True, kind="trunc")
+        out.append(dict(X=L(X), y=L(y), Xs=L(Xs), orders=orders.tolist(), excluded=excluded, order=order,
+                        prior_mean=L(prior_mean), prior_std=L(prior_std), mean=L(m), std=L(sd), cov=L(cv),
+                        mean_0_inf=L(gp.mean(Xs)), cov_2_4=L(gp.cov(Xs, Xs[:3], start=2, end=4)),
+                        basis_1_inf=L(gp.basis(Xs, start=1))))
+    cgp = gsum.ConjugateGaussianProcess(kernel=RBF(0.5), center=0.2, df=5, scale=1.5, optimizer=None)
+    pm, ps = cgp.predict(Xs, return_std=True)
+    _, pc = cgp.predict(Xs, return_cov=True)
+    return dict(cases=out, cgp_prior=dict(Xs=L(Xs), mean=L(pm), std=L(ps), cov=L(pc)))
+
+
 def gen_nonpd():
     """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
     X = np.array([[0.0], [0.5], [0.5], [1.0]])
@@ -310,6 +341,8 @@ def main():
         json.dump(out, f)
     with open(os.path.join(HERE, "notebook_grid.json"), "w") as f:
         json.dump(gen_notebook_grid(), f)
+    with open(os.path.join(HERE, "trunc_predict.json"), "w") as f:
+        json.dump(gen_trunc_predict(), f)
     with open(os.path.join(HERE, "large_lml.json"), "w") as f:
         json.dump(gen_large(), f, indent=1)
     with open(os.path.join(HERE, "large_lml_gp_drawn.json"), "w") as f:

@@ -254,6 +254,66 @@ def test_trunc_lml_array_ratio_ref(small_cases):
     np.testing.assert_allclose(grid[:, 0], a["lml"], rtol=tol)
 
 
+def test_truncation_predict_golden():
+    """TruncationGP.predict(kind='trunc'), mean / cov / basis scaling, and the unfitted (prior) paths of both
+    classes against reference outputs (models.py:1337-1365, 1389-1483, 792-793)."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    from conftest import load_golden
+    g = load_golden("trunc_predict.json")
+    kern = C(1.3) * RBF(0.35) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    for case in g["cases"]:
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        orders, order = np.array(case["orders"]), case["order"]
+        gp = gsum_amd.TruncationGP(kernel=kern, ratio=0.4, ref=3.0, excluded=case["excluded"], center=0.1, disp=0, df=4,
+                                   scale=1.2, optimizer=None)
+        np.testing.assert_allclose(gp.predict(Xs, order=2), case["prior_mean"], rtol=1e-13)
+        np.testing.assert_allclose(gp.predict(Xs, order=2, return_std=True)[1], case["prior_std"], rtol=1e-12)
+        gp.fit(X, y, orders=orders)
+        m, sd = gp.predict(Xs, order=order, return_std=True, kind="trunc")
+        np.testing.assert_allclose(m, case["mean"], rtol=1e-9)
+        np.testing.assert_allclose(sd, case["std"], rtol=1e-8)
+        np.testing.assert_allclose(gp.predict(Xs, order=order, return_cov=True, kind="trunc")[1], case["cov"], rtol=1e-8,
+                                   atol=1e-12 * np.abs(np.array(case["cov"])).max())
+        np.testing.assert_allclose(gp.mean(Xs), case["mean_0_inf"], rtol=1e-9)
+        np.testing.assert_allclose(gp.cov(Xs, Xs[:3], start=2, end=4), case["cov_2_4"], rtol=1e-8,
+                                   atol=1e-12 * np.abs(np.array(case["cov_2_4"])).max())
+        np.testing.assert_allclose(gp.basis(Xs, start=1), case["basis_1_inf"], rtol=1e-13)
+        with pytest.raises(ValueError):
+            gp.predict(Xs, order=17)
+        with pytest.raises(ValueError):
+            gp.predict(Xs, order=order, kind="nope")
+        with pytest.raises(NotImplementedError):
+            gp.predict(Xs, order=order, kind="both")
+    p = g["cgp_prior"]
+    cgp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(0.5), center=0.2, df=5, scale=1.5, optimizer=None)
+    m, s = cgp.predict(np.array(p["Xs"]), return_std=True)
+    np.testing.assert_allclose(m, p["mean"])
+    np.testing.assert_allclose(s, p["std"], rtol=1e-12)
+    np.testing.assert_allclose(cgp.predict(np.array(p["Xs"]), return_cov=True)[1], p["cov"], rtol=1e-12)
+
+
+def test_sixteen_right_hand_sides(ctx):
+    """15 curves + the basis column = GSUM_MAX_RHS; one more is rejected on the host."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    rng = np.random.RandomState(5)
+    for n in (60, 300):
+        X = np.sort(rng.rand(n))[:, None] * n * 0.3
+        y = rng.randn(n, 15)
+        kern = RBF(0.4) + WhiteKernel(1e-4, noise_level_bounds="fixed")
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, disp=1.0, df=2)
+        got = gp.log_marginal_likelihood(theta=kern.theta, X=X, y=y)
+        want = orc.cgp_lml(kern, kern.theta, X, y, disp=1.0, df=2)
+        assert got == pytest.approx(want, rel=lml_tol(kern(X) + 1e-10 * np.eye(n)))
+        gp.fit(X, y)
+        m, s = gp.predict(X[:7] + 0.01, return_std=True)
+        fit = orc.cgp_fit(kern, X, y, disp=1.0, df=2)
+        mo, so = orc.cgp_predict(fit, X[:7] + 0.01, return_std=True)
+        np.testing.assert_allclose(m, mo, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(s, so, rtol=1e-7)
+        with pytest.raises(ValueError):
+            gp.log_marginal_likelihood(theta=kern.theta, X=X, y=rng.randn(n, 16))
+
+
 def test_nonpd_behaviour(small_cases):
     from sklearn.gaussian_process.kernels import RBF
     c = small_cases["nonpd"]

@@ -134,3 +134,41 @@ def test_large_known_answers(large_lml):
             got = orc.trunc_lml(RBF(case["length_scale"]), np.log([case["length_scale"]]), X, y, np.arange(r),
                                 ratio=float(q), ref=1.0, nugget=case["nugget"])
             assert got == pytest.approx(want, rel=1e-12)
+
+
+def test_truncation_mean_cov_predict_against_reference():
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    from conftest import load_golden
+    g = load_golden("trunc_predict.json")
+    kern = C(1.3) * RBF(0.35) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    for case in g["cases"]:
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        orders, excluded, order = np.array(case["orders"]), case["excluded"], case["order"]
+        pri = dict(center=0.1, disp=0, df=4, scale=1.2)
+        # unfitted: prior centre and prior covariance factor
+        f0 = orc.cov_factor(1.2 ** 2, 4)
+        m0 = orc.trunc_predict_trunc(0.1, f0, kern, Xs, 2, 0.4, 3.0, excluded, fitted=False)
+        np.testing.assert_allclose(m0, case["prior_mean"], rtol=1e-13)
+        _, s0 = orc.trunc_predict_trunc(0.1, f0, kern, Xs, 2, 0.4, 3.0, excluded, fitted=False, return_std=True)
+        np.testing.assert_allclose(s0, case["prior_std"], rtol=1e-13)
+        mask = ~np.isin(orders, excluded)
+        c = orc.coefficients(y, 0.4, 3.0, orders)[:, mask]
+        fit = orc.cgp_fit(kern, X, c, **pri)
+        m, sd = orc.trunc_predict_trunc(fit["center"], fit["cov_factor"], kern, Xs, order, 0.4, 3.0, excluded,
+                                        return_std=True)
+        np.testing.assert_allclose(m, case["mean"], rtol=1e-12)
+        np.testing.assert_allclose(sd, case["std"], rtol=1e-11)
+        _, cv = orc.trunc_predict_trunc(fit["center"], fit["cov_factor"], kern, Xs, order, 0.4, 3.0, excluded,
+                                        return_cov=True)
+        np.testing.assert_allclose(cv, case["cov"], rtol=1e-11)
+        np.testing.assert_allclose(orc.trunc_mean(fit["center"], Xs, 0.4, 3.0, excluded=excluded), case["mean_0_inf"], rtol=1e-12)
+        np.testing.assert_allclose(orc.trunc_cov(fit["cov_factor"], kern, Xs, Xs[:3], 0.4, 3.0, 2, 4, excluded),
+                                   case["cov_2_4"], rtol=1e-11)
+        np.testing.assert_allclose(orc.trunc_basis(Xs, 0.4, 3.0, start=1, excluded=excluded), case["basis_1_inf"], rtol=1e-13)
+    p = g["cgp_prior"]
+    Xs = np.array(p["Xs"])
+    m, s = orc.cgp_prior_predict(RBF(0.5), Xs, center=0.2, df=5, scale=1.5, return_std=True)
+    np.testing.assert_allclose(m, p["mean"])
+    np.testing.assert_allclose(s, p["std"], rtol=1e-13)
+    _, cv = orc.cgp_prior_predict(RBF(0.5), Xs, center=0.2, df=5, scale=1.5, return_cov=True)
+    np.testing.assert_allclose(cv, p["cov"], rtol=1e-13)
