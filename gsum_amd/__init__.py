@@ -8,12 +8,12 @@ from .conjugate import (ConjugateGaussianProcess, posterior_from_gram, lml_from_
                         cov_factor)
 from .truncation import TruncationGP
 from .kernels import describe_kernel
-from .grid import shard_range, gather_flat, lml_grid_distributed
+from .grid import shard_range, gather_flat, lml_grid_distributed, predict_distributed
 from ._lib import HipContext, KernelDesc, default_context, load_library
 
 __version__ = "0.1.0"
 __all__ = [
     "coefficients", "partials", "geometric_sum", "ConjugateGaussianProcess", "TruncationGP",
     "posterior_from_gram", "lml_from_gram", "lml_from_gram_batch", "cov_factor", "describe_kernel", "shard_range", "gather_flat",
-    "lml_grid_distributed", "HipContext", "KernelDesc", "default_context", "load_library",
+    "lml_grid_distributed", "predict_distributed", "HipContext", "KernelDesc", "default_context", "load_library",
 ]

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["shard_range", "gather_flat", "lml_grid_distributed"]
+__all__ = ["shard_range", "gather_flat", "lml_grid_distributed", "predict_distributed"]
 
 
 def shard_range(total: int, rank: int = 0, world: int = 1):
@@ -64,3 +64,52 @@ def lml_grid_distributed(evaluate, n_rows: int, n_cols: int, group=None) -> np.n
     lo, hi = shard_range(total, rank, world)
     local = np.asarray(evaluate(shard=(rank, world)), dtype=np.float64).reshape(-1)[lo:hi]
     return gather_flat(local, total, group).reshape(n_rows, n_cols)
+
+
+def predict_distributed(predict, Xnew, n_curves, group=None):
+    """Predictive mean and standard deviation with the new points sharded over ranks.
+
+    Columns of the predictive covariance are independent per new point (gsum/models.py:836), so every rank
+    — holding its own copy of the factor — evaluates ``predict(Xnew[lo:hi], return_std=True)`` for its block
+    and the (m, n_curves) means and (m,) standard deviations come back in one all-gather.  ``predict`` is
+    typically the bound ``ConjugateGaussianProcess.predict`` of a model fitted identically on every rank.
+    """
+    dist = _dist()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
+    Xnew = np.asarray(Xnew, dtype=np.float64)
+    m = Xnew.shape[0]
+    lo, hi = shard_range(m, rank, world)
+    if hi > lo:
+        mean, std = predict(Xnew[lo:hi], return_std=True)
+        mean = np.asarray(mean, dtype=np.float64).reshape(hi - lo, n_curves)
+        std = np.asarray(std, dtype=np.float64).reshape(hi - lo)
+    else:
+        mean, std = np.empty((0, n_curves)), np.empty(0)
+    if dist is None or world == 1:
+        return np.squeeze(mean), std
+    packed = np.concatenate([mean, std[:, None]], axis=1).reshape(-1)      # n_curves + 1 values per point
+    full = _gather_rows(packed, m, n_curves + 1, group).reshape(m, n_curves + 1)
+    return np.squeeze(full[:, :n_curves]), full[:, n_curves]
+
+
+def _gather_rows(local_flat, total_rows, width, group=None):
+    """All-gather row blocks produced with shard_range(total_rows, ...): ``local_flat`` holds this rank's rows,
+    row-major, ``width`` values per row."""
+    dist = _dist()
+    import torch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    chunk = -(-total_rows // world)
+    lo, hi = shard_range(total_rows, rank, world)
+    dev = torch.device("cpu")
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.full((chunk * width,), float("nan"), dtype=torch.float64)
+    buf[: (hi - lo) * width] = torch.from_numpy(np.ascontiguousarray(local_flat, dtype=np.float64))
+    buf = buf.to(dev)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    pieces = []
+    for r_, o in enumerate(outs):
+        l2, h2 = shard_range(total_rows, r_, world)
+        pieces.append(o.cpu().numpy()[: (h2 - l2) * width])
+    return np.concatenate(pieces)

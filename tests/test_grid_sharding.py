@@ -78,6 +78,43 @@ def test_grid_gather_gloo(world, ni, nj):
     assert all(shape == (ni, nj) for _, _, shape in res)
 
 
+def _predict_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+        from oracle import gsum_oracle as orc
+        from gsum_amd.grid import predict_distributed
+        rng = np.random.RandomState(0)
+        X, y = rng.rand(40, 2) * 4, rng.randn(40, 3)
+        Xs = rng.rand(11, 2) * 4                       # 11 points over 2 or 3 ranks: ragged last block
+        kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+        fit = orc.cgp_fit(kern, X, y)
+        mean, std = predict_distributed(lambda Xb, return_std: orc.cgp_predict(fit, Xb, return_std=True), Xs, 3)
+        m0, s0 = orc.cgp_predict(fit, Xs, return_std=True)
+        q.put((rank, bool(np.allclose(mean, m0, rtol=1e-12) and np.allclose(std, s0, rtol=1e-12)), mean.shape, std.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_predict_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    assert all(ms == (11, 3) and ss == (11,) for _, _, ms, ss in res)
+
+
 def test_gather_flat_single_process():
     v = np.arange(5.0)
     np.testing.assert_array_equal(gather_flat(v, 5), v)
