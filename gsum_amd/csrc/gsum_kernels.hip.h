@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void k_lml_small(const double* X, int n, int d
 // columns: every global load of the tile's rows is finished before the epilogue stores.
 // ------------------------------------------------------------------------------------------------
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
                                                      const double* B, int64_t ldb, int M, int N, int K,
                                                      int tri, int beta, double sign,
                                                      unsigned long long* stamps = nullptr, int stagger = 0) {

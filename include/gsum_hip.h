@@ -131,8 +131,8 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
  * With option "diag_stamps" = 1 and n > 4: ms[4..8] = shader-cycle stamps of the last diagonal-block
  * kernel {prologue, column loop, block inverse, total} and its total in 100 MHz ticks. */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
-/* With option "profile_gemm" = 1 every launch of the 128x128-tile MFMA GEMM (the trailing SYRK and the
- * look-ahead column of the Cholesky) is bracketed by HIP events on the stream it is launched on.  This
+/* With option "profile_gemm" = 1 every launch of the 128x128-tile, 8-wave MFMA GEMM (the trailing SYRK of
+ * the Cholesky) is bracketed by HIP events on the stream it is launched on.  This
  * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
  * call, and resets the record. */
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
@@ -152,7 +152,7 @@ int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64
  * MFMAs, vmcnt wait + LDS stores, barrier} for one SYRK launch of order M, depth K. */
 int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, double* out5);
 /* debug: C(MxN) = beta*C + sign * A(MxK) B(NxK)^T through the MFMA tile kernel (cfg 0: 128x128 tile,
- * 1: 32x128 tile, 2: 16x256 tile; tri != 0: lower tiles only, needs M == N). */
+ * 1: 32x128 tile, 2: 16x256 tile, 5: 128x128 tile with 8 waves; tri != 0: lower tiles only, needs M == N). */
 int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const double* A, const double* B,
                        int64_t M, int64_t N, int64_t K, int32_t beta, double sign);
 
