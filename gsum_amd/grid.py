@@ -29,7 +29,7 @@ def _dist():
 def gather_flat(local: np.ndarray, total: int, group=None) -> np.ndarray:
     """All-gather the per-rank slices produced with :func:`shard_range` into the full flat array."""
     dist = _dist()
-    if dist is None or dist.get_world_size(group) == 1:
+    if dist is None:
         if len(local) != total:
             raise ValueError("single process must hold the whole grid")
         return np.asarray(local, dtype=np.float64)
