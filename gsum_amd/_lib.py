@@ -67,6 +67,7 @@ PROTOTYPES = {
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
+    "gsum_probe_cu_mask": (C.c_int, [_p, C.POINTER(C.c_uint32), C.c_int32, C.c_int32, _ip]),
     "gsum_bench_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp]),
     "gsum_debug_gemm_phases": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
@@ -323,6 +324,14 @@ class HipContext:
         v = C.c_double(0)
         self._check(self._lib.gsum_probe_hbm_write(self._h, nbytes, C.byref(v)))
         return float(v.value)
+
+    def probe_cu_mask(self, mask_words=None, nblocks=4096):
+        """Placement of nblocks workgroups under a stream CU mask: array (nblocks, 2) of (XCC id, HW_ID)."""
+        out = np.zeros((nblocks, 2), dtype=np.int64)
+        words = np.asarray(mask_words if mask_words is not None else [], dtype=np.uint32)
+        mp = words.ctypes.data_as(C.POINTER(C.c_uint32)) if words.size else None
+        self._check(self._lib.gsum_probe_cu_mask(self._h, mp, int(words.size), nblocks, out.ctypes.data_as(_ip)))
+        return out
 
     def bench_gemm_nt(self, cfg, M, N, K, tri=False, lda=None, reps=5):
         """(TFLOP/s, us per launch) of the MFMA tile kernel on device-resident random operands."""

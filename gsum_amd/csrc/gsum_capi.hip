@@ -25,7 +25,9 @@ struct gsum_mat {
 // result buffer and a workspace matrix.  Independent evaluations of a batch run on different slots, so
 // the latency-bound panel chain of one overlaps the bulk GEMMs of the others.
 struct gs_slot {
-    hipStream_t sm = nullptr, sp = nullptr;
+    hipStream_t sm = nullptr, sp = nullptr;   // main (bulk) / high-priority panel chain
+    hipStream_t sb = nullptr;        // bulk stream restricted by a CU mask (look-ahead schedules, reserve_cus > 0)
+    int sb_reserve = 0;              // reserve_cus value sb was created for
     std::vector<hipEvent_t> evP, evM;
     hipEvent_t evFork = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -47,6 +49,8 @@ struct gsum_ctx {
     int prio_lo = 0, prio_hi = 0;
     std::string err;
     int lookahead = 1;
+    int reserve_cus = -1;            // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs;
+                                     // -1 = auto: 2 from order 6144 up (measured -3 % at n >= 8192, +1 % below)
     int build_lower_only = 1;
     // resident inputs of the fused path
     double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;
@@ -232,9 +236,7 @@ static int gs_set_border(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const double
 // per byte of C traffic over a plain nb = 128 sweep (the K = 128 update was memory-side bound).  With
 // look-ahead, everything but `bulk` runs on the high-priority panel stream, so the panel chain of step
 // s+1 overlaps bulk(s).  Both streams are joined on the main stream at the end.
-static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
-    const int T = m->T;
-    gs_slot* sl = ctx->cur;
+static int gs_potrf_events(gsum_ctx* ctx, gs_slot* sl, int T) {
     if ((int)sl->evP.size() < T + 1) {
         size_t old = sl->evP.size();
         sl->evP.resize(T + 1);
@@ -244,6 +246,52 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             GS_CHECK(hipEventCreateWithFlags(&sl->evM[i], hipEventDisableTiming));
         }
     }
+    return 0;
+}
+
+// Bulk stream of a look-ahead schedule.  With reserve_cus = R > 0 it carries a CU mask that leaves R CUs of every
+// XCD to the chain kernels: a bulk workgroup holds its CU for ~80 us, and without free CUs every small chain
+// launch first waits for one to retire.  Mask bit i is CU i / 8 of XCD i % 8 (measured with gsum_probe_cu_mask),
+// so clearing the top 8 R bits takes R CUs from each XCD.
+static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* out) {
+    const int R = ctx->reserve_cus >= 0 ? ctx->reserve_cus : (np >= 6144 ? 2 : 0);
+    if (R <= 0) {
+        *out = sl->sm;
+        return 0;
+    }
+    if (sl->sb && sl->sb_reserve != R) {
+        GS_CHECK(hipStreamSynchronize(sl->sb));
+        GS_CHECK(hipStreamDestroy(sl->sb));
+        sl->sb = nullptr;
+    }
+    if (!sl->sb) {
+        hipDeviceProp_t prop;
+        GS_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        if (ncu % 8 != 0 || 8 * R >= ncu) GS_FAIL("reserve_cus: does not fit this device's CU count");
+        std::vector<uint32_t> mask(words, 0u);
+        for (int i = 0; i < ncu - 8 * R; ++i) mask[i >> 5] |= 1u << (i & 31);
+        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sb, (uint32_t)words, mask.data()));
+        sl->sb_reserve = R;
+    }
+    *out = sl->sb;
+    return 0;
+}
+
+static int gs_diag(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
+    gs_slot* sl = ctx->cur;
+    const int64_t c = (int64_t)b * GS_NB;
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld,
+                       m->Linv + (size_t)b * GS_NB * GS_NB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
+    const int T = m->T;
+    gs_slot* sl = ctx->cur;
+    if (gs_potrf_events(ctx, sl, T)) return -1;
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
     GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
@@ -253,10 +301,12 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
     hipStream_t sp = la ? sl->sp : sl->sm;
-    hipStream_t sm = sl->sm;
+    hipStream_t sm = sl->sm, sb = sl->sm;
     if (la) {
+        if (gs_bulk_stream(ctx, sl, m->np, &sb)) return -1;
         GS_CHECK(hipEventRecord(sl->evFork, sm));
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
+        if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
     }
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
@@ -267,18 +317,14 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int Kp = two ? 2 * GS_NB : GS_NB;
         // ---- sub-step a
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c0 * ld + c0, ld, Linv, m->logdet + k, sl->dinfo,
-                           (int)c0, m->diag0 + c0, stamps);
-        GS_CHECK(hipGetLastError());
+        if (gs_diag(ctx, sp, m, k)) return -1;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
         if (gs_gemm(ctx, sp, 1, Pa, ld, Pa, ld, Linv, GS_NB, naug - c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
         if (two) {
             // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
             if (gs_gemm(ctx, sp, 1, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
             double* Linv1 = Linv + GS_NB * GS_NB;
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, sp, A + c1 * ld + c1, ld, Linv1, m->logdet + k + 1,
-                               sl->dinfo, (int)c1, m->diag0 + c1, stamps);
-            GS_CHECK(hipGetLastError());
+            if (gs_diag(ctx, sp, m, k + 1)) return -1;
             double* Pb = A + r2 * ld + c1;
             if (gs_gemm(ctx, sp, 1, Pb, ld, Pb, ld, Linv1, GS_NB, naug - r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
         }
@@ -297,13 +343,14 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             if (gs_gemm(ctx, sp, 1, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
-            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
-            if (gs_gemm(ctx, sm, 5, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
-            GS_CHECK(hipEventRecord(sl->evM[k], sm));
+            GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
+            if (gs_gemm(ctx, sb, 5, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(sl->evM[k], sb));
             prev = k;
         } else {
             // last panel: only the 16x16 corner (the Gram matrix) is left
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
+            if (sb != sm && prev >= 0) GS_CHECK(hipStreamWaitEvent(sm, sl->evM[prev], 0));
             if (gs_gemm(ctx, sm, 5, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
         }
     }
@@ -399,6 +446,7 @@ void gsum_destroy(gsum_ctx* ctx) {
             if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
         if (sl->sm) (void)hipStreamDestroy(sl->sm);
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
+        if (sl->sb) (void)hipStreamDestroy(sl->sb);
     }
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dZ) (void)hipFree(ctx->dZ);
@@ -418,6 +466,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
     else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
+    else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
@@ -876,6 +925,23 @@ int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps) {
     float ms = 0.f;
     GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
     *gbps = (double)(nvec * 16) / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// diagnostic: placement of nblocks workgroups launched on a stream restricted by a CU mask (nwords = 0: no mask)
+int gsum_probe_cu_mask(gsum_ctx* ctx, const uint32_t* mask, int32_t nwords, int32_t nblocks, int64_t* out) {
+    if (!ctx || !out || nblocks <= 0 || nwords < 0 || (nwords > 0 && !mask)) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)nblocks * 16)) return -1;
+    hipStream_t s = nullptr;
+    if (nwords > 0) GS_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask));
+    else GS_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_probe_where, dim3((unsigned)nblocks), dim3(256), 0, s, (long long*)ctx->scratch, 20000);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(out, ctx->scratch, (size_t)nblocks * 16, hipMemcpyDeviceToHost);
+    (void)hipStreamDestroy(s);
+    GS_CHECK(e);
     return 0;
 }
 

@@ -296,18 +296,24 @@ __device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8]
             *fail_col = j0;
             return false;
         }
-        const double r0 = gs_rsqrt_nr(p0);
-        double d0 = p0 * r0;                                            // sqrt(p0) ...
-        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);   // ... corrected to ~0.5 ulp
-        const double l10 = a10 * r0;                                    // L[j1][j0]
-        const double p1 = __builtin_fma(-l10, l10, p1raw);
-        if (!(p1 > t1)) {
+        // The two pivots' reciprocal square roots are independent chains: with q = p1raw p0 - a10^2 (formed
+        // from mailbox values only), p1 = q / p0 and 1/sqrt(p1) = sqrt(p0) rsqrt(q), so rsqrt(q) runs beside
+        // rsqrt(p0) instead of after it.
+        const double qq = __builtin_fma(p1raw, p0, -(a10 * a10));
+        if (!(qq > t1 * p0)) {                  // <=> p1 = q / p0 <= threshold (or NaN)
             *fail_col = j1;
             return false;
         }
-        const double r1 = gs_rsqrt_nr(p1);
-        double d1 = p1 * r1;
-        d1 = __builtin_fma(__builtin_fma(-d1, d1, p1), 0.5 * r1, d1);
+        const double r0 = gs_rsqrt_nr(p0);
+        const double rq = gs_rsqrt_nr(qq);
+        double d0 = p0 * r0;                                            // sqrt(p0) ...
+        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);   // ... corrected to ~0.5 ulp
+        const double l10 = a10 * r0;                                    // L[j1][j0]
+        const double r1 = d0 * rq;                                      // 1 / sqrt(p1)
+        double sq = qq * rq;                                            // sqrt(q), corrected like d0
+        sq = __builtin_fma(__builtin_fma(-sq, sq, qq), 0.5 * rq, sq);
+        const double d1 = sq * r0;                                      // sqrt(p1): the same q as r1, so that
+                                                                        // L_j1j1 r1 = 1 to a few ulp
         if (threadIdx.x == 0) {
             dbuf[j0] = d0;
             dbuf[j1] = d1;
@@ -879,4 +885,16 @@ __global__ __launch_bounds__(256) void k_probe_store(gs_d2* out, int64_t nvec) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     gs_d2 v = {1.0, 2.0};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) out[i] = v;
+}
+
+// diagnostic: where does each workgroup run?  out[2b] = XCC id, out[2b+1] = HW_ID register (CU / SH / SE fields)
+__global__ __launch_bounds__(256) void k_probe_where(long long* out, int spin_cycles) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spin_cycles) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (long long)xcc;
+        out[2 * blockIdx.x + 1] = (long long)hw;
+    }
 }

@@ -59,7 +59,9 @@ int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8),
- * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles).  <0 for an unknown name. */
+ * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
+ * "reserve_cus" (-1 auto, 0..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while a
+ * look-ahead factorisation runs).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
@@ -142,6 +144,9 @@ int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int6
 int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, int32_t waves_per_simd, int32_t n_acc, double* out3);
 /* HBM streaming-store probe: achieved GB/s writing `bytes` with 16-B stores. */
 int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps);
+/* diagnostic: run nblocks workgroups on a stream restricted by a CU mask (hipExtStreamCreateWithCUMask; nwords = 0:
+ * unrestricted) and report where each ran: out[2b] = XCC id, out[2b+1] = the HW_ID register (CU, SH, SE fields). */
+int gsum_probe_cu_mask(gsum_ctx* ctx, const uint32_t* mask, int32_t nwords, int32_t nblocks, int64_t* out);
 /* microbenchmark of the MFMA tile kernel on device-resident pseudo-random operands (leading dimension
  * lda >= K for A and B, as inside the factorisation): out2 = {algorithmic TFLOP/s, microseconds per launch}.
  * tri != 0: SYRK form (B = A, lower tiles only, M == N, flops counted as M(M+1)K). */

@@ -497,6 +497,10 @@ def test_full_size_properties_n8192():
             out[(la, lower)] = ctx.lml_batch([desc], X, Z, 1e-10)
     ctx.set_option("lookahead", 1)
     ctx.set_option("build_lower_only", 1)
+    for reserve in (0, 4):                   # bulk stream with / without a CU mask: scheduling only
+        ctx.set_option("reserve_cus", reserve)
+        out[("reserve", reserve)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    ctx.set_option("reserve_cus", -1)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     for key, (G, s, i) in out.items():
@@ -515,3 +519,38 @@ def test_full_size_properties_n8192():
     K = RBF(0.2)(X[rows], X)
     K[np.arange(len(rows)), rows] += 1e-10
     np.testing.assert_allclose(L[rows] @ L.T, K, rtol=0, atol=1e-13)
+
+
+def test_full_size_properties_n16384_matern_2d():
+    """BASELINE configs[4] (n = 16384, 2-D Matern-5/2 fit + predict) through size-independent properties: L L^T
+    reproduces K on sampled rows; predicting at training inputs returns the training curve (interpolation, nugget
+    -> 0) with a predictive variance that vanishes against the prior's; a prediction sharded over two ranks' row
+    ranges equals the unsharded one bit for bit."""
+    from sklearn.gaussian_process.kernels import Matern
+    rng = np.random.RandomState(5)
+    n = 16384
+    X = rng.rand(n, 2) * 40.0                                   # ~10 points per unit area, length scale 1
+    kern = Matern(length_scale=[1.0, 1.5], nu=2.5)
+    ctx = gsum_amd.default_context(0)
+    desc = gsum_amd.describe_kernel(kern, 2)
+    M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-8)
+    assert ctx.potrf(M) == 0
+    rows = np.array([0, 1, 127, 128, 8191, 8192, 12345, 16383])
+    Lr = M.to_host()
+    M.free()
+    K = kern(X[rows], X)
+    K[np.arange(len(rows)), rows] += 1e-8
+    np.testing.assert_allclose(Lr[rows] @ Lr.T, K, rtol=0, atol=1e-13)
+    del Lr
+    y = np.sin(0.3 * X[:, :1]) * np.cos(0.2 * X[:, 1:]) + 0.1 * rng.randn(n, 1) * 0
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, nugget=1e-8, optimizer=None)
+    gp.fit(X, y)
+    idx = rng.choice(n, 512, replace=False)
+    m, s = gp.predict(X[idx], return_std=True)
+    np.testing.assert_allclose(m, y[idx, 0], rtol=0, atol=1e-5)
+    assert np.all(s < 1e-3 * np.sqrt(gp.cov_factor_))
+    from gsum_amd.grid import shard_range
+    Xnew = rng.rand(256, 2) * 40.0
+    full = gp.predict(Xnew)
+    parts = [gp.predict(Xnew[slice(*shard_range(len(Xnew), r, 2))]) for r in range(2)]
+    np.testing.assert_array_equal(np.concatenate(parts), full)
