@@ -37,6 +37,34 @@ class KernelDesc(C.Structure):
                 f"add={self.additive_const}, white={self.white_noise})")
 
 
+class SeriesScale(C.Structure):
+    """Mirror of ``gsum_series_scale``: cov_ij = factor ref_i ref_j S(ratio_i ratio_j) kernel_ij."""
+    _fields_ = [
+        ("start", C.c_int32),
+        ("end", C.c_int32),
+        ("n_excluded", C.c_int32),
+        ("excluded", C.c_int32 * 16),
+        ("factor", C.c_double),
+    ]
+
+    @classmethod
+    def make(cls, start, end, excluded=None, factor=1.0):
+        """``end`` may be ``numpy.inf`` (infinite sum); ``excluded`` is an int, a sequence or None (helpers.py:149-182)."""
+        sc = cls()
+        if end < start:
+            raise ValueError('end must be greater than or equal to start')          # helpers.py:175-176
+        sc.start = int(start)
+        sc.end = -1 if np.isinf(end) else int(end)
+        exc = [] if excluded is None else [int(e) for e in np.atleast_1d(excluded)]
+        if len(exc) > 16:
+            raise ValueError("at most 16 excluded orders")
+        sc.n_excluded = len(exc)
+        for i, e in enumerate(exc):
+            sc.excluded[i] = e
+        sc.factor = float(factor)
+        return sc
+
+
 _p = C.c_void_p
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -56,6 +84,9 @@ PROTOTYPES = {
     "gsum_forward_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_predict_terms": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
                                      _dp, _dp, _dp]),
+    "gsum_mat_scale_series": (C.c_int, [_p, _p, C.POINTER(SeriesScale), _dp, _dp]),
+    "gsum_predict_terms_series": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
+                                            C.POINTER(SeriesScale), _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "gsum_mat_to_host": (C.c_int, [_p, _p, _dp]),
     "gsum_mat_n": (C.c_int64, [_p]),
     "gsum_mat_free": (None, [_p, _p]),
@@ -123,6 +154,13 @@ class DeviceMatrix:
         out = np.empty((self.n, self.n))
         self._ctx._check(self._ctx._lib.gsum_mat_to_host(self._ctx._h, self._h, _ptr(out)))
         return out
+
+    def scale_series(self, series: "SeriesScale", ref, ratio):
+        """In place: A_ij *= factor ref_i ref_j S(ratio_i ratio_j) (TruncationProcess.cov, models.py:1343-1354)."""
+        ref, ratio = _f64(ref), _f64(ratio)
+        if ref.shape != (self.n,) or ratio.shape != (self.n,):
+            raise ValueError("ref and ratio must have one value per row")
+        self._ctx._check(self._ctx._lib.gsum_mat_scale_series(self._ctx._h, self._h, C.byref(series), _ptr(ref), _ptr(ratio)))
 
     def free(self):
         if self._h is not None and self._ctx._h is not None:
@@ -232,7 +270,8 @@ class HipContext:
         self._check(self._lib.gsum_forward_solve(self._h, L._h, _ptr(rhs), n, k, _ptr(W)))
         return W[:, 0] if squeeze else W
 
-    def predict_terms(self, L: DeviceMatrix, desc: KernelDesc, X, Xs, rhs=None, want_cov=False):
+    def predict_terms(self, L: DeviceMatrix, desc: KernelDesc, X, Xs, rhs=None, want_cov=False, series=None):
+        """``series`` = (SeriesScale, ref_x, ratio_x, ref_s, ratio_s) scales the cross matrix like cov(X, Xs, start, end)."""
         X, Xs = _f64(X), _f64(Xs)
         n, d = X.shape
         m = Xs.shape[0]
@@ -246,8 +285,17 @@ class HipContext:
             k = rhs.shape[1]
             VtW = np.empty((m, k))
         cov = np.empty((m, m)) if want_cov else None
-        self._check(self._lib.gsum_predict_terms(self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m,
-                                                 _ptr(rhs), k, _ptr(colsumsq), _ptr(VtW), _ptr(cov)))
+        if series is None:
+            self._check(self._lib.gsum_predict_terms(self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m,
+                                                     _ptr(rhs), k, _ptr(colsumsq), _ptr(VtW), _ptr(cov)))
+        else:
+            sc, ref_x, ratio_x, ref_s, ratio_s = series
+            ref_x, ratio_x, ref_s, ratio_s = _f64(ref_x), _f64(ratio_x), _f64(ref_s), _f64(ratio_s)
+            if ref_x.shape != (n,) or ratio_x.shape != (n,) or ref_s.shape != (m,) or ratio_s.shape != (m,):
+                raise ValueError("series scaling needs one ref / ratio value per point")
+            self._check(self._lib.gsum_predict_terms_series(
+                self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m, _ptr(rhs), k, C.byref(sc), _ptr(ref_x),
+                _ptr(ratio_x), _ptr(ref_s), _ptr(ratio_s), _ptr(colsumsq), _ptr(VtW), _ptr(cov)))
         return colsumsq, VtW, cov
 
     # -- fused hot path ------------------------------------------------------

@@ -633,9 +633,58 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
 
 // V^T = kernel(Xs, X) L^-T, one row per new point (m x np, row-major): the same right-looking sweep as
 // the factorisation's panel step, with the rows of kernel(Xs, X) in the role of the rows below the panel.
+static int gs_check_series(gsum_ctx* ctx, const gsum_series_scale* sc) {
+    if (sc->start < 0 || (sc->end >= 0 && sc->end < sc->start)) GS_FAIL("series scale: end must be >= start >= 0");
+    if (sc->n_excluded < 0 || sc->n_excluded > GSUM_MAX_EXCLUDED) GS_FAIL("series scale: too many excluded orders");
+    return 0;
+}
+
+int gsum_mat_scale_series(gsum_ctx* ctx, gsum_mat* A, const gsum_series_scale* sc, const double* ref, const double* ratio) {
+    if (!ctx || !A || !sc || !ref || !ratio) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (A->factored) GS_FAIL("scale_series needs an unfactored matrix");
+    if (gs_check_series(ctx, sc)) return -2;
+    const int64_t n = A->n;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)2 * n * 8)) return -1;
+    double* dref = ctx->scratch;
+    double* drat = dref + n;
+    hipStream_t s = ctx->cur->sm;
+    GS_CHECK(hipMemcpyAsync(dref, ref, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    GS_CHECK(hipMemcpyAsync(drat, ratio, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A->A, A->ld, (int)n, (int)n,
+                       dref, drat, dref, drat, *sc);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                            int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                            const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                            const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW, double* cov_out);
+
 int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
                        int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
                        double* colsumsq, double* VtW, double* cov_out) {
+    return gs_predict_terms(ctx, L, desc, X, n, d, Xs, m, RHS, k, nullptr, nullptr, nullptr, nullptr, nullptr, colsumsq,
+                            VtW, cov_out);
+}
+
+int gsum_predict_terms_series(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                              int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                              const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                              const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW,
+                              double* cov_out) {
+    if (!ctx || !sc || !ref_x || !ratio_x || !ref_s || !ratio_s) return -2;
+    if (gs_check_series(ctx, sc)) return -2;
+    return gs_predict_terms(ctx, L, desc, X, n, d, Xs, m, RHS, k, sc, ref_x, ratio_x, ref_s, ratio_s, colsumsq, VtW,
+                            cov_out);
+}
+
+static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                            int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                            const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                            const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW, double* cov_out) {
     if (!ctx || !L || !X || !Xs || !colsumsq) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
     if (gs_check_desc(ctx, desc, d)) return -2;
@@ -646,7 +695,8 @@ int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc,
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t o_xs = 0, o_bt = up((size_t)m * d * 8), o_vw = o_bt + up((size_t)m * ldb * 8),
                  o_ss = o_vw + up((size_t)m * 16 * 8), o_cv = o_ss + up((size_t)m * 8),
-                 total = o_cv + (cov_out ? up((size_t)m * m * 8) : 0);
+                 o_sc = o_cv + (cov_out ? up((size_t)m * m * 8) : 0),
+                 total = o_sc + (sc ? up((size_t)2 * (n + m) * 8) : 0);
     if (gs_upload_X(ctx, X, n, d)) return -1;
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, total)) return -1;
     char* base = (char*)ctx->scratch;
@@ -657,6 +707,18 @@ int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc,
     hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, Bt, ldb, dXs, ctx->dX, (int)m, (int)n,
                        (int)m, (int)np, d, *desc, 0.0, 0);
     GS_CHECK(hipGetLastError());
+    if (sc) {
+        // rows of Bt are the new points, columns the conditioning points
+        double* v = (double*)(base + o_sc);
+        double *d_ref_s = v, *d_rat_s = v + m, *d_ref_x = v + 2 * m, *d_rat_x = v + 2 * m + n;
+        GS_CHECK(hipMemcpyAsync(d_ref_s, ref_s, (size_t)m * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_rat_s, ratio_s, (size_t)m * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_ref_x, ref_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_rat_x, ratio_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m,
+                           (int)n, d_ref_s, d_rat_s, d_ref_x, d_rat_x, *sc);
+        GS_CHECK(hipGetLastError());
+    }
     for (int c = 0; c < L->T; ++c) {
         const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
         double* Linv = L->Linv + (size_t)c * GS_NB * GS_NB;

@@ -840,6 +840,27 @@ __global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int
     out[(int64_t)i * n + j] = v;
 }
 
+// Coefficient covariance -> partial-sum covariance, in place (models.py:1343-1354 with helpers.py:149-182):
+//   A_ij *= factor * ref_r[i] ref_c[j] * S(ratio_r[i] ratio_c[j]),
+//   S(x) = (x^start - x^(end+1)) / (1 - x) - sum_{e excluded, start <= e <= end} x^e;   end < 0: infinite sum, x^(end+1) = 0.
+// Same operation order as the reference's array expression; pow() is within an ulp of numpy's.
+__global__ __launch_bounds__(256) void k_scale_series(double* A, int64_t ld, int rows, int cols, const double* ref_r,
+                                                       const double* ratio_r, const double* ref_c, const double* ratio_c,
+                                                       gsum_series_scale sc) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= cols || i >= rows) return;
+    const double x = ratio_r[i] * ratio_c[j];
+    const double hi = sc.end < 0 ? 0.0 : pow(x, (double)(sc.end + 1));
+    double sum = (pow(x, (double)sc.start) - hi) / (1.0 - x);
+    for (int e = 0; e < sc.n_excluded; ++e) {
+        const int ex = sc.excluded[e];
+        if (ex >= sc.start && (sc.end < 0 || ex <= sc.end)) sum -= pow(x, (double)ex);
+    }
+    const double refm = ref_r[i] * ref_c[j];
+    A[(int64_t)i * ld + j] = (refm * sum) * (sc.factor * A[(int64_t)i * ld + j]);
+}
+
 // ---- probes ------------------------------------------------------------------------------------
 // pseudo-random fill in [-1, 1) (integer hash), so benchmark operands are not zeros (DVFS reads high on zeros)
 __global__ __launch_bounds__(256) void k_fill_random(double* p, int64_t n, unsigned seed) {

@@ -89,23 +89,84 @@ class TruncationGP:
         return self
 
     # -- predict (models.py:1389-1483) ----------------------------------------------------------------
+    def _condition(self, X, Xc, resid, start, end, want_cov):
+        """The conditioning algebra of models.py:1443-1452 / 1464-1473 for K = cov(., ., start, end):
+        returns (K_no K_oo^-1 resid, diag(K_no K_oo^-1 K_on), K_no K_oo^-1 K_on or None).
+
+        The reference solves with LU (numpy.linalg.solve) on cov(Xc, Xc), which carries neither nugget nor
+        WhiteKernel noise (two-argument kernel call).  Here K_oo is built and scaled on the
+        device and factorised by the same Cholesky as the likelihood path: for a positive definite K_oo the two
+        agree to rounding x cond(K_oo); a K_oo that is singular to working precision raises LinAlgError
+        instead of returning LU's arbitrary answer."""
+        import copy
+        from ._lib import SeriesScale
+        gp = self.coeffs_process
+        ctx = gp._context()
+        X = np.asarray(X, dtype=float)
+        Xc = np.asarray(Xc, dtype=float)
+        desc = copy.copy(describe_kernel(gp.kernel_, Xc.shape[1]))
+        desc.white_noise = 0.0                         # kernel_(Xc, Xc) with both arguments given: no white noise
+        sc = SeriesScale.make(start, end, self.excluded, gp.cov_factor_)
+        ref_c, ratio_c = self.ref(Xc), self.ratio(Xc, **self.ratio_kws)
+        ref_n, ratio_n = self.ref(X), self.ratio(X, **self.ratio_kws)
+        K = ctx.kernel_matrix_dev(desc, Xc, diag_add=0.0)
+        try:
+            K.scale_series(sc, ref_c, ratio_c)
+            info = ctx.potrf(K)
+            if info != 0:
+                raise np.linalg.LinAlgError(
+                    'cov(Xc, Xc) is not positive definite to working precision (leading minor %d); the reference '
+                    'conditions on it with LU and no jitter -- use fewer / better separated conditioning points' % info)
+            colsumsq, shift, red = ctx.predict_terms(K, desc, Xc, X, rhs=resid, want_cov=want_cov,
+                                                     series=(sc, ref_c, ratio_c, ref_n, ratio_n))
+        finally:
+            K.free()
+        return shift[:, 0], colsumsq, red
+
     def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both'):
         if not self._fit:
             return self.underlying_properties(X, order, return_cov=return_cov, return_std=return_std)
-        if y is None and order not in self.orders_:
-            raise ValueError('order must be in orders passed to `fit`')            # models.py:1423-1424
+        if Xc is None:
+            Xc = self.X_train_
+        if y is None:
+            if order not in self.orders_:
+                raise ValueError('order must be in orders passed to `fit`')            # models.py:1423-1424
+            if self.y_train_.ndim == 1:
+                y = self.y_train_
+            else:
+                y = np.squeeze(self.y_train_[:, self.orders_ == order])               # models.py:1428
         if kind not in ['both', 'interp', 'trunc']:
             raise ValueError('kind must be one of "both", "interp" or "trunc"')     # models.py:1430-1431
-        if kind != 'trunc' or self.dX_ is not None:
-            # interpolation / constrained truncation condition with LU on an un-jittered matrix
-            # (models.py:1443-1452, 1464-1473): SURVEY.md §8 row f-2, not built yet.
-            raise NotImplementedError("TruncationGP.predict: only kind='trunc' without dX/dy constraints is built")
-        m_pred = self.mean(X=X, start=order + 1, end=np.inf)                        # models.py:1460, 1475
-        if return_std or return_cov:
-            K_pred = self.cov(X=X, Xp=X, start=order + 1, end=np.inf)               # models.py:1461, 1477
-            if return_cov:
-                return m_pred, K_pred
-            return m_pred, np.sqrt(np.diag(K_pred))
+        want_var = return_std or return_cov
+        m_pred, K_pred = 0, 0
+        if kind == 'both' or kind == 'interp':
+            # interpolating prediction of y_order, conditioned on (Xc, y)             models.py:1434-1453
+            m_old = self.mean(X=Xc, start=0, end=order)
+            m_new = self.mean(X=X, start=0, end=order)
+            shift, red_diag, red = self._condition(X, Xc, np.asarray(y, dtype=float) - m_old, 0, order, return_cov)
+            m_pred = m_pred + m_new + shift
+            if want_var:
+                K_nn = self.cov(start=0, end=order, X=X, Xp=X)
+                K_pred = K_pred + (K_nn - red if return_cov else np.diag(K_nn) - red_diag)
+        if kind == 'both' or kind == 'trunc':
+            # truncation error                                                         models.py:1455-1476
+            m_new_trunc = self.mean(X=X, start=order + 1, end=np.inf)
+            K_nn_trunc = self.cov(X=X, Xp=X, start=order + 1, end=np.inf) if want_var else None
+            if self.dX_ is not None:                                                   # constrained
+                m_old_trunc = self.mean(X=self.dX_, start=order + 1, end=np.inf)
+                shift, red_diag, red = self._condition(X, self.dX_, np.asarray(self.dy_, dtype=float) - m_old_trunc,
+                                                       order + 1, np.inf, return_cov)
+                m_pred = m_pred + m_new_trunc + shift
+                if want_var:
+                    K_pred = K_pred + (K_nn_trunc - red if return_cov else np.diag(K_nn_trunc) - red_diag)
+            else:
+                m_pred = m_pred + m_new_trunc
+                if want_var:
+                    K_pred = K_pred + (K_nn_trunc if return_cov else np.diag(K_nn_trunc))
+        if return_cov:
+            return m_pred, K_pred
+        if return_std:
+            return m_pred, np.sqrt(K_pred)          # K_pred holds the diagonal here     models.py:1482
         return m_pred
 
     # -- likelihood (models.py:1485-1507) ---------------------------------------------------------------

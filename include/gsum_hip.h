@@ -54,6 +54,18 @@ typedef struct {
     double white_noise;                /* WhiteKernel noise_level (0.0 if absent)*/
 } gsum_kernel_desc;
 
+/* Scaling of a coefficient covariance into a partial-sum covariance (TruncationProcess.cov, models.py:1343-1354,
+ * with helpers.py:149-182):  cov_ij = factor * ref_i ref_j * S(ratio_i ratio_j) * kernel_ij,
+ *   S(x) = (x^start - x^(end+1)) / (1 - x) - sum over excluded orders e with start <= e <= end of x^e.
+ * end < 0 stands for the infinite sum (x^(end+1) taken as 0, as numpy gives for |x| < 1 and end = inf). */
+#define GSUM_MAX_EXCLUDED 16
+typedef struct {
+    int32_t start, end;
+    int32_t n_excluded;
+    int32_t excluded[GSUM_MAX_EXCLUDED];
+    double factor;
+} gsum_series_scale;
+
 /* ---- context ---------------------------------------------------------------------------------- */
 int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
@@ -100,6 +112,19 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
 int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
                        int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
                        double* colsumsq, double* VtW, double* cov_out);
+
+/* In-place series scaling of an unfactored device matrix (ref, ratio: n host values each): the conditioning matrix
+ * K_oo = cov(Xc, Xc, start, end) of TruncationProcess.predict (models.py:1443, 1466) from kernel(Xc, Xc). */
+int gsum_mat_scale_series(gsum_ctx* ctx, gsum_mat* A, const gsum_series_scale* sc, const double* ref, const double* ratio);
+
+/* gsum_predict_terms with the cross matrix kernel(X, Xs) scaled like cov(X, Xs, start, end) first (ref_x / ratio_x:
+ * n values, ref_s / ratio_s: m values): with L = chol(K_oo) its outputs are the pieces of models.py:1449-1452 and
+ * :1470-1473 -- K_no alpha = VtW, K_no K_oo^-1 K_on = cov_out, its diagonal = colsumsq. */
+int gsum_predict_terms_series(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                              int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                              const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                              const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW,
+                              double* cov_out);
 
 /* copy out: the full symmetric matrix (before potrf) or L with a zeroed upper triangle (after). */
 int gsum_mat_to_host(gsum_ctx* ctx, const gsum_mat* A, double* out);

@@ -308,30 +308,32 @@ def cgp_predict(fit, Xnew, return_std=False, return_cov=False, Xc=None, y=None,
 # truncation-layer mean / cov / predict(kind='trunc')  (reference: gsum/models.py:1337-1365, 1456-1477)
 # --------------------------------------------------------------------------
 
-def _vec(v, n):
+def _vec(v, X):
+    """ratio / ref at the points X: a callable (models.py:1309-1317 wraps scalars into one), a scalar or an array."""
+    if callable(v):
+        return np.asarray(v(X))
+    n = X.shape[0]
     return v * np.ones(n) if np.ndim(v) == 0 else np.asarray(v)
 
 
 def trunc_mean(center, X, ratio, ref, start=0, end=np.inf, excluded=None):
     """ref(X) * geometric_sum(ratio(X)) * (basis @ center).  models.py:1337-1340."""
-    n = X.shape[0]
     coeff_mean = _ones_basis(X) @ np.atleast_1d(center)
-    return _vec(ref, n) * geometric_sum(_vec(ratio, n), start, end, excluded) * coeff_mean
+    return _vec(ref, X) * geometric_sum(_vec(ratio, X), start, end, excluded) * coeff_mean
 
 
 def trunc_cov(factor, kernel, X, Xp=None, ratio=0.5, ref=1, start=0, end=np.inf, excluded=None):
     """ref_mat * geometric_sum(ratio_mat) * cov_factor * kernel(X, Xp).  models.py:1342-1348, 599."""
     coeff_cov = factor * kernel(X, Xp)
     Xp = X if Xp is None else Xp                    # reassigned after the kernel call (models.py:1344)
-    ratio_mat = _vec(ratio, X.shape[0])[:, None] * _vec(ratio, Xp.shape[0])
-    ref_mat = _vec(ref, X.shape[0])[:, None] * _vec(ref, Xp.shape[0])
+    ratio_mat = _vec(ratio, X)[:, None] * _vec(ratio, Xp)
+    ref_mat = _vec(ref, X)[:, None] * _vec(ref, Xp)
     return ref_mat * geometric_sum(ratio_mat, start, end, excluded) * coeff_cov
 
 
 def trunc_basis(X, ratio, ref, start=0, end=np.inf, excluded=None):
     """models.py:1350-1354."""
-    n = X.shape[0]
-    return _vec(ref, n)[:, None] * geometric_sum(_vec(ratio, n)[:, None], start, end, excluded) * _ones_basis(X)
+    return _vec(ref, X)[:, None] * geometric_sum(_vec(ratio, X)[:, None], start, end, excluded) * _ones_basis(X)
 
 
 def trunc_predict_trunc(center, factor, kernel, X, order, ratio, ref, excluded=None, fitted=True,
@@ -345,6 +347,44 @@ def trunc_predict_trunc(center, factor, kernel, X, order, ratio, ref, excluded=N
     K = trunc_cov(factor, kernel, X, X if fitted else None, ratio, ref, start=order + 1, end=np.inf,
                   excluded=excluded)
     return (m, K) if return_cov else (m, np.sqrt(np.diag(K)))
+
+
+def trunc_predict(center, factor, kernel, X, order, ratio, ref, Xc, y, excluded=None, kind="both", dX=None, dy=None,
+                  return_std=False, return_cov=False):
+    """Fitted TruncationProcess.predict for every kind (models.py:1430-1483): the interpolation block conditions
+    y_order on (Xc, y) with covariances over orders 0..order, the truncation block adds the orders beyond, itself
+    conditioned on (dX, dy) when constraints were given to fit.  Conditioning uses numpy.linalg.solve (LU) on the
+    un-jittered cov(Xc, Xc), exactly as the reference (:1449, 1452, 1470, 1473)."""
+    if kind not in ("both", "interp", "trunc"):
+        raise ValueError('kind must be one of "both", "interp" or "trunc"')
+    want = return_std or return_cov
+    m_pred, K_pred = 0, 0
+
+    def block(Xo, resid_from, start, end):
+        m_old = trunc_mean(center, Xo, ratio, ref, start=start, end=end, excluded=excluded)
+        m_new = trunc_mean(center, X, ratio, ref, start=start, end=end, excluded=excluded)
+        K_oo = trunc_cov(factor, kernel, Xo, Xo, ratio, ref, start=start, end=end, excluded=excluded)
+        K_on = trunc_cov(factor, kernel, Xo, X, ratio, ref, start=start, end=end, excluded=excluded)
+        K_nn = trunc_cov(factor, kernel, X, X, ratio, ref, start=start, end=end, excluded=excluded)
+        m = m_new + K_on.T @ np.linalg.solve(K_oo, resid_from - m_old)
+        K = K_nn - K_on.T @ np.linalg.solve(K_oo, K_on) if want else 0
+        return m, K
+
+    if kind in ("both", "interp"):
+        m, K = block(Xc, y, 0, order)
+        m_pred, K_pred = m_pred + m, K_pred + K
+    if kind in ("both", "trunc"):
+        if dX is not None:
+            m, K = block(dX, dy, order + 1, np.inf)
+        else:
+            m = trunc_mean(center, X, ratio, ref, start=order + 1, end=np.inf, excluded=excluded)
+            K = trunc_cov(factor, kernel, X, X, ratio, ref, start=order + 1, end=np.inf, excluded=excluded) if want else 0
+        m_pred, K_pred = m_pred + m, K_pred + K
+    if return_cov:
+        return m_pred, K_pred
+    if return_std:
+        return m_pred, np.sqrt(np.diag(K_pred))
+    return m_pred
 
 
 def cgp_prior_predict(kernel, Xnew, center=0, df=1, scale=1, sd=None, return_std=False, return_cov=False):

@@ -68,3 +68,19 @@ def have_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def interp_case_setup(case):
+    """Kernel, ratio and ref of a tests/golden/trunc_predict_interp.json case (see make_golden.py)."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    kd = case["kernel"]
+    base = RBF(kd["ls"]) if kd["base"] == "rbf" else Matern(kd["ls"], nu=2.5)
+    kern = C(kd["const"]) * base
+    if kd["white"] is not None:
+        kern = kern + WhiteKernel(kd["white"], noise_level_bounds="fixed")
+    if case["ratio"] == "array":
+        ratio = lambda X: 0.3 + 0.1 * X[:, 0]          # noqa: E731
+        ref = lambda X: 2.0 + X[:, 0]                  # noqa: E731
+    else:
+        ratio, ref = case["ratio"], case["ref"]
+    return kern, ratio, ref

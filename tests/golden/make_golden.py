@@ -315,6 +315,68 @@ def gen_trunc_predict():
     return dict(cases=out, cgp_prior=dict(Xs=L(Xs), mean=L(pm), std=L(ps), cov=L(pc)))
 
 
+def gen_trunc_predict_interp():
+    """TruncationGP.predict with kind='interp' / 'both', Xc / y overrides, position-dependent ratio and ref, and a
+    truncation error constrained by (dX, dy) (models.py:1389-1483).  Conditioning sets are kept well separated:
+    the reference conditions on the un-jittered cov(Xc, Xc) (quirk Q7) and cond(K_oo) is recorded per case."""
+    rng = np.random.RandomState(33)
+    Xs = np.linspace(0.03, 1.97, 7)[:, None]
+    specs = [
+        dict(name="const_ratio_rbf", n=8, orders=[0, 1, 2, 3], excluded=None, order_idx=2,
+             kernel=dict(const=1.3, base="rbf", ls=0.35, white=1e-6), ratio=0.4, ref=3.0, constrained=False),
+        dict(name="excluded_rbf", n=7, orders=[0, 2, 3, 4, 5], excluded=[3], order_idx=3,
+             kernel=dict(const=0.8, base="rbf", ls=0.3, white=1e-8), ratio=0.55, ref=1.5, constrained=False),
+        dict(name="array_ratio_matern", n=12, orders=[0, 1, 2, 3, 4], excluded=None, order_idx=2,
+             kernel=dict(const=1.0, base="matern25", ls=0.5, white=None), ratio="array", ref="array", constrained=False),
+        dict(name="constrained_trunc", n=8, orders=[0, 1, 2, 3], excluded=None, order_idx=1,
+             kernel=dict(const=1.1, base="rbf", ls=0.4, white=1e-8), ratio=0.45, ref=2.0, constrained=True),
+    ]
+    out = []
+    for sp in specs:
+        n = sp["n"]
+        X = np.linspace(0, 2, n)[:, None]
+        orders = np.array(sp["orders"])
+        kd = sp["kernel"]
+        base = RBF(kd["ls"]) if kd["base"] == "rbf" else Matern(kd["ls"], nu=2.5)
+        kern = C(kd["const"]) * base
+        if kd["white"] is not None:
+            kern = kern + WhiteKernel(kd["white"], noise_level_bounds="fixed")
+        if sp["ratio"] == "array":
+            ratio = lambda X: 0.3 + 0.1 * X[:, 0]          # noqa: E731
+            ref = lambda X: 2.0 + X[:, 0]                  # noqa: E731
+            ratio_v, ref_v = ratio(X), ref(X)
+        else:
+            ratio, ref = sp["ratio"], sp["ref"]
+            ratio_v, ref_v = ratio, ref
+        c = rng.randn(n, len(orders))
+        y = gsum.partials(c, ratio=ratio_v, ref=ref_v, orders=orders)
+        gp = gsum.TruncationGP(kernel=kern, ratio=ratio, ref=ref, excluded=sp["excluded"], center=0.1, disp=0, df=4,
+                               scale=1.2, optimizer=None)
+        dX = dy = None
+        if sp["constrained"]:
+            dX, dy = np.array([[0.5], [1.5]]), np.array([0.0, 0.02])
+        gp.fit(X, y, orders=orders, dX=dX, dy=dy)
+        order = int(orders[sp["order_idx"]])
+        case = dict(name=sp["name"], X=L(X), y=L(y), Xs=L(Xs), orders=orders.tolist(), excluded=sp["excluded"],
+                    order=order, kernel=kd, ratio=sp["ratio"], ref=sp["ref"], constrained=sp["constrained"],
+                    dX=None if dX is None else L(dX), dy=None if dy is None else L(dy), kinds={})
+        K_oo = gp.cov(start=0, end=order, X=X, Xp=X)
+        case["cond_K_oo"] = float(np.linalg.cond(K_oo))
+        for kind in ("interp", "both", "trunc"):
+            m, sd = gp.predict(Xs, order=order, return_std=True, kind=kind)
+            _, cv = gp.predict(Xs, order=order, return_cov=True, kind=kind)
+            m_only = gp.predict(Xs, order=order, kind=kind)
+            case["kinds"][kind] = dict(mean=L(m), std=L(sd), cov=L(cv), mean_only=L(m_only))
+        # conditioning on a subset with an explicit y (models.py:1401-1406)
+        sub = slice(None, None, 2)
+        yo = np.squeeze(y[:, orders == order])[sub]
+        m, sd = gp.predict(Xs, order=order, return_std=True, Xc=X[sub], y=yo, kind="both")
+        case["subset"] = dict(step=2, mean=L(m), std=L(sd))
+        out.append(case)
+        print("trunc-predict-interp", sp["name"], "cond", case["cond_K_oo"], flush=True)
+    return dict(cases=out)
+
+
 def gen_nonpd():
     """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
     X = np.array([[0.0], [0.5], [0.5], [1.0]])
@@ -343,6 +405,8 @@ def main():
         json.dump(gen_notebook_grid(), f)
     with open(os.path.join(HERE, "trunc_predict.json"), "w") as f:
         json.dump(gen_trunc_predict(), f)
+    with open(os.path.join(HERE, "trunc_predict_interp.json"), "w") as f:
+        json.dump(gen_trunc_predict_interp(), f)
     with open(os.path.join(HERE, "large_lml.json"), "w") as f:
         json.dump(gen_large(), f, indent=1)
     with open(os.path.join(HERE, "large_lml_gp_drawn.json"), "w") as f:

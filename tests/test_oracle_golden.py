@@ -172,3 +172,37 @@ def test_truncation_mean_cov_predict_against_reference():
     np.testing.assert_allclose(s, p["std"], rtol=1e-13)
     _, cv = orc.cgp_prior_predict(RBF(0.5), Xs, center=0.2, df=5, scale=1.5, return_cov=True)
     np.testing.assert_allclose(cv, p["cov"], rtol=1e-13)
+
+
+def test_truncation_predict_all_kinds_against_reference():
+    """TruncationGP.predict kind = interp / both / trunc, Xc / y overrides, array ratio / ref and constrained
+    truncation (models.py:1389-1483): the oracle against the reference's outputs."""
+    from conftest import load_golden, interp_case_setup
+    g = load_golden("trunc_predict_interp.json")
+    for case in g["cases"]:
+        kern, ratio, ref = interp_case_setup(case)
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        orders, excluded, order = np.array(case["orders"]), case["excluded"], case["order"]
+        rv = ratio(X) if callable(ratio) else ratio
+        fv = ref(X) if callable(ref) else ref
+        mask = ~np.isin(orders, excluded)
+        c = orc.coefficients(y, rv, fv, orders)[:, mask]
+        fit = orc.cgp_fit(kern, X, c, center=0.1, disp=0, df=4, scale=1.2)
+        dX = None if case["dX"] is None else np.array(case["dX"])
+        dy = None if case["dy"] is None else np.array(case["dy"])
+        yo = np.squeeze(y[:, orders == order])
+        tol = 1e-15 * case["cond_K_oo"] * 100 + 1e-12
+        for kind, want in case["kinds"].items():
+            kw = dict(excluded=excluded, kind=kind, dX=dX, dy=dy)
+            m, sd = orc.trunc_predict(fit["center"], fit["cov_factor"], kern, Xs, order, ratio, ref, X, yo, return_std=True, **kw)
+            np.testing.assert_allclose(m, want["mean"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(sd ** 2, np.array(want["std"]) ** 2, rtol=1e-9, atol=tol * np.max(np.array(want["std"]) ** 2))
+            _, cv = orc.trunc_predict(fit["center"], fit["cov_factor"], kern, Xs, order, ratio, ref, X, yo, return_cov=True, **kw)
+            np.testing.assert_allclose(cv, want["cov"], rtol=1e-9, atol=tol * np.abs(want["cov"]).max())
+            np.testing.assert_allclose(orc.trunc_predict(fit["center"], fit["cov_factor"], kern, Xs, order, ratio, ref, X, yo, **kw),
+                                       want["mean_only"], rtol=tol, atol=tol)
+        sub = slice(None, None, case["subset"]["step"])
+        m, sd = orc.trunc_predict(fit["center"], fit["cov_factor"], kern, Xs, order, ratio, ref, X[sub], yo[sub],
+                                  excluded=excluded, kind="both", dX=dX, dy=dy, return_std=True)
+        np.testing.assert_allclose(m, case["subset"]["mean"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(sd, case["subset"]["std"], rtol=1e-9)
