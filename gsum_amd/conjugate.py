@@ -19,6 +19,7 @@ import warnings
 
 import numpy as np
 from scipy.optimize import fmin_l_bfgs_b
+from scipy.special import loggamma
 from sklearn.base import clone
 from sklearn.exceptions import ConvergenceWarning
 from sklearn.utils import check_random_state
@@ -26,7 +27,8 @@ from sklearn.utils import check_random_state
 from ._lib import GSUM_MAX_RHS, default_context
 from .kernels import default_kernel, describe_kernel
 
-__all__ = ["ConjugateGaussianProcess", "posterior_from_gram", "lml_from_gram", "lml_from_gram_batch", "cov_factor"]
+__all__ = ["ConjugateGaussianProcess", "ConjugateStudentProcess", "posterior_from_gram", "lml_from_gram",
+           "lml_from_gram_batch", "student_lml_from_gram", "cov_factor"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -124,8 +126,28 @@ def lml_from_gram_batch(G, sum_log_diag, n_points, center0, disp0, df0, scale0):
     return -0.5 * S / var - 0.5 * ny * logdet_K - ny * n_points / 2.0 * np.log(2.0 * np.pi)
 
 
+def student_lml_from_gram(G, sum_log_diag, n_points, center0, disp0, df0, scale0):
+    """ConjugateStudentProcess.log_marginal_likelihood from (G, sum log diag L): the ratio of the normalisation
+    constants of the normal scaled-inverse-chi-squared posterior and prior.  models.py:1186-1259 (value path)."""
+    post = posterior_from_gram(G, n_points, center0, disp0, df0, scale0)
+    ny = np.asarray(G).shape[0] - 1
+    disp0 = np.atleast_2d(np.asarray(disp0, dtype=float))
+
+    def log_norm(df_, scale_, disp_):                                   # models.py:1234-1240
+        norm = loggamma(df_ / 2.) - df_ / 2. * np.log(df_ * scale_ ** 2 / 2.)
+        log_det = np.linalg.slogdet(2 * np.pi * disp_)[1]
+        if log_det != -np.inf:
+            norm += 0.5 * log_det
+        return norm
+
+    logdet_R = 2.0 * sum_log_diag                                       # models.py:1243
+    lml = log_norm(post["df"], np.sqrt(post["scale_sq"]), post["disp"]) - log_norm(df0, scale0, disp0) \
+        - ny / 2. * (n_points * np.log(2 * np.pi) + logdet_R)           # models.py:1250-1251
+    return float(lml), post
+
+
 # ---------------------------------------------------------------------------------------------
-# the class
+# the classes
 # ---------------------------------------------------------------------------------------------
 
 class ConjugateGaussianProcess:
@@ -259,8 +281,23 @@ class ConjugateGaussianProcess:
         G, sld, info = self._context().lml_batch([desc], X, Z, self.nugget)
         if info[0] != 0:
             return -np.inf                                                           # models.py:970-972
-        lml, _ = lml_from_gram(G[0], sld[0], X.shape[0], self.center0, self.disp0, self.df0, self.scale0)
+        lml, _ = self._lml_gram(G[0], sld[0], X.shape[0])
         return lml
+
+    def _lml_gram(self, G, sld, n_points):
+        """(log marginal likelihood, posterior dict) of this process from one Gram matrix."""
+        return lml_from_gram(G, sld, n_points, self.center0, self.disp0, self.df0, self.scale0)
+
+    def _lml_gram_batch(self, G, sld, n_points):
+        return lml_from_gram_batch(G, sld, n_points, self.center0, self.disp0, self.df0, self.scale0)
+
+    def _cov_terms(self, d):
+        """(factor, descriptor) such that the two-argument covariance of the fitted process is
+        factor * kernel_desc(X, Xp): what TruncationProcess conditions with (models.py:599, 1343)."""
+        import copy
+        desc = copy.copy(describe_kernel(self.kernel_, d))
+        desc.white_noise = 0.0                  # kernel_(X, Xp) with both arguments given: no white noise
+        return self.cov_factor_, desc
 
     # -- fit (models.py:630-738) -------------------------------------------------------------------
     def _constrained_optimization(self, obj_func, initial_theta, bounds):
@@ -327,7 +364,7 @@ class ConjugateGaussianProcess:
             self._L_dev = None
             raise np.linalg.LinAlgError("Matrix is not positive definite")    # numpy's message; models.py:711
         G, sld = ctx.forward_gram(self._L_dev, Z)
-        lml, post = lml_from_gram(G, sld, Xd.shape[0], self.center0, self.disp0, self.df0, self.scale0)
+        lml, post = self._lml_gram(G, sld, Xd.shape[0])
         self.log_marginal_likelihood_value_ = lml if lml_opt is None else lml_opt
         self._gram = (G, sld)
         self.center_ = post["center"]                                        # models.py:721-736
@@ -386,10 +423,15 @@ class ConjugateGaussianProcess:
 
     # -- predict (models.py:753-845) ------------------------------------------------
     def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):
+        return self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, False)[0]
+
+    def _predict_core(self, X, return_std, return_cov, Xc, y, pred_noise, want_basis):
+        """predict, plus (want_basis) the conditional basis 1 - R_no R^-1 1 of models.py:1168 from the same
+        triangular solve: one more right-hand-side column."""
         if return_std and return_cov:
             raise RuntimeError('Only one of return_std or return_cov may be True')
         if not self._fit:
-            return self.underlying_properties(X=X, return_std=return_std, return_cov=return_cov)
+            return self.underlying_properties(X=X, return_std=return_std, return_cov=return_cov), None
         self._check_decomposition()
         ctx = self._context()
         X = np.asarray(X, dtype=float)
@@ -412,6 +454,9 @@ class ConjugateGaussianProcess:
             m_old = self.mean(Xc)                                                 # models.py:818
             m_new = self.mean(X)                                                  # models.py:819
             resid = y - m_old[:, None]
+            n_curves = resid.shape[1]
+            if want_basis:
+                resid = np.concatenate([resid, self.basis(Xc)], axis=1)
             m_parts, colsumsq, VtV = [], None, None
             for lo in range(0, resid.shape[1], GSUM_MAX_RHS):
                 want_cov = return_cov and lo == 0
@@ -423,7 +468,9 @@ class ConjugateGaussianProcess:
             if own is not None:
                 own.free()
         # R_no R^-1 (y - m) = (L^-1 R_on)^T (L^-1 (y - m))                         models.py:831-832
-        m_pred = np.squeeze(m_new[:, None] + np.concatenate(m_parts, axis=1))
+        shifts = np.concatenate(m_parts, axis=1)
+        cond_basis = self.basis(X) - shifts[:, n_curves:] if want_basis else None
+        m_pred = np.squeeze(m_new[:, None] + shifts[:, :n_curves])
         if return_std or return_cov:
             var = cov_factor(self.scale_ ** 2, self.df_)                           # models.py:840
             if return_std:
@@ -432,12 +479,12 @@ class ConjugateGaussianProcess:
                 r_diag = diag_nn - colsumsq                                        # models.py:836
                 if pred_noise:
                     r_diag = r_diag + self.nugget                                  # models.py:837-838
-                return m_pred, np.sqrt(np.squeeze(var * r_diag))                   # models.py:841-843
+                return (m_pred, np.sqrt(np.squeeze(var * r_diag))), cond_basis    # models.py:841-843
             R_pred = ctx.kernel_matrix(desc, X) - VtV
             if pred_noise:
                 R_pred += self.nugget * np.eye(len(X))
-            return m_pred, np.squeeze(var * R_pred)
-        return m_pred
+            return (m_pred, np.squeeze(var * R_pred)), cond_basis
+        return m_pred, cond_basis
 
     # -- sampling (models.py:847-879) ----------------------------------------------------------------------
     def sample_y(self, X, n_samples=1, random_state=0, underlying=False):
@@ -451,3 +498,57 @@ class ConjugateGaussianProcess:
         samples = [rng.multivariate_normal(y_mean[:, i], y_cov, n_samples).T[:, np.newaxis]
                    for i in range(y_mean.shape[1])]
         return np.hstack(samples)
+
+
+class ConjugateStudentProcess(ConjugateGaussianProcess):
+    """Conjugate-prior Student-t process; same surface as gsum.ConjugateStudentProcess (models.py:1091-1273).
+
+    It shares fit and the device path with the Gaussian class (the reference's BaseConjugateProcess); what differs
+    is host algebra on the same Gram matrix: the likelihood is a ratio of normalisation constants, and covariances
+    carry the rank-one term basis disp basis^T from integrating out the mean."""
+
+    def _lml_gram(self, G, sld, n_points):
+        return student_lml_from_gram(G, sld, n_points, self.center0, self.disp0, self.df0, self.scale0)
+
+    def _lml_gram_batch(self, G, sld, n_points):
+        return np.array([self._lml_gram(Gi, si, n_points)[0] for Gi, si in zip(G, sld)])
+
+    def _cov_terms(self, d):
+        # var * (corr + basis disp basis^T) with a constant basis is an additive constant in the kernel (:1125)
+        _, desc = super()._cov_terms(d)
+        desc.additive_const += float(self.disp_[0, 0])
+        return cov_factor(self.scale_ ** 2, self.df_), desc
+
+    def cov(self, X, Xp=None):                                           # models.py:1099-1125
+        import copy
+        if not self._fit:
+            df, scale, disp = self.df0, self.scale0, self.disp0
+            kernel = self._default_kernel if self.kernel is None else self.kernel
+        else:
+            df, scale, disp = self.df_, self.scale_, self.disp_
+            kernel = self.kernel_
+        if df <= 2:
+            raise ValueError('df must be greater than 2 for the covariance to exist')
+        X = np.asarray(X, dtype=float)
+        desc = copy.copy(describe_kernel(kernel, X.shape[1]))
+        desc.additive_const += float(np.atleast_2d(disp)[0, 0])
+        corr = self._context().kernel_matrix(desc, X, None if Xp is None else np.asarray(Xp, dtype=float))
+        return cov_factor(scale ** 2, df) * corr
+
+    def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):   # models.py:1127-1184
+        pred, basis = self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, True)
+        if not self._fit:
+            disp = self.disp0
+            var = cov_factor(self.scale0 ** 2, self.df0)
+            basis = self.basis(X)
+        else:
+            disp = self.disp_
+            var = self.cov_factor_
+        mean_cov = var * (basis @ disp @ basis.T)                         # from integrating out the mean, :1174
+        if return_std:
+            mean, std = pred
+            return mean, std + np.sqrt(np.diag(mean_cov))                # standard deviations are added (:1177)
+        if return_cov:
+            mean, cov = pred
+            return mean, cov + mean_cov
+        return pred

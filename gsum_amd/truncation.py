@@ -9,15 +9,17 @@ from __future__ import annotations
 
 import numpy as np
 
-from .conjugate import ConjugateGaussianProcess, lml_from_gram, lml_from_gram_batch
+from .conjugate import ConjugateGaussianProcess, ConjugateStudentProcess
 from .kernels import describe_kernel
 from .series import coefficients, geometric_sum
 
-__all__ = ["TruncationGP"]
+__all__ = ["TruncationGP", "TruncationTP"]
 
 
 class TruncationGP:
     """Same constructor and methods as gsum.TruncationGP (models.py:1307-1335, 1510-1516)."""
+
+    _coeffs_process_class = ConjugateGaussianProcess
 
     def __init__(self, kernel=None, ratio=0.5, ref=1, excluded=None, ratio_kws=None, **kwargs):
         if not callable(ref):
@@ -28,7 +30,7 @@ class TruncationGP:
             self.ratio = lambda X, ratio=ratio: ratio * np.ones(X.shape[0])  # models.py:1314-1317
         else:
             self.ratio = ratio
-        self.coeffs_process = ConjugateGaussianProcess(kernel=kernel, **kwargs)
+        self.coeffs_process = self._coeffs_process_class(kernel=kernel, **kwargs)
         self.kernel = kernel
         self._log_like = None
         self.excluded = excluded
@@ -98,15 +100,13 @@ class TruncationGP:
         device and factorised by the same Cholesky as the likelihood path: for a positive definite K_oo the two
         agree to rounding x cond(K_oo); a K_oo that is singular to working precision raises LinAlgError
         instead of returning LU's arbitrary answer."""
-        import copy
         from ._lib import SeriesScale
         gp = self.coeffs_process
         ctx = gp._context()
         X = np.asarray(X, dtype=float)
         Xc = np.asarray(Xc, dtype=float)
-        desc = copy.copy(describe_kernel(gp.kernel_, Xc.shape[1]))
-        desc.white_noise = 0.0                         # kernel_(Xc, Xc) with both arguments given: no white noise
-        sc = SeriesScale.make(start, end, self.excluded, gp.cov_factor_)
+        factor, desc = gp._cov_terms(Xc.shape[1])      # coefficient covariance = factor * kernel_desc(X, Xp)
+        sc = SeriesScale.make(start, end, self.excluded, factor)
         ref_c, ratio_c = self.ref(Xc), self.ratio(Xc, **self.ratio_kws)
         ref_n, ratio_n = self.ref(X), self.ratio(X, **self.ratio_kws)
         K = ctx.kernel_matrix_dev(desc, Xc, diag_add=0.0)
@@ -229,7 +229,7 @@ class TruncationGP:
         def finish(i, j, G, sld, info):
             if info != 0:
                 return -np.inf
-            lml, _ = lml_from_gram(G, sld, Xd.shape[0], gp.center0, gp.disp0, gp.df0, gp.scale0)
+            lml, _ = gp._lml_gram(G, sld, Xd.shape[0])
             return lml - rhs_for(i)[1]
 
         if mode == "full":
@@ -252,7 +252,7 @@ class TruncationGP:
                 Zi, det = rhs_for(i)
                 ctx.set_inputs(Xd, Zi)
                 G, sld, info = ctx.lml_resident([desc_for(j) for j in js], gp.nugget)
-                vals = lml_from_gram_batch(G, sld, Xd.shape[0], gp.center0, gp.disp0, gp.df0, gp.scale0) - det
+                vals = gp._lml_gram_batch(G, sld, Xd.shape[0]) - det
                 out[i, js] = np.where(info != 0, -np.inf, vals)
         elif mode == "reuse":
             by_theta = {}
@@ -275,3 +275,39 @@ class TruncationGP:
         else:
             raise ValueError('mode must be "full" or "reuse"')
         return out
+
+
+class TruncationTP(TruncationGP):
+    """Student-t truncation process; same surface as gsum.TruncationTP (models.py:1519-1570)."""
+
+    _coeffs_process_class = ConjugateStudentProcess
+
+    def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both'):
+        # like the reference (:1527-1530), `kind` is not forwarded: the Gaussian part is always kind='both'
+        pred = super().predict(X=X, order=order, return_std=return_std, return_cov=return_cov, Xc=Xc, y=y,
+                               pred_noise=pred_noise)
+        if not return_std and not return_cov:
+            return pred
+        if Xc is None:
+            Xc = self.X_train_
+        X = np.asarray(X, dtype=float)
+        var, disp = self.coeffs_process.cov_factor_, self.coeffs_process.disp_
+        basis_lower = np.zeros((X.shape[0], disp.shape[0]))
+        basis_trunc = np.zeros((X.shape[0], disp.shape[0]))
+        if kind == 'both' or kind == 'interp':                              # models.py:1543-1550
+            old = self.basis(X=Xc, start=0, end=order)
+            shift, _, _ = self._condition(X, Xc, old[:, 0], 0, order, False)
+            basis_lower = self.basis(X=X, start=0, end=order) - shift[:, None]
+        if kind == 'both' or kind == 'trunc':                               # models.py:1552-1562
+            if self.dX_ is not None:
+                old = self.basis(X=self.dX_, start=order + 1, end=np.inf)
+                shift, _, _ = self._condition(X, self.dX_, old[:, 0], order + 1, np.inf, False)
+                basis_trunc = self.basis(X=X, start=order + 1, end=np.inf) - shift[:, None]
+            else:
+                basis_trunc = self.basis(start=order + 1, end=np.inf, X=X)
+        mean_cov = var * (basis_lower + basis_trunc) @ disp @ (basis_lower + basis_trunc).T   # models.py:1564
+        if return_std:
+            mean, std = pred
+            return mean, std + np.sqrt(np.diag(mean_cov))
+        mean, cov = pred
+        return mean, cov + mean_cov

@@ -397,3 +397,127 @@ def cgp_prior_predict(kernel, Xnew, center=0, df=1, scale=1, sd=None, return_std
         raise ValueError("df must be greater than 2 for the covariance to exist")
     cov = cov_factor(scale0 ** 2, df0) * kernel(Xnew)
     return (mean, cov) if return_cov else (mean, np.sqrt(np.diag(cov)))
+
+
+# --------------------------------------------------------------------------
+# Student-t process  (reference: gsum/models.py:1091-1273) and TruncationTP (:1519-1570)
+# --------------------------------------------------------------------------
+
+def csp_lml(kernel, theta, X, y, center=0, disp=0, df=1, scale=1, sd=None, nugget=1e-10):
+    """ConjugateStudentProcess.log_marginal_likelihood, value path (models.py:1186-1259, cholesky)."""
+    from scipy.special import loggamma
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    if theta is not None:
+        kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))      # :1202
+    ny = _num_y(y)                                                            # :1192
+    R = kernel(X)                                                             # :1206
+    R[np.diag_indices_from(R)] += nugget                                      # :1208
+    N = R.shape[0]
+    try:
+        L = cholesky(R)                                                       # :1215
+    except np.linalg.LinAlgError:
+        return -np.inf
+    dfn = posterior_df(y, df0)                                                # :1225
+    basis = _ones_basis(X)
+    disp_n = posterior_disp(y, L, basis, disp0)                               # :1238
+    scale_sq = posterior_scale_sq(y if y.ndim > 1 else y[:, None], L, basis, center0, disp0, df0, scale0)   # :1239-1242
+    scale_n = np.sqrt(scale_sq)                                               # :1244
+
+    def log_norm(df_, scale_, disp_):                                         # :1246-1252
+        norm = loggamma(df_ / 2.) - df_ / 2. * np.log(df_ * scale_ ** 2 / 2.)
+        log_det = np.linalg.slogdet(2 * np.pi * disp_)[1]
+        if log_det != -np.inf:
+            norm += 0.5 * log_det
+        return norm
+
+    logdet_R = 2 * np.log(np.diag(L)).sum()                                   # :1255
+    return log_norm(dfn, scale_n, disp_n) - log_norm(df0, scale0, disp0) \
+        - ny / 2. * (N * np.log(2 * np.pi) + logdet_R)                         # :1262-1263
+
+
+def csp_cov(kernel, X, Xp, df, scale, disp):
+    """ConjugateStudentProcess.cov: var * (kernel(X, Xp) + basis disp basis^T).  models.py:1099-1125."""
+    if df <= 2:
+        raise ValueError("df must be greater than 2 for the covariance to exist")
+    corr = kernel(X, Xp)
+    Xp = X if Xp is None else Xp
+    return cov_factor(scale ** 2, df) * (corr + _ones_basis(X) @ np.atleast_2d(disp) @ _ones_basis(Xp).T)
+
+
+def csp_predict(fit, Xnew, return_std=False, return_cov=False, Xc=None, y=None):
+    """Fitted ConjugateStudentProcess.predict = the shared predict plus the covariance from integrating out the
+    mean, var * b disp b^T with the conditional basis b = basis_new - R_no R^-1 basis_old.  models.py:1127-1184.
+    (Standard deviations are ADDED, as the reference does at :1177.)"""
+    pred = cgp_predict(fit, Xnew, return_std=return_std, return_cov=return_cov, Xc=Xc, y=y)
+    kernel, nugget = fit["kernel"], fit["nugget"]
+    if Xc is None:
+        Xc, L = fit["X"], fit["corr_L"]
+    else:
+        L = cholesky(kernel(Xc) + nugget * np.eye(len(Xc)))
+    R_no = kernel(Xnew, Xc)
+    basis = _ones_basis(Xnew) - R_no @ _rsolve(L, _ones_basis(Xc))           # :1168
+    mean_cov = fit["cov_factor"] * (basis @ fit["disp"] @ basis.T)           # :1174
+    if return_std:
+        return pred[0], pred[1] + np.sqrt(np.diag(mean_cov))
+    if return_cov:
+        return pred[0], pred[1] + mean_cov
+    return pred
+
+
+def csp_prior_predict(kernel, Xnew, center=0, disp=0, df=1, scale=1, sd=None, return_std=False, return_cov=False):
+    """Unfitted ConjugateStudentProcess.predict: underlying_properties with the Student covariance, then the
+    basis term once more (models.py:1138-1145, 1174-1183)."""
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    mean = _ones_basis(Xnew) @ center0
+    if not (return_std or return_cov):
+        return mean
+    cov = csp_cov(kernel, Xnew, None, df0, scale0, disp0)
+    b = _ones_basis(Xnew)
+    mean_cov = cov_factor(scale0 ** 2, df0) * (b @ disp0 @ b.T)
+    if return_std:
+        return mean, np.sqrt(np.diag(cov)) + np.sqrt(np.diag(mean_cov))
+    return mean, cov + mean_cov
+
+
+def ttp_predict(fit, X, order, ratio, ref, Xc, y, excluded=None, kind="both", dX=None, dy=None, return_std=False,
+                return_cov=False):
+    """TruncationTP.predict (models.py:1527-1570).  The Gaussian part is TruncationProcess.predict with kind='both'
+    whatever ``kind`` says (it is not forwarded, :1528-1531) and with the Student covariance var (kernel + disp);
+    ``kind`` only selects which conditional bases enter the rank-one term."""
+    var, disp = fit["cov_factor"], fit["disp"]
+    kern_t = _PlusConstant(fit["kernel"], float(disp[0, 0]))
+    factor_t = cov_factor(fit["scale"] ** 2, fit["df"])
+    pred = trunc_predict(fit["center"], factor_t, kern_t, X, order, ratio, ref, Xc, y, excluded=excluded, kind="both",
+                         dX=dX, dy=dy, return_std=return_std, return_cov=return_cov)
+    if not return_std and not return_cov:
+        return pred
+    m = X.shape[0]
+    basis_lower, basis_trunc = np.zeros((m, 1)), np.zeros((m, 1))
+    if kind in ("both", "interp"):
+        K_oo = trunc_cov(factor_t, kern_t, Xc, Xc, ratio, ref, 0, order, excluded)
+        K_no = trunc_cov(factor_t, kern_t, X, Xc, ratio, ref, 0, order, excluded)
+        basis_lower = trunc_basis(X, ratio, ref, 0, order, excluded) \
+            - K_no @ np.linalg.solve(K_oo, trunc_basis(Xc, ratio, ref, 0, order, excluded))
+    if kind in ("both", "trunc"):
+        if dX is not None:
+            K_oo = trunc_cov(factor_t, kern_t, dX, dX, ratio, ref, order + 1, np.inf, excluded)
+            K_no = trunc_cov(factor_t, kern_t, X, dX, ratio, ref, order + 1, np.inf, excluded)
+            basis_trunc = trunc_basis(X, ratio, ref, order + 1, np.inf, excluded) \
+                - K_no @ np.linalg.solve(K_oo, trunc_basis(dX, ratio, ref, order + 1, np.inf, excluded))
+        else:
+            basis_trunc = trunc_basis(X, ratio, ref, order + 1, np.inf, excluded)
+    b = basis_lower + basis_trunc
+    mean_cov = var * b @ disp @ b.T                                           # :1564
+    if return_std:
+        return pred[0], pred[1] + np.sqrt(np.diag(mean_cov))
+    return pred[0], pred[1] + mean_cov
+
+
+class _PlusConstant:
+    """kernel(X, Xp) + c: the Student process's corr + basis disp basis^T for the constant basis."""
+
+    def __init__(self, kernel, c):
+        self.kernel, self.c = kernel, c
+
+    def __call__(self, X, Xp=None):
+        return self.kernel(X, Xp) + self.c

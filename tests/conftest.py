@@ -84,3 +84,13 @@ def interp_case_setup(case):
     else:
         ratio, ref = case["ratio"], case["ref"]
     return kern, ratio, ref
+
+
+def student_kernel(kd):
+    """Kernel of a tests/golden/student.json case (see make_golden.py)."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    base = RBF(kd["ls"]) if kd["base"] == "rbf" else Matern(kd["ls"], nu=2.5)
+    kern = base if kd["const"] is None else C(kd["const"]) * base
+    if kd["white"] is not None:
+        kern = kern + WhiteKernel(kd["white"], noise_level_bounds="fixed")
+    return kern

@@ -377,6 +377,79 @@ def gen_trunc_predict_interp():
     return dict(cases=out)
 
 
+STUDENT_SPECS = [
+    dict(name="rbf_white_disp0", kernel=dict(const=None, base="rbf", ls=0.5, white=1e-6), n=9,
+         priors=dict(center=0.3, disp=0, df=4, scale=1.1), constrained=False),
+    dict(name="rbf_white_disp2", kernel=dict(const=None, base="rbf", ls=0.5, white=1e-6), n=9,
+         priors=dict(center=0.3, disp=2.0, df=4, scale=1.1), constrained=True),
+    dict(name="matern_disp05", kernel=dict(const=1.5, base="matern25", ls=0.7, white=None), n=12,
+         priors=dict(center=-0.2, disp=0.5, df=3.5, scale=0.8), constrained=False),
+]
+
+
+def student_kernel(kd):
+    base = RBF(kd["ls"]) if kd["base"] == "rbf" else Matern(kd["ls"], nu=2.5)
+    kern = base if kd["const"] is None else C(kd["const"]) * base
+    if kd["white"] is not None:
+        kern = kern + WhiteKernel(kd["white"], noise_level_bounds="fixed")
+    return kern
+
+
+def gen_student():
+    """ConjugateStudentProcess (models.py:1091-1273) and TruncationTP (:1519-1570): likelihood values, fitted
+    hyperparameters, cov, predict (fitted / unfitted / Xc-y override) and the truncation predict kinds."""
+    rng = np.random.RandomState(77)
+    Xs = np.linspace(0.07, 1.93, 6)[:, None]
+    out = []
+    for sp in STUDENT_SPECS:
+        n = sp["n"]
+        X = np.linspace(0, 2, n)[:, None]
+        kern = student_kernel(sp["kernel"])
+        pri = sp["priors"]
+        Lc = np.linalg.cholesky(kern(X) + 1e-8 * np.eye(n))
+        c = 0.4 + Lc @ rng.randn(n, 3)                     # smooth coefficient curves
+        case = dict(name=sp["name"], kernel=sp["kernel"], priors=pri, X=L(X), c=L(c), Xs=L(Xs))
+        gp = gsum.ConjugateStudentProcess(kernel=kern, optimizer=None, **pri)
+        case["unfit_cov"] = L(gp.cov(Xs))
+        case["unfit_cov_cross"] = L(gp.cov(Xs, Xs[:2]))
+        case["unfit_std"] = L(gp.predict(Xs, return_std=True)[1])
+        case["unfit_cov_pred"] = L(gp.predict(Xs, return_cov=True)[1])
+        thetas = [kern.theta, kern.theta + 0.3]
+        case["thetas"] = [L(t) for t in thetas]
+        case["lml"] = [float(gp.log_marginal_likelihood(theta=t, X=X, y=c)) for t in thetas]
+        case["lml_1d"] = float(gp.log_marginal_likelihood(theta=thetas[0], X=X, y=c[:, 0]))
+        gp.fit(X, c)
+        case["fit"] = dict(center=L(gp.center_), disp=L(gp.disp_), df=float(gp.df_), scale=float(gp.scale_),
+                           cov_factor=float(gp.cov_factor_), lml_value=float(gp.log_marginal_likelihood_value_))
+        m, sd = gp.predict(Xs, return_std=True)
+        _, cv = gp.predict(Xs, return_cov=True)
+        case["predict"] = dict(mean=L(m), std=L(sd), cov=L(cv), mean_only=L(gp.predict(Xs)))
+        m, sd = gp.predict(Xs, return_std=True, Xc=X[::2], y=c[::2])
+        case["predict_subset"] = dict(step=2, mean=L(m), std=L(sd))
+        case["cov"] = L(gp.cov(Xs))
+        case["cov_cross"] = L(gp.cov(Xs, Xs[:2]))
+        # truncation layer
+        orders = np.arange(3)
+        ypart = gsum.partials(c, ratio=0.5, ref=2.0, orders=orders)
+        tp = gsum.TruncationTP(kernel=kern, ratio=0.5, ref=2.0, optimizer=None, **pri)
+        dX = dy = None
+        if sp["constrained"]:
+            dX, dy = np.array([[0.4], [1.6]]), np.array([0.01, -0.02])
+        tp.fit(X, ypart, orders=orders, dX=dX, dy=dy)
+        tcase = dict(y=L(ypart), orders=orders.tolist(), ratio=0.5, ref=2.0, dX=None if dX is None else L(dX),
+                     dy=None if dy is None else L(dy), order=1,
+                     lml=float(tp.log_marginal_likelihood(theta=thetas[1], ratio=0.45)), kinds={})
+        for kind in ("both", "interp", "trunc"):
+            m, sd = tp.predict(Xs, order=1, return_std=True, kind=kind)
+            _, cv = tp.predict(Xs, order=1, return_cov=True, kind=kind)
+            tcase["kinds"][kind] = dict(mean=L(m), std=L(sd), cov=L(cv), mean_only=L(tp.predict(Xs, order=1, kind=kind)))
+        tcase["cond_K_oo"] = float(np.linalg.cond(tp.cov(X=X, Xp=X, start=0, end=1)))
+        case["trunc"] = tcase
+        out.append(case)
+        print("student", sp["name"], case["lml"], "cond K_oo", tcase["cond_K_oo"], flush=True)
+    return dict(cases=out)
+
+
 def gen_nonpd():
     """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
     X = np.array([[0.0], [0.5], [0.5], [1.0]])
@@ -407,6 +480,8 @@ def main():
         json.dump(gen_trunc_predict(), f)
     with open(os.path.join(HERE, "trunc_predict_interp.json"), "w") as f:
         json.dump(gen_trunc_predict_interp(), f)
+    with open(os.path.join(HERE, "student.json"), "w") as f:
+        json.dump(gen_student(), f)
     with open(os.path.join(HERE, "large_lml.json"), "w") as f:
         json.dump(gen_large(), f, indent=1)
     with open(os.path.join(HERE, "large_lml_gp_drawn.json"), "w") as f:

@@ -634,3 +634,62 @@ def test_truncation_predict_vs_oracle_n600_array_ratio():
         m, cv = gp.predict(Xs, order=order, return_cov=True, kind=kind)
         np.testing.assert_allclose(m, mo, rtol=tol, atol=tol * np.abs(mo).max())
         np.testing.assert_allclose(cv, co, rtol=1e-7, atol=tol * np.abs(co).max())
+
+
+def test_student_process_golden():
+    """ConjugateStudentProcess / TruncationTP on the device against reference outputs (models.py:1091-1273,
+    1519-1570): likelihood values at 1e-10, fitted hyperparameters, cov, predict (fitted, unfitted, Xc / y override)
+    and the truncation predict kinds (conditioning tolerance scaled by cond(K_oo), as for TruncationGP)."""
+    from conftest import load_golden, student_kernel
+    g = load_golden("student.json")
+    for case in g["cases"]:
+        kern = student_kernel(case["kernel"])
+        pri = case["priors"]
+        X, c, Xs = np.array(case["X"]), np.array(case["c"]), np.array(case["Xs"])
+        gp = gsum_amd.ConjugateStudentProcess(kernel=kern, optimizer=None, **pri)
+        np.testing.assert_allclose(gp.cov(Xs), case["unfit_cov"], rtol=1e-13)
+        np.testing.assert_allclose(gp.cov(Xs, Xs[:2]), case["unfit_cov_cross"], rtol=1e-13)
+        np.testing.assert_allclose(gp.predict(Xs, return_std=True)[1], case["unfit_std"], rtol=1e-13)
+        np.testing.assert_allclose(gp.predict(Xs, return_cov=True)[1], case["unfit_cov_pred"], rtol=1e-13)
+        for th, want in zip(case["thetas"], case["lml"]):
+            assert gp.log_marginal_likelihood(theta=np.array(th), X=X, y=c) == pytest.approx(want, rel=1e-10)
+        assert gp.log_marginal_likelihood(theta=np.array(case["thetas"][0]), X=X, y=c[:, 0]) == pytest.approx(case["lml_1d"], rel=1e-10)
+        gp.fit(X, c)
+        f = case["fit"]
+        np.testing.assert_allclose(gp.center_, f["center"], rtol=1e-8)
+        np.testing.assert_allclose(gp.disp_, f["disp"], rtol=1e-9)
+        assert gp.df_ == f["df"]
+        assert gp.scale_ == pytest.approx(f["scale"], rel=1e-8)
+        assert gp.cov_factor_ == pytest.approx(f["cov_factor"], rel=1e-8)
+        assert gp.log_marginal_likelihood_value_ == pytest.approx(f["lml_value"], rel=1e-10)
+        p = case["predict"]
+        m, sd = gp.predict(Xs, return_std=True)
+        np.testing.assert_allclose(m, p["mean"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sd, p["std"], rtol=1e-5)
+        np.testing.assert_allclose(gp.predict(Xs, return_cov=True)[1], p["cov"], rtol=1e-5, atol=1e-8 * np.abs(p["cov"]).max())
+        np.testing.assert_allclose(gp.predict(Xs), p["mean_only"], rtol=1e-7, atol=1e-9)
+        ps = case["predict_subset"]
+        sub = slice(None, None, ps["step"])
+        m, sd = gp.predict(Xs, return_std=True, Xc=X[sub], y=c[sub])
+        np.testing.assert_allclose(m, ps["mean"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sd, ps["std"], rtol=1e-5)
+        np.testing.assert_allclose(gp.cov(Xs), case["cov"], rtol=1e-8)
+        np.testing.assert_allclose(gp.cov(Xs, Xs[:2]), case["cov_cross"], rtol=1e-8)
+        t = case["trunc"]
+        y, orders = np.array(t["y"]), np.array(t["orders"])
+        dX = None if t["dX"] is None else np.array(t["dX"])
+        dy = None if t["dy"] is None else np.array(t["dy"])
+        tp = gsum_amd.TruncationTP(kernel=kern, ratio=t["ratio"], ref=t["ref"], optimizer=None, **pri)
+        tp.fit(X, y, orders=orders, dX=dX, dy=dy)
+        assert tp.log_marginal_likelihood(theta=np.array(case["thetas"][1]), ratio=0.45) == pytest.approx(t["lml"], rel=1e-10)
+        grid = tp.log_marginal_likelihood_grid([np.array(case["thetas"][1])], [{"ratio": 0.45}])
+        assert grid[0, 0] == pytest.approx(t["lml"], rel=1e-10)
+        tol = 1e-13 * t["cond_K_oo"] + 1e-11
+        for kind, want in t["kinds"].items():
+            m, sd = tp.predict(Xs, order=t["order"], return_std=True, kind=kind)
+            scale = np.abs(want["mean"]).max()
+            np.testing.assert_allclose(m, want["mean"], rtol=tol, atol=tol * scale)
+            np.testing.assert_allclose(sd, want["std"], rtol=1e-5)
+            _, cv = tp.predict(Xs, order=t["order"], return_cov=True, kind=kind)
+            np.testing.assert_allclose(cv, want["cov"], rtol=1e-6, atol=tol * np.abs(want["cov"]).max())
+            np.testing.assert_allclose(tp.predict(Xs, order=t["order"], kind=kind), want["mean_only"], rtol=tol, atol=tol * scale)

@@ -206,3 +206,61 @@ def test_truncation_predict_all_kinds_against_reference():
                                   excluded=excluded, kind="both", dX=dX, dy=dy, return_std=True)
         np.testing.assert_allclose(m, case["subset"]["mean"], rtol=tol, atol=tol)
         np.testing.assert_allclose(sd, case["subset"]["std"], rtol=1e-9)
+
+
+def test_student_process_against_reference():
+    """ConjugateStudentProcess / TruncationTP (models.py:1091-1273, 1519-1570): oracle vs reference outputs."""
+    from conftest import load_golden, student_kernel
+    g = load_golden("student.json")
+    for case in g["cases"]:
+        kern = student_kernel(case["kernel"])
+        pri = case["priors"]
+        X, c, Xs = np.array(case["X"]), np.array(case["c"]), np.array(case["Xs"])
+        for th, want in zip(case["thetas"], case["lml"]):
+            assert orc.csp_lml(kern, np.array(th), X, c, **pri) == pytest.approx(want, rel=1e-10)
+        assert orc.csp_lml(kern, np.array(case["thetas"][0]), X, c[:, 0], **pri) == pytest.approx(case["lml_1d"], rel=1e-10)
+        np.testing.assert_allclose(orc.csp_cov(kern, Xs, None, pri["df"], pri["scale"], pri["disp"]), case["unfit_cov"], rtol=1e-13)
+        np.testing.assert_allclose(orc.csp_cov(kern, Xs, Xs[:2], pri["df"], pri["scale"], pri["disp"]), case["unfit_cov_cross"], rtol=1e-13)
+        np.testing.assert_allclose(orc.csp_prior_predict(kern, Xs, return_std=True, **pri)[1], case["unfit_std"], rtol=1e-13)
+        np.testing.assert_allclose(orc.csp_prior_predict(kern, Xs, return_cov=True, **pri)[1], case["unfit_cov_pred"], rtol=1e-13)
+        fit = orc.cgp_fit(kern, X, c, **pri)
+        f = case["fit"]
+        np.testing.assert_allclose(fit["center"], f["center"], rtol=1e-9)
+        np.testing.assert_allclose(fit["disp"], f["disp"], rtol=1e-10)
+        assert fit["df"] == f["df"]
+        assert fit["scale"] == pytest.approx(f["scale"], rel=1e-9)
+        assert fit["cov_factor"] == pytest.approx(f["cov_factor"], rel=1e-9)
+        assert orc.csp_lml(kern, None, X, c, **pri) == pytest.approx(f["lml_value"], rel=1e-10)
+        p = case["predict"]
+        m, sd = orc.csp_predict(fit, Xs, return_std=True)
+        np.testing.assert_allclose(m, p["mean"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(sd, p["std"], rtol=1e-6)
+        np.testing.assert_allclose(orc.csp_predict(fit, Xs, return_cov=True)[1], p["cov"], rtol=1e-6, atol=1e-9 * np.abs(p["cov"]).max())
+        np.testing.assert_allclose(orc.csp_predict(fit, Xs), p["mean_only"], rtol=1e-8, atol=1e-10)
+        ps = case["predict_subset"]
+        sub = slice(None, None, ps["step"])
+        m, sd = orc.csp_predict(fit, Xs, return_std=True, Xc=X[sub], y=c[sub])
+        np.testing.assert_allclose(m, ps["mean"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(sd, ps["std"], rtol=1e-6)
+        np.testing.assert_allclose(orc.csp_cov(kern, Xs, None, fit["df"], fit["scale"], fit["disp"]), case["cov"], rtol=1e-9)
+        np.testing.assert_allclose(orc.csp_cov(kern, Xs, Xs[:2], fit["df"], fit["scale"], fit["disp"]), case["cov_cross"], rtol=1e-9)
+        t = case["trunc"]
+        y, orders = np.array(t["y"]), np.array(t["orders"])
+        cc = orc.coefficients(y, t["ratio"], t["ref"], orders)
+        det = np.sum(len(orders) * np.log(abs(t["ref"])) + np.sum(orders) * np.log(0.45) * np.ones(len(X)))
+        c45 = orc.coefficients(y, 0.45, t["ref"], orders)
+        assert orc.csp_lml(kern, np.array(case["thetas"][1]), X, c45, **pri) - det == pytest.approx(t["lml"], rel=1e-10)
+        tfit = orc.cgp_fit(kern, X, cc, **pri)
+        dX = None if t["dX"] is None else np.array(t["dX"])
+        dy = None if t["dy"] is None else np.array(t["dy"])
+        yo = y[:, orders == t["order"]][:, 0]
+        tol = 1e-15 * t["cond_K_oo"] * 100 + 1e-12
+        for kind, want in t["kinds"].items():
+            kw = dict(kind=kind, dX=dX, dy=dy)
+            m, sd = orc.ttp_predict(tfit, Xs, t["order"], t["ratio"], t["ref"], X, yo, return_std=True, **kw)
+            np.testing.assert_allclose(m, want["mean"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(sd, want["std"], rtol=1e-6)
+            _, cv = orc.ttp_predict(tfit, Xs, t["order"], t["ratio"], t["ref"], X, yo, return_cov=True, **kw)
+            np.testing.assert_allclose(cv, want["cov"], rtol=1e-7, atol=tol * np.abs(want["cov"]).max())
+            np.testing.assert_allclose(orc.ttp_predict(tfit, Xs, t["order"], t["ratio"], t["ref"], X, yo, **kw), want["mean_only"],
+                                       rtol=tol, atol=tol)
