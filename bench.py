@@ -208,6 +208,8 @@ def main():
             "roofline": {"kernel": "k_gemm_nt<4,2,2,4> (128x128-tile, 8-wave fp64 MFMA SYRK, K=256, trailing update)",
                          "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "traffic_from_committed_pmc_pass": "profiles/r01_gemm_pmc.md: 1091 MB HBM per M=8192, K=256 launch "
+                                                            "(FETCH_SIZE x 2 + WRITE_SIZE) against 561 MB algorithmic",
                          "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                          "avg_flops_per_launch": gemm_flops / max(1, gemm_launches),
                          "avg_concurrent_launches": gemm_ms * 1e-3 / elapsed,

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "gsum_forward_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_predict_terms": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
                                      _dp, _dp, _dp]),
+    "gsum_tri_multiply": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_mat_scale_series": (C.c_int, [_p, _p, C.POINTER(SeriesScale), _dp, _dp]),
     "gsum_predict_terms_series": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
                                             C.POINTER(SeriesScale), _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -269,6 +270,21 @@ class HipContext:
         W = np.empty((n, k))
         self._check(self._lib.gsum_forward_solve(self._h, L._h, _ptr(rhs), n, k, _ptr(W)))
         return W[:, 0] if squeeze else W
+
+    def tri_multiply(self, L: DeviceMatrix, Z) -> np.ndarray:
+        """L @ Z for a factorised matrix (any number of columns; 16 per device pass)."""
+        Z = _f64(Z)
+        squeeze = Z.ndim == 1
+        if squeeze:
+            Z = Z[:, None]
+        n, k = Z.shape
+        out = np.empty((n, k))
+        for lo in range(0, k, GSUM_MAX_RHS):
+            zc = np.ascontiguousarray(Z[:, lo:lo + GSUM_MAX_RHS])
+            oc = np.empty_like(zc)
+            self._check(self._lib.gsum_tri_multiply(self._h, L._h, _ptr(zc), n, zc.shape[1], _ptr(oc)))
+            out[:, lo:lo + GSUM_MAX_RHS] = oc
+        return out[:, 0] if squeeze else out
 
     def predict_terms(self, L: DeviceMatrix, desc: KernelDesc, X, Xs, rhs=None, want_cov=False, series=None):
         """``series`` = (SeriesScale, ref_x, ratio_x, ref_s, ratio_s) scales the cross matrix like cov(X, Xs, start, end)."""

@@ -487,12 +487,32 @@ class ConjugateGaussianProcess:
         return m_pred, cond_basis
 
     # -- sampling (models.py:847-879) ----------------------------------------------------------------------
-    def sample_y(self, X, n_samples=1, random_state=0, underlying=False):
+    def sample_y(self, X, n_samples=1, random_state=0, underlying=False, method='svd', jitter=0.0):
+        """``method='svd'`` is the reference's ``rng.multivariate_normal`` on the host (an n x n SVD);
+        ``method='cholesky'`` factorises ``cov + jitter I`` on the device and returns ``mean + L z`` (additive
+        option: the same distribution, not the same numbers for a given seed)."""
         rng = check_random_state(random_state)
         if underlying:
             y_mean, y_cov = self.underlying_properties(X=X, return_cov=True)
         else:
             y_mean, y_cov = self.predict(X, return_cov=True)
+        if method == 'cholesky':
+            ctx = self._context()
+            m = y_cov.shape[0]
+            L = ctx.upload(y_cov + jitter * np.eye(m))
+            try:
+                if ctx.potrf(L) != 0:
+                    raise np.linalg.LinAlgError("predictive covariance is not positive definite: pass jitter > 0")
+                cols = 1 if y_mean.ndim == 1 else y_mean.shape[1]
+                draws = ctx.tri_multiply(L, rng.standard_normal((m, n_samples * cols)))
+            finally:
+                L.free()
+            if y_mean.ndim == 1:
+                return y_mean[:, None] + draws
+            return np.hstack([(y_mean[:, i:i + 1] + draws[:, i * n_samples:(i + 1) * n_samples])[:, np.newaxis]
+                              for i in range(cols)])
+        if method != 'svd':
+            raise ValueError('method must be "svd" or "cholesky"')
         if y_mean.ndim == 1:
             return rng.multivariate_normal(y_mean, y_cov, n_samples).T
         samples = [rng.multivariate_normal(y_mean[:, i], y_cov, n_samples).T[:, np.newaxis]

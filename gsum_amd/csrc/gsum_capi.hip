@@ -631,6 +631,29 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
     return 0;
 }
 
+int gsum_tri_multiply(gsum_ctx* ctx, gsum_mat* L, const double* Z, int64_t n, int32_t k, double* out) {
+    if (!ctx || !L || !Z || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("tri_multiply needs a factorised matrix");
+    if (n != L->n) GS_FAIL("Z has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)2 * n * 16 * 8)) return -1;
+    double* dZ16 = ctx->scratch;
+    double* dOut = dZ16 + (size_t)n * 16;
+    hipStream_t s = ctx->cur->sm;
+    std::vector<double> pad((size_t)n * 16, 0.0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) pad[(size_t)i * 16 + c] = Z[i * k + c];
+    GS_CHECK(hipMemcpyAsync(dZ16, pad.data(), pad.size() * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_tri_multiply, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, L->A, L->ld, (int)n, dZ16, dOut);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(pad.data(), dOut, pad.size() * 8, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) out[i * k + c] = pad[(size_t)i * 16 + c];
+    return 0;
+}
+
 // V^T = kernel(Xs, X) L^-T, one row per new point (m x np, row-major): the same right-looking sweep as
 // the factorisation's panel step, with the rows of kernel(Xs, X) in the role of the rows below the panel.
 static int gs_check_series(gsum_ctx* ctx, const gsum_series_scale* sc) {

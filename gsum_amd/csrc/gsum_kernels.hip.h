@@ -861,6 +861,43 @@ __global__ __launch_bounds__(256) void k_scale_series(double* A, int64_t ld, int
     A[(int64_t)i * ld + j] = (refm * sum) * (sc.factor * A[(int64_t)i * ld + j]);
 }
 
+// out = L Z for the lower-triangular factor (row-major, leading dimension ld), Z and out n x 16 (zero-padded
+// columns): the sampling transform y = mean + L z of a multivariate normal.  One wave per row: lanes stride over the
+// row's columns j <= i (coalesced 8-B loads of L, which is read exactly once: HBM-bound, n^2/2 x 8 B), 16
+// accumulators per lane, then a butterfly reduction.  Z (n x 128 B) stays in L2.
+__global__ __launch_bounds__(256) void k_tri_multiply(const double* L, int64_t ld, int n, const double* Z, double* out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+    const double* row = L + (int64_t)i * ld;
+    for (int j = lane; j <= i; j += 64) {
+        const double l = row[j];
+        const gs_d2* z = reinterpret_cast<const gs_d2*>(Z + (int64_t)j * 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const gs_d2 v = z[q];
+            acc[2 * q] = __builtin_fma(l, v[0], acc[2 * q]);
+            acc[2 * q + 1] = __builtin_fma(l, v[1], acc[2 * q + 1]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double v = acc[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[c] = v;
+    }
+    if (lane < 16) {
+        double v = acc[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
+        out[(int64_t)i * 16 + lane] = v;
+    }
+}
+
 // ---- probes ------------------------------------------------------------------------------------
 // pseudo-random fill in [-1, 1) (integer hash), so benchmark operands are not zeros (DVFS reads high on zeros)
 __global__ __launch_bounds__(256) void k_fill_random(double* p, int64_t n, unsigned seed) {

@@ -105,6 +105,11 @@ int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, 
  * (models.py:479); with gsum_predict_terms it replaces the solve at models.py:831. */
 int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* W);
 
+/* out = L Z (n x k, k <= GSUM_MAX_RHS) for a factorised matrix: the transform y = mean + L z that turns standard
+ * normal draws into draws from N(mean, L L^T).  Replaces the n x n SVD / eigendecomposition inside
+ * rng.multivariate_normal (models.py:869-876) and scipy.stats.multivariate_normal.rvs (datasets.py:69-70). */
+int gsum_tri_multiply(gsum_ctx* ctx, gsum_mat* L, const double* Z, int64_t n, int32_t k, double* out);
+
 /* Predictive pieces for m new points Xs (models.py:822-836), from the factor of
  * kernel(X)+nugget:  V = L^-1 kernel(X, Xs);  colsumsq[j] = sum_i V_ij^2;
  * VtW = V^T Whalf (m x k) with Whalf = L^-1 RHS (RHS n x k host; NULL/k=0 to skip).
