@@ -65,6 +65,16 @@ class SeriesScale(C.Structure):
         return sc
 
 
+class GradParam(C.Structure):
+    """Mirror of ``gsum_grad_param``: which derivative d kernel(X) / d theta_p is."""
+    _fields_ = [("code", C.c_int32), ("dim", C.c_int32), ("weight", C.c_double)]
+
+    AMPLITUDE, LENGTH_ISO, LENGTH_DIM, WHITE, ADDITIVE = range(5)
+
+    def __repr__(self):
+        return f"GradParam(code={self.code}, dim={self.dim}, weight={self.weight})"
+
+
 _p = C.c_void_p
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -93,6 +103,8 @@ PROTOTYPES = {
     "gsum_mat_free": (None, [_p, _p]),
     "gsum_lml_batch": (C.c_int, [_p, _kp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_double,
                                  _dp, _dp, _ip]),
+    "gsum_lml_grad": (C.c_int, [_p, _kp, C.POINTER(GradParam), C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32,
+                                C.c_double, _dp, _dp, _ip, _dp, _dp]),
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
@@ -335,6 +347,24 @@ class HipContext:
         self._check(self._lib.gsum_lml_batch(self._h, arr, nk, _ptr(X), n, d, _ptr(rhs), k, float(nugget),
                                              _ptr(G), _ptr(sld), info.ctypes.data_as(_ip)))
         return G, sld, info
+
+    def lml_grad(self, desc: KernelDesc, params, X, rhs, nugget: float):
+        """One evaluation with gradient pieces: (G (k,k), sld, info, trace (P,), H (P,k,k)); see gsum_lml_grad."""
+        X, rhs = _f64(X), _f64(rhs)
+        n, d = X.shape
+        k = rhs.shape[1]
+        P = len(params)
+        arr = (GradParam * P)()
+        for i, pr in enumerate(params):
+            arr[i].code, arr[i].dim, arr[i].weight = pr.code, pr.dim, pr.weight
+        G = np.empty((k, k))
+        sld = np.empty(1)
+        info = np.empty(1, dtype=np.int64)
+        trace = np.empty(P)
+        H = np.empty((P, k, k))
+        self._check(self._lib.gsum_lml_grad(self._h, C.byref(desc), arr, P, _ptr(X), n, d, _ptr(rhs), k, float(nugget),
+                                            _ptr(G), _ptr(sld), info.ctypes.data_as(_ip), _ptr(trace), _ptr(H)))
+        return G, float(sld[0]), int(info[0]), trace, H
 
     def set_inputs(self, X, rhs):
         X, rhs = _f64(X), _f64(rhs)

@@ -25,10 +25,11 @@ from sklearn.exceptions import ConvergenceWarning
 from sklearn.utils import check_random_state
 
 from ._lib import GSUM_MAX_RHS, default_context
-from .kernels import default_kernel, describe_kernel
+from .kernels import default_kernel, describe_gradient, describe_kernel
 
 __all__ = ["ConjugateGaussianProcess", "ConjugateStudentProcess", "posterior_from_gram", "lml_from_gram",
-           "lml_from_gram_batch", "student_lml_from_gram", "cov_factor"]
+           "lml_from_gram_batch", "student_lml_from_gram", "hyper_gradients_from_gram", "lml_grad_from_gram",
+           "student_lml_grad_from_gram", "cov_factor"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -144,6 +145,81 @@ def student_lml_from_gram(G, sum_log_diag, n_points, center0, disp0, df0, scale0
     lml = log_norm(post["df"], np.sqrt(post["scale_sq"]), post["disp"]) - log_norm(df0, scale0, disp0) \
         - ny / 2. * (n_points * np.log(2 * np.pi) + logdet_R)           # models.py:1250-1251
     return float(lml), post
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients with respect to the kernel's log-hyperparameters (SURVEY.md kernel K6)
+#
+# Every n-vector the reference contracts with dR_p lies in the span of the columns of V = R^-1 [Y | 1], so each
+# einsum('..,jkp,..') at models.py:229, 276, 453-454, 1049 is a bilinear form of H_p = V^T dR_p V (from the device),
+# and the one genuinely n x n contraction is trace_p = tr(R^-1 dR_p).
+# ---------------------------------------------------------------------------------------------
+
+def hyper_gradients_from_gram(G, H, post, center0, disp0, df0):
+    """d center / d theta, d disp / d theta, d scale^2 / d theta (each length P) for the constant basis.
+    models.py:221-232 (compute_center), 271-279 (compute_disp), 447-457 (compute_scale_sq, Woodbury form)."""
+    G = np.asarray(G, dtype=float)
+    H = np.asarray(H, dtype=float)
+    ny = G.shape[0] - 1
+    P = H.shape[0]
+    eta0 = float(np.atleast_1d(center0)[0])
+    V0 = float(np.atleast_2d(disp0)[0, 0])
+    center, disp, df = float(post["center"][0]), float(post["disp"][0, 0]), post["df"]
+    w = np.full(ny, 1.0 / ny)
+    e1 = np.zeros(ny + 1)
+    e1[ny] = 1.0
+    if V0 == 0:                                                   # models.py:203-204, 262-263
+        d_center, d_disp = np.zeros(P), np.zeros(P)
+    else:
+        a_diff = np.append(-w, center)                            # R^-1 (basis center - y_avg) = V a_diff   (:226)
+        d_center = ny * disp * np.array([H[p][ny] @ a_diff for p in range(P)])        # :229
+        d_disp = ny * disp * disp * H[:, ny, ny]                  # :275-276
+    if df0 == np.inf:
+        d_scale_sq = np.zeros(P)                                  # models.py:419-421
+    else:
+        Cc = np.eye(ny + 1)[:, :ny] - np.outer(np.append(w, 0.0), np.ones(ny))        # y - y_avg = Z Cc      (:427)
+        a_c = np.append(w, -eta0)                                 # y_avg - basis center0 = Z a_c             (:431)
+        s = G[ny] @ a_c                                           # basis^T R^-1 (y_avg - basis center0)
+        a_m = ny * (a_c - ny * disp * s * e1)                     # mat_invR_avg_yc = V a_m                   (:439-440)
+        d_scale_sq = np.array([-np.trace(Cc.T @ H[p] @ Cc) - (a_m @ H[p] @ a_m) / ny for p in range(P)]) / df   # :453-455
+    return d_center, d_disp, d_scale_sq
+
+
+def lml_grad_from_gram(G, sum_log_diag, trace, H, n_points, center0, disp0, df0, scale0):
+    """ConjugateGaussianProcess.log_marginal_likelihood(theta, eval_gradient=True) from device pieces: (lml, grad).
+    models.py:989-999, 1022-1024, 1041-1056."""
+    lml, post = lml_from_gram(G, sum_log_diag, n_points, center0, disp0, df0, scale0)
+    G = np.asarray(G, dtype=float)
+    H = np.asarray(H, dtype=float)
+    trace = np.asarray(trace, dtype=float)
+    ny = G.shape[0] - 1
+    d_center, _, d_scale_sq = hyper_gradients_from_gram(G, H, post, center0, disp0, df0)
+    df, var = post["df"], post["cov_factor"]
+    grad_var = cov_factor(d_scale_sq, df)                         # models.py:998
+    center = float(post["center"][0])
+    Cy = np.eye(ny + 1)[:, :ny].copy()
+    Cy[ny, :] = -center                                           # y - mean = Z Cy                            (:1026)
+    quad_G = np.trace(Cy.T @ G @ Cy)                              # sum_l (y_l - m)^T R^-1 (y_l - m)
+    one_G = (G[ny] @ Cy).sum()                                    # sum_l basis^T R^-1 (y_l - m)
+    quad_H = np.array([np.trace(Cy.T @ Hp @ Cy) for Hp in H])
+    # K = var R, K_gradient = var dR + grad_var R (:1022-1024); alpha_l = V Cy[:, l] / var
+    grad = 0.5 * (var * quad_H + grad_var * quad_G) / var ** 2 \
+        - 0.5 * ny * (trace + n_points * grad_var / var) \
+        - d_center * one_G / var                                  # :1049, 1052
+    return lml, grad
+
+
+def student_lml_grad_from_gram(G, sum_log_diag, trace, H, n_points, center0, disp0, df0, scale0):
+    """ConjugateStudentProcess.log_marginal_likelihood(theta, eval_gradient=True): models.py:1227-1236, 1264-1271."""
+    lml, post = student_lml_from_gram(G, sum_log_diag, n_points, center0, disp0, df0, scale0)
+    ny = np.asarray(G).shape[0] - 1
+    _, d_disp, d_scale_sq = hyper_gradients_from_gram(G, H, post, center0, disp0, df0)
+    grad = -(ny / 2.) * np.asarray(trace, dtype=float)            # :1266
+    grad = grad - (post["df"] / 2.) * d_scale_sq / post["scale_sq"]                   # :1269
+    disp = float(post["disp"][0, 0])
+    if disp != 0:
+        grad = grad + 0.5 * d_disp / disp                         # :1271-1272
+    return lml, grad
 
 
 # ---------------------------------------------------------------------------------------------
@@ -268,8 +344,6 @@ class ConjugateGaussianProcess:
                 raise ValueError("Gradient can only be evaluated for theta!=None")   # models.py:940-943
             return self.log_marginal_likelihood_value_
         self._check_decomposition()
-        if eval_gradient:
-            raise NotImplementedError("eval_gradient=True (SURVEY.md §8 f-1) is not built yet")
         kernel = self._active_kernel()
         if theta is not None:
             kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))         # models.py:953
@@ -278,6 +352,14 @@ class ConjugateGaussianProcess:
         X = np.asarray(X, dtype=float)
         Z = self._rhs(X, y)
         desc = describe_kernel(kernel, X.shape[1])
+        if eval_gradient:                                                            # models.py:957-958, 1041-1056
+            params = describe_gradient(kernel, X.shape[1])
+            if not params:
+                return self.log_marginal_likelihood(theta, X=X, y=y), np.zeros(0)
+            G, sld, info, trace, H = self._context().lml_grad(desc, params, X, Z, self.nugget)
+            if info != 0:
+                return -np.inf, np.zeros_like(kernel.theta)                          # models.py:970-972
+            return self._lml_grad_gram(G, sld, trace, H, X.shape[0])
         G, sld, info = self._context().lml_batch([desc], X, Z, self.nugget)
         if info[0] != 0:
             return -np.inf                                                           # models.py:970-972
@@ -291,6 +373,9 @@ class ConjugateGaussianProcess:
     def _lml_gram_batch(self, G, sld, n_points):
         return lml_from_gram_batch(G, sld, n_points, self.center0, self.disp0, self.df0, self.scale0)
 
+    def _lml_grad_gram(self, G, sld, trace, H, n_points):
+        return lml_grad_from_gram(G, sld, trace, H, n_points, self.center0, self.disp0, self.df0, self.scale0)
+
     def _cov_terms(self, d):
         """(factor, descriptor) such that the two-argument covariance of the fitted process is
         factor * kernel_desc(X, Xp): what TruncationProcess conditions with (models.py:599, 1343)."""
@@ -301,9 +386,9 @@ class ConjugateGaussianProcess:
 
     # -- fit (models.py:630-738) -------------------------------------------------------------------
     def _constrained_optimization(self, obj_func, initial_theta, bounds):
-        """models.py:884-900; the objective is value-only here, so L-BFGS differentiates numerically."""
+        """models.py:884-900."""
         if self.optimizer == "fmin_l_bfgs_b":
-            theta_opt, func_min, info = fmin_l_bfgs_b(obj_func, initial_theta, bounds=bounds, approx_grad=True)
+            theta_opt, func_min, info = fmin_l_bfgs_b(obj_func, initial_theta, bounds=bounds)
             if info["warnflag"] != 0:
                 warnings.warn("fmin_l_bfgs_b terminated abnormally with the  state: %s" % info, ConvergenceWarning)
         elif callable(self.optimizer):
@@ -316,7 +401,10 @@ class ConjugateGaussianProcess:
         """models.py:630-669, with the intended argmin over restarts (the reference's ragged
         ``np.array(optima)`` at :664 raises on numpy >= 1.24)."""
         if self.optimizer is not None and self.kernel_.n_dims > 0:
-            def obj_func(theta, eval_gradient=False):
+            def obj_func(theta, eval_gradient=True):                                   # models.py:634-640
+                if eval_gradient:
+                    lml, grad = self.log_marginal_likelihood(theta, eval_gradient=True)
+                    return -lml, -grad
                 return -self.log_marginal_likelihood(theta)
 
             optima = [self._constrained_optimization(obj_func, self.kernel_.theta, self.kernel_.bounds)]
@@ -532,6 +620,9 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
 
     def _lml_gram_batch(self, G, sld, n_points):
         return np.array([self._lml_gram(Gi, si, n_points)[0] for Gi, si in zip(G, sld)])
+
+    def _lml_grad_gram(self, G, sld, trace, H, n_points):
+        return student_lml_grad_from_gram(G, sld, trace, H, n_points, self.center0, self.disp0, self.df0, self.scale0)
 
     def _cov_terms(self, d):
         # var * (corr + basis disp basis^T) with a constant basis is an additive constant in the kernel (:1125)

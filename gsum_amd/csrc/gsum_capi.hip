@@ -56,6 +56,7 @@ struct gsum_ctx {
     double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;
     double* dZ = nullptr; int kZ = 0; size_t dZ_cap = 0;
     double* scratch = nullptr; size_t scratch_cap = 0;
+    double* gws = nullptr; size_t gws_cap = 0;     // gradient path: U = L^-T, R^-1, V^T, per-parameter partials
     double timers[4] = {0, 0, 0, 0};
     unsigned long long* dstamps = nullptr;   // 8 u64: phase stamps of the last diagonal-block kernel
     int diag_stamps = 0;
@@ -123,7 +124,7 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), shmem, s, C, ldc, A, lda, B, ldb, (int)M,
                        (int)N, K, tri, beta, sign, (unsigned long long*)nullptr,
-                       (BM == 128 && BN == 128) ? (ctx->stagger < 0 ? K / 16 : ctx->stagger) : 0);
+                       (BM == 128 && BN == 128) ? (ctx->stagger < 0 ? std::min(K / 16, 32) : ctx->stagger) : 0);
     GS_CHECK(hipGetLastError());
     return 0;
 }
@@ -451,6 +452,7 @@ void gsum_destroy(gsum_ctx* ctx) {
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dZ) (void)hipFree(ctx->dZ);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->gws) (void)hipFree(ctx->gws);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
     for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
     delete ctx;
@@ -921,6 +923,70 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
     int rc = gsum_set_inputs(ctx, X, n, d, RHS, k);
     if (rc) return rc;
     return gsum_lml_resident(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+}
+
+// Gradient pieces on top of one fused evaluation (see include/gsum_hip.h).  After the factorisation the workspace
+// holds L, the 128x128 inverses of its diagonal blocks and W^T = RHS^T L^-T in the border rows; then
+//   U = L^-T      right-looking sweep over block columns on an identity (rows below the current block are still
+//                 zero and are skipped: n^3 / 3 flops, the GEMMs of the prediction path)
+//   R^-1 = U U^T  one lower-tile SYRK launch whose tiles start their K loop at their own first row (n^3 / 3 flops)
+//   V^T = W^T U^T (16 x n), then the fused kernel-gradient contractions, one grid row per hyperparameter.
+int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_param* params, int32_t n_params,
+                  const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget, double* G_out,
+                  double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
+    if (!ctx || !desc || !params || !G_out || !sld_out || !info_out || !trace_out || !H_out) return -2;
+    if (n_params < 1 || n_params > GSUM_MAX_GRAD) GS_FAIL("n_params must be 1..GSUM_MAX_GRAD");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    for (int p = 0; p < n_params; ++p) {
+        if (params[p].code < GSUM_GRAD_AMPLITUDE || params[p].code > GSUM_GRAD_ADDITIVE) GS_FAIL("unknown gradient parameter code");
+        if (params[p].code == GSUM_GRAD_LENGTH_DIM && (params[p].dim < 0 || params[p].dim >= d)) GS_FAIL("gradient parameter dim out of range");
+    }
+    int rc = gsum_set_inputs(ctx, X, n, d, RHS, k);
+    if (rc) return rc;
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    gs_slot* sl = &ctx->slots[0];
+    ctx->cur = sl;
+    ctx->batch_active = 1;
+    if (gs_eval_enqueue(ctx, desc, nugget)) return -1;
+    sl->pending = 0;
+    gsum_mat* m = sl->ws;
+    const int64_t np = m->np, ld = m->ld, ldg = np + GS_BORDER;
+    const int P = n_params;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_u = 0, o_r = up((size_t)np * ldg * 8), o_v = o_r + up((size_t)np * ldg * 8), o_q = o_v + up((size_t)16 * ldg * 8),
+                 o_t = o_q + up((size_t)P * n * 16 * 8), o_o = o_t + up((size_t)P * n * 8), total = o_o + up((size_t)P * 257 * 8);
+    if (gs_reserve(ctx, &ctx->gws, &ctx->gws_cap, total)) return -1;
+    char* base = (char*)ctx->gws;
+    double *U = (double*)(base + o_u), *Ri = (double*)(base + o_r), *Vt = (double*)(base + o_v), *Q = (double*)(base + o_q),
+           *trow = (double*)(base + o_t), *dout = (double*)(base + o_o);
+    hipStream_t s = sl->sm;
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, U, ldg, (int)np);
+    GS_CHECK(hipGetLastError());
+    for (int c = 0; c < m->T; ++c) {
+        const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
+        double* Linv = m->Linv + (size_t)c * GS_NB * GS_NB;
+        if (gs_gemm(ctx, s, 1, U + c0, ldg, U + c0, ldg, Linv, GS_NB, r0, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (r0 < np && gs_gemm(ctx, s, 0, U + r0, ldg, U + c0, ldg, m->A + r0 * ld + c0, ld, r0, np - r0, GS_NB, 0, 1, -1.0)) return -1;
+    }
+    if (gs_gemm(ctx, s, 5, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
+    if (gs_gemm(ctx, s, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
+    gs_grad_params prm;
+    memset(&prm, 0, sizeof prm);
+    for (int p = 0; p < P; ++p) prm.p[p] = params[p];
+    hipLaunchKernelGGL(k_grad_contract, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->dX, (int)n, (int)d, *desc,
+                       prm, Ri, ldg, Vt, ldg, Q, trow);
+    GS_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, dout);
+    GS_CHECK(hipGetLastError());
+    std::vector<double> hout((size_t)P * 257);
+    GS_CHECK(hipMemcpyAsync(hout.data(), dout, hout.size() * 8, hipMemcpyDeviceToHost, s));
+    if (gs_eval_harvest(ctx, sl, G_out, sld_out, info_out)) return -1;      // synchronises the stream
+    for (int p = 0; p < P; ++p) {
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) H_out[((size_t)p * k + a) * k + b] = hout[(size_t)p * 257 + a * 16 + b];
+        trace_out[p] = hout[(size_t)p * 257 + 256];
+    }
+    return 0;
 }
 
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {

@@ -15,9 +15,9 @@ from __future__ import annotations
 import numpy as np
 from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Product, Sum, WhiteKernel)
 
-from ._lib import FAMILY, GSUM_MAX_D, KernelDesc
+from ._lib import FAMILY, GSUM_MAX_D, GradParam, KernelDesc
 
-__all__ = ["describe_kernel", "default_kernel"]
+__all__ = ["describe_kernel", "describe_gradient", "default_kernel"]
 
 
 def default_kernel():
@@ -84,3 +84,38 @@ def describe_kernel(kernel, n_features: int) -> KernelDesc:
         for i, v in enumerate(ls):
             desc.length_scale[i] = float(v)
     return desc
+
+
+def describe_gradient(kernel, n_features: int):
+    """One :class:`GradParam` per component of ``kernel.theta``, in scikit-learn's order (leaves left to right,
+    a leaf's free hyperparameters in alphabetical order): what ``kernel(X, eval_gradient=True)``
+    would put in ``K_gradient[:, :, p]``.  Same kernel family as :func:`describe_kernel`."""
+    describe_kernel(kernel, n_features)                       # same validation, same error messages
+    out = []
+
+    def gp(code, dim=0, weight=0.0):
+        g = GradParam()
+        g.code, g.dim, g.weight = code, dim, float(weight)
+        return g
+
+    for term in _sum_terms(kernel):
+        if isinstance(term, WhiteKernel):
+            if not term.hyperparameter_noise_level.fixed:
+                out.append(gp(GradParam.WHITE, weight=term.noise_level))
+            continue
+        if isinstance(term, ConstantKernel):
+            if not term.hyperparameter_constant_value.fixed:
+                out.append(gp(GradParam.ADDITIVE, weight=term.constant_value))
+            continue
+        for f in _product_factors(term):
+            if isinstance(f, ConstantKernel):
+                if not f.hyperparameter_constant_value.fixed:
+                    out.append(gp(GradParam.AMPLITUDE))
+            elif not f.hyperparameter_length_scale.fixed:      # RBF / Matern: length_scale is the only free one
+                if f.anisotropic:
+                    out.extend(gp(GradParam.LENGTH_DIM, dim=m) for m in range(n_features))
+                else:
+                    out.append(gp(GradParam.LENGTH_ISO))
+    if len(out) != len(kernel.theta):
+        raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
+    return out

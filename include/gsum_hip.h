@@ -66,6 +66,19 @@ typedef struct {
     double factor;
 } gsum_series_scale;
 
+/* One free log-hyperparameter theta_p of the kernel tree, as scikit-learn orders them (k1 before k2, attributes
+ * in alphabetical order): what d kernel(X) / d theta_p is.  AMPLITUDE: a ConstantKernel factor of the stationary
+ * term (gradient = that whole term); LENGTH_ISO / LENGTH_DIM: the (dim-th) length scale; WHITE / ADDITIVE: one
+ * WhiteKernel / additive ConstantKernel term whose own value is `weight` (gradient = weight on the diagonal /
+ * everywhere). */
+#define GSUM_MAX_GRAD 12
+enum { GSUM_GRAD_AMPLITUDE = 0, GSUM_GRAD_LENGTH_ISO = 1, GSUM_GRAD_LENGTH_DIM = 2, GSUM_GRAD_WHITE = 3, GSUM_GRAD_ADDITIVE = 4 };
+typedef struct {
+    int32_t code;
+    int32_t dim;
+    double weight;
+} gsum_grad_param;
+
 /* ---- context ---------------------------------------------------------------------------------- */
 int gsum_init(int device, gsum_ctx** out);
 void gsum_destroy(gsum_ctx* ctx);
@@ -145,6 +158,18 @@ void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A);
 int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
                    int32_t d, const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out,
                    int64_t* info_out);
+
+/* Value AND gradient pieces of one evaluation: everything ConjugateGaussianProcess / ConjugateStudentProcess
+ * .log_marginal_likelihood(theta, eval_gradient=True) needs beyond O(k^2) host algebra.  Replaces
+ * kernel(X, eval_gradient=True) (the n x n x p array at models.py:958, 1204), cho_solve(L, eye(N)) (:1044, 1266)
+ * and the einsum contractions at :229, 276, 453-454, 1049.  With R = kernel(X) + nugget I, V = R^-1 RHS:
+ *   G_out (k x k), sld_out, info_out as gsum_lml_batch;
+ *   trace_out[p] = tr(R^-1 dR_p);  H_out[p] (k x k) = V^T dR_p V,   dR_p = d kernel(X) / d theta_p.
+ * R^-1 is formed on the device as U U^T with U = L^-T (2 n^3 / 3 flops on the MFMA GEMM kernels); dR_p is never
+ * materialised. */
+int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_param* params, int32_t n_params,
+                  const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget, double* G_out,
+                  double* sld_out, int64_t* info_out, double* trace_out, double* H_out);
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one

@@ -521,3 +521,96 @@ class _PlusConstant:
 
     def __call__(self, X, Xp=None):
         return self.kernel(X, Xp) + self.c
+
+
+# --------------------------------------------------------------------------
+# gradient of the log marginal likelihood w.r.t. the kernel's log-hyperparameters
+# (reference: gsum/models.py:957-958, 989-999, 1022-1024, 1041-1056; helpers at :221-232, 271-279, 447-457)
+# --------------------------------------------------------------------------
+
+def _hyper_gradients(y, L, basis, dR, center0, disp0, df0, scale0):
+    """(center, d_center, disp, d_disp, scale_sq, d_scale_sq) as compute_center / compute_disp / compute_scale_sq
+    return them with eval_gradient=True."""
+    ny = _num_y(y)
+    avg = _avg_y(y)
+    P = dR.shape[-1]
+    disp = posterior_disp(y, L, basis, disp0)
+    center = posterior_center(y, L, basis, center0, disp0)
+    invR_basis = _rsolve(L, basis)
+    if np.all(disp0 == 0):                                                     # :203-204, 262-263
+        d_center = np.zeros((*center0.shape, P))
+        d_disp = np.zeros((*disp0.shape, P))
+    else:
+        invR_diff = _rsolve(L, basis @ center - avg)                           # :226
+        d_center = ny * disp @ np.einsum('ji,jkp,k->ip', invR_basis, dR, invR_diff)      # :229
+        invRBV = invR_basis @ disp                                             # :274
+        d_disp = ny * np.einsum('ji,jkp,kl->ilp', invRBV, dR, invRBV)          # :276
+    scale_sq = posterior_scale_sq(y, L, basis, center0, disp0, df0, scale0)
+    if df0 == np.inf:
+        d_scale_sq = np.zeros(P)                                               # :419-421
+    else:
+        yc = y - avg[:, None]
+        invR_yc = _rsolve(L, yc)                                               # :429
+        avg_c = avg - basis @ center0                                          # :431
+        N = len(avg)
+        mat = np.eye(N) - ny * invR_basis @ disp @ basis.T                     # :439
+        m = ny * mat @ _rsolve(L, avg_c)                                       # :440
+        d_scale_sq = -np.einsum('ji,jkp,ki->p', invR_yc, dR, invR_yc)          # :453
+        d_scale_sq -= np.einsum('i,ijp,j->p', m, dR, m) / ny                   # :454
+        d_scale_sq /= posterior_df(y, df0)                                     # :455
+    return center, d_center, disp, d_disp, scale_sq, d_scale_sq
+
+
+def cgp_lml_grad(kernel, theta, X, y, center=0, disp=0, df=1, scale=1, sd=None, nugget=1e-10):
+    """ConjugateGaussianProcess.log_marginal_likelihood(theta, eval_gradient=True): (value, gradient)."""
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))           # :953
+    R, dR = kernel(X, eval_gradient=True)                                      # :958
+    R[np.diag_indices_from(R)] += nugget                                       # :963
+    try:
+        L = cholesky(R)
+    except np.linalg.LinAlgError:
+        return -np.inf, np.zeros_like(theta)                                   # :970-972
+    if y.ndim == 1:
+        y = y[:, np.newaxis]
+    basis = _ones_basis(X)
+    dfn = posterior_df(y, df0)
+    center_n, d_center, _, _, scale2, d_scale2 = _hyper_gradients(y, L, basis, dR, center0, disp0, df0, scale0)
+    grad_var = cov_factor(d_scale2, dfn)                                       # :998
+    grad_mean = basis @ d_center                                               # :999
+    mean = basis @ center_n
+    var = cov_factor(scale2, dfn)
+    Lk = np.sqrt(var) * L
+    K_gradient = var * dR + grad_var * R[:, :, None]                           # :1024
+    y_train = y - mean[:, None]
+    N = R.shape[0]
+    alpha = cho_solve((Lk, True), y_train)
+    ll = -0.5 * np.einsum("ik,ik->k", y_train, alpha) - np.log(np.diag(Lk)).sum() - N / 2 * np.log(2 * np.pi)
+    tmp = np.einsum("ik,jk->ijk", alpha, alpha)                                # :1042
+    tmp -= cho_solve((Lk, True), np.eye(N))[:, :, np.newaxis]                  # :1044
+    g = 0.5 * np.einsum("ijl,ijk->kl", tmp, K_gradient)                        # :1049
+    g -= grad_mean.T @ alpha                                                   # :1052
+    return ll.sum(-1), g.sum(-1)                                               # :1055
+
+
+def csp_lml_grad(kernel, theta, X, y, center=0, disp=0, df=1, scale=1, sd=None, nugget=1e-10):
+    """ConjugateStudentProcess.log_marginal_likelihood(theta, eval_gradient=True) as written at models.py:1227-1236,
+    1264-1272.  (The reference calls ``kernel(X, eval_gradient)`` at :1204, which hands True to the Y argument and
+    raises; the evident intent ``kernel(X, eval_gradient=True)`` is used.  Pinned by finite differences of the
+    reference's value path in tests/golden/gradient.json.)"""
+    center0, disp0, df0, scale0 = _priors(center, disp, df, scale, sd)
+    value = csp_lml(kernel, theta, X, y, center, disp, df, scale, sd, nugget)
+    kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))
+    R, dR = kernel(X, eval_gradient=True)
+    R[np.diag_indices_from(R)] += nugget
+    L = cholesky(R)
+    ny = _num_y(y)
+    y2 = y if y.ndim > 1 else y[:, None]
+    basis = _ones_basis(X)
+    dfn = posterior_df(y, df0)
+    _, _, disp_n, d_disp, scale_sq, d_scale_sq = _hyper_gradients(y2, L, basis, dR, center0, disp0, df0, scale0)
+    g = -(ny / 2.) * np.trace(cho_solve((L, True), dR.reshape(len(X), -1)).reshape(dR.shape), axis1=0, axis2=1)   # :1266
+    g = g - (dfn / 2.) * d_scale_sq / scale_sq                                 # :1269
+    if not np.all(disp_n == 0):
+        g = g + 0.5 * np.einsum('ij,ijp->p', np.linalg.inv(disp_n), d_disp)    # :1271-1272
+    return value, g

@@ -94,3 +94,17 @@ def student_kernel(kd):
     if kd["white"] is not None:
         kern = kern + WhiteKernel(kd["white"], noise_level_bounds="fixed")
     return kern
+
+
+def grad_kernel(kd):
+    """Kernel of a tests/golden/gradient.json case (see make_golden.py)."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    nu = {"rbf": None, "matern25": 2.5, "matern15": 1.5, "matern05": 0.5}[kd["base"]]
+    ls = kd["ls"] if np.ndim(kd["ls"]) == 0 else np.array(kd["ls"], dtype=float)
+    base = RBF(ls) if nu is None else Matern(ls, nu=nu)
+    kern = base if kd["const"] is None else C(kd["const"]) * base
+    if kd["white"] is not None:
+        kern = kern + (WhiteKernel(kd["white"], noise_level_bounds="fixed") if kd["white_fixed"] else WhiteKernel(kd["white"]))
+    if kd["add"] is not None:
+        kern = kern + C(kd["add"])
+    return kern

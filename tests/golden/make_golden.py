@@ -450,6 +450,75 @@ def gen_student():
     return dict(cases=out)
 
 
+GRAD_SPECS = [
+    dict(name="rbf_1d_white_fixed", d=1, n=24, kernel=dict(const=None, base="rbf", ls=0.3, white=1e-6, white_fixed=True, add=None),
+         priors=dict(center=0, disp=0, df=1, scale=1)),
+    dict(name="const_rbf_white_fixed", d=1, n=24, kernel=dict(const=1.4, base="rbf", ls=0.25, white=1e-8, white_fixed=True, add=None),
+         priors=dict(center=0.3, disp=2.0, df=3, scale=1.2)),
+    dict(name="const_matern52_aniso_white_add", d=2, n=30,
+         kernel=dict(const=1.3, base="matern25", ls=[0.5, 0.7], white=0.01, white_fixed=False, add=0.2),
+         priors=dict(center=0.2, disp=1.5, df=3, scale=1.2)),
+    dict(name="matern32_iso_2d", d=2, n=30, kernel=dict(const=None, base="matern15", ls=0.6, white=1e-6, white_fixed=True, add=None),
+         priors=dict(center=-0.1, disp=0, df=2.5, scale=0.9)),
+    dict(name="matern12_aniso", d=2, n=20, kernel=dict(const=0.8, base="matern05", ls=[0.4, 0.9], white=None, white_fixed=True, add=None),
+         priors=dict(center=0, disp=0.7, df=4, scale=1.0)),
+    dict(name="rbf_aniso_sd_prior", d=3, n=30, kernel=dict(const=None, base="rbf", ls=[0.5, 0.8, 1.1], white=1e-6, white_fixed=True, add=None),
+         priors=dict(center=0.1, disp=0.5, sd=1.3)),
+]
+
+
+def grad_kernel(kd):
+    nu = {"rbf": None, "matern25": 2.5, "matern15": 1.5, "matern05": 0.5}[kd["base"]]
+    ls = kd["ls"] if np.ndim(kd["ls"]) == 0 else np.array(kd["ls"], dtype=float)
+    base = RBF(ls) if nu is None else Matern(ls, nu=nu)
+    kern = base if kd["const"] is None else C(kd["const"]) * base
+    if kd["white"] is not None:
+        kern = kern + (WhiteKernel(kd["white"], noise_level_bounds="fixed") if kd["white_fixed"] else WhiteKernel(kd["white"]))
+    if kd["add"] is not None:
+        kern = kern + C(kd["add"])
+    return kern
+
+
+def gen_gradient():
+    """log_marginal_likelihood(theta, eval_gradient=True): value and gradient from the reference's
+    ConjugateGaussianProcess (models.py:957-1056).  The reference's ConjugateStudentProcess gradient path raises
+    (kernel(X, eval_gradient) at :1204 passes True as Y), so for it the fixture holds a Richardson-extrapolated
+    central difference of the reference's VALUE path, which pins the intended formulas of :1227-1272."""
+    rng = np.random.RandomState(99)
+    out = []
+    for sp in GRAD_SPECS:
+        n, d = sp["n"], sp["d"]
+        X = np.sort(rng.rand(n, d), axis=0) * 2.0
+        kern = grad_kernel(sp["kernel"])
+        Lc = np.linalg.cholesky(kern(X) + 1e-8 * np.eye(n))
+        y = 0.25 + Lc @ rng.randn(n, 3)
+        pri = sp["priors"]
+        gp = gsum.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri)
+        sp_ = gsum.ConjugateStudentProcess(kernel=kern, optimizer=None, **pri)
+        case = dict(name=sp["name"], kernel=sp["kernel"], priors=pri, X=L(X), y=L(y), evals=[])
+        for shift in (0.0, 0.2, -0.15):
+            theta = kern.theta + shift
+            val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+            ev = dict(theta=L(theta), lml=float(val), grad=L(grad))
+            if "sd" not in pri:            # df0 = inf: the Student normalisation is inf - inf (nan in the reference too)
+                f = lambda t: sp_.log_marginal_likelihood(t, X=X, y=y)   # noqa: E731
+                fd = np.zeros_like(theta)
+                for p in range(len(theta)):
+                    def cd(h):
+                        tp, tm = theta.copy(), theta.copy()
+                        tp[p] += h
+                        tm[p] -= h
+                        return (f(tp) - f(tm)) / (2 * h)
+                    h = 2e-4
+                    fd[p] = (4 * cd(h / 2) - cd(h)) / 3
+                ev["student_lml"] = float(f(theta))
+                ev["student_grad_fd"] = L(fd)
+            case["evals"].append(ev)
+        out.append(case)
+        print("gradient", sp["name"], case["evals"][0]["lml"], case["evals"][0]["grad"], flush=True)
+    return dict(cases=out)
+
+
 def gen_nonpd():
     """Cholesky failure -> -inf (models.py:968-972); fit raises (models.py:711)."""
     X = np.array([[0.0], [0.5], [0.5], [1.0]])
@@ -480,6 +549,8 @@ def main():
         json.dump(gen_trunc_predict(), f)
     with open(os.path.join(HERE, "trunc_predict_interp.json"), "w") as f:
         json.dump(gen_trunc_predict_interp(), f)
+    with open(os.path.join(HERE, "gradient.json"), "w") as f:
+        json.dump(gen_gradient(), f)
     with open(os.path.join(HERE, "student.json"), "w") as f:
         json.dump(gen_student(), f)
     with open(os.path.join(HERE, "large_lml.json"), "w") as f:

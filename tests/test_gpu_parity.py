@@ -749,3 +749,71 @@ def test_device_sampler_statistics_and_datasets():
     assert ys.shape == (9, 20000)
     np.testing.assert_allclose(ys.mean(axis=1), m, atol=5 * sd.max() / np.sqrt(20000) + 1e-12)
     np.testing.assert_allclose(ys.std(axis=1), sd, rtol=0.05)
+
+
+def test_lml_gradient_golden():
+    """log_marginal_likelihood(theta, eval_gradient=True) on the device (R^-1 = U U^T on the MFMA GEMMs, fused
+    kernel-gradient contractions) against the reference's values and gradients for every kernel family and
+    hyperparameter kind (amplitude, iso / aniso length scales, free white noise, additive constant); the Student
+    process against finite differences of the reference's value path (its own gradient path raises)."""
+    from conftest import load_golden, grad_kernel
+    g = load_golden("gradient.json")
+    for case in g["cases"]:
+        kern = grad_kernel(case["kernel"])
+        X, y, pri = np.array(case["X"]), np.array(case["y"]), case["priors"]
+        cond = np.linalg.cond(kern(X))
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri)
+        sp = gsum_amd.ConjugateStudentProcess(kernel=kern, optimizer=None, **pri)
+        for ev in case["evals"]:
+            theta = np.array(ev["theta"])
+            val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+            vtol = max(1e-10, 1e-17 * cond)      # 1e-10 up to cond(R) = 1e7; two valid Choleskys differ by more beyond
+            assert val == pytest.approx(ev["lml"], rel=vtol)
+            tol = 1e-15 * cond + 1e-9            # tr(R^-1 dR) and V^T dR V carry rounding x cond(R)
+            np.testing.assert_allclose(grad, ev["grad"], rtol=tol, atol=tol * np.abs(ev["grad"]).max())
+            if "student_grad_fd" in ev:
+                val, grad = sp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+                assert val == pytest.approx(ev["student_lml"], rel=vtol)
+                tol = 3e-14 * cond + 1e-8
+                np.testing.assert_allclose(grad, ev["student_grad_fd"], rtol=tol, atol=tol * np.abs(ev["student_grad_fd"]).max())
+    # fixed kernel: empty gradient; failed Cholesky: (-inf, zeros)  (models.py:970-972)
+    from sklearn.gaussian_process.kernels import RBF
+    fixed = gsum_amd.ConjugateGaussianProcess(kernel=RBF(0.5, length_scale_bounds="fixed"), optimizer=None)
+    v, gr = fixed.log_marginal_likelihood(np.zeros(0), eval_gradient=True, X=X[:, :1], y=y)
+    assert np.isfinite(v) and gr.shape == (0,)
+    dup = np.array([[0.0], [0.5], [0.5], [1.0]])
+    bad = gsum_amd.ConjugateGaussianProcess(kernel=RBF(1.0), nugget=0, optimizer=None)
+    v, gr = bad.log_marginal_likelihood(np.log([1.0]), eval_gradient=True, X=dup, y=np.array([[0.1], [0.2], [0.2], [0.3]]))
+    assert v == -np.inf and np.array_equal(gr, np.zeros(1))
+
+
+def test_lml_gradient_vs_oracle_n1500_and_fit():
+    """The blocked path (n > 128: 12 block columns, identity padding) against the oracle's dense gradient, then
+    fit() with the default L-BFGS optimiser driven by the analytic gradient recovers the generating length scale."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    rng = np.random.RandomState(4)
+    n = 1500
+    X = np.sort(rng.rand(n, 2), axis=0) * 12.0
+    kern = C(1.2) * Matern([0.8, 1.1], nu=2.5) + WhiteKernel(1e-4)
+    ctx = gsum_amd.default_context(0)
+    y = gsum_amd.sample_mvn_cholesky(kern, X, 4, mean=np.full(n, 0.2), nugget=1e-10, random_state=2)
+    pri = dict(center=0, disp=0, df=3, scale=1)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri)
+    theta = kern.theta + np.array([0.1, -0.1, 0.15, 0.3])
+    val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+    vo, go = orc.cgp_lml_grad(kern, theta, X, y, **pri)
+    assert val == pytest.approx(vo, rel=1e-10)
+    np.testing.assert_allclose(grad, go, rtol=1e-8, atol=1e-8 * np.abs(go).max())
+    # 1-D fit: the optimiser moves the length scale from 0.5 to near the generating 0.2
+    n1 = 700
+    X1 = np.linspace(0, 20, n1)[:, None]
+    y1 = gsum_amd.sample_mvn_cholesky(RBF(0.2), X1, 5, nugget=1e-8, random_state=9)
+    fitgp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(0.5, length_scale_bounds=(0.05, 2.0)) + WhiteKernel(1e-8, noise_level_bounds="fixed"),
+                                              center=0, disp=0, df=1, scale=1)
+    fitgp.fit(X1, y1)
+    ls = fitgp.kernel_.k1.length_scale
+    assert 0.17 < ls < 0.23
+    # at the optimum the gradient vanishes (relative to its size at the start)
+    _, g_opt = fitgp.log_marginal_likelihood(fitgp.kernel_.theta, eval_gradient=True)
+    _, g_start = fitgp.log_marginal_likelihood(np.log([0.5]), eval_gradient=True)
+    assert abs(g_opt[0]) < 1e-3 * abs(g_start[0])

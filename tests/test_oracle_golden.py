@@ -264,3 +264,25 @@ def test_student_process_against_reference():
             np.testing.assert_allclose(cv, want["cov"], rtol=1e-7, atol=tol * np.abs(want["cov"]).max())
             np.testing.assert_allclose(orc.ttp_predict(tfit, Xs, t["order"], t["ratio"], t["ref"], X, yo, **kw), want["mean_only"],
                                        rtol=tol, atol=tol)
+
+
+def test_lml_gradient_against_reference():
+    """log_marginal_likelihood(theta, eval_gradient=True): oracle vs the reference's values and gradients
+    (ConjugateGaussianProcess), and vs finite differences of the reference's value path (ConjugateStudentProcess,
+    whose own gradient path raises: see make_golden.gen_gradient)."""
+    from conftest import load_golden, grad_kernel
+    g = load_golden("gradient.json")
+    for case in g["cases"]:
+        kern = grad_kernel(case["kernel"])
+        X, y, pri = np.array(case["X"]), np.array(case["y"]), case["priors"]
+        for ev in case["evals"]:
+            theta = np.array(ev["theta"])
+            val, grad = orc.cgp_lml_grad(kern, theta, X, y, **pri)
+            assert val == pytest.approx(ev["lml"], rel=1e-10)
+            np.testing.assert_allclose(grad, ev["grad"], rtol=1e-8, atol=1e-9 * np.abs(ev["grad"]).max())
+            if "student_grad_fd" in ev:
+                val, grad = orc.csp_lml_grad(kern, theta, X, y, **pri)
+                assert val == pytest.approx(ev["student_lml"], rel=1e-10)
+                # the fixture is a finite difference of a value with rounding noise ~ eps cond(R)
+                tol = 3e-14 * np.linalg.cond(kern(X)) + 1e-8
+                np.testing.assert_allclose(grad, ev["student_grad_fd"], rtol=tol, atol=tol * np.abs(ev["student_grad_fd"]).max())
