@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsum_hip.so")
+LIB_PATH = os.environ.get("GSUM_HIP_LIBRARY") or os.path.join(_HERE, "libgsum_hip.so")
 
 GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
