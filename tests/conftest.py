@@ -32,6 +32,8 @@ def make_kernel(spec):
         k = Matern(length_scale=ls, nu=2.5)
     elif fam == "matern32":
         k = Matern(length_scale=ls, nu=1.5)
+    elif fam == "matern12":
+        k = Matern(length_scale=ls, nu=0.5)
     else:
         raise ValueError(fam)
     if spec.get("amplitude") is not None:

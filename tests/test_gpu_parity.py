@@ -73,6 +73,8 @@ KERNEL_SPECS = [
     dict(family="rbf", length_scale=0.25, amplitude=1.7, white=1e-3),
     dict(family="rbf", length_scale=[0.7, 1.3]),
     dict(family="matern52", length_scale=[0.7, 1.3, 0.4], white=1e-6, amplitude=0.3),
+    dict(family="matern12", length_scale=0.8, amplitude=2.0),
+    dict(family="rbf", length_scale=[0.7, 1.3, 0.4, 2.0, 0.9, 1.1, 0.6, 1.7]),      # GSUM_MAX_D = 8 features
 ]
 
 
@@ -817,3 +819,21 @@ def test_lml_gradient_vs_oracle_n1500_and_fit():
     _, g_opt = fitgp.log_marginal_likelihood(fitgp.kernel_.theta, eval_gradient=True)
     _, g_start = fitgp.log_marginal_likelihood(np.log([0.5]), eval_gradient=True)
     assert abs(g_opt[0]) < 1e-3 * abs(g_start[0])
+
+
+def test_maximum_size_property_n24576():
+    """The largest order exercised (a 4.8 GB augmented matrix, 192 block columns): with right-hand sides taken from
+    K itself, G = Z^T K^-1 Z must return K[cols][:, cols] -- a full-size check of build + factorisation + solve that
+    needs no host copy of the matrix.  (16384 is BASELINE's largest configuration; this is 1.5x beyond it.)"""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    rng = np.random.RandomState(8)
+    n = 24576
+    X = rng.rand(n, 2) * 50.0
+    kern = Matern(length_scale=1.0, nu=2.5) + WhiteKernel(1e-2, noise_level_bounds="fixed")
+    cols = np.array([0, 1, 127, 128, 12287, 24575])
+    Z = kern(X, X[cols])
+    Z[cols, np.arange(len(cols))] += 1e-2                      # the one-argument form carries the white noise
+    ctx = gsum_amd.default_context(0)
+    G, sld, info = ctx.lml_batch([gsum_amd.describe_kernel(kern, 2)], X, Z, 0.0)
+    assert info[0] == 0 and np.isfinite(sld[0])
+    np.testing.assert_allclose(G[0], Z[cols], rtol=0, atol=1e-11)

@@ -170,3 +170,49 @@ def test_constructor_and_argument_errors():
     t = gsum_amd.TruncationGP(kernel=RBF(1.0), ratio=lambda X: np.ones((len(X), 1, 1)))
     with pytest.raises(ValueError):
         t.fit(np.zeros((3, 1)), np.zeros((3, 2)), orders=np.arange(2))
+
+
+def test_gradient_parameter_map_follows_sklearn_theta_order():
+    """describe_gradient lists one entry per component of kernel.theta, in scikit-learn's order (leaves left to
+    right, free hyperparameters only): SURVEY.md quirk Q10."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    from gsum_amd.kernels import describe_gradient
+    from gsum_amd._lib import GradParam as P
+    k = C(1.3) * Matern([0.5, 0.7], nu=2.5) + WhiteKernel(0.01) + C(0.2)
+    got = [(g.code, g.dim, g.weight) for g in describe_gradient(k, 2)]
+    assert got == [(P.AMPLITUDE, 0, 0.0), (P.LENGTH_DIM, 0, 0.0), (P.LENGTH_DIM, 1, 0.0), (P.WHITE, 0, 0.01), (P.ADDITIVE, 0, 0.2)]
+    assert len(got) == len(k.theta)
+    k = RBF(0.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    assert [(g.code, g.dim) for g in describe_gradient(k, 3)] == [(P.LENGTH_ISO, 0)]
+    k = WhiteKernel(0.1) + C(2.0, constant_value_bounds="fixed") * RBF(1.0)
+    assert [(g.code, g.weight) for g in describe_gradient(k, 1)] == [(P.WHITE, 0.1), (P.LENGTH_ISO, 0.0)]
+    assert describe_gradient(C(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed"), 1) == []
+    with pytest.raises(NotImplementedError):
+        describe_gradient(RBF(1.0) + RBF(2.0), 1)
+
+
+def test_series_scale_struct_and_student_host_algebra():
+    """SeriesScale mirrors helpers.geometric_sum's argument checks; the Student likelihood from a Gram matrix equals
+    the oracle's dense computation (no GPU involved: G is built with numpy here)."""
+    from gsum_amd._lib import SeriesScale
+    from gsum_amd.conjugate import student_lml_from_gram
+    from sklearn.gaussian_process.kernels import RBF
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import gsum_oracle as orc               # checker only
+    sc = SeriesScale.make(2, np.inf, excluded=[3, 5], factor=1.5)
+    assert (sc.start, sc.end, sc.n_excluded, list(sc.excluded)[:2], sc.factor) == (2, -1, 2, [3, 5], 1.5)
+    with pytest.raises(ValueError):
+        SeriesScale.make(3, 2)
+    rng = np.random.RandomState(0)
+    X = np.linspace(0, 1, 12)[:, None]
+    y = rng.randn(12, 3)
+    kern = RBF(0.1)                                     # well conditioned: this checks algebra, not rounding
+    R = kern(X) + 1e-10 * np.eye(12)
+    Z = np.c_[y, np.ones(12)]
+    G = Z.T @ np.linalg.solve(R, Z)
+    sld = np.log(np.diag(np.linalg.cholesky(R))).sum()
+    for disp in (0, 1.7):
+        got, _ = student_lml_from_gram(G, sld, 12, np.array([0.2]), np.array([[disp]]), 3.0, 1.1)
+        want = orc.csp_lml(kern, None, X, y, center=0.2, disp=disp, df=3.0, scale=1.1)
+        assert got == pytest.approx(want, rel=1e-9)
