@@ -450,6 +450,23 @@ class HipContext:
 _default_ctx = {}
 
 
+def _close_default_contexts():
+    # Streams with a CU mask must be gone before the C++ finalisers of the HIP runtime / a profiler run (rocprofv3
+    # segfaults in __cxa_finalize on a process that exits with one alive): destroy the contexts first.  DeviceMatrix
+    # objects still alive only lose their handle (their frees become no-ops).
+    for ctx in list(_default_ctx.values()):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _default_ctx.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_default_contexts)
+
+
 def default_context(device: int | None = None) -> HipContext:
     """Process-wide context for ``device`` (default: $LOCAL_RANK or 0)."""
     if device is None:

@@ -424,6 +424,8 @@ int gsum_init(int device, gsum_ctx** out) {
     (void)hipMemset(ctx->dstamps, 0, 8 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
+    const char* rc = getenv("GSUM_RESERVE_CUS");
+    if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     const char* bs = getenv("GSUM_BATCH_SLOTS");
     if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;
@@ -953,30 +955,48 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     const int64_t np = m->np, ld = m->ld, ldg = np + GS_BORDER;
     const int P = n_params;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int chunks = (int)std::min<int64_t>(128, (n + 63) / 64), rows_per = (int)((n + chunks - 1) / chunks);
     const size_t o_u = 0, o_r = up((size_t)np * ldg * 8), o_v = o_r + up((size_t)np * ldg * 8), o_q = o_v + up((size_t)16 * ldg * 8),
-                 o_t = o_q + up((size_t)P * n * 16 * 8), o_o = o_t + up((size_t)P * n * 8), total = o_o + up((size_t)P * 257 * 8);
+                 o_t = o_q + up((size_t)P * n * 16 * 8), o_o = o_t + up((size_t)P * n * 8), o_p = o_o + up((size_t)P * 257 * 8),
+                 total = o_p + up((size_t)P * chunks * 257 * 8);
     if (gs_reserve(ctx, &ctx->gws, &ctx->gws_cap, total)) return -1;
     char* base = (char*)ctx->gws;
     double *U = (double*)(base + o_u), *Ri = (double*)(base + o_r), *Vt = (double*)(base + o_v), *Q = (double*)(base + o_q),
-           *trow = (double*)(base + o_t), *dout = (double*)(base + o_o);
+           *trow = (double*)(base + o_t), *dout = (double*)(base + o_o), *part = (double*)(base + o_p);
     hipStream_t s = sl->sm;
     hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, U, ldg, (int)np);
     GS_CHECK(hipGetLastError());
-    for (int c = 0; c < m->T; ++c) {
-        const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
+    // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
+    for (int c = 0; c < m->T; c += 2) {
+        const bool two = c + 1 < m->T;
+        const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
         double* Linv = m->Linv + (size_t)c * GS_NB * GS_NB;
-        if (gs_gemm(ctx, s, 1, U + c0, ldg, U + c0, ldg, Linv, GS_NB, r0, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
-        if (r0 < np && gs_gemm(ctx, s, 0, U + r0, ldg, U + c0, ldg, m->A + r0 * ld + c0, ld, r0, np - r0, GS_NB, 0, 1, -1.0)) return -1;
+        if (gs_gemm(ctx, s, 1, U + c0, ldg, U + c0, ldg, Linv, GS_NB, c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (two) {
+            // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
+            if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c1, ldg, Linv + GS_NB * GS_NB, GS_NB, r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        }
+        if (r2 < np && gs_gemm(ctx, s, 5, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+            return -1;
     }
+    // V^T = W^T U^T needs only U: it runs on the panel stream beside the SYRK
+    GS_CHECK(hipEventRecord(sl->evFork, s));
+    GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
+    if (gs_gemm(ctx, sl->sp, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
+    if (gs_potrf_events(ctx, sl, 1)) return -1;
+    GS_CHECK(hipEventRecord(sl->evP[0], sl->sp));
     if (gs_gemm(ctx, s, 5, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
-    if (gs_gemm(ctx, s, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
+    GS_CHECK(hipStreamWaitEvent(s, sl->evP[0], 0));
     gs_grad_params prm;
     memset(&prm, 0, sizeof prm);
     for (int p = 0; p < P; ++p) prm.p[p] = params[p];
     hipLaunchKernelGGL(k_grad_contract, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->dX, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
     GS_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, dout);
+    hipLaunchKernelGGL(k_grad_reduce1, dim3((unsigned)chunks, (unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, rows_per, part);
+    GS_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_reduce2, dim3((unsigned)P), dim3(256), 0, s, part, chunks, dout);
     GS_CHECK(hipGetLastError());
     std::vector<double> hout((size_t)P * 257);
     GS_CHECK(hipMemcpyAsync(hout.data(), dout, hout.size() * 8, hipMemcpyDeviceToHost, s));

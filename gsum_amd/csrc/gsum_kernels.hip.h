@@ -998,25 +998,41 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, i
     if (lane == 0) trow[(int64_t)p * n + i] = tr;
 }
 
-// out[p][a * 16 + b] = sum_i V[i][a] Q_p[i][b]  (= (V^T dR_p V)_ab),  out[p][256] = sum_i trow_p[i].  One workgroup
-// per parameter, fixed summation order.
-__global__ __launch_bounds__(256) void k_grad_reduce(const double* Vt, int64_t ldv, const double* Q, const double* trow, int n,
-                                                      double* out) {
+// H_p = V^T Q_p (16 x 16) and sum_i trow_p[i], in two deterministic stages.  Stage 1 (grid: chunks x P): chunk c
+// reduces rows [c * rows_per, (c + 1) * rows_per) into part[(p * chunks + c) * 257 ...]; stage 2 (grid: P) adds the
+// chunks in index order.
+__global__ __launch_bounds__(256) void k_grad_reduce1(const double* Vt, int64_t ldv, const double* Q, const double* trow, int n,
+                                                       int rows_per, double* part) {
     __shared__ double red[256];
-    const int t = threadIdx.x, a = t >> 4, b = t & 15, p = blockIdx.x;
+    const int t = threadIdx.x, a = t >> 4, b = t & 15, c = blockIdx.x, p = blockIdx.y;
+    const int lo = c * rows_per, hi = min(n, lo + rows_per);
     const double* Qp = Q + (int64_t)p * n * 16;
     double h = 0.0;
-    for (int i = 0; i < n; ++i) h = __builtin_fma(Vt[(int64_t)a * ldv + i], Qp[(int64_t)i * 16 + b], h);
-    out[(int64_t)p * 257 + t] = h;
+    for (int i = lo; i < hi; ++i) h = __builtin_fma(Vt[(int64_t)a * ldv + i], Qp[(int64_t)i * 16 + b], h);
+    double* o = part + ((int64_t)p * gridDim.x + c) * 257;
+    o[t] = h;
     double ts = 0.0;
-    for (int i = t; i < n; i += 256) ts += trow[(int64_t)p * n + i];
+    for (int i = lo + t; i < hi; i += 256) ts += trow[(int64_t)p * n + i];
     red[t] = ts;
     __syncthreads();
     for (int w = 128; w >= 1; w >>= 1) {
         if (t < w) red[t] += red[t + w];
         __syncthreads();
     }
-    if (t == 0) out[(int64_t)p * 257 + 256] = red[0];
+    if (t == 0) o[256] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_grad_reduce2(const double* part, int chunks, double* out) {
+    const int t = threadIdx.x, p = blockIdx.x;
+    const double* src = part + (int64_t)p * chunks * 257;
+    double h = 0.0;
+    for (int c = 0; c < chunks; ++c) h += src[(int64_t)c * 257 + t];
+    out[(int64_t)p * 257 + t] = h;
+    if (t == 0) {
+        double ts = 0.0;
+        for (int c = 0; c < chunks; ++c) ts += src[(int64_t)c * 257 + 256];
+        out[(int64_t)p * 257 + 256] = ts;
+    }
 }
 
 // ---- probes ------------------------------------------------------------------------------------

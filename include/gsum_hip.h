@@ -81,6 +81,8 @@ typedef struct {
 
 /* ---- context ---------------------------------------------------------------------------------- */
 int gsum_init(int device, gsum_ctx** out);
+/* Call before the process exits: a context may own streams created with a CU mask ("reserve_cus"), and a process that
+ * exits with one alive makes rocprofv3 crash in its finaliser (the Python binding registers an atexit for this). */
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8),
