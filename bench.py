@@ -141,6 +141,9 @@ def main():
         return out
 
     ctx.set_option("batch_slots", args.slots)
+    # set-up, not a step: the per-slot workspaces (0.5 GB each) are allocated on first use; do that here so that a
+    # small --warmup does not leave hipMalloc calls inside the timed region
+    evaluate([descs[i % len(descs)] for i in range(args.slots)])
     if W > 0:
         evaluate([descs[i % len(descs)] for i in range(W)])
     if use_dist:

@@ -325,22 +325,38 @@ def test_nonpd_behaviour(small_cases):
         gp.fit(X, y)                                                                 # models.py:711
 
 
-def test_interpolation_property():
-    """The reference's own hot-path test (gsum/tests/test.py:63-72): nugget=0, predict(X_train) == y_train."""
+REFERENCE_TEST_KERNELS = "rbf_free rbf_fixed rbf_bounded const_rbf const_rbf_plus_const".split()
+
+
+def _reference_test_kernel(name):
+    """The kernel list of the reference's own test module (gsum/tests/test.py:33-48)."""
     from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C
+    return {
+        "rbf_free": lambda: RBF(length_scale=1.0),
+        "rbf_fixed": lambda: RBF(length_scale=1.0, length_scale_bounds="fixed"),
+        "rbf_bounded": lambda: RBF(length_scale=1.0, length_scale_bounds=(1e-3, 1e3)),
+        "const_rbf": lambda: C(1.0, (1e-2, 1e2)) * RBF(length_scale=1.0, length_scale_bounds=(1e-3, 1e3)),
+        "const_rbf_plus_const": lambda: C(1.0, (1e-2, 1e2)) * RBF(length_scale=1.0, length_scale_bounds=(1e-3, 1e3))
+        + C(1e-5, (1e-5, 1e2)),
+    }[name]()
+
+
+@pytest.mark.parametrize("name", REFERENCE_TEST_KERNELS)
+def test_interpolation_property(name):
+    """The reference's own hot-path test, kernel for kernel (gsum/tests/test.py:63-72, test_cgp_interpolation with
+    decomposition='cholesky'): nugget = 0, default optimiser on (the free-parameter kernels run L-BFGS on the device
+    likelihood and its analytic gradient), predict(X_train) == y_train with a vanishing predictive variance."""
     X = np.atleast_2d([1., 3., 5., 6., 7., 8.]).T
     y = (X * np.sin(X)).ravel()
-    for kernel in (RBF(length_scale=1.0, length_scale_bounds="fixed"),
-                   C(1.0, "fixed") * RBF(1.0, "fixed")):
-        gp = gsum_amd.ConjugateGaussianProcess(kernel=kernel, nugget=0).fit(X, y)
-        y_pred, y_cov = gp.predict(X, return_cov=True)
-        np.testing.assert_almost_equal(y_pred, y, decimal=7)
-        np.testing.assert_almost_equal(np.diag(y_cov), 0.0, decimal=10)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=_reference_test_kernel(name), nugget=0).fit(X, y)
+    y_pred, y_cov = gp.predict(X, return_cov=True)
+    np.testing.assert_almost_equal(y_pred, y)                       # the reference's assert_almost_equal (7 decimals)
+    np.testing.assert_almost_equal(np.diag(y_cov), 0.0, decimal=10)
 
 
 def test_fit_with_optimizer_reaches_the_grid_optimum(notebook_grid):
-    """fit() with the default L-BFGS optimiser (numerical gradient until SURVEY §8 f-1 lands) finds the
-    length scale the reference reports (RBF(length_scale=0.199), notebook :1115)."""
+    """fit() with the default L-BFGS optimiser (device likelihood + analytic gradient) finds the length scale the
+    reference reports (RBF(length_scale=0.199), notebook :1115)."""
     from sklearn.gaussian_process.kernels import RBF, WhiteKernel
     g = notebook_grid
     X, y = np.array(g["X_train"]), np.array(g["y_train"])
