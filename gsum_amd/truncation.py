@@ -259,16 +259,39 @@ class TruncationGP:
             for flat in range(lo, hi):
                 i, j = divmod(flat, nj)
                 by_theta.setdefault(j, []).append(i)
+            # A constant ratio only rescales the coefficient curves order by order, c_n(q) = c_n(q0) (q0 / q)^n
+            # (helpers.py:101-106), so G(q) = D G(q0) D with D = diag((q0 / q)^orders, 1): the
+            # whole ratio axis of a theta then costs ONE forward solve.  Position-dependent ratios solve per setting.
+            orders_in = np.asarray(orders)[~np.isin(np.asarray(orders), self.excluded)]
+            const_ratio = {}
+
+            def ratio_const(i):
+                if i not in const_ratio:
+                    kws = ratio_kws_list[i]
+                    kws = kws if isinstance(kws, dict) else {"ratio": kws}
+                    rv = np.atleast_1d(self.ratio(Xd, **kws))
+                    const_ratio[i] = float(rv[0]) if np.all(rv == rv[0]) and rv[0] != 0 else None
+                return const_ratio[i]
+
             for j, rows in by_theta.items():
                 kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
                 L = ctx.kernel_matrix_dev(describe_kernel(kern, Xd.shape[1]), Xd, diag_add=gp.nugget)
                 try:
                     info = ctx.potrf(L)
+                    anchor = None                                   # (ratio, G, sld) of the first constant-ratio row
                     for i in rows:
                         if info != 0:
                             out[i, j] = -np.inf
                             continue
-                        G, sld = ctx.forward_gram(L, rhs_for(i)[0])
+                        q = ratio_const(i)
+                        if q is not None and anchor is not None:
+                            q0, G0, sld = anchor
+                            D = np.append((q0 / q) ** orders_in, 1.0)
+                            G = D[:, None] * G0 * D[None, :]
+                        else:
+                            G, sld = ctx.forward_gram(L, rhs_for(i)[0])
+                            if q is not None:
+                                anchor = (q, G, sld)
                         out[i, j] = finish(i, j, G, sld, 0)
                 finally:
                     L.free()

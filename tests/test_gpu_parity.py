@@ -853,3 +853,24 @@ def test_maximum_size_property_n24576():
     G, sld, info = ctx.lml_batch([gsum_amd.describe_kernel(kern, 2)], X, Z, 0.0)
     assert info[0] == 0 and np.isfinite(sld[0])
     np.testing.assert_allclose(G[0], Z[cols], rtol=0, atol=1e-11)
+
+
+def test_grid_reuse_mode_rescaling_matches_full_n2048():
+    """mode="reuse" derives a constant-ratio axis from one Gram matrix per theta (G(q) = D G(q0) D); it must agree
+    with mode="full" (every point recomputed) on GP-drawn data, excluded orders included."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    n = 2048
+    X = 0.1 * np.arange(n)[:, None]
+    kern = RBF(0.2) + WhiteKernel(1e-10, noise_level_bounds="fixed")
+    orders = np.array([0, 1, 2, 3, 4])
+    c = gsum_amd.sample_mvn_cholesky(RBF(0.2), X, 5, nugget=1e-10, random_state=11)
+    y = gsum_amd.partials(c, ratio=0.5, ref=3.0, orders=orders)
+    gp = gsum_amd.TruncationGP(kernel=kern, ratio=0.5, ref=3.0, excluded=[1], center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y, orders=orders)
+    thetas = [np.log([0.19]), np.log([0.2]), np.log([0.21])]
+    ratios = [0.4, 0.45, 0.5, 0.55, 0.6]
+    full = gp.log_marginal_likelihood_grid(thetas, ratios, mode="full")
+    reuse = gp.log_marginal_likelihood_grid(thetas, ratios, mode="reuse")
+    assert np.all(np.isfinite(full))
+    np.testing.assert_allclose(reuse, full, rtol=1e-10)
+    assert np.unravel_index(np.argmax(reuse), reuse.shape) == np.unravel_index(np.argmax(full), full.shape)
