@@ -67,6 +67,9 @@ struct gsum_ctx {
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
     int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
+    int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
+    int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n / 48),
+                                     // the measured break-even against the pipelined multi-kernel path
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
 };
@@ -470,6 +473,8 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
     else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
+    else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
+    else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
@@ -887,6 +892,44 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
     return 0;
 }
 
+// 128 < n <= GS_MEDIUM_MAX with many evaluations: one workgroup per evaluation (k_lml_medium), 256 in flight
+static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
+                         double* sld_out, int64_t* info_out) {
+    const int k = ctx->kZ;
+    const int64_t n = ctx->nX, np = (n + GS_NB - 1) / GS_NB * GS_NB, T = np / GS_NB, ld = np + GS_BORDER;
+    const int CH = std::min(n_kernels, 512);
+    hipStream_t s = ctx->cur->sm;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int64_t stride = (int64_t)(up((size_t)(np * ld + T * GS_NB * GS_NB + np + 16 * np) * 8) / 8);
+    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
+    char* base = (char*)ctx->scratch;
+    const size_t shmem = 2 * (size_t)(128 + 128) * GS_LSTR * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    std::vector<double> hres((size_t)CH * 258);
+    for (int lo = 0; lo < n_kernels; lo += CH) {
+        const int cnt = std::min(CH, n_kernels - lo);
+        GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lml_medium, dim3(cnt), dim3(256), shmem, s, ctx->dX, (int)n, ctx->dX_d, ctx->dZ, k,
+                           (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res));
+        GS_CHECK(hipGetLastError());
+        GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipStreamSynchronize(s));
+        for (int e = 0; e < cnt; ++e) {
+            const double* r = hres.data() + (size_t)e * 258;
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) G_out[(size_t)(lo + e) * k * k + a * k + b] = r[a * 16 + b];
+            sld_out[lo + e] = r[256];
+            info_out[lo + e] = (int64_t)r[257];
+        }
+    }
+    return 0;
+}
+
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
@@ -897,6 +940,11 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
     if (ctx->nX <= GS_NB && ctx->small_path) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    }
+    const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch : std::max(4, (int)(ctx->nX / 48));
+    if (ctx->nX <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
+        ctx->cur = &ctx->slots[0];
+        return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
     const int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
     if (gs_need_slots(ctx, S)) return -1;

@@ -808,6 +808,269 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused path for 128 < n <= GS_MEDIUM_MAX when MANY evaluations are asked for (a likelihood grid on a few hundred
+// to a couple of thousand points): ONE workgroup per evaluation runs the whole bordered pipeline on its own matrix
+// in HBM (288 GB holds thousands of them), so a launch keeps 256 evaluations in flight, one per CU, with no
+// inter-workgroup dependency and no per-step kernel launches.  Same building blocks as the general path: k_build's
+// kernel functions, gs_diag_block, and a 128x128x(K = 128) MFMA tile routine with the accumulation order of
+// k_gemm_nt (the trailing update is a plain right-looking sweep: per element it subtracts the same products in the
+// same ascending-k order as the two-level schedule, so the factor is bit-identical to the general path's).
+// Per-evaluation scratch: A (np x ld, ld = np + 16) | Linv (T x 128 x 128) | diag0 (np) | W^T (16 x np).
+// ------------------------------------------------------------------------------------------------
+#define GS_MEDIUM_MAX 2048
+
+// C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
+// 64 x 64), LDS: 2 stages x 256 rows x 17 doubles.  Ends with a workgroup barrier after the stores (fenced).
+__device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                                           int M, int N, int K, int beta, double sign, double* lds) {
+    constexpr int WM = 4, WN = 4, BM = 128, BN = 128, NT = 256;
+    constexpr int VECS = 128 * (GS_KC / 2), IT = VECS / NT;        // 1024 16-B vectors per operand tile, 4 per thread
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    gs_d4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = (wm * WM + i) * 16 + fq + 4 * x;
+                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+            }
+        }
+    gs_d2 ra[IT], rb[IT];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int vv = t + i * NT;
+            int ar = vv >> 3, br = vv >> 3;
+            ar = ar < M ? ar : M - 1;
+            br = br < N ? br : N - 1;
+            ra[i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)ar * lda + kc * GS_KC + 2 * (vv & 7));
+            rb[i] = *reinterpret_cast<const gs_d2*>(B + (int64_t)br * ldb + kc * GS_KC + 2 * (vv & 7));
+        }
+    };
+    auto swrite = [&](int stage) {
+        double* sA = lds + stage * (BM + BN) * GS_LSTR;
+        double* sB = sA + BM * GS_LSTR;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int vv = t + i * NT;
+            double* qa = sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
+            qa[0] = ra[i][0] * sign;
+            qa[1] = ra[i][1] * sign;
+            double* qb = sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
+            qb[0] = rb[i][0];
+            qb[1] = rb[i][1];
+        }
+    };
+    const int nk = K / GS_KC;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        if (c + 1 < nk) gload(c + 1);
+        const double* sA = lds + (c & 1) * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
+        const double* sB = lds + (c & 1) * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
+#pragma unroll
+        for (int ks = 0; ks < GS_KC / 4; ++ks) {
+            double af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 16 * GS_LSTR + ks * 4];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 16 * GS_LSTR + ks * 4];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nk) swrite((c + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = (wm * WM + i) * 16 + fq + 4 * x;
+                if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][x];
+            }
+        }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
+                                                     const gsum_kernel_desc* descs, double nugget, double* scratch,
+                                                     int64_t scratch_stride, double* res) {
+    extern __shared__ double lds[];                 // gs_tile128 staging; the kernel-build phase borrows it
+    __shared__ double ldet_blk;
+    __shared__ double ldet_sum;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const gsum_kernel_desc desc = descs[blockIdx.x];
+    const int np = (n + 127) / 128 * 128, T = np / 128;
+    const int64_t ld = np + GS_BORDER;
+    double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
+    double* Linv = A + (int64_t)np * ld;
+    double* diag0 = Linv + (int64_t)T * 128 * 128;
+    double* Wt = diag0 + np;                        // 16 x np, row-major
+    double* out = res + (int64_t)blockIdx.x * 258;
+    // ---- kernel matrix: lower 128x128 tiles, identity padding (k_build's arithmetic)
+    {
+#pragma clang fp contract(off)
+        double* ui = lds;
+        double* uj = lds + 128 * GSUM_MAX_D;
+        for (int bi = 0; bi < T; ++bi)
+            for (int bj = 0; bj <= bi; ++bj) {
+                __syncthreads();
+                for (int idx = t; idx < 128 * d; idx += 256) {
+                    const int r = idx / d, dd = idx - r * d;
+                    const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
+                    const int gi = bi * 128 + r, gj = bj * 128 + r;
+                    ui[idx] = gi < n ? X[(int64_t)gi * d + dd] / ls : 0.0;
+                    uj[idx] = gj < n ? X[(int64_t)gj * d + dd] / ls : 0.0;
+                }
+                __syncthreads();
+                double vj0[GSUM_MAX_D], vj1[GSUM_MAX_D];
+#pragma unroll
+                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+                    vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
+                    vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
+                }
+                for (int rr = w; rr < 128; rr += 4) {
+                    const int gi = bi * 128 + rr;
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+                        if (dd < d) {
+                            const double xi = ui[rr * d + dd];
+                            const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
+                            s0 = s0 + e0 * e0;
+                            s1 = s1 + e1 * e1;
+                        }
+                    }
+                    const double ss[2] = {s0, s1};
+                    double v[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int gj = bj * 128 + 2 * lane + c;
+                        double val;
+                        if (gi >= n || gj >= n) {
+                            val = (gi == gj) ? 1.0 : 0.0;
+                        } else {
+                            const bool dg = gi == gj;
+                            const double bse = dg ? 1.0 : gs_base_value(desc.family, ss[c]);
+                            val = desc.amplitude * bse;
+                            if (dg) val = val + desc.white_noise;
+                            val = val + desc.additive_const;
+                            if (dg) val = val + nugget;
+                        }
+                        if (gi == gj) diag0[gi] = val;
+                        v[c] = val;
+                    }
+                    const gs_d2 o = {v[0], v[1]};
+                    *reinterpret_cast<gs_d2*>(A + (int64_t)gi * ld + bj * 128 + 2 * lane) = o;
+                }
+            }
+    }
+    if (t == 0) ldet_sum = 0.0;
+    __threadfence_block();
+    __syncthreads();
+    // ---- right-looking blocked Cholesky, one block column at a time
+    for (int b = 0; b < T; ++b) {
+        double* Lb = Linv + (int64_t)b * 128 * 128;
+        const int bad = gs_diag_block(A + (int64_t)b * 128 * ld + b * 128, ld, Lb, &ldet_blk, diag0 + b * 128, nullptr);
+        if (bad) {
+            if (t == 0) {
+                out[256] = 0.0;
+                out[257] = (double)(b * 128 + bad);
+            }
+            return;
+        }
+        if (t == 0) ldet_sum += ldet_blk;
+        __threadfence_block();
+        __syncthreads();
+        for (int i = b + 1; i < T; ++i) {           // panel: rows of block i  <-  rows * L_bb^-T
+            double* P = A + (int64_t)i * 128 * ld + b * 128;
+            gs_tile128(P, ld, P, ld, Lb, 128, 128, 128, 128, 0, 1.0, lds);
+        }
+        for (int i = b + 1; i < T; ++i)             // trailing lower tiles
+            for (int j = b + 1; j <= i; ++j)
+                gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
+                           A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, 128, 1, -1.0, lds);
+    }
+    // ---- W^T = Z^T L^-T, block column by block column (left-looking on the 16 right-hand-side rows), on the matrix
+    // cores straight from global memory: wave w owns point-columns [32 w, 32 w + 32) of each 128-column block.
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int b = 0; b < T; ++b) {
+        gs_d4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pc = b * 128 + (2 * w + h) * 16 + fr;        // accumulator column = point index
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int rr = fq + 4 * x;                         // accumulator row = right-hand side
+                acc[h][x] = (rr < k && pc < n) ? Z[(int64_t)pc * k + rr] : 0.0;
+            }
+        }
+        for (int c = 0; c < b; ++c)                                // minus W^T[:, c] L[b, c]^T, ascending k
+            for (int s4 = 0; s4 < 32; ++s4) {
+                const int kk = c * 128 + 4 * s4 + fq;
+                const double av = -Wt[(int64_t)fr * np + kk];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double bv = A[(int64_t)(b * 128 + (2 * w + h) * 16 + fr) * ld + kk];
+                    acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[h], 0, 0, 0);
+                }
+            }
+        // stage the updated rows, then multiply by L_bb^-T
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) lds[(fq + 4 * x) * 129 + (2 * w + h) * 16 + fr] = acc[h][x];
+        __syncthreads();
+        const double* Lb = Linv + (int64_t)b * 128 * 128;
+        gs_d4 o[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        for (int s4 = 0; s4 < 32; ++s4) {
+            const int kk = 4 * s4 + fq;
+            const double av = lds[fr * 129 + kk];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double bv = Lb[((2 * w + h) * 16 + fr) * 128 + kk];
+                o[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o[h], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + b * 128 + (2 * w + h) * 16 + fr] = o[h][x];
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ---- Gram matrix G = W^T W by wave 0 (ascending k), log-det, info
+    if (w == 0) {
+        gs_d4 g = {0.0, 0.0, 0.0, 0.0};
+        for (int s4 = 0; s4 < np / 4; ++s4) {
+            const double wv = Wt[(int64_t)fr * np + 4 * s4 + fq];
+            g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) out[(fq + 4 * x) * 16 + fr] = g[x];
+        if (lane == 0) {
+            out[256] = ldet_sum;
+            out[257] = 0.0;
+        }
+    }
+}
+
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
 // res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
 __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, int np, const double* logdet,

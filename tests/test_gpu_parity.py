@@ -402,6 +402,40 @@ def test_small_fused_path_matches_general_path(ctx, n, d, spec):
         assert (i_small[0] > 0) == (spec.get("white") is None)      # WhiteKernel noise keeps duplicates regular
 
 
+@pytest.mark.parametrize("n,d,spec", [(129, 1, KERNEL_SPECS[0]), (200, 2, KERNEL_SPECS[4]), (384, 1, KERNEL_SPECS[3]),
+                                      (1000, 3, KERNEL_SPECS[5]), (2048, 1, KERNEL_SPECS[1])])
+def test_medium_fused_path_matches_general_path(ctx, n, d, spec):
+    """128 < n <= 2048 with many evaluations per call: one workgroup per evaluation on its own HBM-resident matrix.
+    The factorisation subtracts the same products in the same order as the multi-kernel schedule, the border rows
+    and the Gram matrix likewise: results are bit-identical to the general path, info codes included."""
+    rng = np.random.RandomState(n)
+    X = rng.rand(n, d) * (3 if d > 1 else 0.1 * n)
+    Z = np.concatenate([rng.randn(n, 5), np.ones((n, 1))], axis=1)
+    kern = make_kernel(spec)
+    descs = [gsum_amd.describe_kernel(kern.clone_with_theta(kern.theta + dt), d) for dt in np.linspace(-0.2, 0.2, 7)]
+    ctx.set_inputs(X, Z)
+    ctx.set_option("medium_min_batch", 1)
+    got = ctx.lml_resident(descs, 1e-8)
+    ctx.set_option("medium_path", 0)
+    want = ctx.lml_resident(descs, 1e-8)
+    ctx.set_option("medium_path", 1)
+    assert np.all(want[2] == 0)
+    np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[0], want[0])
+    # a duplicated point in the second block column: same LAPACK-style info on both paths
+    Xd = X.copy()
+    Xd[140 % n] = Xd[131 % n]
+    ctx.set_inputs(Xd, Z)
+    i_med = ctx.lml_resident(descs[:2], 0.0)[2]
+    ctx.set_option("medium_path", 0)
+    i_gen = ctx.lml_resident(descs[:2], 0.0)[2]
+    ctx.set_option("medium_path", 1)
+    ctx.set_option("medium_min_batch", -1)
+    np.testing.assert_array_equal(i_med, i_gen)
+    assert (i_med[0] > 0) == (spec.get("white") is None)
+
+
 def test_notebook_grid_known_answer(notebook_grid):
     """The published MAP of the 80 x 100 (Q, ell) scan: indices (36, 39), bit-exact."""
     from sklearn.gaussian_process.kernels import RBF, WhiteKernel
@@ -874,3 +908,27 @@ def test_grid_reuse_mode_rescaling_matches_full_n2048():
     assert np.all(np.isfinite(full))
     np.testing.assert_allclose(reuse, full, rtol=1e-10)
     assert np.unravel_index(np.argmax(reuse), reuse.shape) == np.unravel_index(np.argmax(full), full.shape)
+
+
+def test_grid_full_mode_medium_size_vs_oracle():
+    """A (ratio x length-scale) scan on 600 points through the class API: every row of 40 thetas runs as one launch of
+    the one-workgroup-per-evaluation path; spot-checked against the oracle, argmax at the generating values."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    n = 600
+    X = np.linspace(0, 30, n)[:, None]
+    orders = np.arange(4)
+    c = gsum_amd.sample_mvn_cholesky(RBF(0.25), X, 4, nugget=1e-6, random_state=21)
+    y = gsum_amd.partials(c, ratio=0.5, ref=2.0, orders=orders)
+    kern = RBF(0.25) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    gp = gsum_amd.TruncationGP(kernel=kern, ratio=0.5, ref=2.0, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y, orders=orders)
+    ls = np.linspace(0.15, 0.35, 41)
+    ratios = [0.4, 0.5, 0.6]
+    grid = gp.log_marginal_likelihood_grid([np.log([v]) for v in ls], ratios, mode="full")
+    assert grid.shape == (3, 41) and np.all(np.isfinite(grid))
+    for i, j in ((0, 0), (1, 20), (2, 40), (1, 7)):
+        want = orc.trunc_lml(kern, np.log([ls[j]]), X, y, orders, ratio=ratios[i], ref=2.0, center=0, disp=0, df=1, scale=1)
+        tol = lml_tol(kern.clone_with_theta(np.log([ls[j]]))(X) + 1e-10 * np.eye(n))
+        assert grid[i, j] == pytest.approx(want, rel=max(1e-10, tol))
+    i, j = np.unravel_index(np.argmax(grid), grid.shape)
+    assert i == 1 and abs(ls[j] - 0.25) < 0.03
