@@ -69,7 +69,7 @@ struct gsum_ctx {
     int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
     int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
     int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n / 48),
-                                     // the measured break-even against the pipelined multi-kernel path
+                                     // (n / 24 above 2048), the measured break-even against the pipelined multi-kernel path
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
 };
@@ -892,15 +892,19 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
     return 0;
 }
 
-// 128 < n <= GS_MEDIUM_MAX with many evaluations: one workgroup per evaluation (k_lml_medium), 256 in flight
+// 128 < n <= GS_MEDIUM_MAX (4096) with many evaluations: one workgroup per evaluation (k_lml_medium), 256 in flight
 static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
                          double* sld_out, int64_t* info_out) {
     const int k = ctx->kZ;
     const int64_t n = ctx->nX, np = (n + GS_NB - 1) / GS_NB * GS_NB, T = np / GS_NB, ld = np + GS_BORDER;
-    const int CH = std::min(n_kernels, 512);
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const int64_t stride = (int64_t)(up((size_t)(np * ld + T * GS_NB * GS_NB + np + 16 * np) * 8) / 8);
+    // evaluations per launch: whole rounds of the 256 CUs (a partial second round would idle most of the chip),
+    // within 40 GB of per-evaluation matrices
+    const int64_t fit = (int64_t)(40e9 / (double)(stride * 8));
+    const int cap = fit >= 512 ? 512 : (fit >= 256 ? 256 : (int)std::max<int64_t>(1, fit));
+    const int CH = std::min(n_kernels, cap);
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
@@ -941,7 +945,8 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch : std::max(4, (int)(ctx->nX / 48));
+    const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
+                                                  : std::max(4, (int)(ctx->nX / (ctx->nX <= 2048 ? 48 : 24)));
     if (ctx->nX <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);

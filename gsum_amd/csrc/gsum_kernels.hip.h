@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused path for 128 < n <= GS_MEDIUM_MAX when MANY evaluations are asked for (a likelihood grid on a few hundred
+// Fused path for 128 < n <= GS_MEDIUM_MAX (4096) when MANY evaluations are asked for (a likelihood grid on a few hundred
 // to a couple of thousand points): ONE workgroup per evaluation runs the whole bordered pipeline on its own matrix
 // in HBM (288 GB holds thousands of them), so a launch keeps 256 evaluations in flight, one per CU, with no
 // inter-workgroup dependency and no per-step kernel launches.  Same building blocks as the general path: k_build's
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 // same ascending-k order as the two-level schedule, so the factor is bit-identical to the general path's).
 // Per-evaluation scratch: A (np x ld, ld = np + 16) | Linv (T x 128 x 128) | diag0 (np) | W^T (16 x np).
 // ------------------------------------------------------------------------------------------------
-#define GS_MEDIUM_MAX 2048
+#define GS_MEDIUM_MAX 4096
 
 // C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
 // 64 x 64), LDS: 2 stages x 256 rows x 17 doubles.  Ends with a workgroup barrier after the stores (fenced).

@@ -87,8 +87,8 @@ void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..8),
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
- * (128 < n <= 2048: calls with at least that many evaluations -- <= 0: auto, max(4, n / 48) -- run one workgroup per
- * evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
+ * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n / 48), n / 24 above 2048 -- run
+ * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
  * "reserve_cus" (-1 auto, 0..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while a
  * look-ahead factorisation runs).  <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
@@ -181,7 +181,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
  * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
  * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs.
  * n <= 128 (the reference's own problem sizes) takes a fused path: one workgroup per evaluation builds K,
- * factors it, solves and reduces, hundreds of evaluations per launch.  128 < n <= 2048 with many evaluations per
+ * factors it, solves and reduces, hundreds of evaluations per launch.  128 < n <= 4096 with many evaluations per
  * call does the same with the matrix of each evaluation in its own HBM scratch (one CU per evaluation). */
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,

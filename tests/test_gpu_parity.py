@@ -403,9 +403,9 @@ def test_small_fused_path_matches_general_path(ctx, n, d, spec):
 
 
 @pytest.mark.parametrize("n,d,spec", [(129, 1, KERNEL_SPECS[0]), (200, 2, KERNEL_SPECS[4]), (384, 1, KERNEL_SPECS[3]),
-                                      (1000, 3, KERNEL_SPECS[5]), (2048, 1, KERNEL_SPECS[1])])
+                                      (1000, 3, KERNEL_SPECS[5]), (2048, 1, KERNEL_SPECS[1]), (4096, 1, KERNEL_SPECS[0])])
 def test_medium_fused_path_matches_general_path(ctx, n, d, spec):
-    """128 < n <= 2048 with many evaluations per call: one workgroup per evaluation on its own HBM-resident matrix.
+    """128 < n <= 4096 with many evaluations per call: one workgroup per evaluation on its own HBM-resident matrix.
     The factorisation subtracts the same products in the same order as the multi-kernel schedule, the border rows
     and the Gram matrix likewise: results are bit-identical to the general path, info codes included."""
     rng = np.random.RandomState(n)
