@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,7 @@ struct gsum_ctx {
                                      // (n / 24 above 2048), the measured break-even against the pipelined multi-kernel path
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
+    std::set<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this context's device
 };
 
 static std::string g_init_error;
@@ -111,11 +113,10 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
     if (M <= 0 || N <= 0) return 0;
     if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
     const size_t shmem = 2 * (size_t)(BM + BN) * GS_LSTR * sizeof(double);
-    static bool attr_set = false;     // per instantiation
     auto kern = k_gemm_nt<WM, WN, WAVES_M, WAVES_N>;
-    if (!attr_set) {
+    if (!ctx->lds_attr_done.count((const void*)kern)) {          // per context: the attribute is per device
         GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+        ctx->lds_attr_done.insert((const void*)kern);
     }
     int64_t blocks;
     if (tri) {
@@ -472,6 +473,15 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
     else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
+    else if (!strcmp(name, "release_scratch")) {
+        // hand the grown work buffers back (the medium path keeps up to 40 GB, the gradient path 2 n^2 doubles)
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        if (ctx->scratch) GS_CHECK(hipFree(ctx->scratch));
+        if (ctx->gws) GS_CHECK(hipFree(ctx->gws));
+        ctx->scratch = ctx->gws = nullptr;
+        ctx->scratch_cap = ctx->gws_cap = 0;
+    }
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
@@ -909,10 +919,9 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
     const size_t shmem = 2 * (size_t)(128 + 128) * GS_LSTR * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->lds_attr_done.count((const void*)k_lml_medium)) {
         GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+        ctx->lds_attr_done.insert((const void*)k_lml_medium);
     }
     std::vector<double> hres((size_t)CH * 258);
     for (int lo = 0; lo < n_kernels; lo += CH) {

@@ -432,6 +432,7 @@ def test_medium_fused_path_matches_general_path(ctx, n, d, spec):
     i_gen = ctx.lml_resident(descs[:2], 0.0)[2]
     ctx.set_option("medium_path", 1)
     ctx.set_option("medium_min_batch", -1)
+    ctx.set_option("release_scratch", 1)          # hand the per-evaluation matrices back; the next call regrows
     np.testing.assert_array_equal(i_med, i_gen)
     assert (i_med[0] > 0) == (spec.get("white") is None)
 
