@@ -7,12 +7,14 @@ factorisations differ by ~cond * eps (measured 3e-7 between LA
 numpy Cholesky), so the bound there is max(1e-10, 1e-16 * cond(R)).  Kernel-matrix entries: 4 ulp
 (different exp implementations).  Indices (argmax, potrf info): exact.
 """
+import os
+
 import numpy as np
 import pytest
 from scipy.linalg import solve_triangular
 from scipy.linalg.lapack import dpotrf
 
-from conftest import make_kernel, prior_kwargs
+from conftest import ROOT, make_kernel, prior_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -933,3 +935,29 @@ def test_grid_full_mode_medium_size_vs_oracle():
         assert grid[i, j] == pytest.approx(want, rel=max(1e-10, tol))
     i, j = np.unravel_index(np.argmax(grid), grid.shape)
     assert i == 1 and abs(ls[j] - 0.25) < 0.03
+
+
+def test_integration_md_binding_runs():
+    """The ctypes stub INTEGRATION.md shows a gsum maintainer (section 2) is executed as written -- only the library
+    path is made absolute -- and returns what the package's own binding returns."""
+    import re
+    from sklearn.gaussian_process.kernels import RBF
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "def gram_and_logdet" in b)
+    stub = stub.replace('C.CDLL("libgsum_hip.so")', 'C.CDLL(%r)' % os.path.join(ROOT, "gsum_amd", "libgsum_hip.so"))
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.RandomState(3)
+    n = 300
+    X = np.sort(rng.rand(n, 1), axis=0) * 30
+    Z = np.c_[rng.randn(n, 4), np.ones(n)]
+    mine = gsum_amd.describe_kernel(RBF(0.7), 1)
+    desc = ns["KernelDesc"]()
+    desc.family, desc.anisotropic, desc.amplitude = mine.family, 0, 1.0
+    desc.length_scale[0] = 0.7
+    G, sld, info = ns["gram_and_logdet"](desc, X, Z, 1e-10)
+    Gw, sw, iw = gsum_amd.default_context(0).lml_batch([mine], X, Z, 1e-10)
+    assert info == 0 and iw[0] == 0
+    np.testing.assert_array_equal(G, Gw[0])
+    assert sld == sw[0]
