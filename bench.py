@@ -21,7 +21,11 @@ import os
 import sys
 import time
 
-import numpy as np
+# Must precede the first GPU touch of the process (torch included): the HIP runtime reads it when it initialises.  One
+# hardware queue per in-flight evaluation instead of 4 shared ones (gsum_amd/_lib.py sets the same default).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -88,7 +92,9 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
     ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
-    ap.add_argument("--slots", type=int, default=3, help="independent evaluations kept in flight per GPU")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="independent evaluations kept in flight per GPU (0 = library default: 10 with >= 8 hardware "
+                         "queues, else 3)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
     args = ap.parse_args()
@@ -140,6 +146,8 @@ def main():
             out[i] = -np.inf if info[i] != 0 else lml_from_gram(G[i], sld[i], n, 0.0, 0.0, 1, 1)[0] - jac
         return out
 
+    if args.slots <= 0:
+        args.slots = 10 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else 3
     ctx.set_option("batch_slots", args.slots)
     # set-up, not a step: the per-slot workspaces (0.5 GB each) are allocated on first use; do that here so that a
     # small --warmup does not leave hipMalloc calls inside the timed region

@@ -38,14 +38,16 @@ struct gs_slot {
     int pending = -1;                // index of the evaluation in flight on this slot
 };
 
-#define GS_MAX_SLOTS 8
+#define GS_MAX_SLOTS 16
 
 struct gsum_ctx {
     int device = 0;
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
-    int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident (3 measured best)
+    int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident: 3 is the measured optimum with
+                                     // the HIP runtime's default of 4 hardware queues, 10 with GPU_MAX_HW_QUEUES >= 8
+                                     // (gsum_init picks by that variable; 12 falls off a cliff)
     int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
@@ -258,6 +260,13 @@ static int gs_potrf_events(gsum_ctx* ctx, gs_slot* sl, int T) {
 // XCD to the chain kernels: a bulk workgroup holds its CU for ~80 us, and without free CUs every small chain
 // launch first waits for one to retire.  Mask bit i is CU i / 8 of XCD i % 8 (measured with gsum_probe_cu_mask),
 // so clearing the top 8 R bits takes R CUs from each XCD.
+// The high-priority panel stream exists only on slots that run a look-ahead schedule: a batch keeps ~10 slots busy
+// on their main streams, and every extra stream competes for the runtime's hardware queues.
+static int gs_panel_stream(gsum_ctx* ctx, gs_slot* sl) {
+    if (!sl->sp) GS_CHECK(hipStreamCreateWithPriority(&sl->sp, hipStreamNonBlocking, ctx->prio_hi));
+    return 0;
+}
+
 static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* out) {
     const int R = ctx->reserve_cus >= 0 ? ctx->reserve_cus : (np >= 6144 ? 2 : 0);
     if (R <= 0) {
@@ -305,6 +314,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
+    if (la && gs_panel_stream(ctx, sl)) return -1;
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm, sb = sl->sm;
     if (la) {
@@ -378,7 +388,6 @@ extern "C" {
 
 static int gs_slot_init(gsum_ctx* ctx, gs_slot* sl) {
     GS_CHECK(hipStreamCreateWithPriority(&sl->sm, hipStreamNonBlocking, ctx->prio_lo));
-    GS_CHECK(hipStreamCreateWithPriority(&sl->sp, hipStreamNonBlocking, ctx->prio_hi));
     GS_CHECK(hipEventCreateWithFlags(&sl->evFork, hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) GS_CHECK(hipEventCreate(&sl->tev[i]));
     GS_CHECK(hipMalloc((void**)&sl->dres, 258 * sizeof(double)));
@@ -430,6 +439,11 @@ int gsum_init(int device, gsum_ctx** out) {
     if (la) ctx->lookahead = atoi(la);
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
+    // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
+    // With the limit raised (GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises) ten evaluations in
+    // flight beat three: 4.75 vs 5.45 ms per evaluation at n = 8192.
+    const char* hq = getenv("GPU_MAX_HW_QUEUES");
+    if (hq && atoi(hq) >= 8) ctx->batch_slots = 10;
     const char* bs = getenv("GSUM_BATCH_SLOTS");
     if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;
@@ -810,7 +824,7 @@ void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->cur->sm);
-        (void)hipStreamSynchronize(ctx->cur->sp);
+        if (ctx->cur->sp) (void)hipStreamSynchronize(ctx->cur->sp);
     }
     gs_mat_release(A);
 }
@@ -1044,6 +1058,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     }
     // V^T = W^T U^T needs only U: it runs on the panel stream beside the SYRK
     GS_CHECK(hipEventRecord(sl->evFork, s));
+    if (gs_panel_stream(ctx, sl)) return -1;
     GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
     if (gs_gemm(ctx, sl->sp, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
     if (gs_potrf_events(ctx, sl, 1)) return -1;
