@@ -237,7 +237,7 @@ def main():
             # flops of ALL its launches in the timed region / wall time of the timed region, i.e. what this
             # kernel delivers on the chip while `evals_in_flight` evaluations share it; per-launch averages
             # (HIP events on the launch stream, what rocprofv3 --stats reports) and the exclusive rate follow.
-            "roofline": {"kernel": "k_gemm_nt<4,2,2,4> (128x128-tile, 8-wave fp64 MFMA SYRK, K=256, trailing update)",
+            "roofline": {"kernel": "k_gemm_nt<4,2,2,4> (128x128-tile, 8-wave fp64 MFMA SYRK, K=256/512, trailing update)",
                          "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "traffic_from_committed_pmc_pass": "profiles/r01_gemm_pmc.md: 1091 MB HBM per M=8192, K=256 launch "
@@ -247,7 +247,8 @@ def main():
                          "avg_concurrent_launches": gemm_ms * 1e-3 / elapsed,
                          "per_launch_tflops_shared": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                          "exclusive_tflops": excl_tflops, "exclusive_frac": excl_tflops / FP64_MFMA_PEAK_TFLOPS,
-                         "flops_per_launch": "lower-triangular SYRK: M(M+1)K algorithmic flops, K = 256"},
+                         "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K (K = 256, or 512 for "
+                                             "the lazily updated far region), lower trapezoid for the near-column updates"},
             "factor_reuse": reuse,
             "lml_sample": float(allvals[0]),
         }
