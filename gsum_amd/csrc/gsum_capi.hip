@@ -53,6 +53,7 @@ struct gsum_ctx {
     std::string err;
     int lookahead = 1;
     double next_algo_flops = -1.0;   // profile only: algorithmic flops of the next cfg-5 launch when not M(M+1)K / 2MNK
+    int bulk_cfg = 6;                // bulk trailing-update kernel: 6 = LDS-direct staging (k_gemm_ld), 5 = register staging
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
     int reserve_cus = -1;            // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs;
                                      // -1 = auto: 2 from order 6144 up (measured -3 % at n >= 8192, +1 % below)
@@ -142,26 +143,28 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
 // cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
 // cfg 5: 128x128 tile (2x4 waves of 64x32, 512 threads, 4 waves per SIMD) — bulk trailing update: +3-9 % over
 //        cfg 0 in interleaved A/B runs (more independent waves per SIMD to fill issue gaps)
-static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
-                   const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
-    const double algo_override = ctx->next_algo_flops;      // consumed by this call whether or not it is profiled
-    ctx->next_algo_flops = -1.0;
-    if (cfg == 5 && ctx->profile_gemm && M > 0 && N > 0) {
-        while (ctx->prof_pool.size() < ctx->prof_next + 2) {
-            hipEvent_t ev;
-            GS_CHECK(hipEventCreate(&ev));
-            ctx->prof_pool.push_back(ev);
+static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    if (cfg == 6) {                                   // LDS-direct staging variant of cfg 5
+        if (M <= 0 || N <= 0) return 0;
+        if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
+        const size_t shmem = 2 * 2 * (size_t)(128 * GS_KC + 2) * sizeof(double);
+        if (!ctx->lds_attr_done.count((const void*)k_gemm_ld)) {
+            GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            ctx->lds_attr_done.insert((const void*)k_gemm_ld);
         }
-        const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
-        ctx->prof_next += 2;
-        GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
-        int rc = gs_launch_gemm<4, 2, 2, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
-        GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
-        // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
-        double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
-        if (algo_override >= 0.0) fl = algo_override;                    // caller knows better (trapezoidal region)
-        ctx->prof_recs.push_back({e0, e1, fl});
-        return rc;
+        int64_t blocks;
+        if (tri) {
+            if (M != N) GS_FAIL("gemm: tri mode needs a square C");
+            const int64_t Tt = (M + 127) / 128;
+            blocks = Tt * (Tt + 1) / 2;
+        } else {
+            blocks = ((M + 127) / 128) * ((N + 127) / 128);
+        }
+        hipLaunchKernelGGL(k_gemm_ld, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
+                           beta, sign, ctx->stagger < 0 ? std::min(K / 16, 32) : ctx->stagger);
+        GS_CHECK(hipGetLastError());
+        return 0;
     }
     switch (cfg) {
         case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
@@ -170,6 +173,35 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
         case 5: return gs_launch_gemm<4, 2, 2, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
     }
     GS_FAIL("gemm: unknown tile configuration");
+}
+
+// cfg GS_BULK stands for the bulk trailing-update kernel the context is configured with (option "bulk_cfg": 6 = the
+// LDS-direct 8-wave tile, 5 = the same tile with register staging); those launches are the ones the profile records.
+#define GS_BULK (-5)
+static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    const double algo_override = ctx->next_algo_flops;      // consumed by this call whether or not it is profiled
+    ctx->next_algo_flops = -1.0;
+    const bool bulk = cfg == GS_BULK;
+    if (bulk) cfg = ctx->bulk_cfg;
+    if (bulk && ctx->profile_gemm && M > 0 && N > 0) {
+        while (ctx->prof_pool.size() < ctx->prof_next + 2) {
+            hipEvent_t ev;
+            GS_CHECK(hipEventCreate(&ev));
+            ctx->prof_pool.push_back(ev);
+        }
+        const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
+        ctx->prof_next += 2;
+        GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
+        int rc = gs_dispatch(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
+        // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
+        double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
+        if (algo_override >= 0.0) fl = algo_override;                    // caller knows better (trapezoidal region)
+        ctx->prof_recs.push_back({e0, e1, fl});
+        return rc;
+    }
+    return gs_dispatch(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
 }
 
 // ---- matrices ---------------------------------------------------------------------------------
@@ -364,22 +396,22 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             if (!deferred && full_next) {
                 // near region only: rows >= r2, columns [r2, r2 + 512); algorithmic work = the lower trapezoid
                 ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * (2 * w2) - (double)(2 * w2) * (2 * w2 - 1));
-                if (gs_gemm(ctx, sm, 5, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, 2 * w2, Kp, 0, 1, -1.0)) return -1;
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, 2 * w2, Kp, 0, 1, -1.0)) return -1;
                 deferred = true;
                 continue;
             }
             if (deferred) {
                 // columns [r2, r2 + 256): this panel only (they had the previous one as "near")
                 ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * w2 - (double)w2 * (w2 - 1));
-                if (gs_gemm(ctx, sm, 5, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, w2, Kp, 0, 1, -1.0)) return -1;
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, w2, Kp, 0, 1, -1.0)) return -1;
                 // everything right of them: the previous panel and this one together (contiguous 512 columns)
                 const int64_t rf = r2 + w2, mf = naug - rf;
                 double* P2 = A + rf * ld + (c0 - w2);
-                if (gs_gemm(ctx, sm, 5, A + rf * ld + rf, ld, P2, ld, P2, ld, mf, mf, (int)(w2 + Kp), 1, 1, -1.0)) return -1;
+                if (gs_gemm(ctx, sm, GS_BULK, A + rf * ld + rf, ld, P2, ld, P2, ld, mf, mf, (int)(w2 + Kp), 1, 1, -1.0)) return -1;
                 deferred = false;
                 continue;
             }
-            if (gs_gemm(ctx, sm, 5, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
             continue;
         }
         GS_CHECK(hipEventRecord(sl->evP[k], sp));
@@ -391,14 +423,14 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
-            if (gs_gemm(ctx, sb, 5, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
             GS_CHECK(hipEventRecord(sl->evM[k], sb));
             prev = k;
         } else {
             // last panel: only the 16x16 corner (the Gram matrix) is left
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
             if (sb != sm && prev >= 0) GS_CHECK(hipStreamWaitEvent(sm, sl->evM[prev], 0));
-            if (gs_gemm(ctx, sm, 5, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
         }
     }
     m->factored = true;
@@ -529,6 +561,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         ctx->scratch_cap = ctx->gws_cap = 0;
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
+    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5) ? 5 : 6;
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
@@ -1087,7 +1120,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
             if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
             if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c1, ldg, Linv + GS_NB * GS_NB, GS_NB, r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
         }
-        if (r2 < np && gs_gemm(ctx, s, 5, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+        if (r2 < np && gs_gemm(ctx, s, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
     // V^T = W^T U^T needs only U: it runs on the panel stream beside the SYRK
@@ -1097,7 +1130,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     if (gs_gemm(ctx, sl->sp, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
     if (gs_potrf_events(ctx, sl, 1)) return -1;
     GS_CHECK(hipEventRecord(sl->evP[0], sl->sp));
-    if (gs_gemm(ctx, s, 5, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
+    if (gs_gemm(ctx, s, GS_BULK, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
     GS_CHECK(hipStreamWaitEvent(s, sl->evP[0], 0));
     gs_grad_params prm;
     memset(&prm, 0, sizeof prm);

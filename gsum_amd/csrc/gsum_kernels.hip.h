@@ -1071,6 +1071,133 @@ __global__ __launch_bounds__(256) void k_lml_medium(const double* X, int n, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2b': the 8-wave 128x128 tile with LDS-DIRECT operand staging (gfx950 global_load_lds_dwordx4): the A / B chunks go
+// from global memory straight into LDS -- no staging VGPRs, no ds_write, no vmcnt-wait-then-store phase.
+//   - An LDS-direct load writes the wave's 64 x 16 B contiguously, so tile rows are unpadded (16 doubles = 128 B); bank
+//     conflicts are avoided by an XOR swizzle chosen on the GLOBAL side: LDS granule g of row r holds k-pair
+//     g ^ ((r >> 1) & 7).  A fragment read (16 rows x 4 k-groups per instruction) then touches 64 distinct 8-B slots.
+//   - The sign cannot ride on the staged operand any more: for sign = -1 the accumulators start as -C, accumulate
+//     +A B^T and are negated on store.  Round-to-nearest is sign-symmetric, so results equal k_gemm_nt's bit for bit.
+// Same tile mapping, tri modes and stagger as k_gemm_nt<4, 2, 2, 4>.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                                                     int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
+                                                     int stagger) {
+    constexpr int WM = 4, WN = 2, WAVES_M = 2, BM = 128, BN = 128;
+    // Per operand tile: even rows in one 8-KB region, odd rows in a second one that starts ONE DOUBLE later, so a row and
+    // its neighbour never share a bank pair (128-B rows alone would put rows 2m and 2m + 1 on the same banks).
+    constexpr int OPER = BM * GS_KC + 2;                // doubles per operand tile (+1 shift, +1 to keep 16-B alignment)
+    constexpr int STAGE = 2 * OPER;                     // doubles per stage
+    extern __shared__ double lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
+    int bm, bn;
+    if (tri) {
+        const int bid = blockIdx.x;
+        bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
+        while ((int64_t)bm * (bm + 1) / 2 > bid) --bm;
+        bn = bid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else {
+        const int tm = (M + BM - 1) / BM;
+        bm = blockIdx.x % tm;
+        bn = blockIdx.x / tm;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    if (tri == 2) {
+        A += m0;
+        B += m0;
+        K -= m0;
+    }
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool neg = sign < 0.0;
+    gs_d4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+                acc[i][j][x] = neg ? -c : c;
+            }
+        }
+    // this wave's four operand slices per chunk: A rows [16 w, 16 w + 16), B rows [16 w, 16 w + 16), 8 rows per load
+    const int lrow = lane >> 3, lg = lane & 7;
+    const double* srcA[2];
+    const double* srcB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 16 * w + 2 * lrow + h;                       // tile row this lane fetches: load h takes parity h
+        const int kp = lg ^ ((r >> 1) & 7);                        // swizzled k-pair
+        int ra = m0 + r, rb = n0 + r;
+        ra = ra < M ? ra : M - 1;
+        rb = rb < N ? rb : N - 1;
+        srcA[h] = A + (int64_t)ra * lda + 2 * kp;
+        srcB[h] = B + (int64_t)rb * ldb + 2 * kp;
+    }
+    auto stage_load = [&](int kc, int stage) {
+        double* base = lds + stage * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // region h (row parity) starts at h * (BM / 2 * GS_KC + 1); this wave's 8 rows of that parity are contiguous
+            double* dstA = base + h * (BM / 2 * GS_KC + 1) + 8 * w * GS_KC;
+            double* dstB = base + OPER + h * (BN / 2 * GS_KC + 1) + 8 * w * GS_KC;
+            __builtin_amdgcn_global_load_lds(srcA[h] + kc * GS_KC, dstA, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB[h] + kc * GS_KC, dstB, 16, 0, 0);
+        }
+    };
+    // fragment addresses inside a parity region: (row >> 1) * 16 + ((2 ks + (fq >> 1)) ^ swz) * 2 + (fq & 1), with
+    // swz = (fr >> 1) & 7 for every 16-row block; odd rows live one double further (region offset)
+    const int swz = (fr >> 1) & 7;
+    const int rsel = (fr & 1) * (BM / 2 * GS_KC + 1) + (fr >> 1) * GS_KC;      // BM == BN
+    int goff[GS_KC / 4];
+#pragma unroll
+    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
+    const int nk = K / GS_KC;
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
+        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rsel;
+        const double* sB = lds + (c & 1) * STAGE + OPER + wn * WN * 8 * GS_KC + rsel;
+#pragma unroll
+        for (int ks = 0; ks < GS_KC / 4; ++ks) {
+            double af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
+            }
+        }
+}
+
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
 // res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
 __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, int np, const double* logdet,
