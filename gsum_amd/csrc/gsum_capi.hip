@@ -360,6 +360,9 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
         if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
     }
+    // panel GEMMs (TRSM against the block inverse, sibling column): the low-latency 32x128 tile when one factorisation
+    // is on the critical path; in a batch latency is irrelevant and the LDS-direct 128x128 tile is 1 % cheaper overall
+    const int ccfg = (la || ctx->bulk_cfg != 6) ? 1 : 6;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
     bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
@@ -372,14 +375,14 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
         if (gs_diag(ctx, sp, m, k)) return -1;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (gs_gemm(ctx, sp, 1, Pa, ld, Pa, ld, Linv, GS_NB, naug - c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, sp, ccfg, Pa, ld, Pa, ld, Linv, GS_NB, naug - c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
         if (two) {
             // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
-            if (gs_gemm(ctx, sp, 1, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
             double* Linv1 = Linv + GS_NB * GS_NB;
             if (gs_diag(ctx, sp, m, k + 1)) return -1;
             double* Pb = A + r2 * ld + c1;
-            if (gs_gemm(ctx, sp, 1, Pb, ld, Pb, ld, Linv1, GS_NB, naug - r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+            if (gs_gemm(ctx, sp, ccfg, Pb, ld, Pb, ld, Linv1, GS_NB, naug - r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
         }
         // ---- trailing update with the whole panel: rows r2.., columns c0..c0+Kp-1
         double* P = A + r2 * ld + c0;
@@ -419,7 +422,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
             // look-ahead columns: need the previous bulk update to have finished with them
             if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evM[prev], 0));
-            if (gs_gemm(ctx, sp, 1, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
