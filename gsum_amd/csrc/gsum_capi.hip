@@ -848,7 +848,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
         const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
         double* Linv = L->Linv + (size_t)c * GS_NB * GS_NB;
         if (gs_gemm(ctx, ctx->cur->sm, 1, Bt + c0, ldb, Bt + c0, ldb, Linv, GS_NB, m, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
-        if (gs_gemm(ctx, ctx->cur->sm, 0, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
+        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
             return -1;
     }
     hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
@@ -864,7 +864,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
         GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
     if (cov_out) {
-        if (gs_gemm(ctx, ctx->cur->sm, 0, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
+        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
         GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
