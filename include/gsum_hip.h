@@ -179,7 +179,8 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one
- * call are independent, so up to "batch_slots" of them are kept in flight on separate stream pairs and
+ * call are independent, so up to "batch_slots" of them (10 with GPU_MAX_HW_QUEUES >= 8 in the environment when the
+ * HIP runtime initialises, else 3) are kept in flight on separate streams and
  * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
  * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs.
  * n <= 128 (the reference's own problem sizes) takes a fused path: one workgroup per evaluation builds K,
