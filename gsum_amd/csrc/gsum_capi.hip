@@ -67,7 +67,9 @@ struct gsum_ctx {
     unsigned long long* dstamps = nullptr;   // 8 u64: phase stamps of the last diagonal-block kernel
     int diag_stamps = 0;
     // optional per-launch HIP-event profile of the big-tile (cfg 0) GEMM launches
-    int profile_gemm = 0;
+    int profile_gemm = 0;            // N > 0: HIP events around the bulk launches of every N-th fused evaluation
+    int prof_eval_count = 0;         // fused evaluations enqueued since profiling was switched on
+    bool prof_this_eval = true;
     std::vector<hipEvent_t> prof_pool;
     struct ProfRec { int e0, e1; double flops; };
     std::vector<ProfRec> prof_recs;
@@ -184,7 +186,7 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
     ctx->next_algo_flops = -1.0;
     const bool bulk = cfg == GS_BULK;
     if (bulk) cfg = ctx->bulk_cfg;
-    if (bulk && ctx->profile_gemm && M > 0 && N > 0) {
+    if (bulk && ctx->profile_gemm && ctx->prof_this_eval && M > 0 && N > 0) {
         while (ctx->prof_pool.size() < ctx->prof_next + 2) {
             hipEvent_t ev;
             GS_CHECK(hipEventCreate(&ev));
@@ -360,9 +362,10 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
         if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
     }
-    // panel GEMMs (TRSM against the block inverse, sibling column): the low-latency 32x128 tile when one factorisation
-    // is on the critical path; in a batch latency is irrelevant and the LDS-direct 128x128 tile is 1 % cheaper overall
-    const int ccfg = (la || ctx->bulk_cfg != 6) ? 1 : 6;
+    // panel GEMMs (TRSM against the block inverse, sibling column) stay on the low-latency 32x128 tile in every mode.
+    // (In a batch the LDS-direct 128x128 tile is 1 % cheaper overall, but then one kernel symbol would serve two
+    // roles and rocprofv3's per-kernel average would no longer be the bulk update's.)
+    const int ccfg = 1;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
     bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
@@ -551,7 +554,11 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return -2;
     if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
     else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
-    else if (!strcmp(name, "profile_gemm")) ctx->profile_gemm = (int)value;
+    else if (!strcmp(name, "profile_gemm")) {
+        ctx->profile_gemm = (int)std::max<int64_t>(0, value);
+        ctx->prof_eval_count = 0;
+        ctx->prof_this_eval = true;
+    }
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
     else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
     else if (!strcmp(name, "release_scratch")) {
@@ -924,6 +931,7 @@ static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double n
         if (gs_mat_alloc(ctx, ctx->nX, &sl->ws)) return -1;
     }
     gsum_mat* m = sl->ws;
+    if (ctx->profile_gemm > 0) ctx->prof_this_eval = (ctx->prof_eval_count++ % ctx->profile_gemm) == 0;
     GS_CHECK(hipEventRecord(sl->tev[0], sl->sm));
     if (gs_build_into(ctx, sl->sm, m, desc, ctx->dX, ctx->dX_d, nugget, ctx->build_lower_only)) return -1;
     if (gs_set_border(ctx, sl->sm, m, ctx->dZ, ctx->kZ)) return -1;

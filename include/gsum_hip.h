@@ -196,8 +196,9 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
  * With option "diag_stamps" = 1 and n > 4: ms[4..8] = shader-cycle stamps of the last diagonal-block
  * kernel {prologue, column loop, block inverse, total} and its total in 100 MHz ticks. */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
-/* With option "profile_gemm" = 1 every launch of the 128x128-tile, 8-wave MFMA GEMM (the trailing SYRK of
- * the Cholesky) is bracketed by HIP events on the stream it is launched on.  This
+/* With option "profile_gemm" = N > 0 every launch of the bulk trailing-update kernel (128x128-tile, 8-wave MFMA GEMM)
+ * of every N-th fused evaluation (the 1st, N+1-th, ... since the option was set; operator-level calls: every launch) is
+ * bracketed by HIP events on the stream it is launched on (N = 1 costs ~5 % of batch throughput, N = 4 ~1 %).  This
  * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
  * call, and resets the record. */
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
