@@ -1009,7 +1009,7 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
-    const size_t shmem = 2 * (size_t)(128 + 128) * GS_LSTR * sizeof(double);
+    const size_t shmem = (size_t)GS_TILE_LD_DOUBLES * sizeof(double);
     if (!ctx->lds_attr_done.count((const void*)k_lml_medium)) {
         GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         ctx->lds_attr_done.insert((const void*)k_lml_medium);

@@ -821,14 +821,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 #define GS_MEDIUM_MAX 4096
 
 // C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
-// 64 x 64), LDS: 2 stages x 256 rows x 17 doubles.  Ends with a workgroup barrier after the stores (fenced).
+// 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld's layout: XOR-swizzled
+// k-pairs, even / odd rows in regions one double apart (no bank conflicts), the sign carried by negated accumulators.
+// LDS: 2 stages x 2 operands x (128 x 16 + 2) doubles.  Ends with a workgroup barrier after the stores (fenced).
+#define GS_TILE_LD_DOUBLES (2 * 2 * (128 * GS_KC + 2))
 __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                                            int M, int N, int K, int beta, double sign, double* lds) {
-    constexpr int WM = 4, WN = 4, BM = 128, BN = 128, NT = 256;
-    constexpr int VECS = 128 * (GS_KC / 2), IT = VECS / NT;        // 1024 16-B vectors per operand tile, 4 per thread
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    constexpr int WM = 4, WN = 4;
+    constexpr int OPER = 128 * GS_KC + 2, STAGE = 2 * OPER, HALF = 64 * GS_KC + 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w & 1, wn = w >> 1;
     const int fr = lane & 15, fq = lane >> 4;
+    const bool neg = sign < 0.0;
     gs_d4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -838,57 +843,64 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = (wm * WM + i) * 16 + fq + 4 * x;
-                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+                acc[i][j][x] = neg ? -c : c;
             }
         }
-    gs_d2 ra[IT], rb[IT];
-    auto gload = [&](int kc) {
+    // this wave stages tile rows [32 w, 32 w + 32) of both operands: per parity h two loads of 8 rows each
+    const int lrow = lane >> 3, lg = lane & 7;
+    const double* srcA[2][2];
+    const double* srcB[2][2];
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int vv = t + i * NT;
-            int ar = vv >> 3, br = vv >> 3;
-            ar = ar < M ? ar : M - 1;
-            br = br < N ? br : N - 1;
-            ra[i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)ar * lda + kc * GS_KC + 2 * (vv & 7));
-            rb[i] = *reinterpret_cast<const gs_d2*>(B + (int64_t)br * ldb + kc * GS_KC + 2 * (vv & 7));
-        }
-    };
-    auto swrite = [&](int stage) {
-        double* sA = lds + stage * (BM + BN) * GS_LSTR;
-        double* sB = sA + BM * GS_LSTR;
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int vv = t + i * NT;
-            double* qa = sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-            qa[0] = ra[i][0] * sign;
-            qa[1] = ra[i][1] * sign;
-            double* qb = sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-            qb[0] = rb[i][0];
-            qb[1] = rb[i][1];
+        for (int q = 0; q < 2; ++q) {
+            const int r = 32 * w + 16 * q + 2 * lrow + h;
+            const int kp = lg ^ ((r >> 1) & 7);
+            const int ra = r < M ? r : M - 1, rb = r < N ? r : N - 1;
+            srcA[h][q] = A + (int64_t)ra * lda + 2 * kp;
+            srcB[h][q] = B + (int64_t)rb * ldb + 2 * kp;
         }
+    auto stage_load = [&](int kc, int stage) {
+        double* base = lds + stage * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                double* dstA = base + h * HALF + (16 * w + 8 * q) * GS_KC;
+                double* dstB = base + OPER + h * HALF + (16 * w + 8 * q) * GS_KC;
+                __builtin_amdgcn_global_load_lds(srcA[h][q] + kc * GS_KC, dstA, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(srcB[h][q] + kc * GS_KC, dstB, 16, 0, 0);
+            }
     };
+    const int swz = (fr >> 1) & 7;
+    const int rsel = (fr & 1) * HALF + (fr >> 1) * GS_KC;
+    int goff[GS_KC / 4];
+#pragma unroll
+    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
     const int nk = K / GS_KC;
-    gload(0);
-    swrite(0);
+    __syncthreads();                                     // the previous user of `lds` is done with it
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < nk; ++c) {
-        if (c + 1 < nk) gload(c + 1);
-        const double* sA = lds + (c & 1) * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
-        const double* sB = lds + (c & 1) * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
+        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
+        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rsel;
+        const double* sB = lds + (c & 1) * STAGE + OPER + wn * WN * 8 * GS_KC + rsel;
 #pragma unroll
         for (int ks = 0; ks < GS_KC / 4; ++ks) {
             double af[WM], bf[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 16 * GS_LSTR + ks * 4];
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 16 * GS_LSTR + ks * 4];
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nk) swrite((c + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #pragma unroll
@@ -899,7 +911,7 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][x];
+                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
             }
         }
     __threadfence_block();
