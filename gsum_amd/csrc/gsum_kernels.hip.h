@@ -995,28 +995,38 @@ __global__ __launch_bounds__(256) void k_lml_medium(const double* X, int n, int 
     if (t == 0) ldet_sum = 0.0;
     __threadfence_block();
     __syncthreads();
-    // ---- right-looking blocked Cholesky, one block column at a time
-    for (int b = 0; b < T; ++b) {
-        double* Lb = Linv + (int64_t)b * 128 * 128;
-        const int bad = gs_diag_block(A + (int64_t)b * 128 * ld + b * 128, ld, Lb, &ldet_blk, diag0 + b * 128, nullptr);
-        if (bad) {
-            if (t == 0) {
-                out[256] = 0.0;
-                out[257] = (double)(b * 128 + bad);
+    // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
+    // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
+    for (int b = 0; b < T; b += 2) {
+        const bool two = b + 1 < T;
+        for (int s = 0; s < (two ? 2 : 1); ++s) {
+            const int c = b + s;
+            double* Lc = Linv + (int64_t)c * 128 * 128;
+            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, Lc, &ldet_blk, diag0 + c * 128, nullptr);
+            if (bad) {
+                if (t == 0) {
+                    out[256] = 0.0;
+                    out[257] = (double)(c * 128 + bad);
+                }
+                return;
             }
-            return;
+            if (t == 0) ldet_sum += ldet_blk;
+            __threadfence_block();
+            __syncthreads();
+            for (int i = c + 1; i < T; ++i) {       // panel: rows of block i  <-  rows * L_cc^-T
+                double* P = A + (int64_t)i * 128 * ld + c * 128;
+                gs_tile128(P, ld, P, ld, Lc, 128, 128, 128, 128, 0, 1.0, lds);
+            }
+            if (s == 0 && two)                      // sibling block column b + 1: the first panel only (K = 128)
+                for (int i = b + 1; i < T; ++i)
+                    gs_tile128(A + (int64_t)i * 128 * ld + (b + 1) * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
+                               A + (int64_t)(b + 1) * 128 * ld + b * 128, ld, 128, 128, 128, 1, -1.0, lds);
         }
-        if (t == 0) ldet_sum += ldet_blk;
-        __threadfence_block();
-        __syncthreads();
-        for (int i = b + 1; i < T; ++i) {           // panel: rows of block i  <-  rows * L_bb^-T
-            double* P = A + (int64_t)i * 128 * ld + b * 128;
-            gs_tile128(P, ld, P, ld, Lb, 128, 128, 128, 128, 0, 1.0, lds);
-        }
-        for (int i = b + 1; i < T; ++i)             // trailing lower tiles
-            for (int j = b + 1; j <= i; ++j)
+        const int Kp = two ? 256 : 128, first = b + (two ? 2 : 1);
+        for (int i = first; i < T; ++i)             // trailing lower tiles: both panels in one pass
+            for (int j = first; j <= i; ++j)
                 gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
-                           A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, 128, 1, -1.0, lds);
+                           A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
     }
     // ---- W^T = Z^T L^-T, block column by block column (left-looking on the 16 right-hand-side rows), on the matrix
     // cores straight from global memory: wave w owns point-columns [32 w, 32 w + 32) of each 128-column block.
