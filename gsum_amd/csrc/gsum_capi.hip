@@ -569,6 +569,10 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         if (ctx->gws) GS_CHECK(hipFree(ctx->gws));
         ctx->scratch = ctx->gws = nullptr;
         ctx->scratch_cap = ctx->gws_cap = 0;
+        for (int i = 0; i < ctx->n_slots_ready; ++i) {         // and the per-slot workspace matrices of the fused path
+            gs_mat_release(ctx->slots[i].ws);
+            ctx->slots[i].ws = nullptr;
+        }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5) ? 5 : 6;
