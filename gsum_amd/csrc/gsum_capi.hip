@@ -1005,15 +1005,15 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const int64_t stride = (int64_t)(up((size_t)(np * ld + T * GS_NB * GS_NB + np + 16 * np) * 8) / 8);
-    // evaluations per launch: whole rounds of the 256 CUs (a partial second round would idle most of the chip),
-    // within 40 GB of per-evaluation matrices
-    const int64_t fit = (int64_t)(40e9 / (double)(stride * 8));
+    // evaluations per launch: whole rounds of the 512 resident workgroups (two per CU; a partial round would idle most
+    // of the chip), within 80 GB of per-evaluation matrices (512 x 134 MB at n = 4096)
+    const int64_t fit = (int64_t)(80e9 / (double)(stride * 8));
     const int cap = fit >= 512 ? 512 : (fit >= 256 ? 256 : (int)std::max<int64_t>(1, fit));
     const int CH = std::min(n_kernels, cap);
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
-    const size_t shmem = (size_t)GS_TILE_LD_DOUBLES * sizeof(double);
+    const size_t shmem = (size_t)std::max<int>(GS_TILE_LD_DOUBLES, GS_DIAG_WS) * sizeof(double);
     if (!ctx->lds_attr_done.count((const void*)k_lml_medium)) {
         GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         ctx->lds_attr_done.insert((const void*)k_lml_medium);

@@ -406,15 +406,19 @@ __device__ __forceinline__ void gs_trtri_col(const double* Ls, const double* Dv,
 // output (zeros above the diagonal).  diag0: the block's 128 original diagonal entries.
 // Returns 0 or the 1-based local column of the first bad pivot (uniform over the workgroup); *logdet_out
 // (written by thread 0 only) = sum_j log L_jj.  Ends with a workgroup barrier after the Linv stores.
+// wsp: the caller's LDS workspace of GS_DIAG_WS doubles (16-B aligned).  Phase 2 keeps the LDS copy of L (Ls, 61 KB)
+// and the diagonal inverses (Dv) there; phase 1's mailboxes and thresholds alias its beginning (they are dead when
+// Ls / Dv are written, one barrier separates the two uses).  Passing the workspace in lets a fused kernel lend the
+// same bytes to its other phases (k_lml_medium: the tile routine's staging buffers) instead of stacking them.
+#define GS_DIAG_WS (28 * GS_LS_BLK + 128 * GS_DV_STR)      // 9792 doubles = 76.5 KB
 __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* logdet_out,
-                                             const double* diag0, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double mail[4 * GS_MB_SIZE];
-    __shared__ double rmail[64];
+                                             const double* diag0, unsigned long long* stamps, double* wsp) {
     __shared__ double dbuf[128];
-    __shared__ double thr[128];
-    __shared__ double Dv[128 * GS_DV_STR];
-    __shared__ double Ls[28 * GS_LS_BLK];           // 61 KB; with Dv and the mailboxes 85 KB: one 73-KB bulk
-                                                    // workgroup still fits on the CU beside this kernel
+    double* Ls = wsp;
+    double* Dv = wsp + 28 * GS_LS_BLK;
+    double* mail = wsp;                              // 4 * GS_MB_SIZE doubles, phase 1 only
+    double* rmail = wsp + 4 * GS_MB_SIZE;            // 64
+    double* thr = rmail + 64;                        // 128
     const int t = threadIdx.x;
     // optional phase stamps (diagnostics only: own buffer, never feeds a result)
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -446,6 +450,7 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
     if (ok) ok = gs_diag_steps<6>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (ok) ok = gs_diag_steps<7>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
     if (!ok) return fail_col + 1;
+    __syncthreads();                                 // every thread is done with the mailboxes: Ls / Dv may overwrite them
     // L back to the matrix (lower part), strictly lower blocks and diagonal inverses to LDS
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
@@ -499,8 +504,10 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
                                                      int* info, int col0, const double* diag0,
                                                      unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // 76.5 KB: one 64-KB bulk workgroup still fits
+                                                                        // on the CU beside this kernel
     if (*info != 0) return;                    // an earlier block already failed (uniform)
-    const int bad = gs_diag_block(A, ld, Linv, logdet, diag0, stamps);
+    const int bad = gs_diag_block(A, ld, Linv, logdet, diag0, stamps, wsd);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
 }
 
@@ -521,6 +528,7 @@ __global__ __launch_bounds__(256) void k_lml_small(const double* X, int n, int d
     __shared__ double dg0[128];
     __shared__ double Wt[16 * 129];
     __shared__ double ldet;
+    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const gsum_kernel_desc desc = descs[blockIdx.x];
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(256) void k_lml_small(const double* X, int n, int d
     __threadfence_block();
     __syncthreads();
     // ---- Cholesky + inverse of the block
-    const int bad = gs_diag_block(A, 128, Linv, &ldet, dg0, nullptr);
+    const int bad = gs_diag_block(A, 128, Linv, &ldet, dg0, nullptr, wsd);
     if (bad) {
         if (t == 0) {
             out[256] = 0.0;
@@ -918,10 +926,12 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
+__global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
                                                      const gsum_kernel_desc* descs, double nugget, double* scratch,
                                                      int64_t scratch_stride, double* res) {
-    extern __shared__ double lds[];                 // gs_tile128 staging; the kernel-build phase borrows it
+    extern __shared__ double lds[];                 // max(GS_DIAG_WS, GS_TILE_LD_DOUBLES) doubles, lent in turn to the kernel
+                                                    // build, the diagonal-block routine and the tile routine: 77.6 KB in
+                                                    // all, so TWO evaluations share a CU
     __shared__ double ldet_blk;
     __shared__ double ldet_sum;
     const int t = threadIdx.x, lane = t & 63;
@@ -1002,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_lml_medium(const double* X, int n, int 
         for (int s = 0; s < (two ? 2 : 1); ++s) {
             const int c = b + s;
             double* Lc = Linv + (int64_t)c * 128 * 128;
-            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, Lc, &ldet_blk, diag0 + c * 128, nullptr);
+            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, Lc, &ldet_blk, diag0 + c * 128, nullptr, lds);
             if (bad) {
                 if (t == 0) {
                     out[256] = 0.0;
