@@ -520,15 +520,15 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // ------------------------------------------------------------------------------------------------
 #define GS_SMALL_SCRATCH (2 * 128 * 128)
 
-__global__ __launch_bounds__(256) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
+__global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
                                                     const gsum_kernel_desc* descs, double nugget, double* scratch,
                                                     double* res) {
 #pragma clang fp contract(off)
-    __shared__ double us[128 * GSUM_MAX_D];
     __shared__ double dg0[128];
-    __shared__ double Wt[16 * 129];
     __shared__ double ldet;
-    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];
+    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // lent to the build (us) and the solve (Wt) too:
+    double* us = wsd;                                                   // 78.6 KB of LDS in all, two evaluations per CU
+    double* Wt = wsd;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const gsum_kernel_desc desc = descs[blockIdx.x];
