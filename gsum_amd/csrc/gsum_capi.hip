@@ -147,6 +147,9 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
 //        cfg 0 in interleaved A/B runs (more independent waves per SIMD to fill issue gaps)
 static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                        const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    // the LDS-direct loads fetch 16 B per lane: operands must be 16-B aligned with even leading dimensions (true for
+    // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
+    if (cfg == 6 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (cfg == 6) {                                   // LDS-direct staging variant of cfg 5
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
