@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The tests load gsum_amd/libgsum_hip.so (CPU suite: symbol table only).  Build it first if it is missing or
+    older than its sources -- the same call `__graft_entry__.build()` makes (hipcc cross-compiles without a GPU)."""
+    try:
+        from gsum_amd import build as _build
+        _build.build()
+    except Exception as exc:          # leave the failure to the tests that need the library, with their own message
+        print(f"[conftest] could not build libgsum_hip.so: {exc}")
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
