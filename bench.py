@@ -187,8 +187,8 @@ def main():
 
     # dominant kernel, exclusive: one SYRK launch of the step-0 shape alone on the GPU (device-resident random
     # operands), for the kernel-quality view next to the in-situ numbers
-    ctx.bench_gemm_nt(6, n - 256, n - 256, 256, True, n + 16, 2)           # warm-up (first launches read low)
-    excl_tflops, excl_us = ctx.bench_gemm_nt(6, n - 256, n - 256, 256, True, n + 16, 4)
+    ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 2)           # warm-up (first launches read low)
+    excl_tflops, excl_us = ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 4)
 
     # factor-reuse mode, reported separately and never mixed into `value`: a 64 x 64 (cbar, ratio)
     # grid at ONE kernel costs one K build + Cholesky + forward solve; ratio rescales the Gram matrix order by
@@ -239,8 +239,8 @@ def main():
             # flops of ALL its launches in the timed region / wall time of the timed region, i.e. what this
             # kernel delivers on the chip while `evals_in_flight` evaluations share it; per-launch averages
             # (HIP events on the launch stream, what rocprofv3 --stats reports) and the exclusive rate follow.
-            "roofline": {"kernel": "k_gemm_ld (128x128-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, K=256/512, "
-                                   "trailing update)",
+            "roofline": {"kernel": "k_gemm_ld3 (128x64-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, 3 workgroups "
+                                   "per CU, K=256/512, trailing update)",
                          "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "traffic_from_committed_pmc_pass": "profiles/r01_gemm_pmc.md: 1047 MB HBM per M=8192, K=256 launch "

@@ -53,7 +53,8 @@ struct gsum_ctx {
     std::string err;
     int lookahead = 1;
     double next_algo_flops = -1.0;   // profile only: algorithmic flops of the next cfg-5 launch when not M(M+1)K / 2MNK
-    int bulk_cfg = 6;                // bulk trailing-update kernel: 6 = LDS-direct staging (k_gemm_ld), 5 = register staging
+    int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
+                                     // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
     int reserve_cus = -1;            // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs;
                                      // -1 = auto: 2 from order 6144 up (measured -3 % at n >= 8192, +1 % below)
@@ -150,6 +151,28 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     // the LDS-direct loads fetch 16 B per lane: operands must be 16-B aligned with even leading dimensions (true for
     // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
     if (cfg == 6 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
+    if (cfg == 7 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
+    if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
+        if (M <= 0 || N <= 0) return 0;
+        if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
+        const size_t shmem = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+        if (!ctx->lds_attr_done.count((const void*)k_gemm_ld3)) {
+            GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            ctx->lds_attr_done.insert((const void*)k_gemm_ld3);
+        }
+        int64_t blocks;
+        if (tri) {
+            if (M != N) GS_FAIL("gemm: tri mode needs a square C");
+            const int64_t Tt = (M + 127) / 128;
+            blocks = Tt * (Tt + 1);
+        } else {
+            blocks = ((M + 127) / 128) * ((N + 63) / 64);
+        }
+        hipLaunchKernelGGL(k_gemm_ld3, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
+                           beta, sign);
+        GS_CHECK(hipGetLastError());
+        return 0;
+    }
     if (cfg == 6) {                                   // LDS-direct staging variant of cfg 5
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
@@ -180,8 +203,9 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     GS_FAIL("gemm: unknown tile configuration");
 }
 
-// cfg GS_BULK stands for the bulk trailing-update kernel the context is configured with (option "bulk_cfg": 6 = the
-// LDS-direct 8-wave tile, 5 = the same tile with register staging); those launches are the ones the profile records.
+// cfg GS_BULK stands for the bulk trailing-update kernel the context is configured with (option "bulk_cfg": 7 = the
+// LDS-direct 128x64 tile, 6 = the LDS-direct 128x128 tile, 5 = that tile with register staging); those launches are
+// the ones the profile records.
 #define GS_BULK (-5)
 static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                    const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
@@ -578,7 +602,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
-    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5) ? 5 : 6;
+    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5 || value == 6) ? (int)value : 7;
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;

@@ -1230,6 +1230,127 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
         }
 }
 
+// K2b'': the LDS-direct tile as 128 x 64 per workgroup, 8 waves of 32 x 32 (4 x 2) -- the shipped bulk kernel (cfg 7).
+// 32 accumulator VGPRs per wave (65 in all) and 48 KB of LDS per workgroup put THREE workgroups = 6 waves per SIMD on a
+// CU instead of two = 4: while one workgroup moves its C tile two others feed the matrix pipe, and twice as many,
+// half-sized tiles quantise better against the resident slots (M = 4096: 1056 tiles on 768 slots instead of 528 on
+// 512).  Costs 50 % more operand loads per flop (served by L2).  Same staging layout and sign handling as k_gemm_ld;
+// results identical bit for bit.  Measured against k_gemm_ld in the same process: equal at M = 7936, +18 % at M = 4096
+// exclusive; -4 % time per pipelined evaluation, -6 % for one factorisation alone (n = 8192).
+__global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign) {
+    constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
+    constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
+    constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
+    extern __shared__ double lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
+    int bm, bn;
+    if (tri) {
+        // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1
+        const int bid = blockIdx.x;
+        bm = (int)((sqrt(4.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) <= bid) ++bm;
+        while ((int64_t)bm * (bm + 1) > bid) --bm;
+        bn = bid - (int)((int64_t)bm * (bm + 1));
+    } else {
+        const int tm = (M + BM - 1) / BM;
+        bm = blockIdx.x % tm;
+        bn = blockIdx.x / tm;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    if (n0 >= N) return;                      // tri: the last row of a ragged matrix may have one column tile too many
+    if (tri == 2) {
+        A += m0;
+        B += m0;
+        K -= m0;
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool neg = sign < 0.0;
+    gs_d4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+                acc[i][j][x] = neg ? -c : c;
+            }
+        }
+    // staging: A has 16 eight-row slices (2 per wave: rows [16 w, 16 w + 16) by parity), B has 8 (1 per wave: wave w
+    // takes parity w & 1 of rows [16 (w >> 1), 16 (w >> 1) + 16))
+    const int lrow = lane >> 3, lg = lane & 7;
+    const double* srcA[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 16 * w + 2 * lrow + h;
+        const int kp = lg ^ ((r >> 1) & 7);
+        int ra = m0 + r;
+        ra = ra < M ? ra : M - 1;
+        srcA[h] = A + (int64_t)ra * lda + 2 * kp;
+    }
+    const int hb = w & 1, gb = w >> 1;
+    const double* srcB;
+    {
+        const int r = 16 * gb + 2 * lrow + hb;
+        const int kp = lg ^ ((r >> 1) & 7);
+        int rb = n0 + r;
+        rb = rb < N ? rb : N - 1;
+        srcB = B + (int64_t)rb * ldb + 2 * kp;
+    }
+    auto stage_load = [&](int kc, int stage) {
+        double* base = lds + stage * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds(srcA[h] + kc * GS_KC, base + h * HALFA + 8 * w * GS_KC, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcB + kc * GS_KC, base + OPA + hb * HALFB + 8 * gb * GS_KC, 16, 0, 0);
+    };
+    const int swz = (fr >> 1) & 7;
+    const int rselA = (fr & 1) * HALFA + (fr >> 1) * GS_KC, rselB = (fr & 1) * HALFB + (fr >> 1) * GS_KC;
+    int goff[GS_KC / 4];
+#pragma unroll
+    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
+    const int nk = K / GS_KC;
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
+        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rselA;
+        const double* sB = lds + (c & 1) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
+#pragma unroll
+        for (int ks = 0; ks < GS_KC / 4; ++ks) {
+            double af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
+            }
+        }
+}
+
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
 // res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
 __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, int np, const double* logdet,

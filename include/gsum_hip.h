@@ -221,7 +221,8 @@ int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64
  * MFMAs, vmcnt wait + LDS stores, barrier} for one SYRK launch of order M, depth K. */
 int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, double* out5);
 /* debug: C(MxN) = beta*C + sign * A(MxK) B(NxK)^T through the MFMA tile kernel (cfg 0: 128x128 tile,
- * 1: 32x128 tile, 2: 16x256 tile, 5: 128x128 tile with 8 waves; tri != 0: lower tiles only, needs M == N). */
+ * 1: 32x128 tile, 2: 16x256 tile, 5: 128x128 tile with 8 waves, 6: the same with LDS-direct operand staging, 7: 128x64
+ * tile with LDS-direct staging, three workgroups per CU; tri != 0: lower tiles only, needs M == N). */
 int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const double* A, const double* B,
                        int64_t M, int64_t N, int64_t K, int32_t beta, double sign);
 

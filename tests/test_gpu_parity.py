@@ -39,7 +39,8 @@ def lml_tol(R):
                                        (1, 32, 128, 128), (1, 700, 128, 128), (1, 50, 16, 384),
                                        (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32),
                                        (5, 128, 128, 128), (5, 300, 300, 256), (5, 130, 70, 64),
-                                       (6, 128, 128, 128), (6, 300, 300, 256), (6, 130, 70, 64), (6, 1000, 257, 512)])
+                                       (6, 128, 128, 128), (6, 300, 300, 256), (6, 130, 70, 64), (6, 1000, 257, 512),
+                                       (7, 128, 128, 128), (7, 300, 300, 256), (7, 130, 70, 64), (7, 1000, 257, 512)])
 def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
     """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
     swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
@@ -49,14 +50,14 @@ def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
     np.testing.assert_allclose(got, C - A @ B.T, rtol=1e-12, atol=1e-12 * K)
     got = ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=0, sign=1.0)
     np.testing.assert_allclose(got, A @ B.T, rtol=1e-12, atol=1e-12 * K)
-    if cfg == 6:        # LDS-direct staging: bit-identical to the register-staged 8-wave tile
+    if cfg in (6, 7):   # LDS-direct staging: bit-identical to the register-staged 8-wave tile
         for beta, sign in ((1, -1.0), (0, 1.0), (1, 1.0)):
-            np.testing.assert_array_equal(ctx.debug_gemm_nt(6, C, A, B, tri=False, beta=beta, sign=sign),
+            np.testing.assert_array_equal(ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=beta, sign=sign),
                                           ctx.debug_gemm_nt(5, C, A, B, tri=False, beta=beta, sign=sign))
 
 
 @pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552])
-@pytest.mark.parametrize("cfg,BM", [(0, 128), (5, 128), (6, 128)])
+@pytest.mark.parametrize("cfg,BM", [(0, 128), (5, 128), (6, 128), (7, 128)])
 def test_mfma_gemm_lower_tiles(ctx, M, cfg, BM):
     """SYRK mode: every element of the lower triangle is updated exactly once (also through the XCD-aware
     tile map, M >= 1024), and tiles that lie wholly above the diagonal are never touched."""
