@@ -23,7 +23,7 @@ import time
 
 # Must precede the first GPU touch of the process (torch included): the HIP runtime reads it when it initialises.  One
 # hardware queue per in-flight evaluation instead of 4 shared ones (gsum_amd/_lib.py sets the same default).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
@@ -93,8 +93,8 @@ def main():
     ap.add_argument("--orders", type=int, default=6)
     ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
     ap.add_argument("--slots", type=int, default=0,
-                    help="independent evaluations kept in flight per GPU (0 = library default: 10 with >= 8 hardware "
-                         "queues, else 3)")
+                    help="independent evaluations kept in flight per GPU (0 = library default: 20 with 32 hardware "
+                         "queues, 3 with the runtime's default 4)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
     args = ap.parse_args()
@@ -146,8 +146,9 @@ def main():
             out[i] = -np.inf if info[i] != 0 else lml_from_gram(G[i], sld[i], n, 0.0, 0.0, 1, 1)[0] - jac
         return out
 
-    if args.slots <= 0:
-        args.slots = 10 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else 3
+    if args.slots <= 0:                      # the library's own policy (gsum_init)
+        nq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        args.slots = 20 if nq >= 24 else 14 if nq >= 12 else 10 if nq >= 8 else 3
     ctx.set_option("batch_slots", args.slots)
     # set-up, not a step: the per-slot workspaces (0.5 GB each) are allocated on first use; do that here so that a
     # small --warmup does not leave hipMalloc calls inside the timed region

@@ -13,10 +13,10 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The HIP runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline keeps ~10 independent
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline keeps 20 independent
 # evaluations in flight on their own streams and wants a queue each.  Read by the runtime when it initialises, so this
 # only takes effect if nothing in the process has touched the GPU yet (import gsum_amd before torch.cuda is used).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 LIB_PATH = os.environ.get("GSUM_HIP_LIBRARY") or os.path.join(_HERE, "libgsum_hip.so")
 

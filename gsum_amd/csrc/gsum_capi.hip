@@ -38,7 +38,7 @@ struct gs_slot {
     int pending = -1;                // index of the evaluation in flight on this slot
 };
 
-#define GS_MAX_SLOTS 16
+#define GS_MAX_SLOTS 24
 
 struct gsum_ctx {
     int device = 0;
@@ -46,8 +46,8 @@ struct gsum_ctx {
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
     int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident: 3 is the measured optimum with
-                                     // the HIP runtime's default of 4 hardware queues, 10 with GPU_MAX_HW_QUEUES >= 8
-                                     // (gsum_init picks by that variable; 12 falls off a cliff)
+                                     // the HIP runtime's default of 4 hardware queues; gsum_init raises it to 10 / 14 / 20
+                                     // when GPU_MAX_HW_QUEUES >= 8 / 12 / 24 is in the environment
     int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
@@ -539,8 +539,13 @@ int gsum_init(int device, gsum_ctx** out) {
     // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
     // With the limit raised (GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises) ten evaluations in
     // flight beat three: 4.75 vs 5.45 ms per evaluation at n = 8192.
+    // (measured with the 128x64 bulk tile, ms per evaluation at 20 / 60 evaluations per call: 32 queues and 20 slots
+    // 3.70 / 3.60; 16 queues and 14 slots 3.94 / 3.73; 10 slots 4.01 / 3.98; 24 slots are unstable)
     const char* hq = getenv("GPU_MAX_HW_QUEUES");
-    if (hq && atoi(hq) >= 8) ctx->batch_slots = 10;
+    const int nq = hq ? atoi(hq) : 4;
+    if (nq >= 24) ctx->batch_slots = 20;
+    else if (nq >= 12) ctx->batch_slots = 14;
+    else if (nq >= 8) ctx->batch_slots = 10;
     const char* bs = getenv("GSUM_BATCH_SLOTS");
     if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;

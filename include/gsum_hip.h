@@ -85,7 +85,7 @@ int gsum_init(int device, gsum_ctx** out);
  * exits with one alive makes rocprofv3 crash in its finaliser (the Python binding registers an atexit for this). */
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
-/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..16),
+/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..24),
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
  * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.4 / 776) -- run
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
@@ -179,8 +179,8 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one
- * call are independent, so up to "batch_slots" of them (10 with GPU_MAX_HW_QUEUES >= 8 in the environment when the
- * HIP runtime initialises, else 3) are kept in flight on separate streams and
+ * call are independent, so up to "batch_slots" of them (20 with GPU_MAX_HW_QUEUES >= 24 in the environment when the
+ * HIP runtime initialises, 10-14 with 8-16, else 3) are kept in flight on separate streams and
  * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
  * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs.
  * n <= 128 (the reference's own problem sizes) takes a fused path: one workgroup per evaluation builds K,

@@ -562,11 +562,11 @@ def test_full_size_properties_n8192():
     ctx.set_option("reserve_cus", -1)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
-    # evaluations in flight: 1, 3 or 10 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
+    # evaluations in flight: 1, 3, 10 or 20 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
     # far trailing region
-    many = [desc] * 10
+    many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for slots, lazy in ((10, 1), (3, 1), (10, 0)):
+    for slots, lazy in ((20, 1), (3, 1), (10, 0)):
         ctx.set_option("batch_slots", slots)
         ctx.set_option("lazy_far", lazy)
         Gs, ss, infos = ctx.lml_resident(many, 1e-10)
@@ -575,7 +575,7 @@ def test_full_size_properties_n8192():
             np.testing.assert_array_equal(Gs[b], G0[0])
             assert ss[b] == s0[0]
     ctx.set_option("lazy_far", 1)
-    ctx.set_option("batch_slots", 10)
+    ctx.set_option("batch_slots", 20)
     for key, (G, s, i) in out.items():
         np.testing.assert_array_equal(G, G0)
         np.testing.assert_array_equal(s, s0)

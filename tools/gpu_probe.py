@@ -55,7 +55,7 @@ ctx.set_inputs(X, Z)
 G_ref = None
 for la in (1, 0):
     ctx.set_option("lookahead", la)
-    for slots in (1, 2, 3, 6, 10, 12):
+    for slots in (1, 3, 10, 14, 20):
         ctx.set_option("batch_slots", slots)
         ctx.lml_resident([desc] * slots, 1e-10)
         nb = 18
@@ -68,7 +68,7 @@ for la in (1, 0):
                         bit_identical=bool((G == G_ref).all()))
         print(key, out[key], flush=True)
 ctx.set_option("lookahead", 1)
-ctx.set_option("batch_slots", 10)
+ctx.set_option("batch_slots", 20)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "probe.json"), "w") as f:
     json.dump(out, f, indent=1)
