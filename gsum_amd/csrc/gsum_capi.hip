@@ -77,7 +77,7 @@ struct gsum_ctx {
     size_t prof_next = 0;
     int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
     int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
-    int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n^1.4 / 776),
+    int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n^1.45 / 985),
                                      // the measured break-even against the pipelined multi-kernel path
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
@@ -1081,9 +1081,9 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    // break-even against the 10-slot pipelined path, measured at n = 512 ... 4096: 8, 19, 50, 98, 146 evaluations
+    // break-even against the 20-slot pipelined path, measured at n = 256 ... 4096: 4, 9, 22, 67, 127, 175 evaluations
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
-                                                  : std::max(4, (int)(pow((double)ctx->nX, 1.4) / 776.0));
+                                                  : std::max(4, (int)(pow((double)ctx->nX, 1.45) / 985.0));
     if (ctx->nX <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);

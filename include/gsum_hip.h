@@ -87,7 +87,7 @@ void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..24),
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
- * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.4 / 776) -- run
+ * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.45 / 985) -- run
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
  * "reserve_cus" (-1 auto, 0..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while a
  * look-ahead factorisation runs), "lazy_far" (0/1: batches at n >= 8192 update the far trailing region every other panel with K = 512),
