@@ -1088,7 +1088,19 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    const int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
+    int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
+    {
+        // every slot owns a workspace matrix of the current order: keep the new ones within 80 % of the free memory
+        const int64_t np = (ctx->nX + GS_NB - 1) / GS_NB * GS_NB, ldw = np + GS_BORDER;
+        const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0;
+        int have = 0;
+        for (int q = 0; q < std::min(S, ctx->n_slots_ready); ++q)
+            if (ctx->slots[q].ws && ctx->slots[q].ws->n == ctx->nX) ++have;
+        size_t free_b = 0, total_b = 0;
+        GS_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const int can_add = (int)std::min<double>(1e6, 0.8 * (double)free_b / ws_bytes);
+        S = std::max(1, std::min(S, have + can_add));
+    }
     if (gs_need_slots(ctx, S)) return -1;
     ctx->batch_active = S;
     int rc = 0;
