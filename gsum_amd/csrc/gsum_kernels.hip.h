@@ -3,10 +3,15 @@
 //   k_build        pairwise-distance + RBF/Matern kernel matrix   (HBM-store bound)
 //   k_set_border   RHS^T -> border rows of the augmented matrix
 //   k_potrf_diag   128x128 diagonal block: Cholesky + inverse, in registers
-//   k_gemm_nt      C (+)= s * A * B^T on v_mfma_f64_16x16x4_f64   (fp64 MFMA bound)
+//   k_gemm_ld3     C (+)= s * A * B^T on v_mfma_f64_16x16x4_f64, 128x64 tiles, operands staged global -> LDS directly,
+//                  three workgroups per CU: the bulk trailing update   (fp64 MFMA bound; k_gemm_ld: 128x128 variant)
+//   k_gemm_nt      the same product with register staging: panel TRSM / sibling / border tiles (32x128, 16x256) and the
+//                  earlier bulk tiles
+//   k_lml_small, k_lml_medium   whole evaluations in one workgroup (n <= 128; 128 < n <= 4096 on HBM-resident matrices)
 //   k_finalize     Gram / log-det read-out of the bordered factorisation
-//   k_rowsumsq     row-wise sum of squares (predictive variance)
-//   probes         fp64 MFMA issue rate, HBM store rate
+//   k_rowsumsq, k_scale_series, k_tri_multiply, k_grad_contract, k_grad_reduce*   prediction, series scaling, sampling and
+//                  gradient contractions
+//   probes         fp64 MFMA issue rate, HBM store rate, workgroup placement under a CU mask
 //
 // Data layout: the factorisation works on ONE augmented row-major fp64 matrix
 //     [ K (np x np, lower triangle)  .            ]      np = n rounded up to 128 (identity padding)
