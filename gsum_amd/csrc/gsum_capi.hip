@@ -56,8 +56,10 @@ struct gsum_ctx {
     int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
-    int reserve_cus = -1;            // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs;
-                                     // -1 = auto: 2 from order 6144 up (measured -3 % at n >= 8192, +1 % below)
+    int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
+                                     // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
+                                     // created after ~20 other streams exist made the same schedule 1.7x slower
+                                     // (measured: 14.3 vs 8.5 ms); -1 = 2 from order 6144 up
     int build_lower_only = 1;
     // resident inputs of the fused path
     double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;

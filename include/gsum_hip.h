@@ -89,8 +89,8 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
  * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.45 / 985) -- run
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
- * "reserve_cus" (-1 auto, 0..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while a
- * look-ahead factorisation runs), "lazy_far" (0/1: batches at n >= 8192 update the far trailing region every other panel with K = 512),
+ * "reserve_cus" (0 = off, the default; 1..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while
+ * a look-ahead factorisation runs; -1: 2 from order 6144 up), "lazy_far" (0/1: batches at n >= 8192 update the far trailing region every other panel with K = 512),
  * "release_scratch" (any value: free the grown work buffers and the per-slot workspace matrices now).
  * <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);

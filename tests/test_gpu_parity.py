@@ -559,7 +559,7 @@ def test_full_size_properties_n8192():
     for reserve in (0, 4):                   # bulk stream with / without a CU mask: scheduling only
         ctx.set_option("reserve_cus", reserve)
         out[("reserve", reserve)] = ctx.lml_batch([desc], X, Z, 1e-10)
-    ctx.set_option("reserve_cus", -1)
+    ctx.set_option("reserve_cus", 0)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     # evaluations in flight: 1, 3, 10 or 20 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
