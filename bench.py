@@ -212,6 +212,12 @@ def main():
         reuse = {"grid": "64 x 64 (cbar = sd prior, ratio) at one kernel", "seconds": dt, "evals_per_s": grid.size / dt,
                  "argmax": [int(v) for v in np.unravel_index(np.argmax(grid), grid.shape)], "mode": "factor-reuse"}
 
+    pmc_traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
+            pmc_traffic = json.load(f)["derived"]["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         potrf_flops = n ** 3 / 3.0
         chol_tflops = potrf_flops / (stage[1] * 1e-3) / 1e12
@@ -243,9 +249,10 @@ def main():
             "roofline": {"kernel": "k_gemm_ld3 (128x64-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, 3 workgroups "
                                    "per CU, K=256/512, trailing update)",
                          "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "traffic_from_committed_pmc_pass": "profiles/r01_gemm_pmc.md: 1047 MB HBM per M=8192, K=256 launch "
-                                                            "(FETCH_SIZE x 2 + WRITE_SIZE) against 561 MB algorithmic",
+                         "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic,
+                         "traffic_source": "HBM bytes of one M=8192, K=256 launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE) from "
+                                           "the committed rocprofv3 --pmc passes, profiles/r01_gemm_pmc.json / .md; PMC cannot be "
+                                           "collected inside bench.py; algorithmic bytes of that launch: 5.61e8",
                          "launches": gemm_launches, "launches_sampled": f"every {PROFILE_EVERY}th evaluation of the timed region",
                          "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                          "avg_flops_per_launch": gemm_flops / max(1, gemm_launches),
