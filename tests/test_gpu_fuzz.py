@@ -1,0 +1,129 @@
+"""Randomised GPU-vs-oracle checks (``-m gpu``): gradients, predictions and truncation predictions on random kernels,
+dimensions, priors and sizes, with tolerances scaled by the conditioning of the matrices involved.  Seeds are fixed,
+so a failure is reproducible; tools/gpu_fuzz.py does the same for the fused likelihood paths against numpy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import gsum_amd  # noqa: E402
+from oracle import gsum_oracle as orc  # noqa: E402  (checker only)
+from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C  # noqa: E402
+
+
+def random_kernel(rng, d, free_white=True):
+    fam = rng.choice(["rbf", "m52", "m32", "m12"])
+    ls = rng.uniform(0.4, 1.5, size=d) if (d > 1 and rng.rand() < 0.5) else float(rng.uniform(0.4, 1.5))
+    base = RBF(ls) if fam == "rbf" else Matern(ls, nu={"m52": 2.5, "m32": 1.5, "m12": 0.5}[fam])
+    kern = base
+    if rng.rand() < 0.6:
+        kern = C(float(rng.uniform(0.5, 2.5))) * kern
+    w = float(10 ** rng.uniform(-6, -2))
+    kern = kern + (WhiteKernel(w) if (free_white and rng.rand() < 0.5) else WhiteKernel(w, noise_level_bounds="fixed"))
+    if rng.rand() < 0.3:
+        kern = kern + C(float(rng.uniform(0.05, 0.5)))
+    return kern
+
+
+def random_priors(rng):
+    p = dict(center=float(rng.uniform(-0.5, 0.5)), disp=float(rng.choice([0.0, rng.uniform(0.3, 2.0)])))
+    if rng.rand() < 0.25:
+        p["sd"] = float(rng.uniform(0.6, 1.8))
+    else:
+        p["df"] = float(rng.uniform(1.0, 6.0))
+        p["scale"] = float(rng.uniform(0.6, 1.8))
+    return p
+
+
+def drawn(rng, kern, X, cols):
+    L = np.linalg.cholesky(kern(X) + 1e-8 * np.eye(len(X)))
+    return 0.2 + L @ rng.randn(len(X), cols)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_lml_gradient_vs_oracle(seed):
+    rng = np.random.RandomState(1000 + seed)
+    d = int(rng.randint(1, 4))
+    n = int(rng.choice([9, 33, 128, 129, 200, 257, 400]))
+    kern = random_kernel(rng, d)
+    X = rng.rand(n, d) * (3.0 + 0.02 * n)
+    y = drawn(rng, kern, X, int(rng.randint(1, 5)))
+    pri = random_priors(rng)
+    theta = kern.theta + rng.uniform(-0.2, 0.2, size=len(kern.theta))
+    cond = np.linalg.cond(kern.clone_with_theta(theta)(X) + 1e-10 * np.eye(n))
+    for cls, ofn in ((gsum_amd.ConjugateGaussianProcess, orc.cgp_lml_grad), (gsum_amd.ConjugateStudentProcess, orc.csp_lml_grad)):
+        if cls is gsum_amd.ConjugateStudentProcess and "sd" in pri:
+            continue                                    # df0 = inf: inf - inf in the reference's Student normalisation
+        gp = cls(kernel=kern, optimizer=None, **pri)
+        val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+        vo, go = ofn(kern, theta, X, y, **pri)
+        assert val == pytest.approx(vo, rel=max(1e-10, 1e-16 * cond))
+        tol = 1e-14 * cond + 1e-9
+        np.testing.assert_allclose(grad, go, rtol=tol, atol=tol * np.abs(go).max())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_fit_predict_vs_oracle(seed):
+    rng = np.random.RandomState(2000 + seed)
+    d = int(rng.randint(1, 4))
+    n = int(rng.choice([7, 64, 128, 130, 300, 700]))
+    m = int(rng.choice([1, 5, 40, 150]))
+    kern = random_kernel(rng, d, free_white=False)
+    X, Xs = rng.rand(n, d) * (3.0 + 0.02 * n), rng.rand(m, d) * (3.0 + 0.02 * n)
+    y = drawn(rng, kern, X, int(rng.randint(1, 4)))
+    pri = random_priors(rng)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri).fit(X, y)
+    fit = orc.cgp_fit(kern, X, y, **pri)
+    cond = np.linalg.cond(fit["corr"] + 1e-10 * np.eye(n))
+    tol = 1e-14 * cond + 1e-10
+    np.testing.assert_allclose(gp.center_, fit["center"], rtol=tol, atol=tol)
+    assert gp.cov_factor_ == pytest.approx(fit["cov_factor"], rel=tol)
+    mo, co = orc.cgp_predict(fit, Xs, return_cov=True)
+    mg, cg = gp.predict(Xs, return_cov=True)
+    np.testing.assert_allclose(mg, mo, rtol=tol, atol=tol * max(1.0, np.abs(mo).max()))
+    np.testing.assert_allclose(cg, co, rtol=1e-6, atol=tol * fit["cov_factor"])
+    sg = gp.predict(Xs, return_std=True)[1]
+    if m > 1:           # with one new point the reference (and the oracle) squeeze the 1 x 1 covariance and np.diag raises
+        so = orc.cgp_predict(fit, Xs, return_std=True)[1]
+        np.testing.assert_allclose(sg ** 2, so ** 2, rtol=1e-6, atol=tol * fit["cov_factor"])
+    else:
+        np.testing.assert_allclose(np.atleast_1d(sg) ** 2, np.atleast_1d(np.diag(np.atleast_2d(co))), rtol=1e-6,
+                                   atol=tol * fit["cov_factor"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_truncation_predict_vs_oracle(seed):
+    rng = np.random.RandomState(3000 + seed)
+    n = int(rng.choice([6, 10, 40, 150]))
+    X = np.sort(rng.rand(n))[:, None] * (0.8 * n)             # ~0.8 apart on average: a well-conditioned K_oo
+    Xs = rng.rand(int(rng.choice([3, 20])), 1) * (0.8 * n)
+    fam = rng.choice(["rbf", "m52"])
+    base = RBF(float(rng.uniform(0.5, 0.9))) if fam == "rbf" else Matern(float(rng.uniform(0.6, 1.2)), nu=2.5)
+    kern = C(float(rng.uniform(0.5, 2.0))) * base + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    orders = np.arange(int(rng.randint(3, 6)))
+    excluded = [1] if rng.rand() < 0.4 else None
+    order = int(orders[-2])
+    if rng.rand() < 0.5:
+        a, b = rng.uniform(0.25, 0.45), rng.uniform(0.0, 0.15)
+        ratio = lambda Xa, a=a, b=b: a + b * np.sin(Xa[:, 0]) ** 2       # noqa: E731
+        ref = lambda Xa: 1.0 + 0.01 * Xa[:, 0]                           # noqa: E731
+    else:
+        ratio, ref = float(rng.uniform(0.3, 0.6)), float(rng.uniform(0.5, 3.0))
+    rv = ratio(X) if callable(ratio) else ratio
+    fv = ref(X) if callable(ref) else ref
+    c = drawn(rng, kern, X, len(orders))
+    y = gsum_amd.partials(c, ratio=rv, ref=fv, orders=orders)
+    pri = dict(center=0.0, disp=0.0, df=3.0, scale=1.0)
+    gp = gsum_amd.TruncationGP(kernel=kern, ratio=ratio, ref=ref, excluded=excluded, optimizer=None, **pri)
+    gp.fit(X, y, orders=orders)
+    cc = orc.coefficients(y, rv, fv, orders)[:, ~np.isin(orders, excluded)]
+    fit = orc.cgp_fit(kern, X, cc, **pri)
+    yo = y[:, orders == order][:, 0]
+    K_oo = orc.trunc_cov(fit["cov_factor"], kern, X, X, ratio, ref, 0, order, excluded)
+    tol = 1e-13 * np.linalg.cond(K_oo) + 1e-10
+    for kind in ("interp", "both", "trunc"):
+        mo, co = orc.trunc_predict(fit["center"], fit["cov_factor"], kern, Xs, order, ratio, ref, X, yo, excluded=excluded,
+                                   kind=kind, return_cov=True)
+        mg, cg = gp.predict(Xs, order=order, return_cov=True, kind=kind)
+        np.testing.assert_allclose(mg, mo, rtol=tol, atol=tol * np.abs(mo).max())
+        np.testing.assert_allclose(cg, co, rtol=1e-6, atol=tol * max(np.abs(co).max(), 1e-300))
