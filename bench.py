@@ -13,7 +13,17 @@ coefficients; X and the right-hand sides are resident in HBM before the timed re
 
 N > 1: one process per GPU; every rank evaluates its own K grid points (weak scaling, no data-path
 collective) and the fp64 likelihood slices are all-gathered over RCCL inside the timed region.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  `python bench.py --gpus N` on its own starts the N ranks itself (child processes of
+torch.distributed.run, before this process touches a GPU) and relays rank 0's line.
+
+The timed K-step region is run `--repeats` times back to back (each bracketed by barrier + synchronize as the
+contract asks); `value` / `ms_per_step` are those of the MEDIAN region, min and max are reported beside it.
+Beyond the contract's keys the line carries (N = 1 only, outside the timed regions): `parity` (the GPU value at
+ell = 0.2 against the CPU baseline's value of the same evaluation; the run exits non-zero above 3e-10),
+`cpu_baseline`, `kernel_time_shares` (HIP-event time of every kernel class inside the timed region), the
+single-evaluation stage times, `factor_reuse` (BASELINE config 4's 64 x 64 (cbar, ratio) grid through the product
+API), `ell_ratio_grid` (the reference-faithful 64 x 64 (ell, ratio) scan, full recompute) and `predict` (BASELINE
+config 5's predictive-variance path, one GPU's share of the new points).
 """
 import argparse
 import json
@@ -22,7 +32,8 @@ import sys
 import time
 
 # Must precede the first GPU touch of the process (torch included): the HIP runtime reads it when it initialises.  One
-# hardware queue per in-flight evaluation instead of 4 shared ones (gsum_amd/_lib.py sets the same default).
+# hardware queue per in-flight evaluation instead of 4 shared ones (what gsum_amd.configure_runtime() does; bench.py is
+# an application of the library and makes that choice for its process).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
@@ -32,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (AMD spec; vector fp64 is the same rate)
 HBM_PEAK_GBS = 8000.0
+PARITY_BOUND = 3e-10
 
 
 def make_workload(n, r, seed=0):
@@ -58,30 +70,104 @@ def available_cpus():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, r, evals):
     """The CPU oracle (same numpy/scipy/sklearn calls as the reference) on this host's cores, BLAS threads
-    = the CPUs this process is allowed to use."""
+    = the CPUs this process is allowed to use; plus numpy.linalg.cholesky alone on the same matrix (GF/s)."""
     from sklearn.gaussian_process.kernels import RBF
     from oracle import gsum_oracle as orc
     threads = available_cpus()
     X, y = make_workload(n, r)
     t = []
     val = None
+    blas = []
     try:
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import threadpool_info, threadpool_limits
         limiter = threadpool_limits(limits=threads)
+        blas = [dict(api=i.get("user_api"), lib=i.get("internal_api"), version=i.get("version"),
+                     threads=i.get("num_threads"), arch=i.get("architecture")) for i in threadpool_info()]
     except Exception:
         limiter = None
     for i in range(evals):
         t0 = time.perf_counter()
         val = orc.trunc_lml(RBF(0.2), np.log([0.2]), X, y, np.arange(r), ratio=0.5, ref=1.0)
         t.append(time.perf_counter() - t0)
+    K = RBF(0.2)(X)
+    K[np.diag_indices_from(K)] += 1e-10
+    tc = []
+    for i in range(2):
+        t0 = time.perf_counter()
+        np.linalg.cholesky(K)
+        tc.append(time.perf_counter() - t0)
+    del K
     if limiter is not None:
         limiter.restore_original_limits()
     best = min(t)
     return dict(value=1.0 / best, unit="evals/s", cores=int(threads), kind="port",
-                sample=f"{evals} full evaluations of oracle.trunc_lml at n={n}, {r} orders (best of {evals}: {best:.2f} s each)",
-                lml=float(val))
+                sample=f"{evals} full evaluations of oracle.trunc_lml at n={n}, {r} orders (best of {evals}: {best:.2f} s "
+                       f"each; all: {', '.join('%.2f' % v for v in t)} s)",
+                lml=float(val), cpu_model=cpu_model(), os_cpu_count=os.cpu_count(), blas=blas,
+                cholesky_alone_gflops=n ** 3 / 3.0 / min(tc) / 1e9, cholesky_alone_s=min(tc))
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of torch.distributed.run -- before
+    this process has touched a GPU, and never by replacing it -- relay their output, return their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def predict_leg(ctx, n, m, reps=3):
+    """BASELINE config 5: n 2-D points, Matern-5/2(ell = [0.7, 1.3]) + White(1e-6), 8 curves,
+    predictive mean + standard deviation at m new points (2048 = one GPU's share of 16384).  The dominant work is the
+    triangular solve V = L^-1 K(X, X*) (n^2 m flops on the matrix cores)."""
+    import gsum_amd
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    r = 8
+    # box sized so that the mean nearest-neighbour spacing is ~0.5 ell: density 1 / (0.5 ell)^2 per unit area
+    side = np.array([0.35, 0.65]) * np.sqrt(n)
+    X = np.random.RandomState(0).rand(n, 2) * side
+    Xs = np.random.RandomState(1).rand(m, 2) * side
+    y = np.random.RandomState(2).randn(n, r)
+    kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None)
+    t0 = time.perf_counter()
+    gp.fit(X, y)
+    fit_s = time.perf_counter() - t0
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        mean, std = gp.predict(Xs, return_std=True)
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    flops = float(n) * n * m            # TRSM on the new points' columns: n^2 m
+    return {"workload": f"n={n} 2-D Matern-5/2(ell=[0.7,1.3]) + White(1e-6), {r} curves, m={m} new points "
+                        f"(BASELINE configs[4], S5; m = one GPU's share of 16384)",
+            "fit_ms": fit_s * 1e3, "predict_ms": best * 1e3, "predict_ms_all": [v * 1e3 for v in ts],
+            "points_per_s": m / best,
+            "roofline": {"kernel": "triangular solve of the new points' columns on the bulk MFMA tile", "bound": "mfma",
+                         "achieved": flops / best / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / best / 1e12 / FP64_MFMA_PEAK_TFLOPS, "flops": "n^2 m",
+                         "note": "end to end (host wall time of predict(), uploads and read-back included)"},
+            "finite": bool(np.isfinite(mean).all() and np.isfinite(std).all()), "std_mean": float(np.mean(std))}
 
 
 def main():
@@ -91,13 +177,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
-    ap.add_argument("--cpu-evals", type=int, default=2, help="CPU-baseline evaluations (0 = skip)")
+    ap.add_argument("--cpu-evals", type=int, default=3, help="CPU-baseline evaluations (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="the timed K-step region is run this many times back to back; value / ms_per_step are the "
+                         "median region, min and max are reported beside it")
     ap.add_argument("--slots", type=int, default=0,
                     help="independent evaluations kept in flight per GPU (0 = library default: 20 with 32 hardware "
                          "queues, 3 with the runtime's default 4)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
+    ap.add_argument("--config", default="lml", choices=["lml", "predict"],
+                    help="lml: the headline line; predict: only BASELINE config 5's predictive-variance leg (for profiling)")
+    ap.add_argument("--extras", type=int, default=1, help="0: skip the legs outside the contract (grids, predict)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -113,8 +208,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend)
-    elif args.gpus != 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if use_dist and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -125,6 +218,13 @@ def main():
 
     n, r, K, W = args.n, args.orders, args.steps, args.warmup
     ctx = gsum_amd.default_context(dev)
+    if args.config == "predict":
+        out = predict_leg(ctx, 16384, 2048, reps=5)
+        if rank == 0:
+            print(json.dumps({"metric": "predict_points_per_sec", "value": out["points_per_s"], "unit": "points/s",
+                              "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": out["workload"]}, "predict": out}), flush=True)
+        return
     X, y = make_workload(n, r)
     c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
     Z = np.concatenate([c, np.ones((n, 1))], axis=1)
@@ -146,84 +246,121 @@ def main():
             out[i] = -np.inf if info[i] != 0 else lml_from_gram(G[i], sld[i], n, 0.0, 0.0, 1, 1)[0] - jac
         return out
 
-    if args.slots <= 0:                      # the library's own policy (gsum_init)
-        nq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-        args.slots = 20 if nq >= 24 else 14 if nq >= 12 else 10 if nq >= 8 else 3
-    ctx.set_option("batch_slots", args.slots)
+    if args.slots > 0:
+        ctx.set_option("batch_slots", args.slots)
     # set-up, not a step: the per-slot workspaces (0.5 GB each) are allocated on first use; do that here so that a
-    # small --warmup does not leave hipMalloc calls inside the timed region
-    evaluate([descs[i % len(descs)] for i in range(args.slots)])
+    # small --warmup does not leave hipMalloc calls inside the timed region.  (The library also times its streams'
+    # real concurrency in this first call and would fall back to 3 in flight if the runtime had fewer queues.)
+    evaluate([descs[i % len(descs)] for i in range(max(args.slots, ctx.get_option("batch_slots")))])
+    slots = ctx.get_option("batch_slots")
+    probe = ctx.queue_probe()
     if W > 0:
         evaluate([descs[i % len(descs)] for i in range(W)])
     if use_dist:
         gather_flat(np.zeros(K), total)          # warm-up of the collective (RCCL sets its rings up lazily)
-    PROFILE_EVERY = 4            # HIP events around the bulk launches of every 4th evaluation (every one costs 5 %)
-    ctx.set_option("profile_gemm", PROFILE_EVERY)
-    ctx.gemm_profile()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    vals = evaluate(descs)
-    allvals = gather_flat(vals, total) if use_dist else vals       # one all-gather of the fp64 slices (RCCL)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    gemm_ms, gemm_flops, gemm_launches = ctx.gemm_profile()
+    PROFILE_EVERY = 4            # HIP events around every launch of every 4th evaluation (every one costs ~5 %)
+
+    def timed_region():
+        ctx.set_option("profile_gemm", PROFILE_EVERY)
+        ctx.kernel_profile()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vals = evaluate(descs)
+        allv = gather_flat(vals, total) if use_dist else vals       # one all-gather of the fp64 slices (RCCL)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        prof = ctx.kernel_profile()
+        return el, allv, prof
+
+    regions = [timed_region() for _ in range(max(1, args.repeats))]
     ctx.set_option("profile_gemm", 0)
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, allvals, prof = regions[order[(len(order) - 1) // 2]]        # the median region (lower median)
+    all_elapsed = [reg[0] for reg in regions]
+    gemm_ms, gemm_flops, gemm_launches = (prof["bulk_update"][k] for k in ("ms", "flops", "launches"))
+
     # single-evaluation stage times (one evaluation alone on the GPU), outside the timed region
     ctx.set_option("batch_slots", 1)
-    stage = np.zeros(4)
+    stage = None
     for i in range(3):
         ctx.lml_resident([descs[0]], 1e-10)
         tm = ctx.timers()
-        stage = np.maximum(stage, 0) if i == 0 else stage
         cur = np.array([tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]])
-        stage = cur if i == 0 else np.minimum(stage, cur)
+        stage = cur if stage is None else np.minimum(stage, cur)
+    ctx.set_option("profile_gemm", 1)
+    ctx.kernel_profile()
+    ctx.lml_resident([descs[0]], 1e-10)
+    single_prof = ctx.kernel_profile()
+    ctx.set_option("profile_gemm", 0)
+    # parity inside the run: the evaluation the CPU baseline times (ell = 0.2 exactly), on the GPU
+    gpu_lml_02 = float(evaluate([gsum_amd.describe_kernel(RBF(0.2), 1)])[0])
+    ctx.set_option("batch_slots", slots)
 
     # dominant kernel, exclusive: one SYRK launch of the step-0 shape alone on the GPU (device-resident random
     # operands), for the kernel-quality view next to the in-situ numbers
     ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 2)           # warm-up (first launches read low)
     excl_tflops, excl_us = ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 4)
 
-    # factor-reuse mode, reported separately and never mixed into `value`: a 64 x 64 (cbar, ratio)
-    # grid at ONE kernel costs one K build + Cholesky + forward solve; ratio rescales the Gram matrix order by
-    # order, the prior scale (cbar = sd) only enters the O(k^2) host algebra
-    reuse = None
-    if rank == 0:
+    reuse = ell_grid = pred = None
+    if rank == 0 and world == 1 and args.extras:
+        orders = np.arange(r)
+        gp = gsum_amd.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None)
+        gp.X_train_, gp.y_train_, gp.orders_ = X, y, orders
+        # factor-reuse mode, reported separately and never mixed into `value`: BASELINE config 4's
+        # 64 x 64 (cbar, ratio) grid at ONE kernel costs one K build + Cholesky + forward solve; ratio rescales the Gram
+        # matrix order by order, the prior scale (cbar = sd) only enters the O(k^2) host algebra
+        cbars, ratios = np.geomspace(0.25, 4, 64), np.linspace(0.3, 0.7, 64)
         t1 = time.perf_counter()
-        Lm = ctx.kernel_matrix_dev(descs[0], X, diag_add=1e-10)
-        ctx.potrf(Lm)
-        G0, sld0 = ctx.forward_gram(Lm, Z)
-        Lm.free()
-        grid = np.empty((64, 64))
-        for a, q in enumerate(np.linspace(0.3, 0.7, 64)):
-            D = np.append((0.5 / q) ** np.arange(r), 1.0)
-            Gq = D[:, None] * G0 * D[None, :]
-            jq = float(np.sum(np.arange(r)) * np.log(q) * n)
-            for b, sd in enumerate(np.linspace(0.5, 2.0, 64)):
-                grid[a, b] = lml_from_gram(Gq, sld0, n, 0.0, 0.0, np.inf, sd)[0] - jq
+        grid = gp.log_marginal_likelihood_grid([np.log([0.2])], list(ratios), scales=cbars, mode="reuse")[:, 0, :]
         dt = time.perf_counter() - t1
-        reuse = {"grid": "64 x 64 (cbar = sd prior, ratio) at one kernel", "seconds": dt, "evals_per_s": grid.size / dt,
-                 "argmax": [int(v) for v in np.unravel_index(np.argmax(grid), grid.shape)], "mode": "factor-reuse"}
+        reuse = {"grid": "64 x 64 (ratio in linspace(0.3, 0.7), cbar = sd prior in geomspace(0.25, 4)) at one kernel, "
+                         "TruncationGP.log_marginal_likelihood_grid(scales=..., mode='reuse')",
+                 "seconds": dt, "evals_per_s": grid.size / dt, "mode": "factor-reuse",
+                 "argmax": [int(v) for v in np.unravel_index(np.argmax(grid), grid.shape)],
+                 "n_neg_inf": int(np.isneginf(grid).sum()),
+                 "note": "white-noise coefficients (timing workload): the maximum sits on the cbar boundary; index parity on "
+                         "GP-drawn data is tests/test_gpu_config4.py"}
+        # the reference-faithful scan (notebook :1444-1459): 64 length scales x 64 ratios, every point recomputed
+        ell_axis = np.linspace(0.05, 0.5, 64)
+        t1 = time.perf_counter()
+        g2 = gp.log_marginal_likelihood_grid([np.log([e]) for e in ell_axis], list(ratios), mode="full")
+        dt = time.perf_counter() - t1
+        ell_grid = {"grid": "64 x 64 (ratio in linspace(0.3, 0.7), ell in linspace(0.05, 0.5)), mode='full': 4096 evaluations, "
+                            "each its own K build + Cholesky + solve (right-hand sides re-uploaded per ratio row)",
+                    "seconds": dt, "evals_per_s": g2.size / dt, "n_neg_inf": int(np.isneginf(g2).sum()),
+                    "argmax": [int(v) for v in np.unravel_index(np.argmax(g2), g2.shape)], "mode": "full-recompute"}
+        ctx.set_option("release_scratch", 1)
+        pred = predict_leg(ctx, 16384, 2048)
+        ctx.set_option("release_scratch", 1)
 
-    pmc_traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
-            pmc_traffic = json.load(f)["derived"]["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    pmc_traffic = pmc_file = None
+    for name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc_traffic = json.load(f)["derived"]["hbm_traffic_bytes_per_launch"]
+            pmc_file = name
+            break
+        except Exception:
+            pass
+    rc = 0
     if rank == 0:
         potrf_flops = n ** 3 / 3.0
         chol_tflops = potrf_flops / (stage[1] * 1e-3) / 1e12
         # all ranks run the same launches; rank 0's record stands for one GPU
         sampled = (K + PROFILE_EVERY - 1) // PROFILE_EVERY          # evaluations 0, 4, 8, ... of the timed K
         chip_tflops = gemm_flops * (K / sampled) / elapsed / 1e12     # every evaluation issues the same launches
+        bytes_written = 4.0 * n * n + 4.0 * n * 128
+        shares = {name: {"ms_per_eval": v["ms"] / sampled, "launches_per_eval": v["launches"] / sampled,
+                         "share_of_stream_time": v["ms"] * (K / sampled) / (slots * elapsed * 1e3)}
+                  for name, v in prof.items()}
         out = {
             "metric": "lml_evals_per_sec", "value": total / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -231,18 +368,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, "
                                    f"{r} orders (BASELINE configs[2], S3)", "n": n, "orders": r,
-                       "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": args.slots},
+                       "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": slots},
+            "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)",
+                        "ms_per_step_median": elapsed / K * 1e3, "ms_per_step_min": min(all_elapsed) / K * 1e3,
+                        "ms_per_step_max": max(all_elapsed) / K * 1e3,
+                        "evals_per_s_all": [total / e for e in all_elapsed]},
+            "queue_probe": probe,
             "single_eval_stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1],
                                      "finalize_d2h": stage[2], "gpu_total": stage[3]},
+            "single_eval_kernel_ms": {name: {"ms": v["ms"], "launches": v["launches"]} for name, v in single_prof.items()},
             "cholesky": {"single_eval_gflops": chol_tflops * 1e3,
                          "single_eval_frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "pipelined_gflops_per_gpu": potrf_flops * K / elapsed / 1e9,
                          "pipelined_frac_of_fp64_mfma_peak": potrf_flops * K / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                          "flops": "n^3/3", "single_eval_ms": stage[1]},
-            "kernel_build": {"gbps_algorithmic_8n2": 8.0 * n * n / (stage[0] * 1e-3) / 1e9,
-                             "gbps_bytes_written": (4.0 * n * n + 4.0 * n * 128) / (stage[0] * 1e-3) / 1e9,
-                             "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128)"},
-            # dominant kernel: the 128x128-tile fp64-MFMA SYRK of the trailing update.  `achieved` = algorithmic
+            "kernel_build": {"gbps_bytes_written": bytes_written / (stage[0] * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": bytes_written / (stage[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128): what the kernel stores",
+                             "us": stage[0] * 1e3},
+            # dominant kernel: the fp64-MFMA SYRK of the trailing update.  `achieved` = algorithmic
             # flops of ALL its launches in the timed region / wall time of the timed region, i.e. what this
             # kernel delivers on the chip while `evals_in_flight` evaluations share it; per-launch averages
             # (HIP events on the launch stream, what rocprofv3 --stats reports) and the exclusive rate follow.
@@ -251,7 +395,7 @@ def main():
                          "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic,
                          "traffic_source": "HBM bytes of one M=8192, K=256 launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE) from "
-                                           "the committed rocprofv3 --pmc passes, profiles/r01_gemm_pmc.json / .md; PMC cannot be "
+                                           f"the committed rocprofv3 --pmc passes, profiles/{pmc_file}; PMC cannot be "
                                            "collected inside bench.py; algorithmic bytes of that launch: 5.61e8",
                          "launches": gemm_launches, "launches_sampled": f"every {PROFILE_EVERY}th evaluation of the timed region",
                          "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
@@ -261,16 +405,34 @@ def main():
                          "exclusive_tflops": excl_tflops, "exclusive_frac": excl_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K (K = 256, or 512 for "
                                              "the lazily updated far region), lower trapezoid for the near-column updates"},
+            "kernel_time_shares": {"classes": shares,
+                                   "note": "HIP-event duration of every launch of every 4th evaluation inside the timed region, per "
+                                           "kernel class, on the launch's own stream; share = class time x (K / sampled) / (evals in "
+                                           "flight x region wall time): the classes sum to <= 1, the rest is stream idle time",
+                                   "sum_of_shares": float(sum(v["share_of_stream_time"] for v in shares.values()))},
             "factor_reuse": reuse,
+            "ell_ratio_grid": ell_grid,
+            "predict": pred,
             "lml_sample": float(allvals[0]),
         }
         if world == 1 and args.cpu_evals > 0:
             out["cpu_baseline"] = cpu_baseline(n, r, args.cpu_evals)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            cpu_v = out["cpu_baseline"]["lml"]
+            rel = abs(gpu_lml_02 - cpu_v) / abs(cpu_v)
+            out["parity"] = {"gpu": gpu_lml_02, "cpu": cpu_v, "rel": rel, "bound": PARITY_BOUND,
+                             "what": "TruncationGP.log_marginal_likelihood(log 0.2, ratio=0.5) of the S3 workload: HIP path vs the "
+                                     "CPU oracle evaluation that cpu_baseline times"}
+            if not rel <= PARITY_BOUND:
+                rc = 3
+        else:
+            out["parity"] = {"gpu": gpu_lml_02, "cpu": None, "rel": None, "bound": PARITY_BOUND}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

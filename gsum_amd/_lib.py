@@ -9,14 +9,28 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import warnings
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The HIP runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline keeps 20 independent
-# evaluations in flight on their own streams and wants a queue each.  Read by the runtime when it initialises, so this
-# only takes effect if nothing in the process has touched the GPU yet (import gsum_amd before torch.cuda is used).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
+
+def configure_runtime(hw_queues: int = 32) -> bool:
+    """Ask the HIP runtime for ``hw_queues`` hardware queues (environment variable ``GPU_MAX_HW_QUEUES``).
+
+    The runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline of ``lml_resident`` keeps up
+    to 20 independent evaluations in flight on their own streams and wants a queue each (267 instead of 180
+    evaluations per second at n = 8192).  The runtime reads the variable once, when it initialises, so call this
+    before ANYTHING in the process touches the GPU (torch.cuda included).  Importing gsum_amd does not change the
+    environment by itself: an application decides this for its whole process.  Returns False, and leaves a value the
+    user already set untouched.  Whatever the environment says, the library times its streams' real concurrency
+    before it trusts more than 4 in-flight evaluations (``HipContext.queue_probe``)."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
+    return True
+
 
 LIB_PATH = os.environ.get("GSUM_HIP_LIBRARY") or os.path.join(_HERE, "libgsum_hip.so")
 
@@ -91,12 +105,14 @@ PROTOTYPES = {
     "gsum_destroy": (None, [_p]),
     "gsum_last_error": (C.c_char_p, [_p]),
     "gsum_set_option": (C.c_int, [_p, C.c_char_p, C.c_int64]),
+    "gsum_get_option": (C.c_int64, [_p, C.c_char_p]),
     "gsum_kernel_build": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, C.c_double, _dp]),
     "gsum_kernel_build_dev": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, C.c_double, C.POINTER(_p)]),
     "gsum_mat_from_host": (C.c_int, [_p, _dp, C.c_int64, C.POINTER(_p)]),
     "gsum_potrf_lower": (C.c_int, [_p, _p, _ip]),
     "gsum_forward_gram": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
     "gsum_forward_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
+    "gsum_cho_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_predict_terms": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
                                      _dp, _dp, _dp]),
     "gsum_tri_multiply": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
@@ -111,9 +127,11 @@ PROTOTYPES = {
     "gsum_lml_grad": (C.c_int, [_p, _kp, C.POINTER(GradParam), C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32,
                                 C.c_double, _dp, _dp, _ip, _dp, _dp]),
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
+    "gsum_resident_shape": (C.c_int, [_p, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
+    "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
     "gsum_probe_cu_mask": (C.c_int, [_p, C.POINTER(C.c_uint32), C.c_int32, C.c_int32, _ip]),
@@ -228,6 +246,20 @@ class HipContext:
     def set_option(self, name: str, value: int):
         self._check(self._lib.gsum_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = int(self._lib.gsum_get_option(self._h, name.encode()))
+        if v < 0 and name not in ("reserve_cus",):
+            raise ValueError(f"unknown option: {name}")
+        return v
+
+    def queue_probe(self):
+        """Result of the stream-concurrency probe that runs before the first batch wanting more than 4 evaluations in
+        flight: dict(streams, concurrency, fell_back_from, batch_slots); streams == 0 means it has not run."""
+        return dict(streams=self.get_option("queue_probe_streams"),
+                    concurrency=self.get_option("queue_probe_concurrency_x100") / 100.0,
+                    fell_back_from=self.get_option("queue_probe_fell_back"),
+                    batch_slots=self.get_option("batch_slots"))
+
     # -- operator level ------------------------------------------------------
     def kernel_matrix(self, desc: KernelDesc, X, Y=None, diag_add: float = 0.0) -> np.ndarray:
         X = _f64(X)
@@ -287,6 +319,21 @@ class HipContext:
         W = np.empty((n, k))
         self._check(self._lib.gsum_forward_solve(self._h, L._h, _ptr(rhs), n, k, _ptr(W)))
         return W[:, 0] if squeeze else W
+
+    def cho_solve(self, L: DeviceMatrix, B) -> np.ndarray:
+        """scipy.linalg.cho_solve((L, True), B) on the device factor (any number of columns; 16 per device pass)."""
+        B = _f64(B)
+        squeeze = B.ndim == 1
+        if squeeze:
+            B = B[:, None]
+        n, k = B.shape
+        out = np.empty((n, k))
+        for lo in range(0, k, GSUM_MAX_RHS):
+            bc = np.ascontiguousarray(B[:, lo:lo + GSUM_MAX_RHS])
+            xc = np.empty_like(bc)
+            self._check(self._lib.gsum_cho_solve(self._h, L._h, _ptr(bc), n, bc.shape[1], _ptr(xc)))
+            out[:, lo:lo + GSUM_MAX_RHS] = xc
+        return out[:, 0] if squeeze else out
 
     def tri_multiply(self, L: DeviceMatrix, Z) -> np.ndarray:
         """L @ Z for a factorised matrix (any number of columns; 16 per device pass)."""
@@ -373,11 +420,18 @@ class HipContext:
 
     def set_inputs(self, X, rhs):
         X, rhs = _f64(X), _f64(rhs)
-        self._k = rhs.shape[1]
         self._check(self._lib.gsum_set_inputs(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(rhs), rhs.shape[1]))
 
+    def resident_shape(self):
+        """(n, d, k) of the inputs gsum_set_inputs left on the device ((0, 0, 0) before the first call)."""
+        n, d, k = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.gsum_resident_shape(self._h, C.byref(n), C.byref(d), C.byref(k)))
+        return int(n.value), int(d.value), int(k.value)
+
     def lml_resident(self, descs, nugget: float):
-        k = self._k
+        k = self.resident_shape()[2]          # the library's own record, not a cached copy
+        if k == 0:
+            raise ValueError("gsum_set_inputs has not been called")
         nk = len(descs)
         G = np.empty((nk, k, k))
         sld = np.empty(nk)
@@ -385,7 +439,21 @@ class HipContext:
         arr = self._desc_array(descs)
         self._check(self._lib.gsum_lml_resident(self._h, arr, nk, float(nugget), _ptr(G), _ptr(sld),
                                                 info.ctypes.data_as(_ip)))
+        self._warn_if_probe_fell_back()
         return G, sld, info
+
+    def _warn_if_probe_fell_back(self):
+        if getattr(self, "_probe_warned", False):
+            return
+        asked = int(self._lib.gsum_get_option(self._h, b"queue_probe_fell_back"))
+        if asked > 0:
+            self._probe_warned = True
+            conc = int(self._lib.gsum_get_option(self._h, b"queue_probe_concurrency_x100")) / 100.0
+            warnings.warn(
+                f"gsum_amd: {asked} evaluations in flight were configured but the HIP runtime runs only {conc:.1f} streams "
+                "side by side (GPU_MAX_HW_QUEUES was not in the environment when the runtime initialised -- call "
+                "gsum_amd.configure_runtime() before anything touches the GPU); the batch pipeline falls back to 3 in flight",
+                RuntimeWarning, stacklevel=3)
 
     # -- measurement ---------------------------------------------------------
     def timers(self):
@@ -412,6 +480,16 @@ class HipContext:
         ms, fl, cnt = C.c_double(0), C.c_double(0), C.c_int64(0)
         self._check(self._lib.gsum_gemm_profile(self._h, C.byref(ms), C.byref(fl), C.byref(cnt)))
         return float(ms.value), float(fl.value), int(cnt.value)
+
+    PROFILE_CLASSES = ("kernel_build", "diag_block", "panel_gemm", "bulk_update", "other")
+
+    def kernel_profile(self):
+        """Per kernel class {name: dict(ms, flops, launches)} of the launches profiled since the last read-out (option
+        "profile_gemm" = N: every launch of every N-th fused evaluation); resets the record."""
+        ms, fl, cnt = np.zeros(5), np.zeros(5), np.zeros(5, dtype=np.int64)
+        self._check(self._lib.gsum_kernel_profile(self._h, _ptr(ms), _ptr(fl), cnt.ctypes.data_as(_ip)))
+        return {name: dict(ms=float(ms[i]), flops=float(fl[i]), launches=int(cnt[i]))
+                for i, name in enumerate(self.PROFILE_CLASSES)}
 
     def probe_mfma_f64(self, iters=10000, waves_per_simd=1, n_acc=8):
         """dict(tflops, cycles_per_mfma, clock_ghz) of a register-resident fp64 MFMA loop."""

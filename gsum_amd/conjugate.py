@@ -18,6 +18,7 @@ from __future__ import annotations
 import warnings
 
 import numpy as np
+from scipy.linalg import cho_solve, inv
 from scipy.optimize import fmin_l_bfgs_b
 from scipy.special import loggamma
 from sklearn.base import clone
@@ -115,7 +116,7 @@ def lml_from_gram_batch(G, sum_log_diag, n_points, center0, disp0, df0, scale0):
         eta = V * (eta0 / V0 + ny * b)
     df = df0 + n_points * ny
     if df0 == np.inf:
-        scale_sq = np.full_like(g, scale0 ** 2)
+        scale_sq = np.broadcast_to(np.asarray(scale0, dtype=float) ** 2, g.shape)       # scale0 may be one value per entry
     else:
         quad = tr - ny * q
         a = q - 2.0 * eta0 * b + eta0 * eta0 * g
@@ -275,6 +276,123 @@ class ConjugateGaussianProcess:
         self._corr_L = None
         self._gram = None
 
+    # -- the reference's classmethod / operator surface (models.py:170-503, 601-628) ---------------------------------
+    # Host utilities on a caller-supplied square root of R, with the reference's signatures.  The classes here never
+    # call them (fit / log_marginal_likelihood read everything off the device's Gram matrix); they are kept so that
+    # user code written against gsum's public surface keeps working.  ``sqrt_R`` is a host array as in the reference
+    # or a device factor (``DeviceMatrix``), in which case the solves run on the GPU (gsum_cho_solve).  All of them
+    # reduce to one solve V = R^-1 [y | basis] and the (n_curves + p) x (n_curves + p) Gram matrix [y | basis]^T V.
+    @staticmethod
+    def num_y(y):                                                  # models.py:601-607
+        return y.shape[1] if np.ndim(y) == 2 else 1
+
+    @staticmethod
+    def avg_y(y):                                                  # models.py:609-628
+        if y.ndim == 1:
+            return np.copy(y)
+        if y.ndim == 2:
+            return np.average(y, axis=1)
+        raise ValueError('y must be two-dimensional, not shape={}'.format(y.shape))
+
+    @staticmethod
+    def solve_sqrt(sqrt_mat, y, decomposition):
+        """R^-1 y from a square root of R (models.py:460-479): the lower Cholesky factor, or for 'eig' either the
+        tuple (eigenvalues, Q) or a square root S with R = S S^T."""
+        from ._lib import DeviceMatrix
+        if decomposition == 'cholesky':
+            if isinstance(sqrt_mat, DeviceMatrix):
+                return sqrt_mat._ctx.cho_solve(sqrt_mat, y)
+            return cho_solve((sqrt_mat, True), y)
+        if decomposition == 'eig':
+            if isinstance(sqrt_mat, tuple):
+                eig, Q = sqrt_mat
+                proj = Q.T @ y
+                return Q @ (proj / (eig if proj.ndim == 1 else eig[:, None]))
+            return np.linalg.solve(sqrt_mat.T, np.linalg.solve(sqrt_mat, y))
+        raise ValueError('decomposition must be either "cholesky" or "eig"')
+
+    @staticmethod
+    def compute_cov_factor(scale_sq, df):                          # models.py:490-503
+        return cov_factor(scale_sq, df)
+
+    @classmethod
+    def _gram_pieces(cls, y, sqrt_R, basis, decomposition, dR=None):
+        """G = [y | basis]^T R^-1 [y | basis] and, with dR (n x n x P), H_p = V^T dR_p V."""
+        y2 = y[:, None] if y.ndim == 1 else y
+        Z = np.concatenate([y2, basis], axis=1)
+        V = cls.solve_sqrt(sqrt_R, Z, decomposition)
+        H = None if dR is None else np.einsum('ia,ijp,jb->pab', V, dR, V)
+        return Z.T @ V, H, y2.shape[1]
+
+    @staticmethod
+    def _need_dR(eval_gradient, dR):
+        if eval_gradient and dR is None:
+            raise ValueError('dR must be given if eval_gradient is True')
+
+    @classmethod
+    def compute_disp(cls, y, sqrt_R, basis, disp0, decomposition, eval_gradient=False, dR=None):   # models.py:234-278
+        cls._need_dR(eval_gradient, dR)
+        if np.all(disp0 == 0):
+            if eval_gradient:
+                return np.zeros_like(disp0), np.zeros((*disp0.shape, dR.shape[-1]))
+            return np.zeros_like(disp0)
+        G, H, ny = cls._gram_pieces(y, sqrt_R, basis, decomposition, dR if eval_gradient else None)
+        disp = inv(inv(disp0) + ny * G[ny:, ny:])
+        if eval_gradient:
+            return disp, ny * np.einsum('ia,pab,bl->ilp', disp.T, H[:, ny:, ny:], disp)
+        return disp
+
+    @classmethod
+    def compute_center(cls, y, sqrt_R, basis, center0, disp0, decomposition, eval_gradient=False, dR=None):   # :170-231
+        cls._need_dR(eval_gradient, dR)
+        if np.all(disp0 == 0):
+            if eval_gradient:
+                return np.copy(center0), np.zeros((*center0.shape, dR.shape[-1]))
+            return np.copy(center0)
+        G, H, ny = cls._gram_pieces(y, sqrt_R, basis, decomposition, dR if eval_gradient else None)
+        w = np.full(ny, 1.0 / ny)
+        disp = inv(inv(disp0) + ny * G[ny:, ny:])
+        center = disp @ (np.linalg.solve(disp0, center0) + ny * (G[ny:, :ny] @ w))
+        if eval_gradient:
+            a_diff = np.concatenate([-w, center])                 # basis center - y_avg = [y | basis] a_diff
+            return center, ny * disp @ np.einsum('pab,b->ap', H[:, ny:, :], a_diff)
+        return center
+
+    @classmethod
+    def compute_df(cls, y, df0, eval_gradient=False, dR=None):     # models.py:281-307
+        cls._need_dR(eval_gradient, dR)
+        df = df0 + y.size
+        if eval_gradient:
+            return df, np.zeros(dR.shape[-1])
+        return df
+
+    @classmethod
+    def compute_scale_sq(cls, y, sqrt_R, basis, center0, disp0, df0, scale0, decomposition,
+                         eval_gradient=False, dR=None):            # models.py:387-457
+        if df0 == np.inf:
+            if eval_gradient:
+                return scale0 ** 2, np.zeros(dR.shape[-1])
+            return scale0 ** 2
+        cls._need_dR(eval_gradient, dR)
+        G, H, ny = cls._gram_pieces(y, sqrt_R, basis, decomposition, dR if eval_gradient else None)
+        p = G.shape[0] - ny
+        center0 = np.atleast_1d(np.asarray(center0, dtype=float))
+        w = np.full(ny, 1.0 / ny)
+        Gyy, Gby, Gbb = G[:ny, :ny], G[ny:, :ny], G[ny:, ny:]
+        disp = np.zeros((p, p)) if np.all(disp0 == 0) else inv(inv(disp0) + ny * Gbb)
+        quad = np.trace(Gyy) - ny * (w @ Gyy @ w)                  # tr((y - ybar)^T R^-1 (y - ybar))
+        a_c = np.concatenate([w, -center0])                        # ybar - basis center0 = [y | basis] a_c
+        s = G[ny:, :] @ a_c                                        # basis^T R^-1 (ybar - basis center0)
+        quad2 = ny * (a_c @ G @ a_c - ny * (s @ disp @ s))         # Woodbury form of models.py:441-445, no n x n matrix
+        df = df0 + y.size
+        scale_sq = (df0 * scale0 ** 2 + quad + quad2) / df
+        if eval_gradient:
+            Cc = np.concatenate([np.eye(ny) - np.outer(w, np.ones(ny)), np.zeros((p, ny))], axis=0)
+            a_m = ny * (a_c - ny * np.concatenate([np.zeros(ny), disp @ s]))
+            d = np.array([-np.trace(Cc.T @ Hp @ Cc) - (a_m @ Hp @ a_m) / ny for Hp in H]) / df
+            return scale_sq, d
+        return scale_sq
+
     # -- priors (models.py:153-167) ------------------------------------------------------------
     @property
     def center0(self):
@@ -372,6 +490,10 @@ class ConjugateGaussianProcess:
 
     def _lml_gram_batch(self, G, sld, n_points):
         return lml_from_gram_batch(G, sld, n_points, self.center0, self.disp0, self.df0, self.scale0)
+
+    def _lml_gram_batch_sd(self, G, sld, n_points, sds):
+        """The same with the prior replaced by ``sd=sds[b]`` per entry (df0 = inf, scale0 = sd: models.py:115-117)."""
+        return lml_from_gram_batch(G, sld, n_points, self.center0, self.disp0, np.inf, np.asarray(sds, dtype=float))
 
     def _lml_grad_gram(self, G, sld, trace, H, n_points):
         return lml_grad_from_gram(G, sld, trace, H, n_points, self.center0, self.disp0, self.df0, self.scale0)
@@ -620,6 +742,12 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
 
     def _lml_gram_batch(self, G, sld, n_points):
         return np.array([self._lml_gram(Gi, si, n_points)[0] for Gi, si in zip(G, sld)])
+
+    def _lml_gram_batch_sd(self, G, sld, n_points, sds):
+        # an infinite prior df has no Student-t normalisation constant (log_norm diverges, models.py:1234-1240); the
+        # reference would return nan there as well
+        return np.array([student_lml_from_gram(Gi, si, n_points, self.center0, self.disp0, np.inf, sd)[0]
+                         for Gi, si, sd in zip(G, sld, sds)])
 
     def _lml_grad_gram(self, G, sld, trace, H, n_points):
         return student_lml_grad_from_gram(G, sld, trace, H, n_points, self.center0, self.disp0, self.df0, self.scale0)

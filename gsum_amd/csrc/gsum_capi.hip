@@ -40,6 +40,11 @@ struct gs_slot {
 
 #define GS_MAX_SLOTS 24
 
+struct gs_inputs {
+    double* X = nullptr; int64_t n = 0; int d = 0; size_t X_cap = 0;     // n x d points
+    double* Z = nullptr; int k = 0; size_t Z_cap = 0;                    // n x k right-hand sides
+};
+
 struct gsum_ctx {
     int device = 0;
     gs_slot slots[GS_MAX_SLOTS];
@@ -61,9 +66,10 @@ struct gsum_ctx {
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
                                      // (measured: 14.3 vs 8.5 ms); -1 = 2 from order 6144 up
     int build_lower_only = 1;
-    // resident inputs of the fused path
-    double* dX = nullptr; int64_t nX = 0; int dX_d = 0; size_t dX_cap = 0;
-    double* dZ = nullptr; int kZ = 0; size_t dZ_cap = 0;
+    // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
+    // point (operator level, gsum_lml_batch, gsum_lml_grad) uploads into `op`.  `in` is the set the fused path reads.
+    gs_inputs op, res;
+    gs_inputs* in = &res;
     double* scratch = nullptr; size_t scratch_cap = 0;
     double* gws = nullptr; size_t gws_cap = 0;     // gradient path: U = L^-T, R^-1, V^T, per-parameter partials
     double timers[4] = {0, 0, 0, 0};
@@ -74,9 +80,12 @@ struct gsum_ctx {
     int prof_eval_count = 0;         // fused evaluations enqueued since profiling was switched on
     bool prof_this_eval = true;
     std::vector<hipEvent_t> prof_pool;
-    struct ProfRec { int e0, e1; double flops; };
+    struct ProfRec { int e0, e1; double flops; int cls; };     // cls: GS_PROF_* below
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
+    int probe_streams = 0;           // queue-concurrency probe (gs_probe_queues): streams timed, observed concurrency,
+    double probe_concurrency = 0.0;  // and whether batch_slots fell back to 3 because of it
+    int probe_fell_back = 0;
     int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
     int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
     int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n^1.45 / 985),
@@ -87,6 +96,9 @@ struct gsum_ctx {
 };
 
 static std::string g_init_error;
+
+// kernel classes of the per-launch HIP-event profile (option "profile_gemm")
+enum { GS_PROF_BUILD = 0, GS_PROF_DIAG = 1, GS_PROF_PANEL = 2, GS_PROF_BULK = 3, GS_PROF_OTHER = 4, GS_PROF_CLASSES = 5 };
 
 #define GS_CHECK(expr)                                                                             \
     do {                                                                                           \
@@ -113,6 +125,26 @@ static int gs_reserve(gsum_ctx* ctx, double** p, size_t* cap, size_t bytes) {
     GS_CHECK(hipMalloc((void**)p, bytes));
     *cap = bytes;
     return 0;
+}
+
+// Bracket the launches enqueued between begin and end (one kernel, as a rule) with HIP events on THEIR stream; only
+// while an evaluation is being profiled.  Returns the record index to hand to gs_prof_end, or -1.
+static int gs_prof_begin(gsum_ctx* ctx, hipStream_t s, int cls, double flops) {
+    if (!ctx->profile_gemm || !ctx->prof_this_eval) return -1;
+    while (ctx->prof_pool.size() < ctx->prof_next + 2) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return -1;
+        ctx->prof_pool.push_back(ev);
+    }
+    const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
+    ctx->prof_next += 2;
+    if (hipEventRecord(ctx->prof_pool[e0], s) != hipSuccess) return -1;
+    ctx->prof_recs.push_back({e0, e1, flops, cls});
+    return (int)ctx->prof_recs.size() - 1;
+}
+
+static void gs_prof_end(gsum_ctx* ctx, hipStream_t s, int rec) {
+    if (rec >= 0) (void)hipEventRecord(ctx->prof_pool[ctx->prof_recs[rec].e1], s);
 }
 
 // ---- GEMM launcher ----------------------------------------------------------------------------
@@ -215,24 +247,14 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
     ctx->next_algo_flops = -1.0;
     const bool bulk = cfg == GS_BULK;
     if (bulk) cfg = ctx->bulk_cfg;
-    if (bulk && ctx->profile_gemm && ctx->prof_this_eval && M > 0 && N > 0) {
-        while (ctx->prof_pool.size() < ctx->prof_next + 2) {
-            hipEvent_t ev;
-            GS_CHECK(hipEventCreate(&ev));
-            ctx->prof_pool.push_back(ev);
-        }
-        const int e0 = (int)ctx->prof_next, e1 = e0 + 1;
-        ctx->prof_next += 2;
-        GS_CHECK(hipEventRecord(ctx->prof_pool[e0], s));
-        int rc = gs_dispatch(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
-        GS_CHECK(hipEventRecord(ctx->prof_pool[e1], s));
-        // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
-        double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
-        if (algo_override >= 0.0) fl = algo_override;                    // caller knows better (trapezoidal region)
-        ctx->prof_recs.push_back({e0, e1, fl});
-        return rc;
-    }
-    return gs_dispatch(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+    if (M <= 0 || N <= 0) return 0;
+    // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
+    double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
+    if (algo_override >= 0.0) fl = algo_override;                        // caller knows better (trapezoidal region)
+    const int rec = gs_prof_begin(ctx, s, bulk ? GS_PROF_BULK : GS_PROF_PANEL, fl);
+    const int rc = gs_dispatch(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+    gs_prof_end(ctx, s, rec);
+    return rc;
 }
 
 // ---- matrices ---------------------------------------------------------------------------------
@@ -284,8 +306,10 @@ static int gs_build_into(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const gsum_k
                          int d, double diag_add, int lower_only) {
     int64_t T = m->T;
     int64_t blocks = lower_only ? T * (T + 1) / 2 : T * T;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_BUILD, 0.0);
     hipLaunchKernelGGL(k_build<false>, dim3((unsigned)blocks), dim3(256), 0, s, m->A, m->ld, dX, (const double*)nullptr,
                        (int)m->n, (int)m->n, (int)m->np, (int)m->np, d, *desc, diag_add, lower_only);
+    gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     m->factored = false;
     return 0;
@@ -293,8 +317,10 @@ static int gs_build_into(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const gsum_k
 
 static int gs_set_border(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const double* dZ, int k) {
     int64_t cols = m->np + GS_BORDER;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_OTHER, 0.0);
     hipLaunchKernelGGL(k_set_border, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, m->A, m->ld, (int)m->n,
                        (int)m->np, dZ, k);
+    gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
 }
@@ -364,8 +390,10 @@ static int gs_diag(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
     gs_slot* sl = ctx->cur;
     const int64_t c = (int64_t)b * GS_NB;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, (double)GS_NB * GS_NB * GS_NB / 3.0);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld,
                        m->Linv + (size_t)b * GS_NB * GS_NB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
 }
@@ -377,7 +405,11 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
     GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
-    hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, sl->sm, A, ld, (int)m->np, m->diag0);
+    {
+        const int rec = gs_prof_begin(ctx, sl->sm, GS_PROF_OTHER, 0.0);
+        hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, sl->sm, A, ld, (int)m->np, m->diag0);
+        gs_prof_end(ctx, sl->sm, rec);
+    }
     GS_CHECK(hipGetLastError());
     // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
@@ -473,8 +505,10 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
 }
 
 static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
+    const int rec = gs_prof_begin(ctx, ctx->cur->sm, GS_PROF_OTHER, 0.0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->cur->sm, m->A, m->ld, (int)m->np, m->logdet, m->T, ctx->cur->dinfo,
                        ctx->cur->dres);
+    gs_prof_end(ctx, ctx->cur->sm, rec);
     GS_CHECK(hipGetLastError());
     GS_CHECK(hipMemcpyAsync(ctx->cur->hres, ctx->cur->dres, 258 * sizeof(double), hipMemcpyDeviceToHost, ctx->cur->sm));
     return 0;
@@ -573,8 +607,10 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
         if (sl->sb) (void)hipStreamDestroy(sl->sb);
     }
-    if (ctx->dX) (void)hipFree(ctx->dX);
-    if (ctx->dZ) (void)hipFree(ctx->dZ);
+    for (gs_inputs* I : {&ctx->op, &ctx->res}) {
+        if (I->X) (void)hipFree(I->X);
+        if (I->Z) (void)hipFree(I->Z);
+    }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->gws) (void)hipFree(ctx->gws);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
@@ -583,6 +619,39 @@ void gsum_destroy(gsum_ctx* ctx) {
 }
 
 const char* gsum_last_error(gsum_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
+    if (!ctx || !name) return -1;
+    if (!strcmp(name, "batch_slots")) return ctx->batch_slots;
+    if (!strcmp(name, "queue_probe_streams")) return ctx->probe_streams;        // 0: the probe has not run
+    if (!strcmp(name, "queue_probe_concurrency_x100")) return (int64_t)(ctx->probe_concurrency * 100.0 + 0.5);
+    if (!strcmp(name, "queue_probe_fell_back")) return ctx->probe_fell_back;
+    if (!strcmp(name, "lookahead")) return ctx->lookahead;
+    if (!strcmp(name, "bulk_cfg")) return ctx->bulk_cfg;
+    return -1;
+}
+
+// Do S streams of this process really run side by side?  gsum_init can only read GPU_MAX_HW_QUEUES from the environment;
+// whether the HIP runtime read the same value depends on who initialised it (a process that touched the GPU before the
+// variable was set keeps the default 4 queues, and streams beyond the queue count share queues: the kernels of different
+// evaluations then serialise and 20 in flight are slower than 3).  So before the first batch that wants more than 4
+// slots, one spinning single-wave kernel per slot stream is timed: S x spin / elapsed is the observed concurrency.
+// Below 70 % of S the batch falls back to 3 slots (the optimum on 4 queues) and says so through gsum_get_option.
+static int gs_probe_queues(gsum_ctx* ctx, int S) {
+    if (gs_need_slots(ctx, S)) return -1;
+    GS_CHECK(hipDeviceSynchronize());
+    const unsigned long long ticks = 30000;                  // 300 us of s_memrealtime (100 MHz)
+    for (int rep = 0; rep < 2; ++rep) {                      // first round: code-object load, stream warm-up
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int q = 0; q < S; ++q) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, ctx->slots[q].sm, ticks);
+        GS_CHECK(hipGetLastError());
+        GS_CHECK(hipDeviceSynchronize());
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ctx->probe_concurrency = (double)S * 300.0 / us;
+    }
+    ctx->probe_streams = S;
+    return 0;
+}
 
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return -2;
@@ -619,21 +688,21 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     return 0;
 }
 
-static int gs_upload_X(gsum_ctx* ctx, const double* X, int64_t n, int d) {
+static int gs_upload_X(gsum_ctx* ctx, gs_inputs* I, const double* X, int64_t n, int d) {
     if (!X || n <= 0) GS_FAIL("X is NULL or empty");
-    if (gs_reserve(ctx, &ctx->dX, &ctx->dX_cap, (size_t)n * d * sizeof(double))) return -1;
-    GS_CHECK(hipMemcpyAsync(ctx->dX, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
-    ctx->nX = n;
-    ctx->dX_d = d;
+    if (gs_reserve(ctx, &I->X, &I->X_cap, (size_t)n * d * sizeof(double))) return -1;
+    GS_CHECK(hipMemcpyAsync(I->X, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
+    I->n = n;
+    I->d = d;
     return 0;
 }
 
-static int gs_upload_Z(gsum_ctx* ctx, const double* Z, int64_t n, int k) {
+static int gs_upload_Z(gsum_ctx* ctx, gs_inputs* I, const double* Z, int64_t n, int k) {
     if (k < 0 || k > GSUM_MAX_RHS) GS_FAIL("k must be 0..GSUM_MAX_RHS");
     if (k > 0 && !Z) GS_FAIL("RHS is NULL");
-    if (gs_reserve(ctx, &ctx->dZ, &ctx->dZ_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
-    if (k > 0) GS_CHECK(hipMemcpyAsync(ctx->dZ, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
-    ctx->kZ = k;
+    if (gs_reserve(ctx, &I->Z, &I->Z_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
+    if (k > 0) GS_CHECK(hipMemcpyAsync(I->Z, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
+    I->k = k;
     return 0;
 }
 
@@ -676,11 +745,11 @@ int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const dou
     if (!ctx || !out) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
     if (gs_check_desc(ctx, desc, d)) return -2;
-    if (gs_upload_X(ctx, X, n, d)) return -1;
+    if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
     gsum_mat* m = nullptr;
     if (gs_mat_alloc(ctx, n, &m)) return -1;
-    if (gs_build_into(ctx, ctx->cur->sm, m, desc, ctx->dX, d, diag_add, ctx->build_lower_only) ||
-        gs_set_border(ctx, ctx->cur->sm, m, ctx->dZ, 0)) {
+    if (gs_build_into(ctx, ctx->cur->sm, m, desc, ctx->op.X, d, diag_add, ctx->build_lower_only) ||
+        gs_set_border(ctx, ctx->cur->sm, m, nullptr, 0)) {
         gs_mat_release(m);
         return -1;
     }
@@ -701,7 +770,7 @@ int gsum_mat_from_host(gsum_ctx* ctx, const double* Ah, int64_t n, gsum_mat** ou
                            ctx->cur->sm, m->A, m->ld, (int)n, (int)m->np);
         e = hipGetLastError();
     }
-    if (e != hipSuccess || gs_set_border(ctx, ctx->cur->sm, m, ctx->dZ, 0)) {
+    if (e != hipSuccess || gs_set_border(ctx, ctx->cur->sm, m, nullptr, 0)) {
         gs_mat_release(m);
         if (e != hipSuccess) ctx->err = std::string("upload failed: ") + hipGetErrorString(e);
         return -1;
@@ -748,8 +817,8 @@ int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, 
     if (!L->factored) GS_FAIL("forward_gram needs a factorised matrix");
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
-    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
+    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
     GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
     if (gs_border_solve(ctx, L)) return -1;
     if (gs_finalize(ctx, L)) return -1;
@@ -766,8 +835,8 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
     if (!L->factored) GS_FAIL("forward_solve needs a factorised matrix");
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
-    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
+    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
     if (gs_border_solve(ctx, L)) return -1;
     std::vector<double> rows((size_t)k * n);
     GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), L->A + L->np * L->ld, (size_t)L->ld * sizeof(double),
@@ -775,6 +844,36 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     for (int64_t i = 0; i < n; ++i)
         for (int c = 0; c < k; ++c) W[i * k + c] = rows[(size_t)c * n + i];
+    return 0;
+}
+
+// scipy.linalg.cho_solve((L, True), B) = L^-T (L^-1 B): the forward half is gs_border_solve (border rows = W^T), the
+// backward half runs right-looking from the last block column to the first, in place on the border rows:
+//   X_c^T = W_c^T L_cc^-1 ;  W^T[:, cols < c0] -= X_c^T L[c rows, cols < c0]        (k_back_first / k_back_step)
+int gsum_cho_solve(gsum_ctx* ctx, gsum_mat* L, const double* B, int64_t n, int32_t k, double* X) {
+    if (!ctx || !L || !B || !X) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("cho_solve needs a factorised matrix");
+    if (n != L->n) GS_FAIL("B has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    hipStream_t s = ctx->cur->sm;
+    if (gs_upload_Z(ctx, &ctx->op, B, n, k)) return -1;
+    if (gs_set_border(ctx, s, L, ctx->op.Z, k)) return -1;
+    if (gs_border_solve(ctx, L)) return -1;
+    double* Brow = L->A + L->np * L->ld;
+    const int T = L->T;
+    hipLaunchKernelGGL(k_back_first, dim3(1), dim3(256), 0, s, Brow, L->ld, L->Linv + (size_t)(T - 1) * GS_NB * GS_NB, (T - 1) * GS_NB);
+    GS_CHECK(hipGetLastError());
+    for (int c = T - 1; c >= 1; --c) {
+        hipLaunchKernelGGL(k_back_step, dim3((unsigned)c), dim3(256), 0, s, L->A, L->ld, Brow, L->Linv, c);
+        GS_CHECK(hipGetLastError());
+    }
+    std::vector<double> rows((size_t)k * n);
+    GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), Brow, (size_t)L->ld * sizeof(double),
+                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) X[i * k + c] = rows[(size_t)c * n + i];
     return 0;
 }
 
@@ -867,14 +966,14 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                  o_ss = o_vw + up((size_t)m * 16 * 8), o_cv = o_ss + up((size_t)m * 8),
                  o_sc = o_cv + (cov_out ? up((size_t)m * m * 8) : 0),
                  total = o_sc + (sc ? up((size_t)2 * (n + m) * 8) : 0);
-    if (gs_upload_X(ctx, X, n, d)) return -1;
+    if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, total)) return -1;
     char* base = (char*)ctx->scratch;
     double *dXs = (double*)(base + o_xs), *Bt = (double*)(base + o_bt), *dVW = (double*)(base + o_vw),
            *dSS = (double*)(base + o_ss), *dCov = (double*)(base + o_cv);
     GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->cur->sm));
     const int64_t tr = (m + 127) / 128, tc = np / 128;
-    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, Bt, ldb, dXs, ctx->dX, (int)m, (int)n,
+    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, Bt, ldb, dXs, ctx->op.X, (int)m, (int)n,
                        (int)m, (int)np, d, *desc, 0.0, 0);
     GS_CHECK(hipGetLastError());
     if (sc) {
@@ -901,8 +1000,8 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     std::vector<double> vw;
     if (k > 0) {
-        if (gs_upload_Z(ctx, RHS, n, k)) return -1;
-        if (gs_set_border(ctx, ctx->cur->sm, L, ctx->dZ, k)) return -1;
+        if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
+        if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
         if (gs_border_solve(ctx, L)) return -1;
         if (gs_gemm(ctx, ctx->cur->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
         vw.resize((size_t)m * 16);
@@ -948,8 +1047,27 @@ int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const 
     GS_CHECK(hipSetDevice(ctx->device));
     ctx->cur = &ctx->slots[0];
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
-    if (gs_upload_X(ctx, X, n, d)) return -1;
-    if (gs_upload_Z(ctx, RHS, n, k)) return -1;
+    if (gs_upload_X(ctx, &ctx->res, X, n, d)) return -1;
+    if (gs_upload_Z(ctx, &ctx->res, RHS, n, k)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    return 0;
+}
+
+int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k) {
+    if (!ctx || !n || !d || !k) return -2;
+    *n = ctx->res.X ? ctx->res.n : 0;
+    *d = ctx->res.X ? ctx->res.d : 0;
+    *k = ctx->res.X ? ctx->res.k : 0;
+    return 0;
+}
+
+// host inputs of gsum_lml_batch / gsum_lml_grad: uploaded into the operator-level set, never into the resident one
+static int gs_upload_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k) {
+    GS_CHECK(hipSetDevice(ctx->device));
+    ctx->cur = &ctx->slots[0];
+    if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
+    if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
+    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
 }
@@ -962,17 +1080,17 @@ static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double n
         gsum_ctx* c; std::chrono::steady_clock::time_point t0;
         ~HostTimer() { c->host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
     } host_timer{ctx, h0};
-    if (!sl->ws || sl->ws->n != ctx->nX) {
+    if (!sl->ws || sl->ws->n != ctx->in->n) {
         GS_CHECK(hipStreamSynchronize(sl->sm));
         gs_mat_release(sl->ws);
         sl->ws = nullptr;
-        if (gs_mat_alloc(ctx, ctx->nX, &sl->ws)) return -1;
+        if (gs_mat_alloc(ctx, ctx->in->n, &sl->ws)) return -1;
     }
     gsum_mat* m = sl->ws;
     if (ctx->profile_gemm > 0) ctx->prof_this_eval = (ctx->prof_eval_count++ % ctx->profile_gemm) == 0;
     GS_CHECK(hipEventRecord(sl->tev[0], sl->sm));
-    if (gs_build_into(ctx, sl->sm, m, desc, ctx->dX, ctx->dX_d, nugget, ctx->build_lower_only)) return -1;
-    if (gs_set_border(ctx, sl->sm, m, ctx->dZ, ctx->kZ)) return -1;
+    if (gs_build_into(ctx, sl->sm, m, desc, ctx->in->X, ctx->in->d, nugget, ctx->build_lower_only)) return -1;
+    if (gs_set_border(ctx, sl->sm, m, ctx->in->Z, ctx->in->k)) return -1;
     GS_CHECK(hipEventRecord(sl->tev[1], sl->sm));
     if (gs_potrf(ctx, m)) return -1;
     GS_CHECK(hipEventRecord(sl->tev[2], sl->sm));
@@ -984,7 +1102,7 @@ static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double n
 
 // wait for the evaluation pending on a slot and copy its results out
 static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sld_out, int64_t* info_out) {
-    const int i = sl->pending, k = ctx->kZ;
+    const int i = sl->pending, k = ctx->in->k;
     if (i < 0) return 0;
     GS_CHECK(hipStreamSynchronize(sl->sm));
     for (int a = 0; a < k; ++a)
@@ -1005,7 +1123,7 @@ static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sl
 // n <= 128: one fused workgroup per evaluation (k_lml_small), up to 512 evaluations per launch
 static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
                         double* sld_out, int64_t* info_out) {
-    const int k = ctx->kZ, CH = 512;
+    const int k = ctx->in->k, CH = 512;
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
@@ -1015,7 +1133,7 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lml_small, dim3(cnt), dim3(256), 0, s, ctx->dX, (int)ctx->nX, ctx->dX_d, ctx->dZ, k,
+        hipLaunchKernelGGL(k_lml_small, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n, ctx->in->d, ctx->in->Z, k,
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), (double*)(base + o_res));
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
@@ -1034,14 +1152,18 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
 // 128 < n <= GS_MEDIUM_MAX (4096) with many evaluations: one workgroup per evaluation (k_lml_medium), 256 in flight
 static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
                          double* sld_out, int64_t* info_out) {
-    const int k = ctx->kZ;
-    const int64_t n = ctx->nX, np = (n + GS_NB - 1) / GS_NB * GS_NB, T = np / GS_NB, ld = np + GS_BORDER;
+    const int k = ctx->in->k;
+    const int64_t n = ctx->in->n, np = (n + GS_NB - 1) / GS_NB * GS_NB, T = np / GS_NB, ld = np + GS_BORDER;
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const int64_t stride = (int64_t)(up((size_t)(np * ld + T * GS_NB * GS_NB + np + 16 * np) * 8) / 8);
     // evaluations per launch: whole rounds of the 512 resident workgroups (two per CU; a partial round would idle most
-    // of the chip), within 80 GB of per-evaluation matrices (512 x 134 MB at n = 4096)
-    const int64_t fit = (int64_t)(80e9 / (double)(stride * 8));
+    // of the chip), within the memory budget below (512 x 134 MB at n = 4096 when the GPU is otherwise empty)
+    size_t free_b = 0, total_b = 0;
+    GS_CHECK(hipMemGetInfo(&free_b, &total_b));
+    // what this call may hold: 80 % of what is free now plus the scratch it already owns, 80 GB at most
+    const double budget = std::min(80e9, 0.8 * (double)free_b + (double)ctx->scratch_cap);
+    const int64_t fit = (int64_t)(budget / (double)(stride * 8));
     const int cap = fit >= 512 ? 512 : (fit >= 256 ? 256 : (int)std::max<int64_t>(1, fit));
     const int CH = std::min(n_kernels, cap);
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
@@ -1056,7 +1178,7 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lml_medium, dim3(cnt), dim3(256), shmem, s, ctx->dX, (int)n, ctx->dX_d, ctx->dZ, k,
+        hipLaunchKernelGGL(k_lml_medium, dim3(cnt), dim3(256), shmem, s, ctx->in->X, (int)n, ctx->in->d, ctx->in->Z, k,
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res));
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
@@ -1072,32 +1194,40 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     return 0;
 }
 
-int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
-                      double* G_out, double* sld_out, int64_t* info_out) {
+static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                     double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
-    if (!ctx->dX) GS_FAIL("gsum_set_inputs has not been called");
+    ctx->in = I;
+    if (!ctx->in->X) GS_FAIL("gsum_set_inputs has not been called");
     for (int i = 0; i < n_kernels; ++i)
-        if (gs_check_desc(ctx, &kernels[i], ctx->dX_d)) return -2;
-    if (ctx->nX <= GS_NB && ctx->small_path) {
+        if (gs_check_desc(ctx, &kernels[i], ctx->in->d)) return -2;
+    if (ctx->in->n <= GS_NB && ctx->small_path) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
     // break-even against the 20-slot pipelined path, measured at n = 256 ... 4096: 4, 9, 22, 67, 127, 175 evaluations
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
-                                                  : std::max(4, (int)(pow((double)ctx->nX, 1.45) / 985.0));
-    if (ctx->nX <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
+                                                  : std::max(4, (int)(pow((double)ctx->in->n, 1.45) / 985.0));
+    if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    }
+    if (ctx->batch_slots > 4 && n_kernels > 4 && ctx->probe_streams < ctx->batch_slots && !ctx->probe_fell_back) {
+        if (gs_probe_queues(ctx, ctx->batch_slots)) return -1;
+        if (ctx->probe_concurrency < 0.7 * ctx->batch_slots) {
+            ctx->probe_fell_back = ctx->batch_slots;
+            ctx->batch_slots = 3;
+        }
     }
     int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
     {
         // every slot owns a workspace matrix of the current order: keep the new ones within 80 % of the free memory
-        const int64_t np = (ctx->nX + GS_NB - 1) / GS_NB * GS_NB, ldw = np + GS_BORDER;
+        const int64_t np = (ctx->in->n + GS_NB - 1) / GS_NB * GS_NB, ldw = np + GS_BORDER;
         const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0;
         int have = 0;
         for (int q = 0; q < std::min(S, ctx->n_slots_ready); ++q)
-            if (ctx->slots[q].ws && ctx->slots[q].ws->n == ctx->nX) ++have;
+            if (ctx->slots[q].ws && ctx->slots[q].ws->n == ctx->in->n) ++have;
         size_t free_b = 0, total_b = 0;
         GS_CHECK(hipMemGetInfo(&free_b, &total_b));
         const int can_add = (int)std::min<double>(1e6, 0.8 * (double)free_b / ws_bytes);
@@ -1123,12 +1253,19 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
     return rc;
 }
 
+int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                      double* G_out, double* sld_out, int64_t* info_out) {
+    if (!ctx) return -2;
+    return gs_lml_on(ctx, &ctx->res, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+}
+
 int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
                    int32_t d, const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out,
                    int64_t* info_out) {
-    int rc = gsum_set_inputs(ctx, X, n, d, RHS, k);
+    if (!ctx) return -2;
+    int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
     if (rc) return rc;
-    return gsum_lml_resident(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    return gs_lml_on(ctx, &ctx->op, kernels, n_kernels, nugget, G_out, sld_out, info_out);
 }
 
 // Gradient pieces on top of one fused evaluation (see include/gsum_hip.h).  After the factorisation the workspace
@@ -1147,8 +1284,9 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
         if (params[p].code < GSUM_GRAD_AMPLITUDE || params[p].code > GSUM_GRAD_ADDITIVE) GS_FAIL("unknown gradient parameter code");
         if (params[p].code == GSUM_GRAD_LENGTH_DIM && (params[p].dim < 0 || params[p].dim >= d)) GS_FAIL("gradient parameter dim out of range");
     }
-    int rc = gsum_set_inputs(ctx, X, n, d, RHS, k);
+    int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
     if (rc) return rc;
+    ctx->in = &ctx->op;
     if (gs_check_desc(ctx, desc, d)) return -2;
     gs_slot* sl = &ctx->slots[0];
     ctx->cur = sl;
@@ -1196,7 +1334,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     gs_grad_params prm;
     memset(&prm, 0, sizeof prm);
     for (int p = 0; p < P; ++p) prm.p[p] = params[p];
-    hipLaunchKernelGGL(k_grad_contract, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->dX, (int)n, (int)d, *desc,
+    hipLaunchKernelGGL(k_grad_contract, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
     GS_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_grad_reduce1, dim3((unsigned)chunks, (unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, rows_per, part);
@@ -1227,22 +1365,35 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
     return 0;
 }
 
-int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
-    if (!ctx || !total_ms || !total_flops || !launches) return -2;
+int gsum_kernel_profile(gsum_ctx* ctx, double* ms5, double* flops5, int64_t* launches5) {
+    if (!ctx || !ms5 || !flops5 || !launches5) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
     GS_CHECK(hipDeviceSynchronize());
-    double ms_sum = 0.0, fl_sum = 0.0;
+    for (int c = 0; c < GS_PROF_CLASSES; ++c) {
+        ms5[c] = flops5[c] = 0.0;
+        launches5[c] = 0;
+    }
     for (auto& r : ctx->prof_recs) {
         float ms = 0.f;
         GS_CHECK(hipEventElapsedTime(&ms, ctx->prof_pool[r.e0], ctx->prof_pool[r.e1]));
-        ms_sum += ms;
-        fl_sum += r.flops;
+        ms5[r.cls] += ms;
+        flops5[r.cls] += r.flops;
+        launches5[r.cls] += 1;
     }
-    *total_ms = ms_sum;
-    *total_flops = fl_sum;
-    *launches = (int64_t)ctx->prof_recs.size();
     ctx->prof_recs.clear();
     ctx->prof_next = 0;
+    return 0;
+}
+
+int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
+    if (!ctx || !total_ms || !total_flops || !launches) return -2;
+    double ms5[GS_PROF_CLASSES], fl5[GS_PROF_CLASSES];
+    int64_t n5[GS_PROF_CLASSES];
+    const int rc = gsum_kernel_profile(ctx, ms5, fl5, n5);
+    if (rc) return rc;
+    *total_ms = ms5[GS_PROF_BULK];
+    *total_flops = fl5[GS_PROF_BULK];
+    *launches = n5[GS_PROF_BULK];
     return 0;
 }
 

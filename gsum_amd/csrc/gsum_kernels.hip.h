@@ -1384,6 +1384,88 @@ __global__ __launch_bounds__(256) void k_rowsumsq(const double* B, int64_t ldb, 
     if (lane == 0) out[row] = s;
 }
 
+// ---- back-substitution half of cho_solve (models.py:479): x^T L = w^T on the 16 border rows, right-looking from the
+// last block column to the first.  Rows = right-hand sides (16), columns = points; everything on the matrix cores
+// straight from global memory (the factor is read exactly once: HBM-bound, 4 n^2 bytes).
+// One 16 x 128 panel times a 128 x 128 row-major matrix:  out[a][j] = sum_k P[a][k] M[k][j].  P comes from LDS
+// (16 rows, stride 129), M from global memory (leading dimension ldm); wave w owns columns [32 w, 32 w + 32).
+__device__ __forceinline__ void gs_panel_times_block(const double* P, const double* M, int64_t ldm, gs_d4 (&o)[2], int w, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    o[0] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+    o[1] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+    for (int s4 = 0; s4 < 32; ++s4) {
+        const int kk = 4 * s4 + fq;
+        const double av = P[fr * 129 + kk];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double bv = M[(int64_t)kk * ldm + (2 * w + h) * 16 + fr];
+            o[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o[h], 0, 0, 0);
+        }
+    }
+}
+
+// X_c^T = W_c^T L_cc^-1 for the LAST block column (c0 = its first column), in place on the border rows.
+__global__ __launch_bounds__(256) void k_back_first(double* Brow, int64_t ld, const double* Linv, int c0) {
+    __shared__ double P[16 * 129];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int idx = t; idx < 16 * 128; idx += 256) P[(idx >> 7) * 129 + (idx & 127)] = Brow[(int64_t)(idx >> 7) * ld + c0 + (idx & 127)];
+    __syncthreads();
+    gs_d4 o[2];
+    gs_panel_times_block(P, Linv, 128, o, w, lane);
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + c0 + (2 * w + h) * 16 + fr] = o[h][x];
+}
+
+// Step c (block column c holds the finished X_c^T): workgroup g < c subtracts X_c^T L[c rows, g cols] from W_g^T; the
+// workgroup of block column c - 1 then finishes it, X_{c-1}^T = W_{c-1}^T L_{c-1,c-1}^-1 (nothing else touches it later).
+__global__ __launch_bounds__(256) void k_back_step(const double* A, int64_t ld, double* Brow, const double* Linv, int c) {
+    __shared__ double P[16 * 129];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = blockIdx.x, c0 = c * 128, g0 = g * 128;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int idx = t; idx < 16 * 128; idx += 256) P[(idx >> 7) * 129 + (idx & 127)] = -Brow[(int64_t)(idx >> 7) * ld + c0 + (idx & 127)];
+    gs_d4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[h][x] = Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr];
+    __syncthreads();
+    const double* Lblk = A + (int64_t)c0 * ld + g0;                 // rows of block c, columns of block g
+    for (int s4 = 0; s4 < 32; ++s4) {
+        const int kk = 4 * s4 + fq;
+        const double av = P[fr * 129 + kk];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double bv = Lblk[(int64_t)kk * ld + (2 * w + h) * 16 + fr];
+            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[h], 0, 0, 0);
+        }
+    }
+    if (g != c - 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr] = acc[h][x];
+        return;
+    }
+    __syncthreads();                                                // every wave is done reading P
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) P[(fq + 4 * x) * 129 + (2 * w + h) * 16 + fr] = acc[h][x];
+    __syncthreads();
+    gs_d4 o[2];
+    gs_panel_times_block(P, Linv + (size_t)g * 128 * 128, 128, o, w, lane);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr] = o[h][x];
+}
+
 // Mirror the lower triangle into the upper one / zero the upper one, into a dense n x n buffer.
 __global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int n, double* out, int zero_upper) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -1628,6 +1710,12 @@ __global__ __launch_bounds__(256) void k_probe_store(gs_d2* out, int64_t nvec) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     gs_d2 v = {1.0, 2.0};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) out[i] = v;
+}
+
+// one wave spinning for `ticks` of the 100 MHz real-time counter: the queue-concurrency probe (gs_probe_queues)
+__global__ __launch_bounds__(64) void k_probe_spin(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
 // diagnostic: where does each workgroup run?  out[2b] = XCC id, out[2b+1] = HW_ID register (CU / SH / SE fields)

@@ -53,17 +53,22 @@ def describe_kernel(kernel, n_features: int) -> KernelDesc:
         if isinstance(term, ConstantKernel):
             desc.additive_const += float(term.constant_value)
             continue
+        factors = _product_factors(term)
+        if all(isinstance(f, ConstantKernel) for f in factors):
+            # a product of constants is one additive constant (C(2) * C(3) adds 6 everywhere): no stationary part
+            desc.additive_const += float(np.prod([f.constant_value for f in factors]))
+            continue
         if base is not None:
             raise NotImplementedError(f"sum of two stationary kernels is not supported on the device: {kernel}")
         amp = 1.0
-        for f in _product_factors(term):
+        for f in factors:
             if isinstance(f, ConstantKernel):
                 amp *= float(f.constant_value)
             elif isinstance(f, (RBF, Matern)) and base is None:
                 base = f
             else:
                 raise NotImplementedError(f"kernel factor {f!r} is not supported on the device (in {kernel})")
-        desc.amplitude = amp
+        desc.amplitude = amp                 # only the term that supplied the stationary base sets the amplitude
     if base is None:
         raise NotImplementedError(f"kernel {kernel} has no RBF/Matern part")
     if isinstance(base, Matern):        # Matern subclasses RBF: test it first
@@ -107,7 +112,13 @@ def describe_gradient(kernel, n_features: int):
             if not term.hyperparameter_constant_value.fixed:
                 out.append(gp(GradParam.ADDITIVE, weight=term.constant_value))
             continue
-        for f in _product_factors(term):
+        factors = _product_factors(term)
+        if all(isinstance(f, ConstantKernel) for f in factors):
+            # d (c1 c2 ...) / d log c_i = the whole product, for every free factor
+            value = float(np.prod([f.constant_value for f in factors]))
+            out.extend(gp(GradParam.ADDITIVE, weight=value) for f in factors if not f.hyperparameter_constant_value.fixed)
+            continue
+        for f in factors:
             if isinstance(f, ConstantKernel):
                 if not f.hyperparameter_constant_value.fixed:
                     out.append(gp(GradParam.AMPLITUDE))

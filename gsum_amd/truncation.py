@@ -191,15 +191,21 @@ class TruncationGP:
         coeff_log_like = result[0] if eval_gradient else result
         return coeff_log_like - det_factor
 
-    def log_marginal_likelihood_grid(self, thetas, ratio_kws_list, X=None, y=None, orders=None, mode="full",
+    def log_marginal_likelihood_grid(self, thetas, ratio_kws_list, scales=None, X=None, y=None, orders=None, mode="full",
                                      shard=None):
-        """Likelihood surface over (ratio settings) x (thetas): ``out[i, j]`` equals
-        ``self.log_marginal_likelihood(thetas[j], **ratio_kws_list[i])``.
+        """Likelihood surface over (ratio settings) x (thetas) [x (prior scales)].
+
+        ``scales=None``: ``out[i, j]`` equals ``self.log_marginal_likelihood(thetas[j], **ratio_kws_list[i])``.
+        ``scales=[cbar_0, ...]``: ``out[i, j, s]`` is the same call on a process whose prior is ``sd=scales[s]``
+        (``df0 = inf, scale0 = cbar``: models.py:115-117, 419-422 -- the only way the reference makes cbar a free
+        axis), every other constructor argument unchanged: the (cbar, ratio) scan of BASELINE config 4 is
+        ``log_marginal_likelihood_grid([theta], ratios, scales=cbars)[:, 0, :]``.
 
         mode="full"   every grid point runs kernel build + Cholesky + solve, like the reference's
-                      nested loop (notebook :1457-1459) — the throughput-comparable mode;
+                      nested loop (notebook :1457-1459) -- the throughput-comparable mode;
         mode="reuse"  one factorisation per theta: all ratio settings share it and only the k-column
-                      forward solve is repeated (never mixed into "full" throughput numbers).
+                      forward solve is repeated; a prior scale only enters the O(k^2) host algebra
+                      (never mixed into "full" throughput numbers).
         ``shard=(rank, world)`` evaluates only this rank's slice of the flattened grid and leaves the
         rest NaN (see gsum_amd.grid for the torch.distributed gather).
         """
@@ -211,11 +217,23 @@ class TruncationGP:
         base = gp._active_kernel()
         ctx = gp._context()
         ni, nj = len(ratio_kws_list), len(thetas)
-        out = np.full((ni, nj), np.nan)
+        if scales is None:
+            ns, scale_vals = 1, None
+        else:
+            scale_vals = np.atleast_1d(np.asarray(scales, dtype=float))
+            if scale_vals.ndim != 1 or scale_vals.size == 0:
+                raise ValueError('scales must be a non-empty 1d sequence of prior standard deviations')
+            ns = scale_vals.size
+        out = np.full((ni, nj, ns), np.nan)
         from .grid import shard_range
-        lo, hi = shard_range(ni * nj, *(shard or (0, 1)))
+        lo, hi = shard_range(ni * nj * ns, *(shard or (0, 1)))
+
+        def shaped(a):
+            return a if scales is not None else a[:, :, 0]
+
         if hi <= lo:
-            return out
+            return shaped(out)
+        n_pts = Xd.shape[0]
         prep = {}
 
         def rhs_for(i):
@@ -226,39 +244,43 @@ class TruncationGP:
                 prep[i] = (gp._rhs(Xd, coeffs), det)
             return prep[i]
 
-        def finish(i, j, G, sld, info):
-            if info != 0:
-                return -np.inf
-            lml, _ = gp._lml_gram(G, sld, Xd.shape[0])
-            return lml - rhs_for(i)[1]
+        def lml_values(G, sld, svals):
+            """Host algebra for a stack of Gram matrices; ``svals[b]`` is the prior scale of entry b (None: the
+            process's own prior)."""
+            if scale_vals is None:
+                return gp._lml_gram_batch(G, sld, n_pts)
+            return gp._lml_gram_batch_sd(G, sld, n_pts, svals)
+
+        desc_of = {}                # one descriptor per theta (clone_with_theta is the slow host step)
+
+        def desc_for(j):
+            if j not in desc_of:
+                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
+                desc_of[j] = describe_kernel(kern, Xd.shape[1])
+            return desc_of[j]
 
         if mode == "full":
             # group this rank's points by ratio setting: they share the right-hand sides, so X and Z go to the
-            # device once per row and the thetas of the row run as ONE pipelined batch (several evaluations
-            # in flight on the GPU); every point still does its own kernel build + Cholesky + solve
+            # device once per row and the (theta, scale) points of the row run as ONE pipelined batch (several
+            # evaluations in flight on the GPU); every point still does its own kernel build + Cholesky + solve
             rows = {}
             for flat in range(lo, hi):
-                i, j = divmod(flat, nj)
-                rows.setdefault(i, []).append(j)
-            desc_of = {}                # one descriptor per theta (clone_with_theta is the slow host step)
-
-            def desc_for(j):
-                if j not in desc_of:
-                    kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
-                    desc_of[j] = describe_kernel(kern, Xd.shape[1])
-                return desc_of[j]
-
-            for i, js in rows.items():
+                i, rest = divmod(flat, nj * ns)
+                rows.setdefault(i, []).append(divmod(rest, ns))
+            for i, pts in rows.items():
                 Zi, det = rhs_for(i)
                 ctx.set_inputs(Xd, Zi)
-                G, sld, info = ctx.lml_resident([desc_for(j) for j in js], gp.nugget)
-                vals = gp._lml_gram_batch(G, sld, Xd.shape[0]) - det
-                out[i, js] = np.where(info != 0, -np.inf, vals)
+                G, sld, info = ctx.lml_resident([desc_for(j) for j, _ in pts], gp.nugget)
+                svals = None if scale_vals is None else scale_vals[[s for _, s in pts]]
+                vals = np.where(info != 0, -np.inf, lml_values(G, sld, svals) - det)
+                for (j, s), v in zip(pts, vals):
+                    out[i, j, s] = v
         elif mode == "reuse":
             by_theta = {}
             for flat in range(lo, hi):
-                i, j = divmod(flat, nj)
-                by_theta.setdefault(j, []).append(i)
+                i, rest = divmod(flat, nj * ns)
+                j, s = divmod(rest, ns)
+                by_theta.setdefault(j, {}).setdefault(i, []).append(s)
             # A constant ratio only rescales the coefficient curves order by order, c_n(q) = c_n(q0) (q0 / q)^n
             # (helpers.py:101-106), so G(q) = D G(q0) D with D = diag((q0 / q)^orders, 1) (SURVEY.md App. A.4): the
             # whole ratio axis of a theta then costs ONE forward solve.  Position-dependent ratios solve per setting.
@@ -274,14 +296,13 @@ class TruncationGP:
                 return const_ratio[i]
 
             for j, rows in by_theta.items():
-                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
-                L = ctx.kernel_matrix_dev(describe_kernel(kern, Xd.shape[1]), Xd, diag_add=gp.nugget)
+                L = ctx.kernel_matrix_dev(desc_for(j), Xd, diag_add=gp.nugget)
                 try:
                     info = ctx.potrf(L)
                     anchor = None                                   # (ratio, G, sld) of the first constant-ratio row
-                    for i in rows:
+                    for i, ss in rows.items():
                         if info != 0:
-                            out[i, j] = -np.inf
+                            out[i, j, ss] = -np.inf
                             continue
                         q = ratio_const(i)
                         if q is not None and anchor is not None:
@@ -292,12 +313,14 @@ class TruncationGP:
                             G, sld = ctx.forward_gram(L, rhs_for(i)[0])
                             if q is not None:
                                 anchor = (q, G, sld)
-                        out[i, j] = finish(i, j, G, sld, 0)
+                        svals = None if scale_vals is None else scale_vals[ss]
+                        Gs = np.broadcast_to(G, (len(ss),) + G.shape)
+                        out[i, j, ss] = lml_values(Gs, np.full(len(ss), sld), svals) - rhs_for(i)[1]
                 finally:
                     L.free()
         else:
             raise ValueError('mode must be "full" or "reuse"')
-        return out
+        return shaped(out)
 
 
 class TruncationTP(TruncationGP):

@@ -94,6 +94,11 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
  * "release_scratch" (any value: free the grown work buffers and the per-slot workspace matrices now).
  * <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
+/* read back: "batch_slots", "lookahead", "bulk_cfg", and the queue-concurrency probe that runs before the first batch
+ * wanting more than 4 evaluations in flight -- "queue_probe_streams" (0: not run yet), "queue_probe_concurrency_x100"
+ * (streams x spin time / elapsed, x 100), "queue_probe_fell_back" (the slot count that was refused: the batch then runs
+ * 3 in flight, the optimum on the runtime's default 4 hardware queues).  -1 for an unknown name. */
+int64_t gsum_get_option(gsum_ctx* ctx, const char* name);
 
 /* ---- operator level (one reference call each) ------------------------------------------------- */
 
@@ -123,6 +128,12 @@ int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, 
 /* W = L^-1 RHS (n x k host, k <= GSUM_MAX_RHS): the forward half of scipy.linalg.cho_solve
  * (models.py:479); with gsum_predict_terms it replaces the solve at models.py:831. */
 int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* W);
+
+/* X = scipy.linalg.cho_solve((L, True), B) = L^-T (L^-1 B) for a factorised matrix: both triangular solves of
+ * solve_sqrt(sqrt_R, y, 'cholesky') (models.py:460-479; call sites :217, 269, 432, 438, 439, 1032).  B, X: n x k host,
+ * row-major, k <= GSUM_MAX_RHS (the product classes never need it -- they read the Gram matrix of the forward half --
+ * but a caller-side solve_sqrt binds to it). */
+int gsum_cho_solve(gsum_ctx* ctx, gsum_mat* L, const double* B, int64_t n, int32_t k, double* X);
 
 /* out = L Z (n x k, k <= GSUM_MAX_RHS) for a factorised matrix: the transform y = mean + L z that turns standard
  * normal draws into draws from N(mean, L L^T).  Replaces the n x n SVD / eigendecomposition inside
@@ -187,6 +198,9 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
  * factors it, solves and reduces, hundreds of evaluations per launch.  128 < n <= 4096 with many evaluations per
  * call does the same with the matrix of each evaluation in its own HBM scratch (one CU per evaluation). */
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
+/* shape of the resident inputs (zeros before the first gsum_set_inputs).  Only gsum_set_inputs writes them: every other
+ * entry point, gsum_lml_batch and gsum_lml_grad included, uploads into buffers of its own. */
+int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k);
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out);
 
@@ -202,6 +216,12 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
  * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
  * call, and resets the record. */
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
+/* The same record for every kernel class of the fused path, five entries each: [0] kernel-matrix build, [1] diagonal
+ * blocks (k_potrf_diag), [2] panel GEMMs (TRSM against the block inverse, sibling and look-ahead columns, border rows),
+ * [3] the bulk trailing update (what gsum_gemm_profile returns), [4] the rest (border set-up, diagonal save, read-out).
+ * Durations are summed per launch, on the stream of the launch: with several evaluations in flight they overlap, so
+ * the sum over classes is bounded by (evaluations in flight) x (wall time), not by the wall time.  Resets the record. */
+int gsum_kernel_profile(gsum_ctx* ctx, double* ms5, double* flops5, int64_t* launches5);
 /* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64, operands in registers, waves_per_simd resident
  * waves on every SIMD, n_acc independent accumulators per wave; n_acc = 1 gives the dependent latency):
  * out3 = {achieved TFLOP/s, shader cycles per MFMA per wave, in-kernel clock GHz}. */

@@ -29,6 +29,7 @@ __all__ = [
     "posterior_center", "posterior_disp", "posterior_df", "posterior_scale_sq",
     "cov_factor", "cgp_lml", "trunc_lml", "cgp_fit", "cgp_predict", "lml_grid",
     "trunc_mean", "trunc_cov", "trunc_basis", "trunc_predict_trunc", "cgp_prior_predict",
+    "cbar_ratio_grid", "cbar_ratio_grid_one_factor",
 ]
 
 
@@ -245,6 +246,67 @@ def lml_grid(kernel, thetas, ratios, X, y, orders, ref=1, excluded=None, **prior
             out[i, j] = trunc_lml(kernel, np.atleast_1d(th), X, y, orders,
                                   ratio=q, ref=ref, excluded=excluded, **priors)
     return out
+
+
+def cbar_ratio_grid(kernel, theta, X, y, orders, ratios, cbars, ref=1, excluded=None, center=0, disp=0,
+                    nugget=1e-10):
+    """BASELINE config 4 spelled the way the reference would: out[a, b] = one full
+    TruncationGP(sd=cbars[b], ...).log_marginal_likelihood(theta, ratio=ratios[a]) call (models.py:115-117 makes
+    ``sd`` the prior df0 = inf, scale0 = sd; :419-422 then fixes scale^2 = sd^2)."""
+    out = np.empty((len(ratios), len(cbars)))
+    for a, q in enumerate(ratios):
+        for b, cbar in enumerate(cbars):
+            out[a, b] = trunc_lml(kernel, theta, X, y, orders, ratio=q, ref=ref, excluded=excluded,
+                                  center=center, disp=disp, sd=cbar, nugget=nugget)
+    return out
+
+
+def cbar_ratio_grid_one_factor(kernel, theta, X, y, orders, ratios, cbars, ref=1, excluded=None, center=0,
+                               disp=0, nugget=1e-10, return_scale=False):
+    """The same surface from ONE Cholesky factorisation, for checking large grids in seconds instead of hours.
+
+    Every grid point shares R = kernel_theta(X) + nugget I (models.py:958-969 depend on theta only).  With
+    sd = cbar the likelihood terms of models.py:1007-1039 are, per curve k,
+        -1/2 (c_k - B eta)^T R^-1 (c_k - B eta) / cbar^2 - 1/2 (N log cbar^2 + 2 sum log L_ii) - N/2 log 2 pi,
+    with c = coefficients(y, ratio, ref, orders) (helpers.py:98-100) and eta from compute_center (:199-220);
+    the truncation layer subtracts the Jacobian of models.py:1503-1506.  The triangular solves are redone for
+    every ratio (no rescaling identity is assumed), only the factor is shared.  Returns -inf everywhere if the
+    factorisation fails (models.py:970-972).  ``return_scale=True`` also returns, per entry, the sum of the magnitudes
+    of the terms the value is the signed sum of (quadratic form, log-determinant, constants, Jacobian): near the
+    maximum of the surface these cancel to a small number, and a comparison tolerance must be relative to them."""
+    orders = np.asarray(orders)
+    n = X.shape[0]
+    center0, disp0 = np.atleast_1d(center), np.atleast_2d(disp)
+    k = kernel.clone_with_theta(np.asarray(theta, dtype=float)) if theta is not None else kernel
+    R = k(X)
+    R[np.diag_indices_from(R)] += nugget
+    out = np.empty((len(ratios), len(cbars)))
+    mag = np.empty_like(out)
+    try:
+        L = cholesky(R)
+    except np.linalg.LinAlgError:
+        out[:] = -np.inf
+        return (out, np.ones_like(out)) if return_scale else out
+    sld = np.log(np.diag(L)).sum()
+    basis = _ones_basis(X)
+    ref_v = ref * np.ones(n) if np.ndim(ref) == 0 else np.asarray(ref)
+    mask = ~np.isin(orders, excluded)
+    orders_in = orders[mask]
+    n_in = len(orders_in)
+    for a, q in enumerate(ratios):
+        ratio_v = q * np.ones(n)
+        c = coefficients(y, ratio_v, ref_v, orders)[:, mask]
+        eta = posterior_center(c, L, basis, center0, disp0)
+        resid = c - (basis @ eta)[:, None]
+        quad = np.einsum("ik,ik->", resid, _rsolve(L, resid))
+        det = np.sum(n_in * np.log(np.abs(ref_v)) + np.sum(orders_in) * np.log(np.abs(ratio_v)))
+        for b, cbar in enumerate(cbars):
+            var = cbar ** 2
+            out[a, b] = (-0.5 * quad / var - 0.5 * n_in * (n * np.log(var) + 2.0 * sld)
+                         - n_in * n / 2 * np.log(2 * np.pi)) - det
+            mag[a, b] = (0.5 * quad / var + 0.5 * n_in * (abs(n * np.log(var)) + abs(2.0 * sld))
+                         + n_in * n / 2 * np.log(2 * np.pi) + abs(det))
+    return (out, mag) if return_scale else out
 
 
 # --------------------------------------------------------------------------

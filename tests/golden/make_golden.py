@@ -533,7 +533,92 @@ def gen_nonpd():
     return dict(X=L(X), y=L(y), lml_is_neg_inf=bool(np.isneginf(v)), fit_raises_linalgerror=raised)
 
 
+def gen_classmethods():
+    """The reference's public classmethod surface (models.py:170-503) on a host Cholesky factor: values and the
+    eval_gradient=True outputs, for a one- and a two-column basis and both dispersion regimes."""
+    rng = np.random.RandomState(77)
+    n = 18
+    X = np.sort(rng.rand(n))[:, None] * 4.0
+    kern = C(1.3) * RBF(0.5)
+    R, dR = kern(X, eval_gradient=True)
+    R[np.diag_indices_from(R)] += 1e-6
+    chol = np.linalg.cholesky(R)
+    y = rng.randn(n, 3) + 0.2
+    out = dict(X=L(X), y=L(y), kernel=dict(amplitude=1.3, length_scale=0.5), nugget=1e-6, cases=[])
+    cgp = gsum.ConjugateGaussianProcess
+    for basis, center0, disp0 in (
+            (np.ones((n, 1)), np.array([0.3]), np.array([[2.0]])),
+            (np.ones((n, 1)), np.array([-0.2]), np.array([[0.0]])),
+            (np.concatenate([np.ones((n, 1)), X], axis=1), np.array([0.3, -0.2]), np.array([[2.0, 0.3], [0.3, 1.0]]))):
+        for df0, scale0 in ((3.0, 1.5), (np.inf, 0.7)):
+            c, dc = cgp.compute_center(y, chol, basis, center0, disp0, 'cholesky', eval_gradient=True, dR=dR)
+            V, dV = cgp.compute_disp(y, chol, basis, disp0, 'cholesky', eval_gradient=True, dR=dR)
+            df, ddf = cgp.compute_df(y, df0, eval_gradient=True, dR=dR)
+            s2, ds2 = cgp.compute_scale_sq(y, chol, basis, center0, disp0, df0, scale0, 'cholesky',
+                                           eval_gradient=True, dR=dR)
+            out["cases"].append(dict(
+                basis_cols=int(basis.shape[1]), center0=L(center0), disp0=L(disp0),
+                df0=("inf" if np.isinf(df0) else df0), scale0=scale0,
+                center=L(c), d_center=L(dc), disp=L(V), d_disp=L(dV), df=float(df), d_df=L(ddf),
+                scale_sq=float(s2), d_scale_sq=L(ds2),
+                cov_factor=float(cgp.compute_cov_factor(s2, df)),
+                center_1d_y=L(cgp.compute_center(y[:, 0], chol, basis, center0, disp0, 'cholesky')),
+                scale_sq_1d_y=float(cgp.compute_scale_sq(y[:, 0], chol, basis, center0, disp0, df0, scale0, 'cholesky'))))
+    B = rng.randn(n, 4)
+    w, Q = np.linalg.eigh(R)
+    out["solve_sqrt"] = dict(B=L(B), chol=L(cgp.solve_sqrt(chol, B, 'cholesky')),
+                             eig_tuple=L(cgp.solve_sqrt((w, Q), B, 'eig')),
+                             eig_sqrt=L(cgp.solve_sqrt(Q * np.sqrt(w), B, 'eig')),
+                             vec=L(cgp.solve_sqrt(chol, B[:, 0], 'cholesky')))
+    out["num_y"] = [int(cgp.num_y(y)), int(cgp.num_y(y[:, 0]))]
+    out["avg_y"] = L(cgp.avg_y(y))
+    return out
+
+
+def gen_cbar_ratio_grid():
+    """BASELINE config 4 in miniature: the (cbar, ratio) likelihood surface, cbar realised the only way the reference
+    allows (sd=cbar: df0 = inf, scale0 = cbar; models.py:115-117, 419-422), every entry one call of
+    TruncationGP.log_marginal_likelihood.  Coefficients are drawn from the GP with cbar = 1, ratio = 0.5, so the
+    maximum is interior.  Also an (ell, ratio) strip with the default prior."""
+    n, r = 192, 5
+    X = 0.1 * np.arange(n)[:, None]
+    K = RBF(0.2)(X)
+    K[np.diag_indices_from(K)] += 1e-10
+    c = np.linalg.cholesky(K) @ np.random.RandomState(5).randn(n, r)
+    y = gsum.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+    cbars = np.geomspace(0.25, 4, 9)
+    ratios = np.linspace(0.3, 0.7, 9)
+    theta = np.log([0.2])
+    grid = np.empty((len(ratios), len(cbars)))
+    for b, cbar in enumerate(cbars):
+        gp = gsum.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, sd=cbar, optimizer=None)
+        gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
+        for a, q in enumerate(ratios):
+            grid[a, b] = gp.log_marginal_likelihood(theta=theta, ratio=q)
+    ells = np.linspace(0.12, 0.3, 7)
+    gp = gsum.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
+    strip = np.array([[gp.log_marginal_likelihood(theta=np.log([e]), ratio=q) for e in ells] for q in ratios])
+    return dict(n=n, r=r, dx=0.1, length_scale=0.2, nugget=1e-10, seed=5,
+                recipe="c = cholesky(RBF(0.2)(X) + 1e-10 I) @ RandomState(5).randn(n, r); y = partials(c, 0.5, 1.0)",
+                cbars=L(cbars), ratios=L(ratios), grid_ratio_by_cbar=L(grid),
+                argmax=[int(v) for v in np.unravel_index(np.argmax(grid), grid.shape)],
+                ells=L(ells), strip_ratio_by_ell=L(strip),
+                strip_argmax=[int(v) for v in np.unravel_index(np.argmax(strip), strip.shape)])
+
+
 def main():
+    only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
+    if only:
+        gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid)
+        for name in only:
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(gens[name](), f, indent=1)
+        return
+    with open(os.path.join(HERE, "classmethods.json"), "w") as f:
+        json.dump(gen_classmethods(), f, indent=1)
+    with open(os.path.join(HERE, "cbar_ratio_grid.json"), "w") as f:
+        json.dump(gen_cbar_ratio_grid(), f, indent=1)
     out = {}
     out["helpers"] = gen_helpers()
     out["cgp"] = gen_cgp_cases()

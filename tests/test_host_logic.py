@@ -216,3 +216,93 @@ def test_series_scale_struct_and_student_host_algebra():
         got, _ = student_lml_from_gram(G, sld, 12, np.array([0.2]), np.array([[disp]]), 3.0, 1.1)
         want = orc.csp_lml(kern, None, X, y, center=0.2, disp=disp, df=3.0, scale=1.1)
         assert got == pytest.approx(want, rel=1e-9)
+
+
+def _classmethod_case_inputs(g):
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C
+    X, y = np.array(g["X"]), np.array(g["y"])
+    kern = C(g["kernel"]["amplitude"]) * RBF(g["kernel"]["length_scale"])
+    R, dR = kern(X, eval_gradient=True)
+    R[np.diag_indices_from(R)] += g["nugget"]
+    return X, y, np.linalg.cholesky(R), dR, R
+
+
+def test_reference_classmethod_surface_against_reference():
+    """SURVEY.md 8(b) 'Python surface to preserve', name by name: the compute_* / solve_sqrt / num_y / avg_y classmethods
+    with the reference's signatures (models.py:170-503, 601-628), on a host factor, against outputs of the reference
+    itself (tests/golden/classmethods.json)."""
+    from conftest import load_golden
+    g = load_golden("classmethods.json")
+    X, y, chol, dR, R = _classmethod_case_inputs(g)
+    n = len(X)
+    for cls in (gsum_amd.ConjugateGaussianProcess, gsum_amd.ConjugateStudentProcess):
+        for name in ("compute_center", "compute_disp", "compute_df", "compute_scale_sq", "compute_cov_factor",
+                     "solve_sqrt", "num_y", "avg_y"):
+            assert callable(getattr(cls, name)), name
+    cgp = gsum_amd.ConjugateGaussianProcess
+    for case in g["cases"]:
+        basis = np.ones((n, 1)) if case["basis_cols"] == 1 else np.concatenate([np.ones((n, 1)), X], axis=1)
+        center0, disp0 = np.array(case["center0"]), np.array(case["disp0"])
+        df0 = np.inf if case["df0"] == "inf" else case["df0"]
+        scale0 = case["scale0"]
+        c, dc = cgp.compute_center(y, chol, basis, center0, disp0, 'cholesky', eval_gradient=True, dR=dR)
+        V, dV = cgp.compute_disp(y, chol, basis, disp0, 'cholesky', eval_gradient=True, dR=dR)
+        df, ddf = cgp.compute_df(y, df0, eval_gradient=True, dR=dR)
+        s2, ds2 = cgp.compute_scale_sq(y, chol, basis, center0, disp0, df0, scale0, 'cholesky', eval_gradient=True, dR=dR)
+        for got, key in ((c, "center"), (dc, "d_center"), (V, "disp"), (dV, "d_disp"), (ddf, "d_df"), (ds2, "d_scale_sq")):
+            want = np.array(case[key])
+            assert np.shape(got) == want.shape, key
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=key)
+        assert df == case["df"]
+        assert s2 == pytest.approx(case["scale_sq"], rel=1e-10)
+        assert cgp.compute_cov_factor(s2, df) == pytest.approx(case["cov_factor"], rel=1e-10)
+        # value-only calls, 1-D y, keyword form as the reference's own callers use them (models.py:1001-1002)
+        np.testing.assert_allclose(cgp.compute_center(y=y[:, 0], sqrt_R=chol, basis=basis, center0=center0, disp0=disp0,
+                                                      decomposition='cholesky'), case["center_1d_y"], rtol=1e-9)
+        assert cgp.compute_scale_sq(y=y[:, 0], sqrt_R=chol, basis=basis, center0=center0, disp0=disp0, df0=df0,
+                                    scale0=scale0, decomposition='cholesky') == pytest.approx(case["scale_sq_1d_y"], rel=1e-10)
+        with pytest.raises(ValueError):
+            cgp.compute_disp(y, chol, basis, disp0, 'cholesky', eval_gradient=True)       # dR missing (models.py:263)
+    ss = g["solve_sqrt"]
+    B = np.array(ss["B"])
+    w, Q = np.linalg.eigh(R)
+    np.testing.assert_allclose(cgp.solve_sqrt(chol, B, 'cholesky'), ss["chol"], rtol=1e-9)
+    np.testing.assert_allclose(cgp.solve_sqrt(chol, B[:, 0], 'cholesky'), ss["vec"], rtol=1e-9)
+    np.testing.assert_allclose(cgp.solve_sqrt((w, Q), B, 'eig'), ss["eig_tuple"], rtol=1e-6)
+    np.testing.assert_allclose(cgp.solve_sqrt(Q * np.sqrt(w), B, 'eig'), ss["eig_sqrt"], rtol=1e-6)
+    with pytest.raises(ValueError):
+        cgp.solve_sqrt(chol, B, 'lu')                                                     # models.py:477
+    assert [cgp.num_y(y), cgp.num_y(y[:, 0])] == g["num_y"]
+    np.testing.assert_allclose(cgp.avg_y(y), g["avg_y"], rtol=1e-14)
+
+
+def test_constant_only_product_terms_are_additive():
+    """A Product with no stationary factor is an additive constant (advisor finding, round 1): C(2) * C(3) adds 6
+    everywhere and must not overwrite the amplitude of the stationary term."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    d = gsum_amd.describe_kernel(RBF(0.3) + C(2.0) * C(3.0), 1)
+    assert (d.amplitude, d.additive_const) == (1.0, 6.0)
+    d = gsum_amd.describe_kernel(C(2.0) * C(3.0) + C(1.5) * RBF(0.3) + WhiteKernel(0.1), 1)
+    assert (d.amplitude, d.additive_const, d.white_noise) == (1.5, 6.0, 0.1)
+    from gsum_amd.kernels import describe_gradient
+    from gsum_amd._lib import GradParam
+    k = C(1.5) * RBF(0.3) + C(2.0) * C(3.0, constant_value_bounds="fixed")
+    gp = describe_gradient(k, 1)
+    assert [p.code for p in gp] == [GradParam.AMPLITUDE, GradParam.LENGTH_ISO, GradParam.ADDITIVE]
+    assert gp[2].weight == 6.0
+    X = np.linspace(0, 1, 5)[:, None]
+    K, dK = k(X, eval_gradient=True)
+    np.testing.assert_allclose(dK[:, :, 2], 6.0)            # d (c1 c2) / d log c1 = c1 c2 everywhere
+    with pytest.raises(NotImplementedError):
+        gsum_amd.describe_kernel(C(2.0) * C(3.0), 1)
+
+
+def test_importing_the_package_leaves_the_environment_alone():
+    """GPU_MAX_HW_QUEUES is the application's decision (gsum_amd.configure_runtime), not an import side effect."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import gsum_amd; "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; assert gsum_amd.configure_runtime(16); "
+            "assert os.environ['GPU_MAX_HW_QUEUES'] == '16'; assert not gsum_amd.configure_runtime(32); "
+            "assert os.environ['GPU_MAX_HW_QUEUES'] == '16'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

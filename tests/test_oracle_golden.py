@@ -286,3 +286,34 @@ def test_lml_gradient_against_reference():
                 # the fixture is a finite difference of a value with rounding noise ~ eps cond(R)
                 tol = 3e-14 * np.linalg.cond(kern(X)) + 1e-8
                 np.testing.assert_allclose(grad, ev["student_grad_fd"], rtol=tol, atol=tol * np.abs(ev["student_grad_fd"]).max())
+
+
+def _config4_inputs(g):
+    from sklearn.gaussian_process.kernels import RBF
+    n, r = g["n"], g["r"]
+    X = g["dx"] * np.arange(n)[:, None]
+    K = RBF(g["length_scale"])(X)
+    K[np.diag_indices_from(K)] += g["nugget"]
+    c = np.linalg.cholesky(K) @ np.random.RandomState(g["seed"]).randn(n, r)
+    return X, orc.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+
+
+def test_cbar_ratio_grid_against_reference():
+    """BASELINE config 4 in miniature (tests/golden/cbar_ratio_grid.json, written by the reference): the per-point
+    restatement, the one-factorisation checker used at n = 8192, argmax interior and equal."""
+    from conftest import load_golden
+    from sklearn.gaussian_process.kernels import RBF
+    g = load_golden("cbar_ratio_grid.json")
+    X, y = _config4_inputs(g)
+    want = np.array(g["grid_ratio_by_cbar"])
+    theta = np.log([g["length_scale"]])
+    orders = np.arange(g["r"])
+    full = orc.cbar_ratio_grid(RBF(0.2), theta, X, y, orders, g["ratios"], g["cbars"])
+    one = orc.cbar_ratio_grid_one_factor(RBF(0.2), theta, X, y, orders, g["ratios"], g["cbars"])
+    np.testing.assert_allclose(full, want, rtol=1e-11)
+    np.testing.assert_allclose(one, want, rtol=1e-11)
+    am = list(np.unravel_index(np.argmax(one), one.shape))
+    assert am == g["argmax"] and 0 < am[0] < len(g["ratios"]) - 1 and 0 < am[1] < len(g["cbars"]) - 1
+    strip = np.array([[orc.trunc_lml(RBF(0.2), np.log([e]), X, y, orders, ratio=q) for e in g["ells"]] for q in g["ratios"]])
+    np.testing.assert_allclose(strip, np.array(g["strip_ratio_by_ell"]), rtol=1e-10)
+    assert list(np.unravel_index(np.argmax(strip), strip.shape)) == g["strip_argmax"]
