@@ -130,6 +130,7 @@ PROTOTYPES = {
     "gsum_resident_shape": (C.c_int, [_p, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
+    "gsum_debug_diag_stamps": (C.c_int, [_p, _ip]),
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -474,6 +475,11 @@ class HipContext:
         tot, ticks = v[7], v[8]
         return dict(prologue_cyc=v[4], loop_cyc=v[5], inverse_cyc=v[6], total_cyc=tot,
                     total_us=ticks * 0.01, clock_ghz=(tot / ticks * 0.1) if ticks else 0.0)
+
+    def diag_stamps_raw(self):
+        v = np.zeros(64, dtype=np.int64)
+        self._check(self._lib.gsum_debug_diag_stamps(self._h, v.ctypes.data_as(_ip)))
+        return v
 
     def gemm_profile(self):
         """(total ms, total algorithmic flops, launches) of the profiled big-tile GEMM launches; resets."""

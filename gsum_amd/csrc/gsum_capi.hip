@@ -16,7 +16,10 @@ struct gsum_mat {
     int64_t n = 0, np = 0, ld = 0;
     int T = 0;                 // np / 128
     double* A = nullptr;       // (np + 16) x ld augmented matrix
-    double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L
+    double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L (diag_algo 1: by the factorisation;
+                               // diag_algo 2: lazily, from the tables, for the consumers that multiply by L_bb^-1)
+    double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks (diag_algo 2)
+    bool have_ltab = false, have_linv = false;
     double* logdet = nullptr;  // T per-block sums of log L_ii
     double* diag0 = nullptr;   // np original diagonal entries (pivot-cancellation test)
     bool factored = false;
@@ -66,6 +69,10 @@ struct gsum_ctx {
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
                                      // (measured: 14.3 vs 8.5 ms); -1 = 2 from order 6144 up
     int build_lower_only = 1;
+    int bulk_lds_pad = 0;            // bytes of dynamic LDS the bulk kernel asks for in look-ahead schedules (0 = what it needs)
+    int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
+    int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
+                                     // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
     // point (operator level, gsum_lml_batch, gsum_lml_grad) uploads into `op`.  `in` is the set the fused path reads.
     gs_inputs op, res;
@@ -189,9 +196,11 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
-        const size_t shmem = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+        size_t shmem = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+        // experiment knob: pad the request so that fewer bulk workgroups share a CU and chain kernels find LDS at once
+        if (ctx->bulk_lds_pad > 0 && ctx->batch_active < 3) shmem = std::max(shmem, (size_t)ctx->bulk_lds_pad);
         if (!ctx->lds_attr_done.count((const void*)k_gemm_ld3)) {
-            GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             ctx->lds_attr_done.insert((const void*)k_gemm_ld3);
         }
         int64_t blocks;
@@ -267,11 +276,13 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     m->T = (int)(m->np / GS_NB);
     hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->Linv, (size_t)m->T * GS_NB * GS_NB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->Ltab, (size_t)m->T * GS_LTAB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->logdet, (size_t)m->T * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->diag0, (size_t)m->np * sizeof(double));
     if (e != hipSuccess) {
         if (m->A) (void)hipFree(m->A);
         if (m->Linv) (void)hipFree(m->Linv);
+        if (m->Ltab) (void)hipFree(m->Ltab);
         if (m->logdet) (void)hipFree(m->logdet);
         if (m->diag0) (void)hipFree(m->diag0);
         delete m;
@@ -286,6 +297,7 @@ static void gs_mat_release(gsum_mat* m) {
     if (!m) return;
     if (m->A) (void)hipFree(m->A);
     if (m->Linv) (void)hipFree(m->Linv);
+    if (m->Ltab) (void)hipFree(m->Ltab);
     if (m->logdet) (void)hipFree(m->logdet);
     if (m->diag0) (void)hipFree(m->diag0);
     delete m;
@@ -301,16 +313,43 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
     return 0;
 }
 
+// Kernel-matrix build launcher: picks the template instance (family, one-dimensional fast path) of k_build2, or the
+// round-1 kernel with option "build_algo" = 1.  tri != 0: lower 128-column tiles of a square padded matrix only.
+template <bool CROSS>
+static int gs_launch_build(gsum_ctx* ctx, hipStream_t s, double* out, int64_t ldo, const double* X, const double* Y, int64_t n,
+                           int64_t m, int64_t prow, int64_t pcol, int d, const gsum_kernel_desc* desc, double diag_add, int tri) {
+    if (ctx->build_algo == 1) {
+        const int64_t tr = (prow + 127) / 128, tc = (pcol + 127) / 128;
+        const int64_t blocks = tri ? tr * (tr + 1) / 2 : tr * tc;
+        hipLaunchKernelGGL(k_build<CROSS>, dim3((unsigned)blocks), dim3(256), 0, s, out, ldo, X, Y, (int)n, (int)m, (int)prow,
+                           (int)pcol, d, *desc, diag_add, tri);
+        GS_CHECK(hipGetLastError());
+        return 0;
+    }
+    const int64_t tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS, tc = (pcol + 127) / 128, t128 = (prow + 127) / 128;
+    const int64_t blocks = tri ? 4 * (t128 * (t128 + 1) / 2) : tr * tc;
+#define GS_B2_LAUNCH(FAM, D1)                                                                                              \
+    hipLaunchKernelGGL((k_build2<CROSS, FAM, D1>), dim3((unsigned)blocks), dim3(256), 0, s, out, ldo, X, Y, (int)n, (int)m, \
+                       (int)prow, (int)pcol, d, *desc, diag_add, tri)
+    const bool d1 = d == 1;
+    switch (desc->family) {
+        case GSUM_RBF: if (d1) GS_B2_LAUNCH(GSUM_RBF, true); else GS_B2_LAUNCH(GSUM_RBF, false); break;
+        case GSUM_MATERN52: if (d1) GS_B2_LAUNCH(GSUM_MATERN52, true); else GS_B2_LAUNCH(GSUM_MATERN52, false); break;
+        case GSUM_MATERN32: if (d1) GS_B2_LAUNCH(GSUM_MATERN32, true); else GS_B2_LAUNCH(GSUM_MATERN32, false); break;
+        default: if (d1) GS_B2_LAUNCH(GSUM_MATERN12, true); else GS_B2_LAUNCH(GSUM_MATERN12, false); break;
+    }
+#undef GS_B2_LAUNCH
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
 // K1 into an augmented matrix (square, symmetric form).  X must already be on the device.
 static int gs_build_into(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, const gsum_kernel_desc* desc, const double* dX,
                          int d, double diag_add, int lower_only) {
-    int64_t T = m->T;
-    int64_t blocks = lower_only ? T * (T + 1) / 2 : T * T;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_BUILD, 0.0);
-    hipLaunchKernelGGL(k_build<false>, dim3((unsigned)blocks), dim3(256), 0, s, m->A, m->ld, dX, (const double*)nullptr,
-                       (int)m->n, (int)m->n, (int)m->np, (int)m->np, d, *desc, diag_add, lower_only);
+    const int rc = gs_launch_build<false>(ctx, s, m->A, m->ld, dX, nullptr, m->n, m->n, m->np, m->np, d, desc, diag_add, lower_only);
     gs_prof_end(ctx, s, rec);
-    GS_CHECK(hipGetLastError());
+    if (rc) return rc;
     m->factored = false;
     return 0;
 }
@@ -391,10 +430,38 @@ static int gs_diag(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
     const int64_t c = (int64_t)b * GS_NB;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, (double)GS_NB * GS_NB * GS_NB / 3.0);
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld,
-                       m->Linv + (size_t)b * GS_NB * GS_NB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    if (m->have_linv)          // this factorisation runs the round-1 kernel (see gs_potrf)
+        hipLaunchKernelGGL(k_potrf_diag<1>, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Linv + (size_t)b * GS_NB * GS_NB,
+                           (double*)nullptr, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    else
+        hipLaunchKernelGGL(k_potrf_diag<2>, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, (double*)nullptr,
+                           m->Ltab + (size_t)b * GS_LTAB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// P (M rows x 128 columns, leading dimension ldp)  <-  P L_bb^-T for diagonal block b of the factor m: blocked
+// substitution against the block's tables (k_panel), or -- for a factor made by the round-1 kernel -- the product with
+// the explicit inverse on the 32 x 128 MFMA tile.
+static int gs_trsm_rows(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
+    if (M <= 0) return 0;
+    if (!m->have_ltab)
+        return gs_gemm(ctx, s, 1, P, ldp, P, ldp, m->Linv + (size_t)b * GS_NB * GS_NB, GS_NB, M, GS_NB, GS_NB, 0, 0, 1.0);
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, (double)M * GS_NB * GS_NB);
+    hipLaunchKernelGGL(k_panel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the explicit 128 x 128 inverses of the diagonal blocks, for the consumers that want them (cho_solve's back-substitution)
+static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
+    if (m->have_linv) return 0;
+    if (!m->have_ltab) GS_FAIL("internal: factor has neither tables nor inverses");
+    hipLaunchKernelGGL(k_trtri_blocks, dim3((unsigned)m->T), dim3(256), 0, s, m->Ltab, m->Linv);
+    GS_CHECK(hipGetLastError());
+    m->have_linv = true;
     return 0;
 }
 
@@ -402,6 +469,8 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int T = m->T;
     gs_slot* sl = ctx->cur;
     if (gs_potrf_events(ctx, sl, T)) return -1;
+    m->have_linv = ctx->diag_algo == 1;        // round-1 kernel: explicit inverses, TRSM as a product with them
+    m->have_ltab = !m->have_linv;              // round-2 kernel: substitution tables, TRSM by blocked substitution
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
     GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
@@ -436,17 +505,15 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
         const int Kp = two ? 2 * GS_NB : GS_NB;
         // ---- sub-step a
-        double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
         if (gs_diag(ctx, sp, m, k)) return -1;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (gs_gemm(ctx, sp, ccfg, Pa, ld, Pa, ld, Linv, GS_NB, naug - c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
         if (two) {
             // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
             if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            double* Linv1 = Linv + GS_NB * GS_NB;
             if (gs_diag(ctx, sp, m, k + 1)) return -1;
             double* Pb = A + r2 * ld + c1;
-            if (gs_gemm(ctx, sp, ccfg, Pb, ld, Pb, ld, Linv1, GS_NB, naug - r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+            if (gs_trsm_rows(ctx, sp, m, k + 1, Pb, ld, naug - r2)) return -1;
         }
         // ---- trailing update with the whole panel: rows r2.., columns c0..c0+Kp-1
         double* P = A + r2 * ld + c0;
@@ -566,8 +633,8 @@ int gsum_init(int device, gsum_ctx** out) {
         return -1;
     }
     ctx->cur = &ctx->slots[0];
-    if ((e = hipMalloc((void**)&ctx->dstamps, 8 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
-    (void)hipMemset(ctx->dstamps, 0, 8 * sizeof(unsigned long long));
+    if ((e = hipMalloc((void**)&ctx->dstamps, 64 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
+    (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
     const char* rc = getenv("GSUM_RESERVE_CUS");
@@ -640,14 +707,15 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
 static int gs_probe_queues(gsum_ctx* ctx, int S) {
     if (gs_need_slots(ctx, S)) return -1;
     GS_CHECK(hipDeviceSynchronize());
-    const unsigned long long ticks = 30000;                  // 300 us of s_memrealtime (100 MHz)
+    const unsigned long long ticks = 300000;                 // 3 ms of s_memrealtime (100 MHz): long against the ~0.2 ms it
+                                                             // takes the host to enqueue 20 launches
     for (int rep = 0; rep < 2; ++rep) {                      // first round: code-object load, stream warm-up
         const auto t0 = std::chrono::steady_clock::now();
         for (int q = 0; q < S; ++q) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, ctx->slots[q].sm, ticks);
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipDeviceSynchronize());
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        ctx->probe_concurrency = (double)S * 300.0 / us;
+        ctx->probe_concurrency = (double)S * 3000.0 / us;
     }
     ctx->probe_streams = S;
     return 0;
@@ -678,6 +746,9 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
+    else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
+    else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;
+    else if (!strcmp(name, "bulk_lds_pad")) ctx->bulk_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(80 * 1024, value));
     else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5 || value == 6) ? (int)value : 7;
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
@@ -726,14 +797,9 @@ int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double*
     double* dO = (double*)(base + off_o);
     GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, ctx->cur->sm));
     if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, ctx->cur->sm));
-    const int64_t tr = (n + 127) / 128, tc = (ldo + 127) / 128;
-    if (cross)
-        hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, dO, ldo, dXl, dYl, (int)n, (int)m,
-                           (int)n, (int)ldo, d, *desc, 0.0, 0);
-    else
-        hipLaunchKernelGGL(k_build<false>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, dO, ldo, dXl,
-                           (const double*)nullptr, (int)n, (int)n, (int)n, (int)ldo, d, *desc, diag_add, 0);
-    GS_CHECK(hipGetLastError());
+    if (cross ? gs_launch_build<true>(ctx, ctx->cur->sm, dO, ldo, dXl, dYl, n, m, n, ldo, d, desc, 0.0, 0)
+              : gs_launch_build<false>(ctx, ctx->cur->sm, dO, ldo, dXl, nullptr, n, n, n, ldo, d, desc, diag_add, 0))
+        return -1;
     GS_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dO, (size_t)ldo * sizeof(double),
                               (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->cur->sm));
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
@@ -801,8 +867,7 @@ static int gs_border_solve(gsum_ctx* ctx, gsum_mat* m) {
     double* Brow = A + m->np * ld;
     for (int k = 0; k < m->T; ++k) {
         const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
-        double* Linv = m->Linv + (size_t)k * GS_NB * GS_NB;
-        if (gs_gemm(ctx, ctx->cur->sm, 2, Brow + c0, ld, Brow + c0, ld, Linv, GS_NB, GS_BORDER, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_trsm_rows(ctx, ctx->cur->sm, m, k, Brow + c0, ld, GS_BORDER)) return -1;
         if (gs_gemm(ctx, ctx->cur->sm, 2, Brow + r0, ld, Brow + c0, ld, A + r0 * ld + c0, ld, GS_BORDER, naug - r0, GS_NB, 0, 1,
                     -1.0))
             return -1;
@@ -860,6 +925,7 @@ int gsum_cho_solve(gsum_ctx* ctx, gsum_mat* L, const double* B, int64_t n, int32
     if (gs_upload_Z(ctx, &ctx->op, B, n, k)) return -1;
     if (gs_set_border(ctx, s, L, ctx->op.Z, k)) return -1;
     if (gs_border_solve(ctx, L)) return -1;
+    if (gs_need_linv(ctx, s, L)) return -1;
     double* Brow = L->A + L->np * L->ld;
     const int T = L->T;
     hipLaunchKernelGGL(k_back_first, dim3(1), dim3(256), 0, s, Brow, L->ld, L->Linv + (size_t)(T - 1) * GS_NB * GS_NB, (T - 1) * GS_NB);
@@ -972,10 +1038,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     double *dXs = (double*)(base + o_xs), *Bt = (double*)(base + o_bt), *dVW = (double*)(base + o_vw),
            *dSS = (double*)(base + o_ss), *dCov = (double*)(base + o_cv);
     GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->cur->sm));
-    const int64_t tr = (m + 127) / 128, tc = np / 128;
-    hipLaunchKernelGGL(k_build<true>, dim3((unsigned)(tr * tc)), dim3(256), 0, ctx->cur->sm, Bt, ldb, dXs, ctx->op.X, (int)m, (int)n,
-                       (int)m, (int)np, d, *desc, 0.0, 0);
-    GS_CHECK(hipGetLastError());
+    if (gs_launch_build<true>(ctx, ctx->cur->sm, Bt, ldb, dXs, ctx->op.X, m, n, m, np, d, desc, 0.0, 0)) return -1;
     if (sc) {
         // rows of Bt are the new points, columns the conditioning points
         double* v = (double*)(base + o_sc);
@@ -990,8 +1053,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     }
     for (int c = 0; c < L->T; ++c) {
         const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
-        double* Linv = L->Linv + (size_t)c * GS_NB * GS_NB;
-        if (gs_gemm(ctx, ctx->cur->sm, 1, Bt + c0, ldb, Bt + c0, ldb, Linv, GS_NB, m, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_trsm_rows(ctx, ctx->cur->sm, L, c, Bt + c0, ldb, m)) return -1;
         if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
             return -1;
     }
@@ -1312,12 +1374,11 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     for (int c = 0; c < m->T; c += 2) {
         const bool two = c + 1 < m->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
-        double* Linv = m->Linv + (size_t)c * GS_NB * GS_NB;
-        if (gs_gemm(ctx, s, 1, U + c0, ldg, U + c0, ldg, Linv, GS_NB, c1, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+        if (gs_trsm_rows(ctx, s, m, c, U + c0, ldg, c1)) return -1;
         if (two) {
             // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
             if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c1, ldg, Linv + GS_NB * GS_NB, GS_NB, r2, GS_NB, GS_NB, 0, 0, 1.0)) return -1;
+            if (gs_trsm_rows(ctx, s, m, c + 1, U + c1, ldg, r2)) return -1;
         }
         if (r2 < np && gs_gemm(ctx, s, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
@@ -1362,6 +1423,14 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
         for (int i = 4; i < n && i < 9; ++i) ms[i] = (double)st[i - 4];
         if (n > 9) ms[9] = ctx->host_enqueue_ms;
     }
+    return 0;
+}
+
+int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64) {
+    if (!ctx || !out64) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    GS_CHECK(hipDeviceSynchronize());
+    GS_CHECK(hipMemcpy(out64, ctx->dstamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -187,6 +187,258 @@ __global__ __launch_bounds__(256) void k_build(double* out, int64_t ldo, const d
     }
 }
 
+// ---- second version of the kernel build (round 2) ---------------------------------------------------------------
+// The first version was bound by instruction issue, not by HBM: a runtime switch over the kernel family and a runtime
+// loop over the input dimensions inside the per-entry loop, the 2^(j/16) table read through divergent global loads from
+// constant memory, a 64-bit float -> integer conversion, and diagonal / padding tests on every entry: ~90 VALU
+// instructions per entry, 89 us for the 34 M entries of the n = 8192 lower triangle (3.1 TB/s of stores).  Here the
+// family and the one-dimensional case are template parameters, the table lives in LDS, the exponent goes through
+// v_cvt_i32_f64, tiles that touch neither the diagonal nor the padding skip every test, and a workgroup takes 32 x 128
+// entries (8320 tiles at n = 8192: 4 rounds of the 2048 resident workgroups instead of 1.02 with a one-tile tail).
+// Same arithmetic, operation for operation (array_equal to scikit-learn is asserted on the device for every family).
+__device__ __forceinline__ double gs_exp_np_t(double x, const double* th, const double* tl) {
+#pragma clang fp contract(off)
+    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
+    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
+    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
+    const double t = __builtin_fma(x, L2E, SH);
+    const double nn = t - SH;
+    const double dd = __builtin_fma(x, L2E, -nn);
+    const double N = dd < 0.0 ? nn - 0.0625 : nn;
+    const int k16 = (int)(N * 16.0);                      // |N| < 1022: exact in 32 bits
+    const int j = k16 & 15;
+    double R = __builtin_fma(-N, L2H, x);
+    R = __builtin_fma(-N, L2L, R);
+    const double R2 = R * R;
+    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
+    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
+    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
+    double pp = __builtin_fma(R2, pA, pB);
+    pp = __builtin_fma(R2, pp, pC);
+    const double q = __builtin_fma(pp, R, tl[j]);
+    const double thj = th[j];
+    const double res = __builtin_fma(thj, q, thj);
+    return ldexp(res, k16 >> 4);
+}
+
+template <int FAM>
+__device__ __forceinline__ double gs_base_value_t(double s, const double* th, const double* tl) {
+#pragma clang fp contract(off)
+    if (FAM == GSUM_RBF) return gs_exp_np_t(-0.5 * s, th, tl);
+    const double dist = sqrt(s);
+    if (FAM == GSUM_MATERN52) {
+        const double t = dist * 2.23606797749979;      // math.sqrt(5)
+        return (1.0 + t + (t * t) / 3.0) * gs_exp_np_t(-t, th, tl);
+    }
+    if (FAM == GSUM_MATERN32) {
+        const double t = dist * 1.7320508075688772;    // math.sqrt(3)
+        return (1.0 + t) * gs_exp_np_t(-t, th, tl);
+    }
+    return gs_exp_np_t(-dist, th, tl);
+}
+
+// Branch-free form for the build kernel's inner loop.  Two argument ranges need no table arithmetic at all:
+//   x < -745.2       exp(x) is exactly 0.0 in fp64 (below half the smallest denormal) -- on a grid with dx = 0.5 l that
+//                    is every entry more than 39 length scales from the diagonal, i.e. most of a large matrix;
+//   |x| < 707.7      the table algorithm (gs_exp_np_t's fast path).
+// What is left (the band -745.2 <= x <= -707.7 where the result is a denormal, overflow, NaN) is flagged and recomputed
+// by the caller with the library exp, wave-uniformly, so that the common paths carry no per-entry branch.
+__device__ __forceinline__ double gs_exp_np_nobranch(double x, const double* th, const double* tl, bool& slow) {
+#pragma clang fp contract(off)
+    const bool far = x < -745.2;
+    const bool inr = fabs(x) < 0x1.61da04cbafe44p+9;
+    slow = !(far || inr);
+    const double xs = inr ? x : 0.0;
+    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
+    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
+    const double t = __builtin_fma(xs, L2E, SH);
+    const double nn = t - SH;
+    const double dd = __builtin_fma(xs, L2E, -nn);
+    const double N = dd < 0.0 ? nn - 0.0625 : nn;
+    const int k16 = (int)(N * 16.0);
+    const int j = k16 & 15;
+    double R = __builtin_fma(-N, L2H, xs);
+    R = __builtin_fma(-N, L2L, R);
+    const double R2 = R * R;
+    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
+    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
+    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
+    double pp = __builtin_fma(R2, pA, pB);
+    pp = __builtin_fma(R2, pp, pC);
+    const double q = __builtin_fma(pp, R, tl[j]);
+    const double thj = th[j];
+    const double res = ldexp(__builtin_fma(thj, q, thj), k16 >> 4);
+    return far ? 0.0 : res;
+}
+
+// base value with the exp argument's class reported: far = the exponential is exactly zero
+template <int FAM>
+__device__ __forceinline__ double gs_base_value_nb(double s, const double* th, const double* tl, bool& slow) {
+#pragma clang fp contract(off)
+    if (FAM == GSUM_RBF) return gs_exp_np_nobranch(-0.5 * s, th, tl, slow);
+    const double dist = sqrt(s);
+    if (FAM == GSUM_MATERN52) {
+        const double t = dist * 2.23606797749979;
+        return (1.0 + t + (t * t) / 3.0) * gs_exp_np_nobranch(-t, th, tl, slow);
+    }
+    if (FAM == GSUM_MATERN32) {
+        const double t = dist * 1.7320508075688772;
+        return (1.0 + t) * gs_exp_np_nobranch(-t, th, tl, slow);
+    }
+    return gs_exp_np_nobranch(-dist, th, tl, slow);
+}
+
+// is the exponential of this squared scaled distance exactly zero?  (the argument of exp is -0.5 s, -sqrt(5 s), ...)
+template <int FAM>
+__device__ __forceinline__ bool gs_base_is_zero(double s) {
+    if (FAM == GSUM_RBF) return s > 1490.5;                       // -0.5 s < -745.25
+    if (FAM == GSUM_MATERN52) return s > 111100.0;                // sqrt(5 s) > 745.3
+    if (FAM == GSUM_MATERN32) return s > 185200.0;                // sqrt(3 s) > 745.4
+    return s > 555500.0;                                          // sqrt(s) > 745.3
+}
+
+#define GS_B2_ROWS 32
+// One 32 x 128 tile per 256-thread workgroup: wave w takes rows 8 w .. 8 w + 7, two at a time; each lane owns two adjacent
+// columns (one 16-B store per row, 1 KiB per wave-instruction).  Grid: CROSS or tri == 0: (prow / 32 rounded up) x (pcol /
+// 128 rounded up) tiles, row-slice fastest; tri != 0: the 128-column tiles on or below the diagonal, four row slices each.
+template <bool CROSS, int FAM, bool D1>
+__global__ __launch_bounds__(256) void k_build2(double* out, int64_t ldo, const double* X, const double* Y, int n, int m,
+                                                 int prow, int pcol, int d, gsum_kernel_desc desc, double diag_add, int tri) {
+#pragma clang fp contract(off)
+    __shared__ double ui[GS_B2_ROWS * GSUM_MAX_D];
+    __shared__ double uj[128 * GSUM_MAX_D];
+    __shared__ double tab[32];
+    const int t = threadIdx.x;
+    int bi, bj;                                        // 32-row slice index, 128-column tile index
+    if (tri) {
+        const int bid = blockIdx.x >> 2;
+        int b128 = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(b128 + 1) * (b128 + 2) / 2 <= bid) ++b128;
+        while ((int64_t)b128 * (b128 + 1) / 2 > bid) --b128;
+        bj = bid - (int)((int64_t)b128 * (b128 + 1) / 2);
+        bi = 4 * b128 + (blockIdx.x & 3);
+    } else {
+        const int tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS;
+        bi = blockIdx.x % tr;
+        bj = blockIdx.x / tr;
+    }
+    const double* Yp = CROSS ? Y : X;
+    const int ny = CROSS ? m : n;
+    const int r0 = bi * GS_B2_ROWS, c0 = bj * 128;
+    if (t < 16) tab[t] = gs_exp_th[t];
+    else if (t < 32) tab[t] = gs_exp_tl[t - 16];
+    for (int idx = t; idx < 128 * d; idx += 256) {
+        const int r = idx / d, dd = idx - r * d;
+        const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
+        const int gj = c0 + r;
+        uj[idx] = gj < ny ? Yp[(int64_t)gj * d + dd] / ls : 0.0;
+        if (r < GS_B2_ROWS) {
+            const int gi = r0 + r;
+            ui[idx] = gi < n ? X[(int64_t)gi * d + dd] / ls : 0.0;
+        }
+    }
+    __syncthreads();
+    const double* th = tab;
+    const double* tl = tab + 16;
+    const int lane = t & 63, w = t >> 6;
+    const int gj0 = c0 + 2 * lane;
+    if (gj0 >= pcol) return;
+    double vj0[D1 ? 1 : GSUM_MAX_D], vj1[D1 ? 1 : GSUM_MAX_D];
+    if (D1) {
+        vj0[0] = uj[2 * lane];
+        vj1[0] = uj[2 * lane + 1];
+    } else {
+#pragma unroll
+        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+            vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
+            vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
+        }
+    }
+    // a tile is plain when no entry needs a diagonal or padding rule: then value = amplitude * base + additive
+    const bool plain = CROSS ? (r0 + GS_B2_ROWS <= n && c0 + 128 <= m)
+                             : (r0 + GS_B2_ROWS <= n && c0 + 128 <= n && (c0 + 128 <= r0 || r0 + GS_B2_ROWS <= c0));
+    const double amp = desc.amplitude, addc = desc.additive_const;
+#pragma unroll 1
+    for (int rp = 0; rp < 8; rp += 2) {
+        double s[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = 8 * w + rp + h;
+            if (D1) {
+                const double xi = ui[rr];
+                const double e0 = xi - vj0[0], e1 = xi - vj1[0];
+                s[h][0] = e0 * e0;
+                s[h][1] = e1 * e1;
+            } else {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+                    if (dd < d) {
+                        const double xi = ui[rr * d + dd];
+                        const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
+                        s0 = s0 + e0 * e0;
+                        s1 = s1 + e1 * e1;
+                    }
+                }
+                s[h][0] = s0;
+                s[h][1] = s1;
+            }
+        }
+        double v[2][2];
+        if (plain) {
+            // wave-uniform short cut: every exponential of these 2 x 128 entries is exactly zero
+            const bool nz = !(gs_base_is_zero<FAM>(s[0][0]) && gs_base_is_zero<FAM>(s[0][1]) && gs_base_is_zero<FAM>(s[1][0]) &&
+                              gs_base_is_zero<FAM>(s[1][1]));
+            if (__builtin_amdgcn_ballot_w64(nz) == 0) {
+                const double z = amp * 0.0 + addc;
+                v[0][0] = v[0][1] = v[1][0] = v[1][1] = z;
+            } else {
+                bool slow[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) v[h][c] = amp * gs_base_value_nb<FAM>(s[h][c], th, tl, slow[h][c]) + addc;
+                if (__builtin_amdgcn_ballot_w64(slow[0][0] || slow[0][1] || slow[1][0] || slow[1][1]) != 0) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (slow[h][c]) v[h][c] = amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int gi = r0 + 8 * w + rp + h, gj = gj0 + c;
+                    double val;
+                    if (CROSS) {
+                        val = (gi < n && gj < m) ? amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc : 0.0;
+                    } else if (gi >= n || gj >= n) {
+                        val = (gi == gj) ? 1.0 : 0.0;                 // identity padding up to a multiple of 128
+                    } else {
+                        const bool dg = gi == gj;
+                        const double b = dg ? 1.0 : gs_base_value_t<FAM>(s[h][c], th, tl);   // np.fill_diagonal(K, 1)
+                        val = amp * b;
+                        if (dg) val = val + desc.white_noise;
+                        val = val + addc;
+                        if (dg) val = val + diag_add;
+                    }
+                    v[h][c] = val;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gi = r0 + 8 * w + rp + h;
+            if (gi < prow) {
+                const gs_d2 o = {v[h][0], v[h][1]};
+                *reinterpret_cast<gs_d2*>(out + (int64_t)gi * ldo + gj0) = o;
+            }
+        }
+    }
+}
+
 // Border rows np..np+15 of the augmented matrix: row c = column c of RHS (n x k, row-major), zero
 // beyond k / n, and a zero 16x16 corner.
 __global__ __launch_bounds__(256) void k_set_border(double* A, int64_t ld, int n, int np, const double* Z, int k) {
@@ -416,8 +668,8 @@ __device__ __forceinline__ void gs_trtri_col(const double* Ls, const double* Dv,
 // Ls / Dv are written, one barrier separates the two uses).  Passing the workspace in lets a fused kernel lend the
 // same bytes to its other phases (k_lml_medium: the tile routine's staging buffers) instead of stacking them.
 #define GS_DIAG_WS (28 * GS_LS_BLK + 128 * GS_DV_STR)      // 9792 doubles = 76.5 KB
-__device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* logdet_out,
-                                             const double* diag0, unsigned long long* stamps, double* wsp) {
+__device__ __forceinline__ int gs_diag_block_v1(double* A, int64_t ld, double* Linv, double* logdet_out,
+                                                const double* diag0, unsigned long long* stamps, double* wsp) {
     __shared__ double dbuf[128];
     double* Ls = wsp;
     double* Dv = wsp + 28 * GS_LS_BLK;
@@ -505,14 +757,432 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2a, second version (round 2): the 128x128 diagonal block as an 8 x 8 grid of 16x16 micro-blocks that live in the
+// ACCUMULATOR REGISTERS of the four waves for the whole factorisation; only the pivot recurrence of one 16x16 micro-block
+// at a time is scalar work, and it runs inside ONE wave with no barrier and no LDS round trip per column.
+//
+// Register image.  Wave w owns block rows w and 7 - w (9 micro-blocks, 72 VGPRs).  For micro-block (i, k) with current
+// value M the four registers hold  P[x](lane l) = -M[l & 15][(l >> 4) + 4 x].  Read as an MFMA accumulator that is
+// -M^T; read as the A operand of k-step x it is -M; read as the B operand of k-step x it is -M^T (all three with the
+// same k numbering kappa(x, g) = g + 4 x).  Hence, with no data movement and no negation anywhere:
+//   panel solve   L_ij^T = D_j M_ij^T :  P_ij <- mfma(A = D_j from LDS,             B = P_ij)         (D_j = L_jj^-1)
+//   update        M_ik^T -= L_kj L_ij^T:  P_ik <- mfma(A = -L_kj = P_kj dumped to LDS, B = P_ij, C = P_ik)
+// and the LDS copy of the panel ("dump": register x of lane l at [x][l], conflict-free both ways) is also the A operand
+// -L_ip the block inverse needs afterwards.
+// Pivot recurrence (gs_potf2_16): the owner wave turns its micro-block into one row per lane (lanes 0..15) with the
+// rows of the identity beside it (lanes 16..31).  Column step c: the pivot and the scaled column entries l_k come out
+// of their lanes with v_readlane into SGPRs, every lane does a[k] -= a[c] l_k -- the same instruction stream gives L in
+// lanes 0..15 and L^-T in lanes 16..31 (column operations applied to the identity), so the micro-block inverse D_j
+// costs nothing.  ~45 instructions per column instead of a barrier + mailbox round trip (~1200 cycles) per two columns.
+// Schedule per micro-block column j: [barrier] panel solve + dump [barrier] the owner of row j + 1 updates its diagonal
+// micro-block and runs the pivot recurrence at once while the other waves apply the remaining updates.
+// Semantics unchanged: LAPACK dpotf2's pivot test plus the lost-every-bit threshold (see above), the first failing column
+// reported; L in place (lower part only), L^-1 of the whole block to Linv, sum of log L_jj.
+// Workspace: 28 panel blocks (56 KB) + 8 micro-block inverses (17 KB) + 128 thresholds = 9472 doubles <= GS_DIAG_WS.
+// ------------------------------------------------------------------------------------------------
+#define GS_D2_LS 0
+#define GS_D2_DV (28 * 256)
+#define GS_D2_THR (GS_D2_DV + 8 * 16 * GS_DV_STR)
+
+__device__ __forceinline__ double gs_readlane_f64(double v, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void gs_wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across the point
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Accumulation order (what the log-likelihood's last digits depend on; measured against the extended-precision values of
+// tests/golden/large_truth.json).  An entry of the factor is (a_ik - sum_p l_ip l_kp) / l_kk.  Subtracting the products
+// from a_ik one by one, as a right-looking update does, rounds every partial result at the magnitude of a_ik, although
+// the products of far-away columns are tiny and only the last few are large: on the S2 / S3 inputs (pivots ~ 1e-8 of the
+// diagonal) that put the log-likelihood 6-20 x further from the true value than LAPACK.  Here the products are summed
+// FROM ZERO in ascending p, in accumulators of their own (S), and the sum is subtracted once -- the order of a
+// left-looking dot product -- while the schedule stays right-looking.  The pivot recurrence continues the same sums.
+// Pivot recurrence of micro-block JB in one wave, entirely in the register image -- no LDS round trip, no per-lane row
+// arrays.  Pjj: the ORIGINAL block (-A_jj^T, symmetric), Sjj: the products accumulated so far (+sum_p L_jp L_jp^T).  Column
+// c = g + 4 x of a symmetric 16 x 16 matrix M sits in register x of the sixteen lanes of group g (lane & 15 = row), so
+//   e   = A[x] - S[x]                     column c of the Schur complement on group g (one subtraction of the sum)
+//   p   = readlane(e, 16 g + c)           the pivot;  1 / sqrt(p) by v_rsq + two Newton steps, uniform
+//   m   = e / sqrt(p)                     column c of L on group g;  ms = its part strictly below the diagonal, else 0
+//   S  += ms ms^T                         ONE v_mfma_f64_16x16x4 with ms as A and B operand in k-slot g (the other three
+//                                         slots are zeros): the rank-1 update of all 256 sums
+//   V   : column c scaled, V -= v_c l^T   a second MFMA (A = -ms, B = v_c): the column operations applied to the identity,
+//                                         V -> L^-T, whose transpose D_j = L_jj^-1 goes to the table row-major
+// ~35 instructions per column, two of them MFMAs, against ~70 VALU + v_readlane for a row-per-lane formulation (9.3 k
+// cycles per micro-block measured) and a barrier + LDS mailbox per two columns in round 1.
+// Ablk: the block's origin in the matrix.  Dvj: its 16 x 17 slot of the inverse table.  Returns the failing local column or -1.
+template <int JB>
+__device__ __forceinline__ int gs_potf2_16(const gs_d4& Pjj, const gs_d4& Sjj, double* Ablk, int64_t ld, double* Dvj,
+                                           const double* thr, double* dbuf, int lane, unsigned long long* stamps = nullptr) {
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned long long tq0 = 0;
+    if (stamps) tq0 = __builtin_amdgcn_s_memtime();
+    gs_d4 Aa, S = Sjj, V, Lo = {0.0, 0.0, 0.0, 0.0}, Rs = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        Aa[x] = -Pjj[x];
+        V[x] = (fr == fq + 4 * x) ? 1.0 : 0.0;
+    }
+    const double tl = thr[16 * JB + fr];
+    int fail = -1;
+    // The pivot of column c is the Schur complement's diagonal entry a_cc - S_cc.  S_cc receives its last product,
+    // l_{c,c-1}^2, from the MFMA of column c - 1; waiting for that MFMA would put its latency into the dependent chain
+    // pivot -> rsqrt -> column -> pivot.  The same fma is therefore done once more on the side, on three values read out
+    // of their lanes: p_c = a_cc - fma(l, l, S_cc before), bit for bit what the accumulator will hold.
+    double p = gs_readlane_f64(Aa[0], 0) - gs_readlane_f64(S[0], 0);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int g = c & 3, x = c >> 2;
+        const double t = gs_readlane_f64(tl, c);
+        if (fail < 0 && !(p > t)) fail = c;   // wave-uniform (both operands came through SGPRs); catches NaN
+        const double r0 = gs_rsqrt_nr(p);
+        double d0 = p * r0;                                             // sqrt(p) ...
+        d0 = __builtin_fma(__builtin_fma(-d0, d0, p), 0.5 * r0, d0);    // ... corrected to ~0.5 ulp
+        const bool ing = fq == g;
+        const double e = Aa[x] - S[x];        // column c of the Schur complement (group g): ONE subtraction of the sum
+        const double m = e * r0;
+        const double ms = (ing && fr > c) ? m : 0.0;
+        Lo[x] = ing ? ((fr == c) ? d0 : ms) : Lo[x];
+        Rs[x] = ing ? r0 : Rs[x];             // column c of V is scaled at the end (it is never updated after this step)
+        const double vc = ing ? V[x] * r0 : 0.0;
+        if (c < 15) {                         // next pivot on the side (see above)
+            const int g1 = (c + 1) & 3, x1 = (c + 1) >> 2, src = 16 * g1 + c + 1;
+            const double l1 = gs_readlane_f64(ms, 16 * g + c + 1);
+            p = gs_readlane_f64(Aa[x1], src) - __builtin_fma(l1, l1, gs_readlane_f64(S[x1], src));
+        }
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms, ms, S, 0, 0, 0);
+        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms, vc, V, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);    // keep the columns apart: hoisting the next columns' lane masks and
+                                              // v_readlane results ahead ran the kernel out of SGPRs (spills through v_writelane)
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int cc = fq + 4 * x;
+        if (cc <= fr) Ablk[(int64_t)fr * ld + cc] = Lo[x];                    // L_jj, lower part
+        if (cc == fr) dbuf[16 * JB + fr] = Lo[x];                             // its diagonal, for the log-determinant
+        Dvj[cc * GS_DV_STR + fr] = V[x] * Rs[x];                              // D_j[a][b] = V[b][a], row-major
+    }
+    if (stamps && lane == 0) stamps[24 + JB] = __builtin_amdgcn_s_memtime() - tq0;      // diagnostics: cycles of this recurrence
+    return fail;
+}
+
+// C (acc) += A (dumped block at `blk`: [x][lane]) * B (registers)
+__device__ __forceinline__ void gs_d2_upd(gs_d4& Cc, const double* blk, const gs_d4& Bb, int lane) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[x * 64 + lane], Bb[x], Cc, 0, 0, 0);
+}
+
+// X^T = D_J (A^T - sum)  in the register image:  P <- mfma(D_J, P + S), dumped to the panel table
+template <int J>
+__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, int row, int lane) {
+    const gs_d4 E = Pb + Sb;
+    gs_d4 T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], E[x], T, 0, 0, 0);
+    Pb = T;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) Ls[((row * (row - 1) / 2 + J) * 4 + x) * 64 + lane] = T[x];
+}
+
+template <int W, int J>
+__device__ __forceinline__ void gs_d2_trsm_dump(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W],
+                                                const double* Dv, double* Ls, int lane) {
+    constexpr int R0 = W, R1 = 7 - W;
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (R1 > J) {                   // R1 >= R0: nothing to do for either row otherwise
+        double av[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) av[x] = Dv[(J * 16 + fr) * GS_DV_STR + fq + 4 * x];
+        if constexpr (R0 > J) gs_d2_solve_dump<J>(P0[J], S0[J], av, Ls, R0, lane);
+        gs_d2_solve_dump<J>(P1[J], S1[J], av, Ls, R1, lane);
+    }
+}
+
+// after panel column J is in LDS: add its products to the sums; the owner of row J + 1 finishes the sum of its diagonal
+// micro-block first and runs the pivot recurrence on it before its other updates.  Returns the failing local column of
+// micro-block J + 1 or -1.
+template <int W, int J>
+__device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
+                                            int64_t ld, double* Dv, double* scr, const double* Ls, const double* thr, double* dbuf,
+                                            int lane, unsigned long long* stamps) {
+    constexpr int R0 = W, R1 = 7 - W, N = J + 1;
+    int fail = -1;
+    if constexpr (R0 == N) {
+        gs_d2_upd(S0[N], Ls + (N * (N - 1) / 2 + J) * 256, P0[J], lane);
+        fail = gs_potf2_16<N>(P0[N], S0[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
+    } else if constexpr (R1 == N) {
+        gs_d2_upd(S1[N], Ls + (N * (N - 1) / 2 + J) * 256, P1[J], lane);
+        fail = gs_potf2_16<N>(P1[N], S1[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
+    }
+    if constexpr (R0 > N) {
+#pragma unroll
+        for (int k = N; k <= R0; ++k) gs_d2_upd(S0[k], Ls + (k * (k - 1) / 2 + J) * 256, P0[J], lane);
+    }
+    if constexpr (R1 > N) {
+#pragma unroll
+        for (int k = N; k <= R1; ++k) gs_d2_upd(S1[k], Ls + (k * (k - 1) / 2 + J) * 256, P1[J], lane);
+    }
+    return fail;
+}
+
+template <int W, int J>
+__device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
+                                           int64_t ld, double* Dv, double* scr, double* Ls, const double* thr, double* dbuf,
+                                           int* fail_sh, int lane, unsigned long long* stamps) {
+    __syncthreads();                                          // D_J (and a failure flag) visible
+    if (stamps && W == 0 && lane == 0) stamps[8 + 2 * J] = __builtin_amdgcn_s_memtime();       // diagnostics only
+    if (*fail_sh >= 0) return false;
+    gs_d2_trsm_dump<W, J>(P0, P1, S0, S1, Dv, Ls, lane);
+    __syncthreads();                                          // panel column J visible
+    if (stamps && W == 0 && lane == 0) stamps[9 + 2 * J] = __builtin_amdgcn_s_memtime();
+    if constexpr (J < 7) {
+        const int f = gs_d2_update<W, J>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, lane, stamps);
+        if (f >= 0 && lane == 0) *fail_sh = 16 * (J + 1) + f;
+    }
+    return true;
+}
+
+// phase 1 of wave W: returns false if a pivot failed (every wave leaves at the same barrier)
+template <int W>
+__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, const double* thr, double* dbuf,
+                                           int* fail_sh, int lane, unsigned long long* stamps) {
+    constexpr int R0 = W, R1 = 7 - W;
+    const int fr = lane & 15, fq = lane >> 4;
+    gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
+#pragma unroll
+    for (int k = 0; k <= R0; ++k) {
+        S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            // the diagonal micro-block is read from its lower triangle only (mirrored): the recurrence wants it symmetric
+            const int cc = fq + 4 * x, rr = (k == R0 && cc > fr) ? cc : fr, cl = (k == R0 && cc > fr) ? fr : cc;
+            P0[k][x] = -A[(int64_t)(16 * R0 + rr) * ld + 16 * k + cl];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= R1; ++k) {
+        S1[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int cc = fq + 4 * x, rr = (k == R1 && cc > fr) ? cc : fr, cl = (k == R1 && cc > fr) ? fr : cc;
+            P1[k][x] = -A[(int64_t)(16 * R1 + rr) * ld + 16 * k + cl];
+        }
+    }
+    if constexpr (W == 0) {
+        const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);
+        if (f >= 0 && lane == 0) *fail_sh = f;
+    }
+    if (!gs_d2_step<W, 0>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 1>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 2>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 3>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 4>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 5>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 6>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 7>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    // strictly lower micro-blocks back to the matrix (the diagonal ones were stored by the pivot recurrence)
+#pragma unroll
+    for (int k = 0; k < R0; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R0 + fr) * ld + 16 * k + fq + 4 * x] = -P0[k][x];
+#pragma unroll
+    for (int k = 0; k < R1; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R1 + fr) * ld + 16 * k + fq + 4 * x] = -P1[k][x];
+    return true;
+}
+
+// One block column J of L^-1 on the matrix cores, from the panel dumps (A operand: -L_ip) and the micro-block inverses.
+template <int J>
+__device__ __forceinline__ void gs_trtri_col2(const double* Ls, const double* Dv, double* Linv, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    gs_d4 X[8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) X[J][x] = Dv[(J * 16 + fq + 4 * x) * GS_DV_STR + fr];      // X_JJ = D_J in accumulator layout
+#pragma unroll
+    for (int i = J + 1; i < 8; ++i) {
+        gs_d4 T = {0.0, 0.0, 0.0, 0.0};                                                      // -sum_p L_ip X_pJ
+#pragma unroll
+        for (int p = J; p < i; ++p) gs_d2_upd(T, Ls + (i * (i - 1) / 2 + p) * 256, X[p], lane);
+        gs_d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double av = Dv[(i * 16 + fr) * GS_DV_STR + 4 * s4 + fq];                 // A operand: D_i
+            R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], R, 0, 0, 0);
+        }
+        X[i] = R;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            Linv[(16 * i + fq + 4 * x) * 128 + 16 * J + fr] = (i < J) ? 0.0 : X[i][x];
+}
+
+// the whole 128 x 128 inverse: wave w builds block columns w and 7 - w
+__device__ __forceinline__ void gs_trtri_block(const double* Ls, const double* Dv, double* Linv, int w, int lane) {
+    if (w == 0) {
+        gs_trtri_col2<0>(Ls, Dv, Linv, lane);
+        gs_trtri_col2<7>(Ls, Dv, Linv, lane);
+    } else if (w == 1) {
+        gs_trtri_col2<1>(Ls, Dv, Linv, lane);
+        gs_trtri_col2<6>(Ls, Dv, Linv, lane);
+    } else if (w == 2) {
+        gs_trtri_col2<2>(Ls, Dv, Linv, lane);
+        gs_trtri_col2<5>(Ls, Dv, Linv, lane);
+    } else {
+        gs_trtri_col2<3>(Ls, Dv, Linv, lane);
+        gs_trtri_col2<4>(Ls, Dv, Linv, lane);
+    }
+}
+
+// Contract as gs_diag_block_v1 (see there), except for what it leaves behind:
+//   - the substitution tables of the block stay in the caller's LDS workspace, wsp[0 .. GS_LTAB): the 28 panel dumps
+//     (-L_kj in A-operand layout) and the 8 micro-block inverses D_j.  gs_panel16 solves rows against them;
+//   - Ltab != NULL: the same GS_LTAB doubles are copied to global memory for kernels that come later;
+//   - Linv != NULL: the explicit 128 x 128 inverse is built too (phase 2; 15 k cycles that nothing on the
+//     factorisation's own path needs any more).
+#define GS_LTAB (GS_D2_DV + 8 * 16 * GS_DV_STR)          // 9344 doubles = 73 KB
+__device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet_out,
+                                             const double* diag0, unsigned long long* stamps, double* wsp) {
+    __shared__ double dbuf[128];
+    __shared__ int fail_sh;
+    double* Ls = wsp + GS_D2_LS;
+    double* Dv = wsp + GS_D2_DV;
+    double* thr = wsp + GS_D2_THR;
+    double* scr = nullptr;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    unsigned long long st0 = 0, sr0 = 0, st2 = 0;
+    if (stamps) {
+        st0 = __builtin_amdgcn_s_memtime();
+        sr0 = __builtin_amdgcn_s_memrealtime();
+        if (t == 0) stamps[7] = st0;
+    }
+    if (t < 128) {
+        const double d0 = diag0[t];
+        thr[t] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
+    }
+    if (t == 0) fail_sh = -1;
+    __syncthreads();
+    bool ok;
+    if (w == 0) ok = gs_d2_wave<0>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
+    else if (w == 1) ok = gs_d2_wave<1>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
+    else if (w == 2) ok = gs_d2_wave<2>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
+    else ok = gs_d2_wave<3>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
+    if (!ok) return fail_sh + 1;                       // uniform: every wave read the flag behind the same barrier
+    if (stamps) st2 = __builtin_amdgcn_s_memtime();
+    if (t < 128) dbuf[t] = log(dbuf[t]);
+    if (Ltab) {
+        const gs_d2* src = reinterpret_cast<const gs_d2*>(wsp);
+        gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab);
+        for (int i = t; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
+    }
+    if (Linv) gs_trtri_block(Ls, Dv, Linv, w, lane);
+    __threadfence_block();
+    __syncthreads();
+    if (t == 0) {
+        double sl = 0.0;
+        for (int j = 0; j < 128; ++j) sl += dbuf[j];
+        *logdet_out = sl;
+        if (stamps) {
+            const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
+            stamps[0] = 0;              // (the loads are part of phase 1 in this version)
+            stamps[1] = st2 - st0;      // phase 1 (micro-block factorisation)
+            stamps[2] = st3 - st2;      // table export (+ block inverse when asked for)
+            stamps[3] = st3 - st0;      // total shader cycles
+            stamps[4] = sr3 - sr0;      // total 100 MHz ticks
+        }
+    }
+    return 0;
+}
+
+// ---- rows against a factored diagonal block: blocked substitution on the matrix cores ---------------------------
+// X L_bb^T = B for 16 rows of B (128 columns), in place, by ONE wave, from the block's substitution tables in LDS: the
+// rows are eight micro-blocks in the register image of gs_diag_block (P_k = -B_k^T), and column step j is
+//     S   <- sum_{p<j} (-L_jp) P_p        (from zero, ascending p)
+//     P_j <- D_j (P_j + S)                (X_j^T = D_j (B_j - sum_{p<j} X_p L_jp^T)^T)
+// -- the arithmetic the rows below a diagonal micro-block go through inside gs_diag_block, with no pivoting work.  Only the
+// 16 x 16 inverses D_j multiply, the off-diagonal part of L_bb enters through products with L itself: this is forward
+// substitution at micro-block granularity, backward stable up to cond(L_jj) of 16 x 16 blocks, where a product with the
+// explicit 128 x 128 inverse (round 1) loses cond(L_bb): measured against the extended-precision value of the S2 / S3
+// log-likelihoods that product was 6-20 x further from the truth than LAPACK.  144 MFMAs per 16 rows instead of 256.
+// rows: pointer to the first of the 16 rows at the block's first column; nvalid: rows that exist (others read as 0).
+__device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid, const double* tab, int lane) {
+    const double* Ls = tab + GS_D2_LS;
+    const double* Dv = tab + GS_D2_DV;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool live = fr < nvalid;
+    gs_d4 P[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) P[k][x] = live ? -rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        gs_d4 S = {0.0, 0.0, 0.0, 0.0};                                // + sum_{p<j} L_jp X_p^T, from zero in ascending p
+#pragma unroll
+        for (int pp = 0; pp < j; ++pp) gs_d2_upd(S, Ls + (j * (j - 1) / 2 + pp) * 256, P[pp], lane);
+        const gs_d4 E = P[j] + S;                                      // -(B_j - sum)^T: one subtraction of the whole sum
+        gs_d4 T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(Dv[(j * 16 + fr) * GS_DV_STR + fq + 4 * x], E[x], T, 0, 0, 0);
+        P[j] = T;
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] = -P[k][x];
+    }
+}
+
+// global -> LDS copy of one block's substitution tables (256 threads); ends with a barrier
+__device__ __forceinline__ void gs_load_ltab(double* tab, const double* Ltab) {
+    const gs_d2* src = reinterpret_cast<const gs_d2*>(Ltab);
+    gs_d2* dst = reinterpret_cast<gs_d2*>(tab);
+    for (int i = threadIdx.x; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
+    __syncthreads();
+}
+
+// rows [0, M) x 128 columns at P (leading dimension ld)  <-  rows * L_bb^-T, 64 rows per workgroup (16 per wave)
+__global__ __launch_bounds__(256) void k_panel(double* P, int64_t ld, int M, const double* Ltab) {
+    __shared__ __attribute__((aligned(16))) double tab[GS_LTAB];
+    gs_load_ltab(tab, Ltab);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (blockIdx.x * 4 + w) * 16;
+    if (r0 >= M) return;
+    gs_panel16(P + (int64_t)r0 * ld, ld, M - r0, tab, lane);
+}
+
+// explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
+// multiply by L_bb^-1: the back-substitution half of cho_solve)
+__global__ __launch_bounds__(256) void k_trtri_blocks(const double* Ltab, double* Linv) {
+    __shared__ __attribute__((aligned(16))) double tab[GS_LTAB];
+    gs_load_ltab(tab, Ltab + (size_t)blockIdx.x * GS_LTAB);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gs_trtri_block(tab + GS_D2_LS, tab + GS_D2_DV, Linv + (size_t)blockIdx.x * 128 * 128, w, lane);
+}
+
 // info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
-__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* logdet,
+// ALGO 1: the round-1 routine (explicit inverse to Linv).  ALGO 2: micro-block routine, substitution tables to Ltab.
+template <int ALGO>
+__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet,
                                                      int* info, int col0, const double* diag0,
                                                      unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // 76.5 KB: one 64-KB bulk workgroup still fits
                                                                         // on the CU beside this kernel
     if (*info != 0) return;                    // an earlier block already failed (uniform)
-    const int bad = gs_diag_block(A, ld, Linv, logdet, diag0, stamps, wsd);
+    const int bad = ALGO == 1 ? gs_diag_block_v1(A, ld, Linv, logdet, diag0, stamps, wsd)
+                              : gs_diag_block(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
 }
 
@@ -521,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // ONE workgroup per evaluation builds K, factors it, solves for the right-hand sides and reduces the Gram
 // matrix; a launch evaluates a whole row of a likelihood grid.  Same arithmetic as the general path
 // (k_build's kernel functions, gs_diag_block), per-evaluation scratch in global memory (L2-resident).
-//   scratch per evaluation: A (128x128) | Linv (128x128);   res per evaluation: 258 doubles as k_finalize.
+//   scratch per evaluation: A (128x128) | W^T (16x128, in a 128x128 slot);   res per evaluation: 258 doubles as k_finalize.
 // ------------------------------------------------------------------------------------------------
 #define GS_SMALL_SCRATCH (2 * 128 * 128)
 
@@ -533,12 +1203,11 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     __shared__ double ldet;
     __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // lent to the build (us) and the solve (Wt) too:
     double* us = wsd;                                                   // 78.6 KB of LDS in all, two evaluations per CU
-    double* Wt = wsd;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const gsum_kernel_desc desc = descs[blockIdx.x];
     double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
-    double* Linv = A + 128 * 128;
+    double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
     double* out = res + (int64_t)blockIdx.x * 258;
     // ---- kernel matrix (full symmetric 128x128 tile, identity padding beyond n)
     for (int idx = t; idx < 128 * d; idx += 256) {
@@ -590,8 +1259,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     }
     __threadfence_block();
     __syncthreads();
-    // ---- Cholesky + inverse of the block
-    const int bad = gs_diag_block(A, 128, Linv, &ldet, dg0, nullptr, wsd);
+    // ---- Cholesky of the block; its substitution tables stay in wsd
+    const int bad = gs_diag_block(A, 128, (double*)nullptr, (double*)nullptr, &ldet, dg0, nullptr, wsd);
     if (bad) {
         if (t == 0) {
             out[256] = 0.0;
@@ -599,34 +1268,24 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
         }
         return;
     }
-    // ---- W^T = Z^T L^-T on the matrix cores: wave w owns column blocks 2w, 2w+1 of the 16 x 128 result.
-    // A operand: Z^T (row r = right-hand side, k = point), B operand: rows of L^-1 (lower triangular: only
-    // K blocks up to the column block contribute)
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int jb = 2 * w + h;
-        gs_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb <= jb; ++kb) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int kk = 16 * kb + 4 * s4 + fq;
-                const double av = (fr < k && kk < n) ? Z[(int64_t)kk * k + fr] : 0.0;
-                const double bv = Linv[(16 * jb + fr) * 128 + kk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Wt[(fq + 4 * x) * 129 + 16 * jb + fr] = acc[x];
+    // ---- W^T = Z^T L^-T: the right-hand sides as 16 rows of 128 points, solved by one wave against the tables
+    for (int idx = t; idx < 16 * 128; idx += 256) {
+        const int c = idx >> 7, i = idx & 127;
+        Wt[idx] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
     }
+    __threadfence_block();
     __syncthreads();
+    if (w == 0) gs_panel16(Wt, 128, 16, wsd, lane);
+    __threadfence_block();
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
     // ---- Gram matrix G = W^T W (16 x 16, K = 128) by wave 0
     if (w == 0) {
         gs_d4 g = {0.0, 0.0, 0.0, 0.0};
         for (int kb = 0; kb < 8; ++kb) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double wv = Wt[fr * 129 + 16 * kb + 4 * s4 + fq];
+                const double wv = Wt[fr * 128 + 16 * kb + 4 * s4 + fq];
                 g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
             }
         }
@@ -945,8 +1604,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     const int np = (n + 127) / 128 * 128, T = np / 128;
     const int64_t ld = np + GS_BORDER;
     double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
-    double* Linv = A + (int64_t)np * ld;
-    double* diag0 = Linv + (int64_t)T * 128 * 128;
+    double* Ltab = A + (int64_t)np * ld;            // T x GS_LTAB substitution tables (in a T x 128 x 128 slot)
+    double* diag0 = Ltab + (int64_t)T * 128 * 128;
     double* Wt = diag0 + np;                        // 16 x np, row-major
     double* out = res + (int64_t)blockIdx.x * 258;
     // ---- kernel matrix: lower 128x128 tiles, identity padding (k_build's arithmetic)
@@ -1016,8 +1675,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
         const bool two = b + 1 < T;
         for (int s = 0; s < (two ? 2 : 1); ++s) {
             const int c = b + s;
-            double* Lc = Linv + (int64_t)c * 128 * 128;
-            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, Lc, &ldet_blk, diag0 + c * 128, nullptr, lds);
+            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, (double*)nullptr, Ltab + (int64_t)c * GS_LTAB,
+                                          &ldet_blk, diag0 + c * 128, nullptr, lds);
             if (bad) {
                 if (t == 0) {
                     out[256] = 0.0;
@@ -1028,10 +1687,11 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
             if (t == 0) ldet_sum += ldet_blk;
             __threadfence_block();
             __syncthreads();
-            for (int i = c + 1; i < T; ++i) {       // panel: rows of block i  <-  rows * L_cc^-T
-                double* P = A + (int64_t)i * 128 * ld + c * 128;
-                gs_tile128(P, ld, P, ld, Lc, 128, 128, 128, 128, 0, 1.0, lds);
-            }
+            // panel: rows below <- rows * L_cc^-T by blocked substitution against the tables gs_diag_block left in lds,
+            // 16 rows per wave at a time
+            for (int br = w; br < (T - c - 1) * 8; br += 4)
+                gs_panel16(A + ((int64_t)(c + 1) * 128 + 16 * br) * ld + c * 128, ld, 16, lds, lane);
+            __threadfence_block();
             if (s == 0 && two)                      // sibling block column b + 1: the first panel only (K = 128)
                 for (int i = b + 1; i < T; ++i)
                     gs_tile128(A + (int64_t)i * 128 * ld + (b + 1) * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
@@ -1067,28 +1727,15 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                     acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[h], 0, 0, 0);
                 }
             }
-        // stage the updated rows, then multiply by L_bb^-T
-        __syncthreads();
+        // the updated rows go to W^T, then one wave solves them against block b's tables
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) lds[(fq + 4 * x) * 129 + (2 * w + h) * 16 + fr] = acc[h][x];
+            for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + b * 128 + (2 * w + h) * 16 + fr] = acc[h][x];
+        __threadfence_block();
         __syncthreads();
-        const double* Lb = Linv + (int64_t)b * 128 * 128;
-        gs_d4 o[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        for (int s4 = 0; s4 < 32; ++s4) {
-            const int kk = 4 * s4 + fq;
-            const double av = lds[fr * 129 + kk];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double bv = Lb[((2 * w + h) * 16 + fr) * 128 + kk];
-                o[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o[h], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + b * 128 + (2 * w + h) * 16 + fr] = o[h][x];
+        gs_load_ltab(lds, Ltab + (int64_t)b * GS_LTAB);
+        if (w == 0) gs_panel16(Wt + b * 128, np, 16, lds, lane);
         __threadfence_block();
         __syncthreads();
     }

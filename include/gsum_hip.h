@@ -210,6 +210,10 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
  * With option "diag_stamps" = 1 and n > 4: ms[4..8] = shader-cycle stamps of the last diagonal-block
  * kernel {prologue, column loop, block inverse, total} and its total in 100 MHz ticks. */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
+/* diagnostic: the 64 raw stamp words of the last diagonal-block kernel run with "diag_stamps" = 1 ([0..4] as above;
+ * round-2 kernel: [7] start, [8 + 2j], [9 + 2j] wave 0 behind the two barriers of micro-block column j, [24 + j] cycles
+ * of the pivot recurrence of micro-block j). */
+int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64);
 /* With option "profile_gemm" = N > 0 every launch of the bulk trailing-update kernel (128x128-tile, 8-wave MFMA GEMM)
  * of every N-th fused evaluation (the 1st, N+1-th, ... since the option was set; operator-level calls: every launch) is
  * bracketed by HIP events on the stream it is launched on (N = 1 costs ~5 % of batch throughput, N = 4 ~1 %).  This

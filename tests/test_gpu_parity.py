@@ -497,13 +497,13 @@ def test_large_known_answers_gp_drawn(idx):
 
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_large_known_answers_uniform_grid(large_lml, idx):
-    """S2/S3 exactly as SURVEY.md §8c states them (uniform grid, white-noise coefficients).  With
-    lambda_min(K) = 2.7e-8 the quadratic form is dominated by the smallest eigen-directions, and two valid
-    fp64 factorisations of the SAME matrix disagree by up to 1.1e-10 in the lml (LAPACK vs an unblocked
-    right-looking Cholesky, both on the CPU: tests/test_blocked_algorithm.py::test_intrinsic_spread...);
-    the reference's own value is ~3e-11 from the long-double answer.  The bound here is therefore 3e-10;
-    the 1e-10 bar is enforced on the conditioned variant above and, for this input, on the factorisation
-    alone (same K on both sides) below."""
+    """S2/S3 exactly as SURVEY.md §8c states them (uniform grid, white-noise coefficients): lambda_min(K) = 2.7e-8, the
+    quadratic form is dominated by the smallest eigen-directions and its last digits depend on the ORDER of the fp64
+    operations.  Round 1 passed this at 3e-10 only: its diagonal-block kernel subtracted products from the matrix one by
+    one (right-looking).  The round-2 kernels sum the products from zero and subtract once (the order of LAPACK's dot
+    products): against the extended-precision value of the same fp64 inputs (tests/golden/large_truth.json) the HIP path
+    is now as close as LAPACK (1.5e-11 vs 2.2e-11 at n = 8192), and this test holds the north-star bound, 1e-10, against the
+    reference's own values."""
     from sklearn.gaussian_process.kernels import RBF
     case = large_lml[idx]
     n, r = case["n"], case["r"]
@@ -513,7 +513,7 @@ def test_large_known_answers_uniform_grid(large_lml, idx):
     gp.X_train_, gp.y_train_, gp.orders_ = X, y, np.arange(r)
     for q, want in case["lml"].items():
         got = gp.log_marginal_likelihood(theta=np.log([case["length_scale"]]), ratio=float(q))
-        assert got == pytest.approx(want, rel=3e-10), (n, q, got, want)
+        assert got == pytest.approx(want, rel=1e-10), (n, q, got, want)
 
 
 def test_lml_vs_oracle_n2048_matern_2d():

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Single-factorisation latency at n = 8192 against the knobs that shape the look-ahead schedule."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import gsum_amd  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF  # noqa: E402
+
+ctx = gsum_amd.default_context(0)
+n, r = 8192, 6
+X = 0.1 * np.arange(n)[:, None]
+Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
+desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+ctx.set_inputs(X, Z)
+ctx.set_option("batch_slots", 1)
+
+
+def run(label):
+    ts = []
+    for _ in range(6):
+        ctx.lml_resident([desc], 1e-10)
+        ts.append(ctx.timers()["potrf_ms"])
+    print(f"{label:40s} potrf ms min {min(ts):.3f} median {sorted(ts)[3]:.3f}", flush=True)
+
+
+for rep in range(2):
+    for pad in (0, 56 * 1024, 72 * 1024, 80 * 1024):
+        for R in (0, 4):
+            ctx.set_option("reserve_cus", R)
+            ctx.set_option("bulk_lds_pad", pad)
+            run(f"bulk_lds_pad={pad} reserve_cus={R}")
+ctx.set_option("bulk_lds_pad", 0)
+ctx.set_option("reserve_cus", 0)
+ctx.set_option("bulk_cfg", 7)
+ctx.set_option("lookahead", 0)
+run("lookahead=0")
