@@ -30,6 +30,8 @@ struct gsum_mat {
 // the latency-bound panel chain of one overlaps the bulk GEMMs of the others.
 struct gs_slot {
     hipStream_t sm = nullptr, sp = nullptr;   // main (bulk) / high-priority panel chain
+    hipStream_t su = nullptr;        // gradient path: the U = L^-T sweep, trailing the factorisation panel by panel
+    hipEvent_t evU = nullptr;
     hipStream_t sb = nullptr;        // bulk stream restricted by a CU mask (look-ahead schedules, reserve_cus > 0)
     int sb_reserve = 0;              // reserve_cus value sb was created for
     std::vector<hipEvent_t> evP, evM;
@@ -673,6 +675,8 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->sm) (void)hipStreamDestroy(sl->sm);
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
         if (sl->sb) (void)hipStreamDestroy(sl->sb);
+        if (sl->su) (void)hipStreamDestroy(sl->su);
+        if (sl->evU) (void)hipEventDestroy(sl->evU);
     }
     for (gs_inputs* I : {&ctx->op, &ctx->res}) {
         if (I->X) (void)hipFree(I->X);
@@ -1051,10 +1055,21 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                            (int)n, d_ref_s, d_rat_s, d_ref_x, d_rat_x, *sc);
         GS_CHECK(hipGetLastError());
     }
-    for (int c = 0; c < L->T; ++c) {
-        const int64_t c0 = (int64_t)c * GS_NB, r0 = c0 + GS_NB;
+    // V^T = kernel(Xs, X) L^-T by a right-looking sweep, two block columns per trailing update (K = 256) like the
+    // factorisation: the trailing part of Bt is read and written once per 256 eliminated columns instead of once per 128
+    // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work)
+    const int sib_cfg = m >= 1024 ? GS_BULK : 1;
+    for (int c = 0; c < L->T; c += 2) {
+        const bool two = c + 1 < L->T;
+        const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
         if (gs_trsm_rows(ctx, ctx->cur->sm, L, c, Bt + c0, ldb, m)) return -1;
-        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r0, ldb, Bt + c0, ldb, L->A + r0 * ld + c0, ld, m, np - r0, GS_NB, 0, 1, -1.0))
+        if (two) {
+            if (gs_gemm(ctx, ctx->cur->sm, sib_cfg, Bt + c1, ldb, Bt + c0, ldb, L->A + c1 * ld + c0, ld, m, GS_NB, GS_NB, 0, 1, -1.0))
+                return -1;
+            if (gs_trsm_rows(ctx, ctx->cur->sm, L, c + 1, Bt + c1, ldb, m)) return -1;
+        }
+        if (r2 < np && gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, np - r2,
+                               (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
     hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
@@ -1070,7 +1085,10 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
         GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
     if (cov_out) {
-        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 0, 0, 1.0)) return -1;
+        // V^T V is symmetric: lower tiles only (half the flops of the square product), then mirrored in place
+        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 1, 0, 1.0)) return -1;
+        hipLaunchKernelGGL(k_mirror_lower, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->cur->sm, dCov, m, (int)m);
+        GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     }
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
@@ -1368,21 +1386,36 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     double *U = (double*)(base + o_u), *Ri = (double*)(base + o_r), *Vt = (double*)(base + o_v), *Q = (double*)(base + o_q),
            *trow = (double*)(base + o_t), *dout = (double*)(base + o_o), *part = (double*)(base + o_p);
     hipStream_t s = sl->sm;
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, U, ldg, (int)np);
+    // U = L^-T trails the factorisation on a stream of its own: block columns c, c + 1 of the sweep need the factor's
+    // columns c0 .. c0 + 255 and their tables, which are final once the panel chain of that outer step has run (event
+    // evP[c] of the look-ahead schedule).  One factorisation alone is bound by its panel chain, with most of the chip idle
+    // behind it -- the sweep's GEMMs (n^3 / 3 flops) fill that time instead of following it (5.5 ms at n = 8192).
+    const bool trail = ctx->lookahead != 0 && ctx->batch_active < 3;       // the condition under which gs_potrf records evP
+    if (!sl->su) {
+        GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evU, hipEventDisableTiming));
+    }
+    hipStream_t su = sl->su;
+    GS_CHECK(hipEventRecord(sl->evU, s));                                  // everything enqueued so far (nothing of U is in use)
+    if (!trail) GS_CHECK(hipStreamWaitEvent(su, sl->evU, 0));              // no per-panel events: the sweep follows the factorisation
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, su, U, ldg, (int)np);
     GS_CHECK(hipGetLastError());
     // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
     for (int c = 0; c < m->T; c += 2) {
         const bool two = c + 1 < m->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
-        if (gs_trsm_rows(ctx, s, m, c, U + c0, ldg, c1)) return -1;
+        if (trail) GS_CHECK(hipStreamWaitEvent(su, sl->evP[c], 0));
+        if (gs_trsm_rows(ctx, su, m, c, U + c0, ldg, c1)) return -1;
         if (two) {
             // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
-            if (gs_gemm(ctx, s, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            if (gs_trsm_rows(ctx, s, m, c + 1, U + c1, ldg, r2)) return -1;
+            if (gs_gemm(ctx, su, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            if (gs_trsm_rows(ctx, su, m, c + 1, U + c1, ldg, r2)) return -1;
         }
-        if (r2 < np && gs_gemm(ctx, s, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+        if (r2 < np && gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
+    GS_CHECK(hipEventRecord(sl->evU, su));
+    GS_CHECK(hipStreamWaitEvent(s, sl->evU, 0));
     // V^T = W^T U^T needs only U: it runs on the panel stream beside the SYRK
     GS_CHECK(hipEventRecord(sl->evFork, s));
     if (gs_panel_stream(ctx, sl)) return -1;

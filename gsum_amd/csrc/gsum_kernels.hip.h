@@ -2113,6 +2113,13 @@ __global__ __launch_bounds__(256) void k_back_step(const double* A, int64_t ld, 
         for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr] = o[h][x];
 }
 
+// upper triangle <- lower triangle, in place (rows are written coalesced; the strided reads hit L2 for the sizes this serves)
+__global__ __launch_bounds__(256) void k_mirror_lower(double* A, int64_t ld, int n) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < n && j > i) A[(int64_t)i * ld + j] = A[(int64_t)j * ld + i];
+}
+
 // Mirror the lower triangle into the upper one / zero the upper one, into a dense n x n buffer.
 __global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int n, double* out, int zero_upper) {
     const int j = blockIdx.x * 256 + threadIdx.x;

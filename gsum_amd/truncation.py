@@ -7,6 +7,8 @@ grid scan that the reference spells as a nested Python loop over ``log_marginal_
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 from .conjugate import ConjugateGaussianProcess, ConjugateStudentProcess
@@ -42,6 +44,10 @@ class TruncationGP:
         self.dX_ = None
         self.dy_ = None
         self.coeffs_ = None
+        # predict() conditions on cov(Xc, Xc), which carries no nugget (reference quirk Q7).  When that matrix is singular
+        # to working precision the device Cholesky fails; by default the conditioning is then retried with the smallest
+        # relative diagonal jitter that makes it factorise, with a RuntimeWarning.  True: raise LinAlgError instead.
+        self.strict_conditioning = False
 
     # -- scaled mean / cov / basis (models.py:1337-1365) -----------------------------------------
     def mean(self, X, start=0, end=np.inf):
@@ -98,8 +104,8 @@ class TruncationGP:
         The reference solves with LU (numpy.linalg.solve) on cov(Xc, Xc), which carries neither nugget nor
         WhiteKernel noise (two-argument kernel call).  Here K_oo is built and scaled on the
         device and factorised by the same Cholesky as the likelihood path: for a positive definite K_oo the two
-        agree to rounding x cond(K_oo); a K_oo that is singular to working precision raises LinAlgError
-        instead of returning LU's arbitrary answer."""
+        agree to rounding x cond(K_oo); a K_oo that is singular to working precision is retried with a small relative
+        jitter (RuntimeWarning), or raises LinAlgError when ``strict_conditioning`` is set."""
         from ._lib import SeriesScale
         gp = self.coeffs_process
         ctx = gp._context()
@@ -109,18 +115,31 @@ class TruncationGP:
         sc = SeriesScale.make(start, end, self.excluded, factor)
         ref_c, ratio_c = self.ref(Xc), self.ratio(Xc, **self.ratio_kws)
         ref_n, ratio_n = self.ref(X), self.ratio(X, **self.ratio_kws)
-        K = ctx.kernel_matrix_dev(desc, Xc, diag_add=0.0)
-        try:
-            K.scale_series(sc, ref_c, ratio_c)
-            info = ctx.potrf(K)
-            if info != 0:
+        # The reference solves with LU on a matrix that is, for the dense RBF training sets it is used on, singular to
+        # working precision (cond >= 1e16) and still returns usable numbers.  A Cholesky factorisation of the same
+        # matrix fails; rather than regress those workflows the conditioning is retried with a relative jitter on the
+        # diagonal of the correlation matrix, smallest first, and says so.
+        for jitter in (0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6):
+            K = ctx.kernel_matrix_dev(desc, Xc, diag_add=jitter)
+            try:
+                K.scale_series(sc, ref_c, ratio_c)
+                info = ctx.potrf(K)
+                if info == 0:
+                    colsumsq, shift, red = ctx.predict_terms(K, desc, Xc, X, rhs=resid, want_cov=want_cov,
+                                                             series=(sc, ref_c, ratio_c, ref_n, ratio_n))
+                    break
+            finally:
+                K.free()
+            if self.strict_conditioning:
                 raise np.linalg.LinAlgError(
                     'cov(Xc, Xc) is not positive definite to working precision (leading minor %d); the reference '
                     'conditions on it with LU and no jitter -- use fewer / better separated conditioning points' % info)
-            colsumsq, shift, red = ctx.predict_terms(K, desc, Xc, X, rhs=resid, want_cov=want_cov,
-                                                     series=(sc, ref_c, ratio_c, ref_n, ratio_n))
-        finally:
-            K.free()
+        else:
+            raise np.linalg.LinAlgError('cov(Xc, Xc) is not positive definite even with a relative jitter of 1e-6')
+        if jitter > 0.0:
+            warnings.warn('cov(Xc, Xc) is singular to working precision: conditioned with a relative diagonal jitter of %g '
+                          '(the reference solves this system with LU and no jitter; set strict_conditioning=True to get '
+                          'LinAlgError instead)' % jitter, RuntimeWarning, stacklevel=3)
         return shift[:, 0], colsumsq, red
 
     def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both'):

@@ -331,3 +331,33 @@ def test_large_cases_against_extended_precision_truth():
         json.dump(rows, f, indent=1)
     for row in rows:
         assert row["hip_rel_err"] <= 1e-10, row
+
+
+def test_predict_vs_oracle_n4096_m1024_eight_curves():
+    """BASELINE config 5's path at a size the oracle answers in seconds: n = 4096 2-D points, Matern-5/2 + White(1e-6),
+    8 curves, 1024 new points -- predictive mean, standard deviation and the full predictive covariance (the sweep runs
+    K = 256 two-column steps, the covariance reduction is a lower-tile SYRK mirrored on the device).  Variance tolerance
+    1e-10 * cov_factor_ (two valid fp64 formulations already differ by 5e-11 relative)."""
+    n, m, r = 4096, 1024, 8
+    rng = np.random.RandomState(3)
+    side = np.array([0.35, 0.65]) * np.sqrt(n)
+    X = rng.rand(n, 2) * side
+    Xs = rng.rand(m, 2) * side
+    y = rng.randn(n, r) + 0.3
+    kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    priors = dict(center=0.1, disp=1.5, df=2, scale=0.7)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **priors)
+    gp.fit(X, y)
+    fit = orc.cgp_fit(kern, X, y, **priors)
+    assert gp.cov_factor_ == pytest.approx(fit["cov_factor"], rel=1e-10)
+    mean, std = gp.predict(Xs, return_std=True)
+    mo, so = orc.cgp_predict(fit, Xs, return_std=True)
+    assert mean.shape == (m, r) and std.shape == (m,)
+    np.testing.assert_allclose(mean, mo, rtol=1e-9, atol=1e-9 * np.abs(mo).max())
+    np.testing.assert_allclose(std ** 2, so ** 2, rtol=1e-9, atol=1e-10 * fit["cov_factor"])
+    mean2, cov = gp.predict(Xs[:300], return_cov=True)
+    mo2, co = orc.cgp_predict(fit, Xs[:300], return_cov=True)
+    np.testing.assert_array_equal(mean2, mean[:300])
+    np.testing.assert_array_equal(cov, cov.T)                        # mirrored from the lower tiles
+    np.testing.assert_allclose(cov, co, rtol=1e-9, atol=1e-10 * fit["cov_factor"])
+    np.testing.assert_allclose(np.diag(cov), std[:300] ** 2, rtol=1e-9, atol=1e-11 * fit["cov_factor"])
