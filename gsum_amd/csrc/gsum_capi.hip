@@ -20,6 +20,8 @@ struct gsum_mat {
                                // diag_algo 2: lazily, from the tables, for the consumers that multiply by L_bb^-1)
     double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks (diag_algo 2)
     bool have_ltab = false, have_linv = false;
+    std::vector<double> solved_rhs;     // host copy of the right-hand sides whose forward solve W^T = (L^-1 RHS)^T the border rows
+    int solved_k = -1;                  // hold (-1: none): a repeated predict / forward_gram with the same RHS skips the solve
     double* logdet = nullptr;  // T per-block sums of log L_ii
     double* diag0 = nullptr;   // np original diagonal entries (pivot-cancellation test)
     bool factored = false;
@@ -473,6 +475,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     if (gs_potrf_events(ctx, sl, T)) return -1;
     m->have_linv = ctx->diag_algo == 1;        // round-1 kernel: explicit inverses, TRSM as a product with them
     m->have_ltab = !m->have_linv;              // round-2 kernel: substitution tables, TRSM by blocked substitution
+    m->solved_k = -1;
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
     GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
@@ -879,6 +882,20 @@ static int gs_border_solve(gsum_ctx* ctx, gsum_mat* m) {
     return 0;
 }
 
+// border rows <- (L^-1 RHS)^T, corner <- -W^T W; skipped when the rows already hold the solve of the same RHS (predict is
+// called again and again with the same training residual: T x 2 dependent launches saved per call)
+static int gs_border_prepare(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int k) {
+    const size_t cnt = (size_t)n * k;
+    if (L->solved_k == k && L->solved_rhs.size() == cnt && !memcmp(L->solved_rhs.data(), RHS, cnt * sizeof(double))) return 0;
+    L->solved_k = -1;
+    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
+    if (gs_border_solve(ctx, L)) return -1;
+    L->solved_rhs.assign(RHS, RHS + cnt);
+    L->solved_k = k;
+    return 0;
+}
+
 int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* G,
                       double* sum_log_diag) {
     if (!ctx || !L || !G || !sum_log_diag) return -2;
@@ -886,10 +903,8 @@ int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, 
     if (!L->factored) GS_FAIL("forward_gram needs a factorised matrix");
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
-    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
     GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
-    if (gs_border_solve(ctx, L)) return -1;
+    if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
     if (gs_finalize(ctx, L)) return -1;
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     for (int i = 0; i < k; ++i)
@@ -904,9 +919,7 @@ int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n,
     if (!L->factored) GS_FAIL("forward_solve needs a factorised matrix");
     if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
-    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
-    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
-    if (gs_border_solve(ctx, L)) return -1;
+    if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
     std::vector<double> rows((size_t)k * n);
     GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), L->A + L->np * L->ld, (size_t)L->ld * sizeof(double),
                               (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, ctx->cur->sm));
@@ -926,9 +939,8 @@ int gsum_cho_solve(gsum_ctx* ctx, gsum_mat* L, const double* B, int64_t n, int32
     if (n != L->n) GS_FAIL("B has the wrong number of rows");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
     hipStream_t s = ctx->cur->sm;
-    if (gs_upload_Z(ctx, &ctx->op, B, n, k)) return -1;
-    if (gs_set_border(ctx, s, L, ctx->op.Z, k)) return -1;
-    if (gs_border_solve(ctx, L)) return -1;
+    if (gs_border_prepare(ctx, L, B, n, k)) return -1;
+    L->solved_k = -1;                  // the back-substitution below overwrites the border rows in place
     if (gs_need_linv(ctx, s, L)) return -1;
     double* Brow = L->A + L->np * L->ld;
     const int T = L->T;
@@ -1077,9 +1089,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     std::vector<double> vw;
     if (k > 0) {
-        if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
-        if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
-        if (gs_border_solve(ctx, L)) return -1;
+        if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
         if (gs_gemm(ctx, ctx->cur->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
         vw.resize((size_t)m * 16);
         GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
@@ -1420,7 +1430,8 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     GS_CHECK(hipEventRecord(sl->evFork, s));
     if (gs_panel_stream(ctx, sl)) return -1;
     GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
-    if (gs_gemm(ctx, sl->sp, 2, Vt, ldg, m->A + np * ld, ld, U, ldg, GS_BORDER, np, (int)np, 0, 0, 1.0)) return -1;
+    hipLaunchKernelGGL(k_upper_times_rows, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, sl->sp, U, ldg, (int)np, m->A + np * ld, ld, Vt, ldg);
+    GS_CHECK(hipGetLastError());
     if (gs_potrf_events(ctx, sl, 1)) return -1;
     GS_CHECK(hipEventRecord(sl->evP[0], sl->sp));
     if (gs_gemm(ctx, s, GS_BULK, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;

@@ -1113,16 +1113,19 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
 // explicit 128 x 128 inverse (round 1) loses cond(L_bb): measured against the extended-precision value of the S2 / S3
 // log-likelihoods that product was 6-20 x further from the truth than LAPACK.  144 MFMAs per 16 rows instead of 256.
 // rows: pointer to the first of the 16 rows at the block's first column; nvalid: rows that exist (others read as 0).
-__device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid, const double* tab, int lane) {
-    const double* Ls = tab + GS_D2_LS;
-    const double* Dv = tab + GS_D2_DV;
+__device__ __forceinline__ void gs_panel16_load(gs_d4 (&P)[8], const double* rows, int64_t ld, int nvalid, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     const bool live = fr < nvalid;
-    gs_d4 P[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int x = 0; x < 4; ++x) P[k][x] = live ? -rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] : 0.0;
+}
+
+__device__ __forceinline__ void gs_panel16_solve(gs_d4 (&P)[8], const double* tab, int lane) {
+    const double* Ls = tab + GS_D2_LS;
+    const double* Dv = tab + GS_D2_DV;
+    const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         gs_d4 S = {0.0, 0.0, 0.0, 0.0};                                // + sum_{p<j} L_jp X_p^T, from zero in ascending p
@@ -1135,12 +1138,23 @@ __device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid,
             T = __builtin_amdgcn_mfma_f64_16x16x4f64(Dv[(j * 16 + fr) * GS_DV_STR + fq + 4 * x], E[x], T, 0, 0, 0);
         P[j] = T;
     }
-    if (live) {
+}
+
+__device__ __forceinline__ void gs_panel16_store(const gs_d4 (&P)[8], double* rows, int64_t ld, int nvalid, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    if (fr < nvalid) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int x = 0; x < 4; ++x) rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] = -P[k][x];
     }
+}
+
+__device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid, const double* tab, int lane) {
+    gs_d4 P[8];
+    gs_panel16_load(P, rows, ld, nvalid, lane);
+    gs_panel16_solve(P, tab, lane);
+    gs_panel16_store(P, rows, ld, nvalid, lane);
 }
 
 // global -> LDS copy of one block's substitution tables (256 threads); ends with a barrier
@@ -1151,15 +1165,31 @@ __device__ __forceinline__ void gs_load_ltab(double* tab, const double* Ltab) {
     __syncthreads();
 }
 
+// the same copy without staging registers: global_load_lds_dwordx4 moves each wave's 64 x 16 B straight into LDS
+// (wave w of the workgroup's 4 takes every fourth 1-KiB piece); the caller waits (vmcnt) and synchronises
+__device__ __forceinline__ void gs_load_ltab_direct(double* tab, const double* Ltab, int w, int lane) {
+    constexpr int PIECES = GS_LTAB * 8 / 1024;                 // 73 whole 1-KiB pieces (GS_LTAB * 8 = 74752 = 73 KiB)
+    for (int pc = w; pc < PIECES; pc += 4)
+        __builtin_amdgcn_global_load_lds(Ltab + pc * 128 + 2 * lane, tab + pc * 128, 16, 0, 0);
+}
+
 // rows [0, M) x 128 columns at P (leading dimension ld)  <-  rows * L_bb^-T, 64 rows per workgroup (16 per wave)
 __global__ __launch_bounds__(256) void k_panel(double* P, int64_t ld, int M, const double* Ltab) {
     __shared__ __attribute__((aligned(16))) double tab[GS_LTAB];
-    gs_load_ltab(tab, Ltab);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gs_load_ltab_direct(tab, Ltab, w, lane);
     const int r0 = (blockIdx.x * 4 + w) * 16;
+    // the rows are fetched while the tables are still in flight
+    const int nvalid = M - r0;
+    double* rows = P + (int64_t)(r0 < M ? r0 : 0) * ld;
+    gs_d4 Pr[8];
+    gs_panel16_load(Pr, rows, ld, r0 < M ? nvalid : 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (r0 >= M) return;
-    gs_panel16(P + (int64_t)r0 * ld, ld, M - r0, tab, lane);
+    gs_panel16_solve(Pr, tab, lane);
+    gs_panel16_store(Pr, rows, ld, nvalid, lane);
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
@@ -2186,6 +2216,38 @@ __global__ __launch_bounds__(256) void k_tri_multiply(const double* L, int64_t l
 #pragma unroll
         for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
         out[(int64_t)i * 16 + lane] = v;
+    }
+}
+
+// Vt[c][j] = sum_{k >= j} U[j][k] Wt[c][k] for an upper-triangular U (row-major, n x n) and 16 rows Wt: V^T = W^T U^T of
+// the gradient path.  One wave per row of U (read once, coalesced: HBM-bound, 4 n^2 bytes), 16 accumulators per lane,
+// butterfly reduction.  (As a 16 x n x n GEMM on 16 x 256 tiles this had 32 workgroups with K = n each: 3.7 ms at n = 8192.)
+__global__ __launch_bounds__(256) void k_upper_times_rows(const double* U, int64_t ldu, int n, const double* Wt, int64_t ldw,
+                                                           double* Vt, int64_t ldv) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    double acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+    const double* row = U + (int64_t)j * ldu;
+    for (int k = (j & ~63) + lane; k < n; k += 64) {
+        const double u = k >= j ? row[k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(u, Wt[(int64_t)c * ldw + k], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double v = acc[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[c] = v;
+    }
+    if (lane < 16) {
+        double v = acc[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
+        Vt[(int64_t)lane * ldv + j] = v;
     }
 }
 
