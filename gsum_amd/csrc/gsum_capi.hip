@@ -58,8 +58,8 @@ struct gsum_ctx {
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
     int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident: 3 is the measured optimum with
-                                     // the HIP runtime's default of 4 hardware queues; gsum_init raises it to 10 / 14 / 20
-                                     // when GPU_MAX_HW_QUEUES >= 8 / 12 / 24 is in the environment
+                                     // the HIP runtime's default of 4 hardware queues; gsum_init raises it to 8 / 12 / 16
+                                     // when GPU_MAX_HW_QUEUES >= 8 / 12 / 16 is in the environment
     int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
@@ -645,15 +645,17 @@ int gsum_init(int device, gsum_ctx** out) {
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
-    // With the limit raised (GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises) ten evaluations in
-    // flight beat three: 4.75 vs 5.45 ms per evaluation at n = 8192.
-    // (measured with the 128x64 bulk tile, ms per evaluation at 20 / 60 evaluations per call: 32 queues and 20 slots
-    // 3.70 / 3.60; 16 queues and 14 slots 3.94 / 3.73; 10 slots 4.01 / 3.98; 24 slots are unstable)
+    // With the limit raised (GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises) every in-flight evaluation
+    // owns a queue: 16 in flight run 3.7-3.8 ms per evaluation at n = 8192 against 4.9 for 3 in flight on the default 4
+    // queues.  Twenty in flight are 2-3 % faster still in a process that owns the GPU alone, but the device schedules at
+    // most 24 user compute queues without time-slicing them: with an RCCL communicator (or any other stream owner) in
+    // the process, 20 + its queues cross that line and throughput collapses to 148 evaluations per second (measured
+    // under torchrun, round 2; 16 in flight: 263).  Hence 16 by default; "batch_slots" / GSUM_BATCH_SLOTS override.
     const char* hq = getenv("GPU_MAX_HW_QUEUES");
     const int nq = hq ? atoi(hq) : 4;
-    if (nq >= 24) ctx->batch_slots = 20;
-    else if (nq >= 12) ctx->batch_slots = 14;
-    else if (nq >= 8) ctx->batch_slots = 10;
+    if (nq >= 16) ctx->batch_slots = 16;
+    else if (nq >= 12) ctx->batch_slots = 12;
+    else if (nq >= 8) ctx->batch_slots = 8;
     const char* bs = getenv("GSUM_BATCH_SLOTS");
     if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;

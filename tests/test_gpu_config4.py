@@ -215,8 +215,9 @@ def test_resident_inputs_survive_other_calls(ctx):
 
 def test_queue_probe_reports_real_concurrency(ctx):
     """Before trusting more than 4 evaluations in flight the library times its streams (gs_probe_queues).  Here the test
-    process asked for 32 hardware queues before HIP initialised (tests/conftest.py), so 20 streams must run side by side
-    and the configured slot count must stand."""
+    process asked for 32 hardware queues before HIP initialised (tests/conftest.py), so the library's default of 16 in-flight
+    evaluations must run side by side and stand (16, not 20: the device time-slices user compute queues beyond 24, and an
+    RCCL communicator in the same process needs a few)."""
     assert os.environ.get("GPU_MAX_HW_QUEUES") == "32"
     rng = np.random.RandomState(1)
     n = 2304
@@ -231,9 +232,9 @@ def test_queue_probe_reports_real_concurrency(ctx):
     finally:
         ctx.set_option("medium_path", 1)
     pr = ctx.queue_probe()
-    assert pr["streams"] >= 20 and pr["fell_back_from"] == 0
+    assert pr["streams"] >= 16 and pr["fell_back_from"] == 0
     assert pr["concurrency"] >= 0.7 * pr["streams"], pr
-    assert pr["batch_slots"] == 20
+    assert pr["batch_slots"] == 16
 
 
 def test_potrf_info_pattern_matches_lapack_on_notebook_like_inputs(ctx):
