@@ -816,56 +816,72 @@ __device__ __forceinline__ void gs_wave_lds_sync() {
 // ~35 instructions per column, two of them MFMAs, against ~70 VALU + v_readlane for a row-per-lane formulation (9.3 k
 // cycles per micro-block measured) and a barrier + LDS mailbox per two columns in round 1.
 // Ablk: the block's origin in the matrix.  Dvj: its 16 x 17 slot of the inverse table.  Returns the failing local column or -1.
+// PAIR IMAGE of the diagonal micro-blocks.  The recurrence below eliminates two columns per step (the two pivots'
+// reciprocal square roots are independent dependent-chains; done one after the other they are most of a column's ~430
+// cycles), and for that both columns of a pair must sit in the same lanes.  A diagonal micro-block M (symmetric) is
+// therefore held permuted: with rho(i) = (i >> 2) + 4 (i & 3), register x of lane l holds M[rho^-1(l & 15)][4 (l >> 4) + x]
+// -- columns 4 g .. 4 g + 3 in the sixteen lanes of group g.  Seen as an MFMA accumulator this is Pi M Pi^T for the
+// permutation Pi of rho, so rank-1 updates with vectors indexed the same way (lane & 15 = rho(row)) need nothing else:
+// the sums S_jj reach it by reading the panel dumps with a permuted lane index (gs_d2_upd_diag), A_jj by loading it so.
+__device__ __forceinline__ int gs_pair_row(int lane) { return 4 * (lane & 3) + ((lane & 15) >> 2); }   // rho^-1(lane & 15)
+#define GS_PAIR_LANE(r, c) (16 * ((c) >> 2) + ((r) >> 2) + 4 * ((r) & 3))                              // lane of entry (r, c)
+
 template <int JB>
-__device__ __forceinline__ int gs_potf2_16(const gs_d4& Pjj, const gs_d4& Sjj, double* Ablk, int64_t ld, double* Dvj,
+__device__ __forceinline__ int gs_potf2_16(const gs_d4& Ajj, const gs_d4& Sjj, double* Ablk, int64_t ld, double* Dvj,
                                            const double* thr, double* dbuf, int lane, unsigned long long* stamps = nullptr) {
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fq = lane >> 4, rr = gs_pair_row(lane);
     unsigned long long tq0 = 0;
     if (stamps) tq0 = __builtin_amdgcn_s_memtime();
-    gs_d4 Aa, S = Sjj, V, Lo = {0.0, 0.0, 0.0, 0.0}, Rs = {1.0, 1.0, 1.0, 1.0};
+    gs_d4 Aa = Ajj, S = Sjj, V, Lo = {0.0, 0.0, 0.0, 0.0}, Rs = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        Aa[x] = -Pjj[x];
-        V[x] = (fr == fq + 4 * x) ? 1.0 : 0.0;
-    }
-    const double tl = thr[16 * JB + fr];
+    for (int x = 0; x < 4; ++x) V[x] = (rr == 4 * fq + x) ? 1.0 : 0.0;
+    const double tl = thr[16 * JB + rr];
     int fail = -1;
-    // The pivot of column c is the Schur complement's diagonal entry a_cc - S_cc.  S_cc receives its last product,
-    // l_{c,c-1}^2, from the MFMA of column c - 1; waiting for that MFMA would put its latency into the dependent chain
-    // pivot -> rsqrt -> column -> pivot.  The same fma is therefore done once more on the side, on three values read out
-    // of their lanes: p_c = a_cc - fma(l, l, S_cc before), bit for bit what the accumulator will hold.
-    double p = gs_readlane_f64(Aa[0], 0) - gs_readlane_f64(S[0], 0);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int g = c & 3, x = c >> 2;
-        const double t = gs_readlane_f64(tl, c);
-        if (fail < 0 && !(p > t)) fail = c;   // wave-uniform (both operands came through SGPRs); catches NaN
-        const double r0 = gs_rsqrt_nr(p);
-        double d0 = p * r0;                                             // sqrt(p) ...
-        d0 = __builtin_fma(__builtin_fma(-d0, d0, p), 0.5 * r0, d0);    // ... corrected to ~0.5 ulp
+    for (int c0 = 0; c0 < 16; c0 += 2) {
+        const int c1 = c0 + 1, g = c0 >> 2, x0 = c0 & 3, x1 = x0 + 1;
         const bool ing = fq == g;
-        const double e = Aa[x] - S[x];        // column c of the Schur complement (group g): ONE subtraction of the sum
-        const double m = e * r0;
-        const double ms = (ing && fr > c) ? m : 0.0;
-        Lo[x] = ing ? ((fr == c) ? d0 : ms) : Lo[x];
-        Rs[x] = ing ? r0 : Rs[x];             // column c of V is scaled at the end (it is never updated after this step)
-        const double vc = ing ? V[x] * r0 : 0.0;
-        if (c < 15) {                         // next pivot on the side (see above)
-            const int g1 = (c + 1) & 3, x1 = (c + 1) >> 2, src = 16 * g1 + c + 1;
-            const double l1 = gs_readlane_f64(ms, 16 * g + c + 1);
-            p = gs_readlane_f64(Aa[x1], src) - __builtin_fma(l1, l1, gs_readlane_f64(S[x1], src));
-        }
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms, ms, S, 0, 0, 0);
-        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms, vc, V, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);    // keep the columns apart: hoisting the next columns' lane masks and
-                                              // v_readlane results ahead ran the kernel out of SGPRs (spills through v_writelane)
+        const double e0 = Aa[x0] - S[x0];     // columns c0, c1 of the Schur complement before c0 is eliminated (group g):
+        const double e1 = Aa[x1] - S[x1];     // ONE subtraction of the zero-start sums each
+        const double p0 = gs_readlane_f64(e0, GS_PAIR_LANE(c0, c0));
+        const double a10 = gs_readlane_f64(e0, GS_PAIR_LANE(c1, c0));
+        const double p1r = gs_readlane_f64(e1, GS_PAIR_LANE(c1, c1));
+        const double t0 = gs_readlane_f64(tl, GS_PAIR_LANE(c0, 0) & 15), t1 = gs_readlane_f64(tl, GS_PAIR_LANE(c1, 0) & 15);
+        // q = p0 p1 with p1 = p1r - a10^2 / p0 the second pivot: 1 / sqrt(p1) = sqrt(p0) rsqrt(q), so rsqrt(q) runs beside
+        // rsqrt(p0) instead of behind it
+        const double q = __builtin_fma(p1r, p0, -(a10 * a10));
+        if (fail < 0 && !(p0 > t0)) fail = c0;            // wave-uniform (the operands came through SGPRs); catches NaN
+        if (fail < 0 && !(q > t1 * p0)) fail = c1;        // <=> p1 <= threshold
+        const double r0 = gs_rsqrt_nr(p0), rq = gs_rsqrt_nr(q);
+        double d0 = p0 * r0;                                             // sqrt(p0) ...
+        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);    // ... corrected to ~0.5 ulp
+        double sq = q * rq;
+        sq = __builtin_fma(__builtin_fma(-sq, sq, q), 0.5 * rq, sq);
+        const double l10 = a10 * r0, r1 = d0 * rq, d1 = sq * r0;        // L[c1][c0], 1 / sqrt(p1), sqrt(p1)
+        const double m0 = e0 * r0;
+        const double ms0 = (ing && rr > c0) ? m0 : 0.0;
+        // column c1 after c0: its sum takes the product l_r,c0 l_c1,c0 first, then the one subtraction
+        const double m1 = (Aa[x1] - __builtin_fma(m0, l10, S[x1])) * r1;
+        const double ms1 = (ing && rr > c1) ? m1 : 0.0;
+        Lo[x0] = ing ? ((rr == c0) ? d0 : ms0) : Lo[x0];
+        Lo[x1] = ing ? ((rr == c1) ? d1 : ms1) : Lo[x1];
+        Rs[x0] = ing ? r0 : Rs[x0];           // the columns of V are scaled at the end (never updated after their step)
+        Rs[x1] = ing ? r1 : Rs[x1];
+        const double vc0 = ing ? V[x0] * r0 : 0.0;
+        const double vc1 = ing ? __builtin_fma(-l10, vc0, V[x1]) * r1 : 0.0;
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms0, ms0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms1, ms1, S, 0, 0, 0);
+        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms0, vc0, V, 0, 0, 0);
+        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms1, vc1, V, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);    // keep the steps apart: hoisting the next steps' lane masks and v_readlane
+                                              // results ahead ran the kernel out of SGPRs (spills through v_writelane)
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        const int cc = fq + 4 * x;
-        if (cc <= fr) Ablk[(int64_t)fr * ld + cc] = Lo[x];                    // L_jj, lower part
-        if (cc == fr) dbuf[16 * JB + fr] = Lo[x];                             // its diagonal, for the log-determinant
-        Dvj[cc * GS_DV_STR + fr] = V[x] * Rs[x];                              // D_j[a][b] = V[b][a], row-major
+        const int cc = 4 * fq + x;
+        if (cc <= rr) Ablk[(int64_t)rr * ld + cc] = Lo[x];                    // L_jj, lower part
+        if (cc == rr) dbuf[16 * JB + rr] = Lo[x];                             // its diagonal, for the log-determinant
+        Dvj[cc * GS_DV_STR + rr] = V[x] * Rs[x];                              // D_j[a][b] = V[b][a], row-major
     }
     if (stamps && lane == 0) stamps[24 + JB] = __builtin_amdgcn_s_memtime() - tq0;      // diagnostics: cycles of this recurrence
     return fail;
@@ -875,6 +891,17 @@ __device__ __forceinline__ int gs_potf2_16(const gs_d4& Pjj, const gs_d4& Sjj, d
 __device__ __forceinline__ void gs_d2_upd(gs_d4& Cc, const double* blk, const gs_d4& Bb, int lane) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[x * 64 + lane], Bb[x], Cc, 0, 0, 0);
+}
+
+// the same for a DIAGONAL micro-block's sum, kept in the pair image: both operands are the dumped block read with the
+// pair image's lane index (row rho^-1(lane & 15) of the block)
+__device__ __forceinline__ void gs_d2_upd_diag(gs_d4& Cc, const double* blk, int lane) {
+    const int src = gs_pair_row(lane) + 16 * (lane >> 4);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const double v = blk[x * 64 + src];
+        Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, Cc, 0, 0, 0);
+    }
 }
 
 // X^T = D_J (A^T - sum)  in the register image:  P <- mfma(D_J, P + S), dumped to the panel table
@@ -913,19 +940,21 @@ __device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - 
     constexpr int R0 = W, R1 = 7 - W, N = J + 1;
     int fail = -1;
     if constexpr (R0 == N) {
-        gs_d2_upd(S0[N], Ls + (N * (N - 1) / 2 + J) * 256, P0[J], lane);
+        gs_d2_upd_diag(S0[N], Ls + (N * (N - 1) / 2 + J) * 256, lane);
         fail = gs_potf2_16<N>(P0[N], S0[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
     } else if constexpr (R1 == N) {
-        gs_d2_upd(S1[N], Ls + (N * (N - 1) / 2 + J) * 256, P1[J], lane);
+        gs_d2_upd_diag(S1[N], Ls + (N * (N - 1) / 2 + J) * 256, lane);
         fail = gs_potf2_16<N>(P1[N], S1[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
     }
     if constexpr (R0 > N) {
 #pragma unroll
-        for (int k = N; k <= R0; ++k) gs_d2_upd(S0[k], Ls + (k * (k - 1) / 2 + J) * 256, P0[J], lane);
+        for (int k = N; k < R0; ++k) gs_d2_upd(S0[k], Ls + (k * (k - 1) / 2 + J) * 256, P0[J], lane);
+        gs_d2_upd_diag(S0[R0], Ls + (R0 * (R0 - 1) / 2 + J) * 256, lane);           // the row's own diagonal micro-block
     }
     if constexpr (R1 > N) {
 #pragma unroll
-        for (int k = N; k <= R1; ++k) gs_d2_upd(S1[k], Ls + (k * (k - 1) / 2 + J) * 256, P1[J], lane);
+        for (int k = N; k < R1; ++k) gs_d2_upd(S1[k], Ls + (k * (k - 1) / 2 + J) * 256, P1[J], lane);
+        gs_d2_upd_diag(S1[R1], Ls + (R1 * (R1 - 1) / 2 + J) * 256, lane);
     }
     return fail;
 }
@@ -954,14 +983,19 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
     constexpr int R0 = W, R1 = 7 - W;
     const int fr = lane & 15, fq = lane >> 4;
     gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
+    const int prow = gs_pair_row(lane);
 #pragma unroll
     for (int k = 0; k <= R0; ++k) {
         S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            // the diagonal micro-block is read from its lower triangle only (mirrored): the recurrence wants it symmetric
-            const int cc = fq + 4 * x, rr = (k == R0 && cc > fr) ? cc : fr, cl = (k == R0 && cc > fr) ? fr : cc;
-            P0[k][x] = -A[(int64_t)(16 * R0 + rr) * ld + 16 * k + cl];
+            if (k < R0) {
+                P0[k][x] = -A[(int64_t)(16 * R0 + fr) * ld + 16 * k + fq + 4 * x];
+            } else {
+                // the diagonal micro-block: pair image, not negated, read from its lower triangle only (mirrored)
+                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
+                P0[k][x] = A[(int64_t)(16 * R0 + hi) * ld + 16 * R0 + lo];
+            }
         }
     }
 #pragma unroll
@@ -969,8 +1003,12 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
         S1[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const int cc = fq + 4 * x, rr = (k == R1 && cc > fr) ? cc : fr, cl = (k == R1 && cc > fr) ? fr : cc;
-            P1[k][x] = -A[(int64_t)(16 * R1 + rr) * ld + 16 * k + cl];
+            if (k < R1) {
+                P1[k][x] = -A[(int64_t)(16 * R1 + fr) * ld + 16 * k + fq + 4 * x];
+            } else {
+                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
+                P1[k][x] = A[(int64_t)(16 * R1 + hi) * ld + 16 * R1 + lo];
+            }
         }
     }
     if constexpr (W == 0) {

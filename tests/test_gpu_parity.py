@@ -562,11 +562,11 @@ def test_full_size_properties_n8192():
     ctx.set_option("reserve_cus", 0)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
-    # evaluations in flight: 1, 3, 10 or 20 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
+    # evaluations in flight: 1, 3, 10 or 16 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
     # far trailing region
     many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for slots, lazy in ((20, 1), (3, 1), (10, 0)):
+    for slots, lazy in ((16, 1), (3, 1), (10, 0)):
         ctx.set_option("batch_slots", slots)
         ctx.set_option("lazy_far", lazy)
         Gs, ss, infos = ctx.lml_resident(many, 1e-10)
@@ -575,7 +575,7 @@ def test_full_size_properties_n8192():
             np.testing.assert_array_equal(Gs[b], G0[0])
             assert ss[b] == s0[0]
     ctx.set_option("lazy_far", 1)
-    ctx.set_option("batch_slots", 20)
+    ctx.set_option("batch_slots", 16)
     for key, (G, s, i) in out.items():
         np.testing.assert_array_equal(G, G0)
         np.testing.assert_array_equal(s, s0)
@@ -851,7 +851,8 @@ def test_lml_gradient_golden():
         for ev in case["evals"]:
             theta = np.array(ev["theta"])
             val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
-            vtol = max(1e-10, 1e-17 * cond)      # 1e-10 up to cond(R) = 1e7; two valid Choleskys differ by more beyond
+            vtol = max(1e-10, 3e-17 * cond)      # 1e-10 up to cond(R) = 3e6; two valid Choleskys differ by more beyond
+                                                 # (cond * eps = 2e-16 cond is the scale; the largest case has cond = 1.5e9)
             assert val == pytest.approx(ev["lml"], rel=vtol)
             tol = 1e-15 * cond + 1e-9            # tr(R^-1 dR) and V^T dR V carry rounding x cond(R)
             np.testing.assert_allclose(grad, ev["grad"], rtol=tol, atol=tol * np.abs(ev["grad"]).max())
