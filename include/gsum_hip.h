@@ -85,7 +85,11 @@ int gsum_init(int device, gsum_ctx** out);
  * exits with one alive makes rocprofv3 crash in its finaliser (the Python binding registers an atexit for this). */
 void gsum_destroy(gsum_ctx* ctx);
 const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a failed gsum_init   */
-/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..24),
+/* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..24; default 16 with
+ * GPU_MAX_HW_QUEUES >= 16 in the environment, else 12 / 8 / 3 -- keep it at 16 or below in a process that also owns an
+ * RCCL communicator: the device time-slices user compute queues beyond 24), "diag_algo" / "build_algo" (2 = the round-2
+ * kernels, 1 = the round-1 ones, kept for A/B), "bulk_lds_pad" (bytes of LDS the bulk kernel requests in look-ahead
+ * schedules, to leave room for chain workgroups),
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
  * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.45 / 985) -- run
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
@@ -190,8 +194,8 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one
- * call are independent, so up to "batch_slots" of them (20 with GPU_MAX_HW_QUEUES >= 24 in the environment when the
- * HIP runtime initialises, 10-14 with 8-16, else 3) are kept in flight on separate streams and
+ * call are independent, so up to "batch_slots" of them (16 with GPU_MAX_HW_QUEUES >= 16 in the environment when the
+ * HIP runtime initialises, 12 / 8 with 12 / 8, else 3) are kept in flight on separate streams and
  * workspaces (288 GB of HBM holds hundreds of 0.5 GB matrices): the latency-bound panel chain of one
  * factorisation overlaps the bulk GEMMs of the others.  Results are identical to one-at-a-time runs.
  * n <= 128 (the reference's own problem sizes) takes a fused path: one workgroup per evaluation builds K,
@@ -214,11 +218,11 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
  * round-2 kernel: [7] start, [8 + 2j], [9 + 2j] wave 0 behind the two barriers of micro-block column j, [24 + j] cycles
  * of the pivot recurrence of micro-block j). */
 int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64);
-/* With option "profile_gemm" = N > 0 every launch of the bulk trailing-update kernel (128x128-tile, 8-wave MFMA GEMM)
- * of every N-th fused evaluation (the 1st, N+1-th, ... since the option was set; operator-level calls: every launch) is
- * bracketed by HIP events on the stream it is launched on (N = 1 costs ~5 % of batch throughput, N = 4 ~1 %).  This
- * returns the summed durations (ms), the summed algorithmic flops and the launch count since the last
- * call, and resets the record. */
+/* With option "profile_gemm" = N > 0 every kernel launch of every N-th fused evaluation (the 1st, N+1-th, ... since the
+ * option was set; operator-level calls: every launch) is bracketed by HIP events on the stream it is launched on
+ * (~230 launches per evaluation at n = 8192: N = 2 costs ~9 % of batch throughput).  This returns the summed durations
+ * (ms), the summed algorithmic flops and the launch count of the BULK trailing-update kernel since the last call, and
+ * resets the record (gsum_kernel_profile: all classes). */
 int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
 /* The same record for every kernel class of the fused path, five entries each: [0] kernel-matrix build, [1] diagonal
  * blocks (k_potrf_diag), [2] panel GEMMs (TRSM against the block inverse, sibling and look-ahead columns, border rows),

@@ -293,13 +293,21 @@ def cbar_ratio_grid_one_factor(kernel, theta, X, y, orders, ratios, cbars, ref=1
     mask = ~np.isin(orders, excluded)
     orders_in = orders[mask]
     n_in = len(orders_in)
+    # residuals of every ratio side by side, then ONE cho_solve call for all of them (scipy copies the 0.5 GB factor
+    # on every call: 64 calls took 4 minutes at n = 8192, one call takes seconds); column for column the same solve
+    resids, dets = [], []
     for a, q in enumerate(ratios):
         ratio_v = q * np.ones(n)
         c = coefficients(y, ratio_v, ref_v, orders)[:, mask]
         eta = posterior_center(c, L, basis, center0, disp0)
-        resid = c - (basis @ eta)[:, None]
-        quad = np.einsum("ik,ik->", resid, _rsolve(L, resid))
-        det = np.sum(n_in * np.log(np.abs(ref_v)) + np.sum(orders_in) * np.log(np.abs(ratio_v)))
+        resids.append(c - (basis @ eta)[:, None])
+        dets.append(np.sum(n_in * np.log(np.abs(ref_v)) + np.sum(orders_in) * np.log(np.abs(ratio_v))))
+    R_all = np.concatenate(resids, axis=1)
+    S_all = _rsolve(L, R_all)
+    for a, q in enumerate(ratios):
+        cols = slice(a * n_in, (a + 1) * n_in)
+        quad = np.einsum("ik,ik->", R_all[:, cols], S_all[:, cols])
+        det = dets[a]
         for b, cbar in enumerate(cbars):
             var = cbar ** 2
             out[a, b] = (-0.5 * quad / var - 0.5 * n_in * (n * np.log(var) + 2.0 * sld)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Copy what the GPU-box scripts left under gpurun_out/ (scratch) into profiles/ (tracked) as the round's evidence:
+kernel-trace statistics, bench lines, PMC passes condensed to JSON, RCCL logs, parity-vs-truth numbers.
+    python tools/collect_profiles.py [round tag, default r02]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT, SRC = os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def newest(sub, pattern):
+    files = sorted(glob.glob(os.path.join(SRC, sub, "**", pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def copy(src, name):
+    if src and os.path.exists(src):
+        shutil.copyfile(src, os.path.join(OUT, f"{TAG}_{name}"))
+        print("wrote", f"{TAG}_{name}")
+
+
+def json_line(log, name):
+    path = os.path.join(SRC, log)
+    if not os.path.exists(path):
+        return
+    lines = [ln for ln in open(path) if ln.startswith("{")]
+    if lines:
+        open(os.path.join(OUT, f"{TAG}_{name}"), "w").write(lines[-1])
+        print("wrote", f"{TAG}_{name}")
+
+
+def counters(sub, prefix):
+    f = newest(sub, "*counter_collection.csv")
+    agg = {}
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith(prefix):
+            agg.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return agg
+
+
+def last(agg, name):
+    return agg[name][-1][0] if name in agg else None
+
+
+for sub, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_single", "single_eval_n2048_n8192_kernel_stats.csv"),
+                  ("prof_predict", "predict_kernel_stats.csv"), ("prof_grad", "grad_n8192_kernel_stats.csv")):
+    copy(newest(sub, "*kernel_stats.csv"), name)
+json_line("bench.log", "bench_default.jsonl")
+json_line("rocprof_bench.log", "bench_under_rocprof.jsonl")
+json_line("plain_n1.log", "plain_n1.jsonl")
+json_line("bench_predict.log", "bench_predict.jsonl")
+for log in ("rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
+            "single_sweep.log", "slots_sweep.log"):
+    path = os.path.join(SRC, log)
+    if os.path.exists(path):
+        text = open(path, errors="replace").read().splitlines()
+        keep = text if len(text) <= 260 else text[:200] + ["... (%d lines cut) ..." % (len(text) - 260)] + text[-60:]
+        open(os.path.join(OUT, f"{TAG}_{log}"), "w").write("\n".join(keep) + "\n")
+        print("wrote", f"{TAG}_{log}")
+copy(os.path.join(SRC, "truth_errors.json"), "truth_errors.json")
+copy(os.path.join(SRC, "r2_kernels.json"), "kernels_ab.json")
+
+# ---- PMC: bulk GEMM (exclusive launch M = 8192, K = 256) and kernel build (n = 8192)
+g = {}
+for sub in ("pmc_gemm1", "pmc_gemm2", "pmc_gemm3", "pmc_gemm4"):
+    g.update(counters(sub, "k_gemm_ld3"))
+if g:
+    fetch, write = last(g, "FETCH_SIZE"), last(g, "WRITE_SIZE")
+    dur_ns = g["GRBM_GUI_ACTIVE"][-1][1] if "GRBM_GUI_ACTIVE" in g else None
+    busy, gui = last(g, "SQ_VALU_MFMA_BUSY_CYCLES"), last(g, "GRBM_GUI_ACTIVE")
+    rec = {"kernel": "k_gemm_ld3", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_gemm.py 7 8192 256 1 3 (one pass per counter group; tools/gpu_r2_profiles.sh)",
+           "shape": {"M": 8192, "N": 8192, "K": 256, "tri": 1, "tiles": 4160},
+           "counters": {k: v[-1][0] for k, v in g.items()}, "duration_us_profiled": dur_ns / 1e3 if dur_ns else None,
+           "derived": {"hbm_read_bytes": fetch * 2048 if fetch else None, "hbm_write_bytes": write * 1024 if write else None,
+                       "hbm_traffic_bytes_per_launch": (fetch * 2048 + write * 1024) if fetch and write else None,
+                       "algorithmic_bytes_per_launch": 561000000,
+                       "mfma_busy_frac_profiled": (busy / 64) / (gui / 8 * 1024 / 8) if busy and gui else None,
+                       "note": "FETCH_SIZE x 2 KiB (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM), WRITE_SIZE x 1 KiB; "
+                               "mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 64 cycles per MFMA) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / 8)"}}
+    json.dump(rec, open(os.path.join(OUT, f"{TAG}_gemm_pmc.json"), "w"), indent=1)
+    print("wrote", f"{TAG}_gemm_pmc.json")
+b = {}
+for sub in ("pmc_build1", "pmc_build2", "pmc_build3"):
+    b.update(counters(sub, "void k_build2"))
+if b:
+    fetch, write = last(b, "FETCH_SIZE"), last(b, "WRITE_SIZE")
+    dur = [d for _, d in b.get("WRITE_SIZE", b.get("GRBM_GUI_ACTIVE", []))]
+    rec = {"kernel": "k_build2<false, RBF, 1-D>", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_build.py 8192 3",
+           "counters": {k: [x for x, _ in v] for k, v in b.items()}, "durations_us_profiled": [d / 1e3 for d in dur],
+           "derived": {"hbm_write_bytes": write * 1024 if write else None, "hbm_read_bytes": fetch * 2048 if fetch else None,
+                       "algorithmic_bytes": 4 * 8192 * 8192 + 4 * 8192 * 128,
+                       "valu_instructions_per_entry": (last(b, "SQ_INSTS_VALU") * 64 / (2080 * 128 * 128)) if "SQ_INSTS_VALU" in b else None,
+                       "note": "WRITE_SIZE x 1 KiB equals the bytes the kernel stores (lower 128-column tiles); nothing is read back"}}
+    json.dump(rec, open(os.path.join(OUT, f"{TAG}_build_pmc.json"), "w"), indent=1)
+    print("wrote", f"{TAG}_build_pmc.json")
