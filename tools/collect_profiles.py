@@ -82,9 +82,9 @@ if g:
            "derived": {"hbm_read_bytes": fetch * 2048 if fetch else None, "hbm_write_bytes": write * 1024 if write else None,
                        "hbm_traffic_bytes_per_launch": (fetch * 2048 + write * 1024) if fetch and write else None,
                        "algorithmic_bytes_per_launch": 561000000,
-                       "mfma_busy_frac_profiled": (busy / 64) / (gui / 8 * 1024 / 8) if busy and gui else None,
+                       "mfma_busy_frac_profiled": busy / (gui / 8 * 1024) if busy and gui else None,
                        "note": "FETCH_SIZE x 2 KiB (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM), WRITE_SIZE x 1 KiB; "
-                               "mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 64 cycles per MFMA) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / 8)"}}
+                               "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs = cycles the launch took, x 1024 SIMDs)"}}
     json.dump(rec, open(os.path.join(OUT, f"{TAG}_gemm_pmc.json"), "w"), indent=1)
     print("wrote", f"{TAG}_gemm_pmc.json")
 b = {}

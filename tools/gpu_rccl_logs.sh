@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -m gsum_amd.build
-A="--steps 20 --warmup 3 --cpu-evals 0 --extras 0 --repeats 5"
+A="--steps 32 --warmup 3 --cpu-evals 0 --extras 0 --repeats 5"
 NCCL_DEBUG=INFO timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 $A --backend nccl > gpurun_out/rccl_world1.log 2>&1; echo "world1 nccl rc=$?"
 grep -c "NCCL INFO" gpurun_out/rccl_world1.log; grep "^{" gpurun_out/rccl_world1.log | cut -c1-160
 timeout -k 10 300 python bench.py $A > gpurun_out/plain_n1.log 2>&1; echo "plain rc=$?"; grep "^{" gpurun_out/plain_n1.log | cut -c1-160
