@@ -19,6 +19,7 @@ struct gsum_mat {
     double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L (diag_algo 1: by the factorisation;
                                // diag_algo 2: lazily, from the tables, for the consumers that multiply by L_bb^-1)
     double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks (diag_algo 2)
+    double* Lsib = nullptr;    // (T / 2 + 1) x GS_LSIB: L(j+1, j) of every outer step in operand layout (k_potrf_diag256 -> k_panel256)
     bool have_ltab = false, have_linv = false;
     std::vector<double> solved_rhs;     // host copy of the right-hand sides whose forward solve W^T = (L^-1 RHS)^T the border rows
     int solved_k = -1;                  // hold (-1: none): a repeated predict / forward_gram with the same RHS skips the solve
@@ -36,8 +37,12 @@ struct gs_slot {
     hipEvent_t evU = nullptr;
     hipStream_t sb = nullptr;        // bulk stream restricted by a CU mask (look-ahead schedules, reserve_cus > 0)
     int sb_reserve = 0;              // reserve_cus value sb was created for
+    hipStream_t sc = nullptr, srm = nullptr;   // windowed schedule with reserve_cus > 0: the chain on the reserved CUs ONLY,
+                                               // the rest stream on the bulk stream's CUs
+    hipStream_t sr = nullptr;        // windowed look-ahead schedule: the rows below the window (panel rest, far look-ahead columns)
     std::vector<hipEvent_t> evP, evM;
-    hipEvent_t evFork = nullptr;
+    std::vector<hipEvent_t> evW;     // windowed schedule: five events per outer step (GS_EVW_*)
+    hipEvent_t evFork = nullptr, evR = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
     double* dres = nullptr; int* dinfo = nullptr;
     double* hres = nullptr;          // pinned
@@ -75,6 +80,10 @@ struct gsum_ctx {
     int build_lower_only = 1;
     int bulk_lds_pad = 0;            // bytes of dynamic LDS the bulk kernel asks for in look-ahead schedules (0 = what it needs)
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
+    int chain_fused = 0;             // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
+                                     // (k_panel256) instead of diag / panel / sibling update / diag / panel; 0 = the five launches
+    int chain_window = 0;            // look-ahead schedule: 1 = windowed (only the rows the next panels need are on the chain's
+                                     // stream, the rest of each panel trails on a stream of its own), 0 = whole panels on the chain
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
                                      // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
@@ -281,12 +290,15 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->Linv, (size_t)m->T * GS_NB * GS_NB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->Ltab, (size_t)m->T * GS_LTAB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->Lsib, (size_t)(m->T / 2 + 1) * GS_LSIB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->logdet, (size_t)m->T * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->diag0, (size_t)m->np * sizeof(double));
     if (e != hipSuccess) {
         if (m->A) (void)hipFree(m->A);
         if (m->Linv) (void)hipFree(m->Linv);
         if (m->Ltab) (void)hipFree(m->Ltab);
+    if (m->Lsib) (void)hipFree(m->Lsib);
+        if (m->Lsib) (void)hipFree(m->Lsib);
         if (m->logdet) (void)hipFree(m->logdet);
         if (m->diag0) (void)hipFree(m->diag0);
         delete m;
@@ -302,6 +314,7 @@ static void gs_mat_release(gsum_mat* m) {
     if (m->A) (void)hipFree(m->A);
     if (m->Linv) (void)hipFree(m->Linv);
     if (m->Ltab) (void)hipFree(m->Ltab);
+    if (m->Lsib) (void)hipFree(m->Lsib);
     if (m->logdet) (void)hipFree(m->logdet);
     if (m->diag0) (void)hipFree(m->diag0);
     delete m;
@@ -404,6 +417,22 @@ static int gs_panel_stream(gsum_ctx* ctx, gs_slot* sl) {
     return 0;
 }
 
+enum { GS_EVW_D0 = 0, GS_EVW_T0 = 1, GS_EVW_D1 = 2, GS_EVW_T1 = 3, GS_EVW_NEW = 4, GS_EVW_FAR = 5, GS_EVW_N = 6 };
+
+static int gs_window_streams(gsum_ctx* ctx, gs_slot* sl, int T) {
+    if (!sl->sr) {
+        GS_CHECK(hipStreamCreateWithPriority(&sl->sr, hipStreamNonBlocking, ctx->prio_hi));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evR, hipEventDisableTiming));
+    }
+    const size_t want = (size_t)GS_EVW_N * (T + 1);
+    for (size_t i = sl->evW.size(); i < want; ++i) {
+        hipEvent_t ev;
+        GS_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        sl->evW.push_back(ev);
+    }
+    return 0;
+}
+
 static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* out) {
     const int R = ctx->reserve_cus >= 0 ? ctx->reserve_cus : (np >= 6144 ? 2 : 0);
     if (R <= 0) {
@@ -411,18 +440,23 @@ static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* o
         return 0;
     }
     if (sl->sb && sl->sb_reserve != R) {
-        GS_CHECK(hipStreamSynchronize(sl->sb));
-        GS_CHECK(hipStreamDestroy(sl->sb));
-        sl->sb = nullptr;
+        for (hipStream_t* q : {&sl->sb, &sl->sc, &sl->srm}) {
+            if (!*q) continue;
+            GS_CHECK(hipStreamSynchronize(*q));
+            GS_CHECK(hipStreamDestroy(*q));
+            *q = nullptr;
+        }
     }
     if (!sl->sb) {
         hipDeviceProp_t prop;
         GS_CHECK(hipGetDeviceProperties(&prop, ctx->device));
         const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
         if (ncu % 8 != 0 || 8 * R >= ncu) GS_FAIL("reserve_cus: does not fit this device's CU count");
-        std::vector<uint32_t> mask(words, 0u);
-        for (int i = 0; i < ncu - 8 * R; ++i) mask[i >> 5] |= 1u << (i & 31);
+        std::vector<uint32_t> mask(words, 0u), rmask(words, 0u);
+        for (int i = 0; i < ncu; ++i) (i < ncu - 8 * R ? mask : rmask)[i >> 5] |= 1u << (i & 31);
         GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sb, (uint32_t)words, mask.data()));
+        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->srm, (uint32_t)words, mask.data()));
+        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sc, (uint32_t)words, rmask.data()));
         sl->sb_reserve = R;
     }
     *out = sl->sb;
@@ -453,7 +487,30 @@ static int gs_trsm_rows(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, 
     if (!m->have_ltab)
         return gs_gemm(ctx, s, 1, P, ldp, P, ldp, m->Linv + (size_t)b * GS_NB * GS_NB, GS_NB, M, GS_NB, GS_NB, 0, 0, 1.0);
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, (double)M * GS_NB * GS_NB);
-    hipLaunchKernelGGL(k_panel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB);
+    hipLaunchKernelGGL(k_panel, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// blocks b, b + 1 (b even) of the factor in one launch, and the rows below them in one launch (see the kernels)
+static int gs_diag256(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
+    gs_slot* sl = ctx->cur;
+    const int64_t c = (int64_t)b * GS_NB;
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
+    hipLaunchKernelGGL(k_potrf_diag256, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB,
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
+    if (M <= 0) return 0;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
+    hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB);
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
@@ -466,6 +523,126 @@ static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
     hipLaunchKernelGGL(k_trtri_blocks, dim3((unsigned)m->T), dim3(256), 0, s, m->Ltab, m->Linv);
     GS_CHECK(hipGetLastError());
     m->have_linv = true;
+    return 0;
+}
+
+// Windowed look-ahead schedule (one factorisation alone).  rocprofv3's timeline of the whole-panel schedule below showed
+// what bounds it: the chain D -> panel -> sibling update -> D -> panel -> look-ahead update runs every kernel over ALL
+// rows under the panel, so beside the bulk update each of them queues for CU slots (panel 44 us, sibling 55 us, look-ahead
+// 100 us at n = 8192 against 17 / 15 / 43 us alone) and the chain, not the bulk update, sets the pace from the fifth outer
+// step on.  But the NEXT diagonal blocks only need the rows just below the panel.  So the chain's stream (sp) now works on
+// a window of rows [c0, r2 + 512) only -- the current panel's rows that the next two panels' diagonal blocks and top rows
+// come from -- with kernels of at most 640 rows, and everything below the window trails on a second stream (sr):
+//   sp : D(j)  Ptop(j)  U1top  D(j+1)  Ptop(j+1)  LAtop      rows [c1, Wend),  LAtop: rows [r2, Wend) x cols [r2, r2+256)
+//   sr : Prest(j)  U1rest  Prest(j+1)  LAnew  LAfar            rows [Wend, naug); LAnew = the 256 rows that enter the next
+//                                                              step's window, LAfar = the rest of the look-ahead columns
+//   sb : bulk(s)                                               rows, cols >= r2 + 256 (lower tiles, K = 256)
+// Step s + 1's window rows [r2 + 128, r2 + 768) come from LAtop (sp order) and LAnew (event); the rest rows of step s + 1
+// follow LAfar in sr's order.  Every element still receives the same products in the same ascending order: the regions
+// are a partition of the whole-panel schedule's launches, results are bit-identical to it.
+static int gs_potrf_window(gsum_ctx* ctx, gsum_mat* m, hipStream_t sb) {
+    gs_slot* sl = ctx->cur;
+    const int T = m->T;
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    // with reserved CUs the chain runs on them ALONE and the rest stream keeps off them: a small chain kernel whose
+    // workgroups land beside bulk waves shares their matrix pipe and takes 3-6x its time (rocprofv3: 20-workgroup sibling
+    // update 47 us, diagonal block 60-95 us)
+    const bool masked = sb != sl->sm && sl->sc && sl->srm;
+    hipStream_t sm = sl->sm, sp = masked ? sl->sc : sl->sp, sr = masked ? sl->srm : sl->sr;
+    const int ccfg = 1;
+    const bool fused = ctx->chain_fused != 0;
+    auto EV = [&](int k, int which) { return sl->evW[(size_t)GS_EVW_N * k + which]; };
+    int prev = -1, pending_new = -1, pending_far = -1;
+    bool rest_used = false;
+    for (int k = 0; k < T; k += 2) {
+        const bool two = k + 1 < T;
+        const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
+        const int64_t r2 = two ? c1 + GS_NB : c1;
+        const int Kp = two ? 2 * GS_NB : GS_NB;
+        const int64_t Wend = std::min<int64_t>(r2 + 4 * GS_NB, naug), mr = naug - Wend;
+        double* Pa = A + c1 * ld + c0;
+        // ---- the chain, window rows only
+        if (two && fused) {
+            if (gs_diag256(ctx, sp, m, k)) return -1;
+            GS_CHECK(hipEventRecord(EV(k, GS_EVW_D1), sp));
+            if (pending_new >= 0) GS_CHECK(hipStreamWaitEvent(sp, EV(pending_new, GS_EVW_NEW), 0));
+            if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, Wend - r2)) return -1;
+        } else {
+            if (gs_diag(ctx, sp, m, k)) return -1;
+            GS_CHECK(hipEventRecord(EV(k, GS_EVW_D0), sp));
+            if (pending_new >= 0) GS_CHECK(hipStreamWaitEvent(sp, EV(pending_new, GS_EVW_NEW), 0));
+            if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, Wend - c1)) return -1;
+            GS_CHECK(hipEventRecord(EV(k, GS_EVW_T0), sp));
+            if (two) {
+                if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, Wend - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                if (gs_diag(ctx, sp, m, k + 1)) return -1;
+                GS_CHECK(hipEventRecord(EV(k, GS_EVW_D1), sp));
+                if (gs_trsm_rows(ctx, sp, m, k + 1, A + r2 * ld + c1, ld, Wend - r2)) return -1;
+            }
+        }
+        GS_CHECK(hipEventRecord(EV(k, GS_EVW_T1), sp));
+        // ---- the rows below the window
+        if (mr > 0) {
+            rest_used = true;
+            double* Ra = A + Wend * ld + c0;
+            if (pending_far >= 0) GS_CHECK(hipStreamWaitEvent(sr, EV(pending_far, GS_EVW_FAR), 0));
+            if (two && fused) {
+                GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D1), 0));
+                if (gs_panel256(ctx, sr, m, k, Ra, ld, mr)) return -1;
+            } else {
+                GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D0), 0));
+                if (gs_trsm_rows(ctx, sr, m, k, Ra, ld, mr)) return -1;
+                if (two) {
+                    GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_T0), 0));
+                    if (gs_gemm(ctx, sr, ccfg, A + Wend * ld + c1, ld, Ra, ld, Pa, ld, mr, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                    GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D1), 0));
+                    if (gs_trsm_rows(ctx, sr, m, k + 1, A + Wend * ld + c1, ld, mr)) return -1;
+                }
+            }
+            GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_T1), 0));
+            GS_CHECK(hipEventRecord(sl->evP[k], sr));               // the whole panel of this outer step is final
+        } else {
+            GS_CHECK(hipEventRecord(sl->evP[k], sp));
+        }
+        pending_new = pending_far = -1;
+        double* P = A + r2 * ld + c0;                               // panel rows r2.., both block columns
+        if (r2 < m->np) {
+            const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2), r3 = r2 + wn, m3 = naug - r3;
+            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evM[prev], 0));
+            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, Wend - r2, wn, Kp, 0, 1, -1.0)) return -1;
+            GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
+            if (mr > 0) {
+                // the 256 rows that enter the next step's window: small, ahead of everything else on the rest stream
+                if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sr, sl->evM[prev], 0));
+                const int64_t mnew = std::min<int64_t>(2 * GS_NB, mr);
+                if (gs_gemm(ctx, sr, ccfg, A + Wend * ld + r2, ld, A + Wend * ld + c0, ld, P, ld, mnew, wn, Kp, 0, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(EV(k, GS_EVW_NEW), sr));
+                pending_new = k;
+                if (mr > mnew) {
+                    // the rest of the look-ahead columns: at the head of the bulk stream, where the chip has just come free
+                    const int64_t rf = Wend + mnew;
+                    if (gs_gemm(ctx, sb, ccfg, A + rf * ld + r2, ld, A + rf * ld + c0, ld, P, ld, naug - rf, wn, Kp, 0, 1, -1.0)) return -1;
+                    GS_CHECK(hipEventRecord(EV(k, GS_EVW_FAR), sb));
+                    pending_far = k;
+                }
+            }
+            double* P3 = A + r3 * ld + c0;
+            if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(sl->evM[k], sb));
+            prev = k;
+        } else {
+            // last panel: only the 16x16 corner (the Gram matrix) is left
+            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
+            if (sb != sm && prev >= 0) GS_CHECK(hipStreamWaitEvent(sm, sl->evM[prev], 0));
+            if (rest_used) {
+                GS_CHECK(hipEventRecord(sl->evR, sr));
+                GS_CHECK(hipStreamWaitEvent(sm, sl->evR, 0));
+            }
+            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, naug - r2, naug - r2, Kp, 1, 1, -1.0)) return -1;
+        }
+    }
+    m->factored = true;
     return 0;
 }
 
@@ -496,6 +673,15 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         GS_CHECK(hipEventRecord(sl->evFork, sm));
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
         if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
+        if (ctx->chain_window && m->have_ltab) {
+            if (gs_window_streams(ctx, sl, T)) return -1;
+            GS_CHECK(hipStreamWaitEvent(sl->sr, sl->evFork, 0));
+            if (sl->sc && sb != sm) {
+                GS_CHECK(hipStreamWaitEvent(sl->sc, sl->evFork, 0));
+                GS_CHECK(hipStreamWaitEvent(sl->srm, sl->evFork, 0));
+            }
+            return gs_potrf_window(ctx, m, sb);
+        }
     }
     // panel GEMMs (TRSM against the block inverse, sibling column) stay on the low-latency 32x128 tile in every mode.
     // (In a batch the LDS-direct 128x128 tile is 1 % cheaper overall, but then one kernel symbol would serve two
@@ -509,16 +695,22 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
         const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
         const int Kp = two ? 2 * GS_NB : GS_NB;
-        // ---- sub-step a
-        if (gs_diag(ctx, sp, m, k)) return -1;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
-        if (two) {
-            // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
-            if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            if (gs_diag(ctx, sp, m, k + 1)) return -1;
-            double* Pb = A + r2 * ld + c1;
-            if (gs_trsm_rows(ctx, sp, m, k + 1, Pb, ld, naug - r2)) return -1;
+        if (two && ctx->chain_fused && m->have_ltab) {
+            // both diagonal blocks in one launch, then both panels of the rows below in one
+            if (gs_diag256(ctx, sp, m, k)) return -1;
+            if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
+        } else {
+            // ---- sub-step a
+            if (gs_diag(ctx, sp, m, k)) return -1;
+            if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
+            if (two) {
+                // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
+                if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                if (gs_diag(ctx, sp, m, k + 1)) return -1;
+                double* Pb = A + r2 * ld + c1;
+                if (gs_trsm_rows(ctx, sp, m, k + 1, Pb, ld, naug - r2)) return -1;
+            }
         }
         // ---- trailing update with the whole panel: rows r2.., columns c0..c0+Kp-1
         double* P = A + r2 * ld + c0;
@@ -642,6 +834,10 @@ int gsum_init(int device, gsum_ctx** out) {
     (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
+    const char* cf = getenv("GSUM_CHAIN_FUSED");
+    if (cf) ctx->chain_fused = atoi(cf) != 0;
+    const char* cw = getenv("GSUM_CHAIN_WINDOW");
+    if (cw) ctx->chain_window = atoi(cw) != 0;
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
@@ -679,7 +875,12 @@ void gsum_destroy(gsum_ctx* ctx) {
             if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
         if (sl->sm) (void)hipStreamDestroy(sl->sm);
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
+        if (sl->sr) (void)hipStreamDestroy(sl->sr);
+        for (auto ev : sl->evW) (void)hipEventDestroy(ev);
+        if (sl->evR) (void)hipEventDestroy(sl->evR);
         if (sl->sb) (void)hipStreamDestroy(sl->sb);
+        if (sl->sc) (void)hipStreamDestroy(sl->sc);
+        if (sl->srm) (void)hipStreamDestroy(sl->srm);
         if (sl->su) (void)hipStreamDestroy(sl->su);
         if (sl->evU) (void)hipEventDestroy(sl->evU);
     }
@@ -762,6 +963,8 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
+    else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
+    else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);

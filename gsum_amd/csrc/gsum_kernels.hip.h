@@ -905,81 +905,90 @@ __device__ __forceinline__ void gs_d2_upd_diag(gs_d4& Cc, const double* blk, int
 }
 
 // X^T = D_J (A^T - sum)  in the register image:  P <- mfma(D_J, P + S), dumped to the panel table
-template <int J>
-__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, int row, int lane) {
+// FULL: all 28 dumps stay in LDS (the fused kernels solve rows against them afterwards).  !FULL: LDS holds only the
+// CURRENT panel column (slot = block row; a column is read in its own step only) and every dump goes straight to the
+// global table Lg -- 35 KB of LDS instead of 77, so the stand-alone kernel fits into the place ONE bulk workgroup
+// leaves behind on a busy CU.
+#define GS_LS_SLOT(FULL, row, J) ((FULL) ? ((row) * ((row) - 1) / 2 + (J)) : (row))
+template <int J, bool FULL>
+__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, double* Lg, int row, int lane) {
     const gs_d4 E = Pb + Sb;
     gs_d4 T = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int x = 0; x < 4; ++x) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], E[x], T, 0, 0, 0);
     Pb = T;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) Ls[((row * (row - 1) / 2 + J) * 4 + x) * 64 + lane] = T[x];
+    for (int x = 0; x < 4; ++x) Ls[(GS_LS_SLOT(FULL, row, J) * 4 + x) * 64 + lane] = T[x];
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) Lg[((row * (row - 1) / 2 + J) * 4 + x) * 64 + lane] = T[x];
+    }
 }
 
-template <int W, int J>
+template <int W, int J, bool FULL>
 __device__ __forceinline__ void gs_d2_trsm_dump(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W],
-                                                const double* Dv, double* Ls, int lane) {
+                                                const double* Dv, double* Ls, double* Lg, int lane) {
     constexpr int R0 = W, R1 = 7 - W;
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (R1 > J) {                   // R1 >= R0: nothing to do for either row otherwise
         double av[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) av[x] = Dv[(J * 16 + fr) * GS_DV_STR + fq + 4 * x];
-        if constexpr (R0 > J) gs_d2_solve_dump<J>(P0[J], S0[J], av, Ls, R0, lane);
-        gs_d2_solve_dump<J>(P1[J], S1[J], av, Ls, R1, lane);
+        if constexpr (R0 > J) gs_d2_solve_dump<J, FULL>(P0[J], S0[J], av, Ls, Lg, R0, lane);
+        gs_d2_solve_dump<J, FULL>(P1[J], S1[J], av, Ls, Lg, R1, lane);
     }
 }
 
 // after panel column J is in LDS: add its products to the sums; the owner of row J + 1 finishes the sum of its diagonal
 // micro-block first and runs the pivot recurrence on it before its other updates.  Returns the failing local column of
 // micro-block J + 1 or -1.
-template <int W, int J>
+template <int W, int J, bool FULL>
 __device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
                                             int64_t ld, double* Dv, double* scr, const double* Ls, const double* thr, double* dbuf,
                                             int lane, unsigned long long* stamps) {
     constexpr int R0 = W, R1 = 7 - W, N = J + 1;
     int fail = -1;
     if constexpr (R0 == N) {
-        gs_d2_upd_diag(S0[N], Ls + (N * (N - 1) / 2 + J) * 256, lane);
+        gs_d2_upd_diag(S0[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
         fail = gs_potf2_16<N>(P0[N], S0[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
     } else if constexpr (R1 == N) {
-        gs_d2_upd_diag(S1[N], Ls + (N * (N - 1) / 2 + J) * 256, lane);
+        gs_d2_upd_diag(S1[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
         fail = gs_potf2_16<N>(P1[N], S1[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
     }
     if constexpr (R0 > N) {
 #pragma unroll
-        for (int k = N; k < R0; ++k) gs_d2_upd(S0[k], Ls + (k * (k - 1) / 2 + J) * 256, P0[J], lane);
-        gs_d2_upd_diag(S0[R0], Ls + (R0 * (R0 - 1) / 2 + J) * 256, lane);           // the row's own diagonal micro-block
+        for (int k = N; k < R0; ++k) gs_d2_upd(S0[k], Ls + GS_LS_SLOT(FULL, k, J) * 256, P0[J], lane);
+        gs_d2_upd_diag(S0[R0], Ls + GS_LS_SLOT(FULL, R0, J) * 256, lane);           // the row's own diagonal micro-block
     }
     if constexpr (R1 > N) {
 #pragma unroll
-        for (int k = N; k < R1; ++k) gs_d2_upd(S1[k], Ls + (k * (k - 1) / 2 + J) * 256, P1[J], lane);
-        gs_d2_upd_diag(S1[R1], Ls + (R1 * (R1 - 1) / 2 + J) * 256, lane);
+        for (int k = N; k < R1; ++k) gs_d2_upd(S1[k], Ls + GS_LS_SLOT(FULL, k, J) * 256, P1[J], lane);
+        gs_d2_upd_diag(S1[R1], Ls + GS_LS_SLOT(FULL, R1, J) * 256, lane);
     }
     return fail;
 }
 
-template <int W, int J>
+template <int W, int J, bool FULL>
 __device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
-                                           int64_t ld, double* Dv, double* scr, double* Ls, const double* thr, double* dbuf,
+                                           int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, const double* thr, double* dbuf,
                                            int* fail_sh, int lane, unsigned long long* stamps) {
     __syncthreads();                                          // D_J (and a failure flag) visible
     if (stamps && W == 0 && lane == 0) stamps[8 + 2 * J] = __builtin_amdgcn_s_memtime();       // diagnostics only
     if (*fail_sh >= 0) return false;
-    gs_d2_trsm_dump<W, J>(P0, P1, S0, S1, Dv, Ls, lane);
+    gs_d2_trsm_dump<W, J, FULL>(P0, P1, S0, S1, Dv, Ls, Lg, lane);
     __syncthreads();                                          // panel column J visible
     if (stamps && W == 0 && lane == 0) stamps[9 + 2 * J] = __builtin_amdgcn_s_memtime();
     if constexpr (J < 7) {
-        const int f = gs_d2_update<W, J>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, lane, stamps);
+        const int f = gs_d2_update<W, J, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, lane, stamps);
         if (f >= 0 && lane == 0) *fail_sh = 16 * (J + 1) + f;
     }
     return true;
 }
 
 // phase 1 of wave W: returns false if a pivot failed (every wave leaves at the same barrier)
-template <int W>
-__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, const double* thr, double* dbuf,
-                                           int* fail_sh, int lane, unsigned long long* stamps) {
+template <int W, bool FULL>
+__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, const double* thr,
+                                           double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
     constexpr int R0 = W, R1 = 7 - W;
     const int fr = lane & 15, fq = lane >> 4;
     gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
@@ -1015,14 +1024,14 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
         const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);
         if (f >= 0 && lane == 0) *fail_sh = f;
     }
-    if (!gs_d2_step<W, 0>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 1>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 2>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 3>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 4>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 5>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 6>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 7>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 0, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 1, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 2, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 3, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 4, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 5, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 6, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+    if (!gs_d2_step<W, 7, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
     // strictly lower micro-blocks back to the matrix (the diagonal ones were stored by the pivot recurrence)
 #pragma unroll
     for (int k = 0; k < R0; ++k)
@@ -1086,13 +1095,18 @@ __device__ __forceinline__ void gs_trtri_block(const double* Ls, const double* D
 //   - Linv != NULL: the explicit 128 x 128 inverse is built too (phase 2; 15 k cycles that nothing on the
 //     factorisation's own path needs any more).
 #define GS_LTAB (GS_D2_DV + 8 * 16 * GS_DV_STR)          // 9344 doubles = 73 KB
+// LDS layout of the !FULL mode: 8 panel-column slots | the 8 micro-block inverses | 128 thresholds   (4352 doubles = 34 KB)
+#define GS_D2C_DV (8 * 256)
+#define GS_D2C_THR (GS_D2C_DV + 8 * 16 * GS_DV_STR)
+#define GS_D2C_WS (GS_D2C_THR + 128)
+template <bool FULL = true>
 __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet_out,
                                              const double* diag0, unsigned long long* stamps, double* wsp) {
     __shared__ double dbuf[128];
     __shared__ int fail_sh;
     double* Ls = wsp + GS_D2_LS;
-    double* Dv = wsp + GS_D2_DV;
-    double* thr = wsp + GS_D2_THR;
+    double* Dv = wsp + (FULL ? GS_D2_DV : GS_D2C_DV);
+    double* thr = wsp + (FULL ? GS_D2_THR : GS_D2C_THR);
     double* scr = nullptr;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1109,19 +1123,26 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
     if (t == 0) fail_sh = -1;
     __syncthreads();
     bool ok;
-    if (w == 0) ok = gs_d2_wave<0>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
-    else if (w == 1) ok = gs_d2_wave<1>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
-    else if (w == 2) ok = gs_d2_wave<2>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
-    else ok = gs_d2_wave<3>(A, ld, Dv, scr, Ls, thr, dbuf, &fail_sh, lane, stamps);
+    if (w == 0) ok = gs_d2_wave<0, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
+    else if (w == 1) ok = gs_d2_wave<1, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
+    else if (w == 2) ok = gs_d2_wave<2, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
+    else ok = gs_d2_wave<3, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
     if (!ok) return fail_sh + 1;                       // uniform: every wave read the flag behind the same barrier
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
     if (t < 128) dbuf[t] = log(dbuf[t]);
-    if (Ltab) {
-        const gs_d2* src = reinterpret_cast<const gs_d2*>(wsp);
-        gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab);
-        for (int i = t; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
+    if constexpr (FULL) {
+        if (Ltab) {
+            const gs_d2* src = reinterpret_cast<const gs_d2*>(wsp);
+            gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab);
+            for (int i = t; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
+        }
+        if (Linv) gs_trtri_block(Ls, Dv, Linv, w, lane);
+    } else {
+        // the panel dumps went to Ltab as they were made; only the micro-block inverses are left to export
+        const gs_d2* src = reinterpret_cast<const gs_d2*>(Dv);
+        gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab + GS_D2_DV);
+        for (int i = t; i < 8 * 16 * GS_DV_STR / 2; i += 256) dst[i] = src[i];
     }
-    if (Linv) gs_trtri_block(Ls, Dv, Linv, w, lane);
     __threadfence_block();
     __syncthreads();
     if (t == 0) {
@@ -1211,23 +1232,130 @@ __device__ __forceinline__ void gs_load_ltab_direct(double* tab, const double* L
         __builtin_amdgcn_global_load_lds(Ltab + pc * 128 + 2 * lane, tab + pc * 128, 16, 0, 0);
 }
 
-// rows [0, M) x 128 columns at P (leading dimension ld)  <-  rows * L_bb^-T, 64 rows per workgroup (16 per wave)
-__global__ __launch_bounds__(256) void k_panel(double* P, int64_t ld, int M, const double* Ltab) {
-    __shared__ __attribute__((aligned(16))) double tab[GS_LTAB];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gs_load_ltab_direct(tab, Ltab, w, lane);
-    const int r0 = (blockIdx.x * 4 + w) * 16;
-    // the rows are fetched while the tables are still in flight
-    const int nvalid = M - r0;
-    double* rows = P + (int64_t)(r0 < M ? r0 : 0) * ld;
-    gs_d4 Pr[8];
-    gs_panel16_load(Pr, rows, ld, r0 < M ? nvalid : 0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+// ---- the same substitution with the tables read straight from GLOBAL memory (L2 / L1 hits: every wave of a launch
+// reads the same 73 KB), software-pipelined through registers: no LDS, no barrier, one wave per workgroup.  What it
+// buys is placement, not arithmetic: beside the bulk update every CU holds three bulk workgroups and 1 KB of free LDS,
+// and a 73-KB table workgroup waited for two of them to retire on the SAME CU (rocprofv3: 100-200 us per call in the
+// first third of a factorisation, 20 us alone).  A lone wave with ~200 VGPRs and no LDS fits on any SIMD at once.
+// Step j's table blocks (j panel dumps + D_j) are fetched one to two steps ahead; bit-identical to gs_panel16_solve.
+template <int J>
+__device__ __forceinline__ void gs_ptab_fetch(gs_d4 (&buf)[8], const double* tab, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int pp = 0; pp < J; ++pp)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) buf[pp][x] = tab[GS_D2_LS + ((J * (J - 1) / 2 + pp) * 4 + x) * 64 + lane];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) buf[J][x] = tab[GS_D2_DV + (J * 16 + fr) * GS_DV_STR + fq + 4 * x];
+}
+
+template <int J>
+__device__ __forceinline__ void gs_ptab_step(gs_d4 (&P)[8], const gs_d4 (&buf)[8]) {
+    gs_d4 S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int pp = 0; pp < J; ++pp)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) S = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[pp][x], P[pp][x], S, 0, 0, 0);
+    const gs_d4 E = P[J] + S;
+    gs_d4 T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) T = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[J][x], E[x], T, 0, 0, 0);
+    P[J] = T;
+}
+
+__device__ __forceinline__ void gs_panel16_solve_g(gs_d4 (&P)[8], const double* tab, int lane) {
+    gs_d4 b0[8], b1[8], b2[8], b3[8];
+    gs_ptab_fetch<0>(b0, tab, lane);
+    gs_ptab_fetch<1>(b1, tab, lane);
+    gs_ptab_fetch<2>(b2, tab, lane);
+    gs_ptab_fetch<3>(b3, tab, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    gs_ptab_step<0>(P, b0);
+    gs_ptab_step<1>(P, b1);
+    gs_ptab_fetch<4>(b0, tab, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    gs_ptab_step<2>(P, b2);
+    gs_ptab_step<3>(P, b3);
+    gs_ptab_fetch<5>(b1, tab, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    gs_ptab_step<4>(P, b0);
+    gs_ptab_fetch<6>(b2, tab, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    gs_ptab_step<5>(P, b1);
+    gs_ptab_fetch<7>(b3, tab, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    gs_ptab_step<6>(P, b2);
+    gs_ptab_step<7>(P, b3);
+}
+
+// rows [0, M) x 128 columns at P (leading dimension ld)  <-  rows * L_bb^-T, 16 rows per single-wave workgroup
+__global__ __launch_bounds__(64) void k_panel(double* P, int64_t ld, int M, const double* Ltab) {
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
-    gs_panel16_solve(Pr, tab, lane);
-    gs_panel16_store(Pr, rows, ld, nvalid, lane);
+    __builtin_amdgcn_s_setprio(3);          // chain kernel: ahead of the bulk waves it shares the SIMD with
+    double* rows = P + (int64_t)r0 * ld;
+    gs_d4 Pr[8];
+    gs_panel16_load(Pr, rows, ld, M - r0, lane);
+    gs_panel16_solve_g(Pr, Ltab, lane);
+    gs_panel16_store(Pr, rows, ld, M - r0, lane);
+}
+
+// ---- two block columns at once ------------------------------------------------------------------------------------
+// Lsib: the 128 x 128 block L(j+1, j) as 64 micro-block dumps in A-operand layout, [(c * 8 + k) * 256 + x * 64 + lane]
+// = register image of (-L_ck) -- what k_potrf_diag256 leaves behind for the rows below.
+#define GS_LSIB (64 * 256)
+
+// P1 (register image of the rows' second 128 columns)  +=  sum_k (-L_ck) P0_k : the sibling-column update
+// B[:, j+1] -= X_j L(j+1, j)^T of these 16 rows, products in ascending k on accumulators that START as the matrix entries
+// -- element for element the arithmetic of k_gemm_nt on the same block (sign-mirrored), so the fused kernels below stay
+// bit-identical to the three-launch sequence panel / sibling update / panel.
+__device__ __forceinline__ void gs_sib_fetch(gs_d4 (&buf)[8], const double* Lsib, int c, int lane) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) buf[kb][x] = Lsib[((c * 8 + kb) * 4 + x) * 64 + lane];
+}
+
+__device__ __forceinline__ void gs_sib_apply(gs_d4& acc, const gs_d4 (&buf)[8], const gs_d4 (&P0)[8]) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[kb][x], P0[kb][x], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void gs_sib_update(gs_d4 (&P1)[8], const gs_d4 (&P0)[8], const double* Lsib, int lane) {
+    gs_d4 ba[8], bb[8];
+    gs_sib_fetch(ba, Lsib, 0, lane);
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        gs_sib_fetch(bb, Lsib, c + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        gs_sib_apply(P1[c], ba, P0);
+        if (c + 2 < 8) gs_sib_fetch(ba, Lsib, c + 2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        gs_sib_apply(P1[c + 1], bb, P0);
+    }
+}
+
+// rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
+//   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
+// (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
+__global__ __launch_bounds__(64) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
+                                                  const double* Ltab1) {
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= M) return;
+    __builtin_amdgcn_s_setprio(3);
+    double* rows = P + (int64_t)r0 * ld;
+    gs_d4 P0[8], P1[8];
+    gs_panel16_load(P0, rows, ld, M - r0, lane);
+    gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
+    gs_panel16_solve_g(P0, Ltab0, lane);
+    gs_panel16_store(P0, rows, ld, M - r0, lane);
+    gs_sib_update(P1, P0, Lsib, lane);
+    gs_panel16_solve_g(P1, Ltab1, lane);
+    gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
@@ -1246,12 +1374,77 @@ template <int ALGO>
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet,
                                                      int* info, int col0, const double* diag0,
                                                      unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // 76.5 KB: one 64-KB bulk workgroup still fits
-                                                                        // on the CU beside this kernel
+    // ALGO 2: 34 KB (one panel column at a time in LDS, dumps exported as they are made) -- with its 124 VGPRs the
+    // workgroup fits where ONE bulk workgroup (53 KB, 8 waves) has just retired; at 77 KB it waited for two on the same CU
+    // while lower-priority bulk workgroups kept taking the single slots (rocprofv3: 90-250 us per call beside the bulk update)
+    __shared__ __attribute__((aligned(16))) double wsd[ALGO == 1 ? GS_DIAG_WS : GS_D2C_WS];
     if (*info != 0) return;                    // an earlier block already failed (uniform)
+    if (ALGO == 2) __builtin_amdgcn_s_setprio(3);      // the chain's one workgroup: ahead of the bulk waves on its SIMDs
     const int bad = ALGO == 1 ? gs_diag_block_v1(A, ld, Linv, logdet, diag0, stamps, wsd)
-                              : gs_diag_block(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
+                              : gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
+}
+
+// Two diagonal blocks in one launch: the 256 x 256 diagonal super-block of an outer step, by one workgroup.
+//   A00 = L00 L00^T (gs_diag_block);  L10 = A10 L00^-T (blocked substitution, two 16-row groups per wave);
+//   A11 -= L10 L10^T (lower micro-tiles, on accumulators that start as the matrix entries, ascending k: k_gemm_nt's
+//   arithmetic);  A11 = L11 L11^T (gs_diag_block).
+// Replaces diag / panel / sibling update / diag on the chain of a factorisation: four dependent launches, two of them
+// over all rows below, become one; the rows below go through k_panel256 afterwards.  L10 is also left in Lsib (operand
+// layout) for that kernel.  Tables of both blocks to Ltab[0], Ltab[GS_LTAB].
+__global__ __launch_bounds__(256) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
+                                                       int col0, const double* diag0, unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
+    if (*info != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    int bad = gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
+    if (bad) {
+        if (t == 0) *info = col0 + bad;
+        return;
+    }
+    __threadfence();                            // the tables just written are read back from global memory below
+    __syncthreads();
+    // ---- L10: groups w and 7 - w of the 128 rows below
+    double* A10 = A + (int64_t)128 * ld;
+    const int g0 = w, g1 = 7 - w;
+    gs_d4 Pa[8], Pb[8];
+    gs_panel16_load(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
+    gs_panel16_load(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
+    gs_panel16_solve_g(Pa, Ltab, lane);
+    gs_panel16_solve_g(Pb, Ltab, lane);
+    gs_panel16_store(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
+    gs_panel16_store(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            Lsib[((g0 * 8 + k) * 4 + x) * 64 + lane] = Pa[k][x];
+            Lsib[((g1 * 8 + k) * 4 + x) * 64 + lane] = Pb[k][x];
+        }
+    __threadfence();
+    __syncthreads();
+    // ---- A11 -= L10 L10^T: micro-tile (c, c') for c' in {g0, g1}, c >= c'.  A operand: dump of group c (-L_c,kb),
+    // B operand: own registers (image of group c').  Accumulator = -(tile) in the standard orientation.
+    double* A11 = A10 + 128;
+    auto tile = [&](int c, int cp, const gs_d4 (&Pq)[8]) {
+        gs_d4 acc;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[x] = -A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr];
+        gs_d4 buf[8];
+        gs_sib_fetch(buf, Lsib, c, lane);
+        gs_sib_apply(acc, buf, Pq);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr] = -acc[x];
+    };
+    for (int c = g0; c < 8; ++c) tile(c, g0, Pa);
+    for (int c = g1; c < 8; ++c) tile(c, g1, Pb);
+    __threadfence();
+    __syncthreads();
+    bad = gs_diag_block<false>(A11, ld, (double*)nullptr, Ltab + GS_LTAB, logdet + 1, diag0 + 128, nullptr, wsd);
+    if (bad && t == 0) *info = col0 + 128 + bad;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -137,9 +137,12 @@ def spd(n, seed, cond=1e4):
 
 
 @pytest.mark.parametrize("n", [1, 5, 128, 129, 200, 384, 1000])
-@pytest.mark.parametrize("lookahead", [1, 0])
+@pytest.mark.parametrize("lookahead", [1, 0, 2, 3])
 def test_potrf_matches_lapack(ctx, n, lookahead):
-    ctx.set_option("lookahead", lookahead)
+    # 2 / 3: the fused chain kernels (k_potrf_diag256 + k_panel256), whole-panel and windowed look-ahead
+    ctx.set_option("chain_fused", 1 if lookahead >= 2 else 0)
+    ctx.set_option("chain_window", 1 if lookahead == 3 else 0)
+    ctx.set_option("lookahead", min(lookahead, 1))
     A = spd(n, n)
     M = ctx.upload(A)
     np.testing.assert_array_equal(M.to_host(), np.tril(A) + np.tril(A, -1).T)
@@ -157,11 +160,15 @@ def test_potrf_matches_lapack(ctx, n, lookahead):
     np.testing.assert_allclose(ctx.forward_solve(M, Z), W, rtol=1e-8, atol=1e-10 * np.abs(W).max())
     M.free()
     ctx.set_option("lookahead", 1)
+    ctx.set_option("chain_fused", 0)
+    ctx.set_option("chain_window", 0)
 
 
-@pytest.mark.parametrize("n,bad", [(6, 3), (200, 0), (200, 130), (300, 299), (384, 255)])
-def test_potrf_info_matches_lapack(ctx, n, bad):
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("n,bad", [(6, 3), (200, 0), (200, 130), (300, 299), (384, 255), (600, 300)])
+def test_potrf_info_matches_lapack(ctx, n, bad, fused):
     """Not positive definite -> LAPACK-style info (index exact), as numpy.linalg.cholesky's LinAlgError."""
+    ctx.set_option("chain_fused", fused)
     A = spd(n, 7, cond=10.0)
     A[bad, bad] = -1.0
     _, info = dpotrf(A, lower=1)
@@ -173,6 +180,7 @@ def test_potrf_info_matches_lapack(ctx, n, bad):
     M = ctx.upload(A)
     assert ctx.potrf(M) == bad + 1
     M.free()
+    ctx.set_option("chain_fused", 0)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -560,6 +568,17 @@ def test_full_size_properties_n8192():
         ctx.set_option("reserve_cus", reserve)
         out[("reserve", reserve)] = ctx.lml_batch([desc], X, Z, 1e-10)
     ctx.set_option("reserve_cus", 0)
+    # the alternative chain schedules ("Chain experiments"): two diagonal blocks per launch + both panels of the
+    # rows below in one, and the windowed look-ahead with and without reserved CUs -- all partitions / fusions of the same
+    # products in the same order
+    for fused, window, reserve, la in ((1, 0, 0, 1), (1, 1, 0, 1), (0, 1, 0, 1), (1, 1, 2, 1), (1, 0, 0, 0)):
+        ctx.set_option("chain_fused", fused)
+        ctx.set_option("chain_window", window)
+        ctx.set_option("reserve_cus", reserve)
+        ctx.set_option("lookahead", la)
+        out[("chain", fused, window, reserve, la)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    for name, v in (("chain_fused", 0), ("chain_window", 0), ("reserve_cus", 0), ("lookahead", 1)):
+        ctx.set_option(name, v)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     # evaluations in flight: 1, 3, 10 or 16 per call is scheduling only; so is the batch mode's lazy K = 512 update of the

@@ -29,11 +29,15 @@ def run(label):
 
 
 for rep in range(2):
-    for pad in (0, 56 * 1024, 72 * 1024, 80 * 1024):
-        for R in (0, 4):
-            ctx.set_option("reserve_cus", R)
-            ctx.set_option("bulk_lds_pad", pad)
-            run(f"bulk_lds_pad={pad} reserve_cus={R}")
+    for fused in (1, 0):
+        ctx.set_option("chain_fused", fused)
+        for win in (1, 0):
+            ctx.set_option("chain_window", win)
+            for R in (0, 2):
+                ctx.set_option("reserve_cus", R)
+                run(f"fused={fused} window={win} reserve_cus={R}")
+ctx.set_option("chain_fused", 1)
+ctx.set_option("chain_window", 1)
 ctx.set_option("bulk_lds_pad", 0)
 ctx.set_option("reserve_cus", 0)
 ctx.set_option("bulk_cfg", 7)
