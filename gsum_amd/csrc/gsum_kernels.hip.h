@@ -826,6 +826,21 @@ __device__ __forceinline__ void gs_wave_lds_sync() {
 __device__ __forceinline__ int gs_pair_row(int lane) { return 4 * (lane & 3) + ((lane & 15) >> 2); }   // rho^-1(lane & 15)
 #define GS_PAIR_LANE(r, c) (16 * ((c) >> 2) + ((r) >> 2) + 4 * ((r) & 3))                              // lane of entry (r, c)
 
+// v is zero outside lane row g (16 lanes): the same values in row g ^ 1, zero elsewhere.  v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second; ODD = g & 1.
+__device__ __forceinline__ double gs_row_to_sibling(double v, bool ODD) {     // ODD folds after unrolling
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    if (ODD) {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, 0u, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, 0u, false, false);
+        return __hiloint2double((int)b[1], (int)a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane16_swap(0u, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(0u, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]);
+    }
+}
+
 template <int JB>
 __device__ __forceinline__ int gs_potf2_16(const gs_d4& Ajj, const gs_d4& Sjj, double* Ablk, int64_t ld, double* Dvj,
                                            const double* thr, double* dbuf, int lane, unsigned long long* stamps = nullptr) {
@@ -869,10 +884,12 @@ __device__ __forceinline__ int gs_potf2_16(const gs_d4& Ajj, const gs_d4& Sjj, d
         Rs[x1] = ing ? r1 : Rs[x1];
         const double vc0 = ing ? V[x0] * r0 : 0.0;
         const double vc1 = ing ? __builtin_fma(-l10, vc0, V[x1]) * r1 : 0.0;
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms0, ms0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ms1, ms1, S, 0, 0, 0);
-        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms0, vc0, V, 0, 0, 0);
-        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ms1, vc1, V, 0, 0, 0);
+        // both rank-1 updates of the pair in ONE MFMA each: column c1's vector moves to the sibling lane row (g ^ 1, a
+        // different k-slot) with v_permlane16_swap, so the instruction sums ms0 ms0^T + ms1 ms1^T (two of its four k-slots)
+        const double ab = ms0 + gs_row_to_sibling(ms1, (g & 1) != 0);
+        const double vb = vc0 + gs_row_to_sibling(vc1, (g & 1) != 0);
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, ab, S, 0, 0, 0);
+        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ab, vb, V, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);    // keep the steps apart: hoisting the next steps' lane masks and v_readlane
                                               // results ahead ran the kernel out of SGPRs (spills through v_writelane)
     }
@@ -911,7 +928,8 @@ __device__ __forceinline__ void gs_d2_upd_diag(gs_d4& Cc, const double* blk, int
 // leaves behind on a busy CU.
 #define GS_LS_SLOT(FULL, row, J) ((FULL) ? ((row) * ((row) - 1) / 2 + (J)) : (row))
 template <int J, bool FULL>
-__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, double* Lg, int row, int lane) {
+__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, double* Lg, double* A,
+                                                 int64_t ld, int row, int lane) {
     const gs_d4 E = Pb + Sb;
     gs_d4 T = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -919,6 +937,7 @@ __device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, con
     Pb = T;
 #pragma unroll
     for (int x = 0; x < 4; ++x) Ls[(GS_LS_SLOT(FULL, row, J) * 4 + x) * 64 + lane] = T[x];
+
     if constexpr (!FULL) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) Lg[((row * (row - 1) / 2 + J) * 4 + x) * 64 + lane] = T[x];
@@ -927,27 +946,45 @@ __device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, con
 
 template <int W, int J, bool FULL>
 __device__ __forceinline__ void gs_d2_trsm_dump(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W],
-                                                const double* Dv, double* Ls, double* Lg, int lane) {
+                                                const double* Dv, double* Ls, double* Lg, double* A, int64_t ld, int lane) {
     constexpr int R0 = W, R1 = 7 - W;
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (R1 > J) {                   // R1 >= R0: nothing to do for either row otherwise
         double av[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) av[x] = Dv[(J * 16 + fr) * GS_DV_STR + fq + 4 * x];
-        if constexpr (R0 > J) gs_d2_solve_dump<J, FULL>(P0[J], S0[J], av, Ls, Lg, R0, lane);
-        gs_d2_solve_dump<J, FULL>(P1[J], S1[J], av, Ls, Lg, R1, lane);
+        if constexpr (R0 > J) gs_d2_solve_dump<J, FULL>(P0[J], S0[J], av, Ls, Lg, A, ld, R0, lane);
+        gs_d2_solve_dump<J, FULL>(P1[J], S1[J], av, Ls, Lg, A, ld, R1, lane);
     }
 }
 
 // after panel column J is in LDS: add its products to the sums; the owner of row J + 1 finishes the sum of its diagonal
 // micro-block first and runs the pivot recurrence on it before its other updates.  Returns the failing local column of
 // micro-block J + 1 or -1.
+// the blocks of panel column J this wave solved are final: back to the matrix.  Issued in the update phase -- by the
+// wave that runs the next pivot recurrence only after it, by the others first -- so the scattered 8-byte stores are off
+// the chain (at the end of the kernel they were 8 k cycles of tail, in the solve phase 1-1.5 k per step)
+template <int W, int J>
+__device__ __forceinline__ void gs_d2_store_col(const gs_d4 (&P0)[W + 1], const gs_d4 (&P1)[8 - W], double* A, int64_t ld, int lane) {
+    constexpr int R0 = W, R1 = 7 - W;
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (R0 > J) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R0 + fr) * ld + 16 * J + fq + 4 * x] = -P0[J][x];
+    }
+    if constexpr (R1 > J) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R1 + fr) * ld + 16 * J + fq + 4 * x] = -P1[J][x];
+    }
+}
+
 template <int W, int J, bool FULL>
 __device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
                                             int64_t ld, double* Dv, double* scr, const double* Ls, const double* thr, double* dbuf,
                                             int lane, unsigned long long* stamps) {
     constexpr int R0 = W, R1 = 7 - W, N = J + 1;
     int fail = -1;
+    if constexpr (R0 != N && R1 != N) gs_d2_store_col<W, J>(P0, P1, A, ld, lane);
     if constexpr (R0 == N) {
         gs_d2_upd_diag(S0[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
         fail = gs_potf2_16<N>(P0[N], S0[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
@@ -955,6 +992,7 @@ __device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - 
         gs_d2_upd_diag(S1[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
         fail = gs_potf2_16<N>(P1[N], S1[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
     }
+    if constexpr (R0 == N || R1 == N) gs_d2_store_col<W, J>(P0, P1, A, ld, lane);
     if constexpr (R0 > N) {
 #pragma unroll
         for (int k = N; k < R0; ++k) gs_d2_upd(S0[k], Ls + GS_LS_SLOT(FULL, k, J) * 256, P0[J], lane);
@@ -975,7 +1013,7 @@ __device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W
     __syncthreads();                                          // D_J (and a failure flag) visible
     if (stamps && W == 0 && lane == 0) stamps[8 + 2 * J] = __builtin_amdgcn_s_memtime();       // diagnostics only
     if (*fail_sh >= 0) return false;
-    gs_d2_trsm_dump<W, J, FULL>(P0, P1, S0, S1, Dv, Ls, Lg, lane);
+    gs_d2_trsm_dump<W, J, FULL>(P0, P1, S0, S1, Dv, Ls, Lg, A, ld, lane);
     __syncthreads();                                          // panel column J visible
     if (stamps && W == 0 && lane == 0) stamps[9 + 2 * J] = __builtin_amdgcn_s_memtime();
     if constexpr (J < 7) {
@@ -1032,15 +1070,7 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
     if (!gs_d2_step<W, 5, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
     if (!gs_d2_step<W, 6, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
     if (!gs_d2_step<W, 7, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    // strictly lower micro-blocks back to the matrix (the diagonal ones were stored by the pivot recurrence)
-#pragma unroll
-    for (int k = 0; k < R0; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R0 + fr) * ld + 16 * k + fq + 4 * x] = -P0[k][x];
-#pragma unroll
-    for (int k = 0; k < R1; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R1 + fr) * ld + 16 * k + fq + 4 * x] = -P1[k][x];
+    // (the strictly lower micro-blocks went back to the matrix as they were solved, the diagonal ones from the pivot recurrence)
     return true;
 }
 
