@@ -1025,12 +1025,13 @@ __device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W
 
 // phase 1 of wave W: returns false if a pivot failed (every wave leaves at the same barrier)
 template <int W, bool FULL>
-__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, const double* thr,
-                                           double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
+__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, double* thr,
+                                           double d0, double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
     constexpr int R0 = W, R1 = 7 - W;
     const int fr = lane & 15, fq = lane >> 4;
     gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
     const int prow = gs_pair_row(lane);
+
 #pragma unroll
     for (int k = 0; k <= R0; ++k) {
         S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
@@ -1058,7 +1059,12 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
             }
         }
     }
+    // pivot thresholds (d0 was requested before the block, so it is the oldest load in flight): waves 0 and 1 store 64
+    // each.  No barrier: the first recurrence reads entries 0..15, which its own wave wrote (LDS operations of one wave
+    // execute in order); every later reader is behind the barriers of step 0.
+    if constexpr (W < 2) thr[threadIdx.x] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
     if constexpr (W == 0) {
+        gs_wave_lds_sync();
         const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);
         if (f >= 0 && lane == 0) *fail_sh = f;
     }
@@ -1146,17 +1152,15 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
         sr0 = __builtin_amdgcn_s_memrealtime();
         if (t == 0) stamps[7] = st0;
     }
-    if (t < 128) {
-        const double d0 = diag0[t];
-        thr[t] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
-    }
-    if (t == 0) fail_sh = -1;
-    __syncthreads();
+    if (t == 0) fail_sh = -1;                           // first read behind the first barrier of step 0
+    double d0 = 0.0;
+    if (t < 128) d0 = diag0[t];                         // the thresholds' load goes out ahead of the block's (see gs_d2_wave)
+    __builtin_amdgcn_sched_barrier(0);
     bool ok;
-    if (w == 0) ok = gs_d2_wave<0, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
-    else if (w == 1) ok = gs_d2_wave<1, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
-    else if (w == 2) ok = gs_d2_wave<2, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
-    else ok = gs_d2_wave<3, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, dbuf, &fail_sh, lane, stamps);
+    if (w == 0) ok = gs_d2_wave<0, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
+    else if (w == 1) ok = gs_d2_wave<1, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
+    else if (w == 2) ok = gs_d2_wave<2, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
+    else ok = gs_d2_wave<3, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
     if (!ok) return fail_sh + 1;                       // uniform: every wave read the flag behind the same barrier
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
     if (t < 128) dbuf[t] = log(dbuf[t]);
@@ -1175,10 +1179,14 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
     }
     __threadfence_block();
     __syncthreads();
+    if (w == 0) {
+        // sum of the 128 logs by one wave: two per lane, then a fixed xor tree (deterministic)
+        double sl = dbuf[lane] + dbuf[lane + 64];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sl += __shfl_xor(sl, off, 64);
+        if (lane == 0) *logdet_out = sl;
+    }
     if (t == 0) {
-        double sl = 0.0;
-        for (int j = 0; j < 128; ++j) sl += dbuf[j];
-        *logdet_out = sl;
         if (stamps) {
             const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
             stamps[0] = 0;              // (the loads are part of phase 1 in this version)
