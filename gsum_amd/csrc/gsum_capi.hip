@@ -40,7 +40,7 @@ struct gs_slot {
     hipStream_t sc = nullptr, srm = nullptr;   // windowed schedule with reserve_cus > 0: the chain on the reserved CUs ONLY,
                                                // the rest stream on the bulk stream's CUs
     hipStream_t sr = nullptr;        // windowed look-ahead schedule: the rows below the window (panel rest, far look-ahead columns)
-    std::vector<hipEvent_t> evP, evM;
+    std::vector<hipEvent_t> evP, evM, evA;
     std::vector<hipEvent_t> evW;     // windowed schedule: five events per outer step (GS_EVW_*)
     hipEvent_t evFork = nullptr, evR = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -80,6 +80,8 @@ struct gsum_ctx {
     int build_lower_only = 1;
     int bulk_lds_pad = 0;            // bytes of dynamic LDS the bulk kernel asks for in look-ahead schedules (0 = what it needs)
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
+    int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
+    int la_depth2 = 0;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
     int chain_fused = 0;             // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
                                      // (k_panel256) instead of diag / panel / sibling update / diag / panel; 0 = the five launches
     int chain_window = 0;            // look-ahead schedule: 1 = windowed (only the rows the next panels need are on the chain's
@@ -168,14 +170,15 @@ static void gs_prof_end(gsum_ctx* ctx, hipStream_t s, int rec) {
 }
 
 // ---- GEMM launcher ----------------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int PF = 1>
 static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda,
                           const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
     constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
     if (M <= 0 || N <= 0) return 0;
     if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
     const size_t shmem = 2 * (size_t)(BM + BN) * GS_LSTR * sizeof(double);
-    auto kern = k_gemm_nt<WM, WN, WAVES_M, WAVES_N>;
+    if (PF > 1 && K % (GS_KC * PF) != 0) GS_FAIL("gemm: the prefetch ring needs K to be a multiple of 64");
+    auto kern = k_gemm_nt<WM, WN, WAVES_M, WAVES_N, false, PF>;
     if (!ctx->lds_attr_done.count((const void*)kern)) {          // per context: the attribute is per device
         GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         ctx->lds_attr_done.insert((const void*)kern);
@@ -252,7 +255,9 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     }
     switch (cfg) {
         case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
-        case 1: return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+        case 1:
+            if (ctx->chain_prefetch && K % 64 == 0) return gs_launch_gemm<2, 2, 1, 4, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+            return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 2: return gs_launch_gemm<1, 4, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 5: return gs_launch_gemm<4, 2, 2, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
     }
@@ -398,9 +403,11 @@ static int gs_potrf_events(gsum_ctx* ctx, gs_slot* sl, int T) {
         size_t old = sl->evP.size();
         sl->evP.resize(T + 1);
         sl->evM.resize(T + 1);
+        sl->evA.resize(T + 1);
         for (size_t i = old; i < sl->evP.size(); ++i) {
             GS_CHECK(hipEventCreateWithFlags(&sl->evP[i], hipEventDisableTiming));
             GS_CHECK(hipEventCreateWithFlags(&sl->evM[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evA[i], hipEventDisableTiming));
         }
     }
     return 0;
@@ -748,13 +755,28 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         GS_CHECK(hipEventRecord(sl->evP[k], sp));
         if (r2 < m->np) {
             const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
-            // look-ahead columns: need the previous bulk update to have finished with them
-            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evM[prev], 0));
+            // look-ahead columns: need the previous bulk update to have finished with THEM (evA: see below)
+            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evA[prev], 0));
             if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
-            if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            // The bulk update goes out in two launches: first the 256 columns the panel AFTER the next one lives in, then
+            // everything right of them.  The next step's look-ahead update waits for the first only, so the chain is a
+            // whole outer step ahead of the bulk stream instead of starting when the previous bulk update ends: in the
+            // first third of a factorisation (bulk-bound) the chain then hides under the bulk update completely.
+            const int64_t wa = std::min<int64_t>(2 * GS_NB, m->np - r3);
+            if (ctx->la_depth2 && wa > 0 && m3 > wa) {
+                ctx->next_algo_flops = (double)Kp * (2.0 * (double)m3 * wa - (double)wa * (wa - 1));
+                if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, wa, Kp, 0, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(sl->evA[k], sb));
+                const int64_t r4 = r3 + wa, m4 = naug - r4;
+                double* P4 = A + r4 * ld + c0;
+                if (gs_gemm(ctx, sb, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, Kp, 1, 1, -1.0)) return -1;
+            } else {
+                if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(sl->evA[k], sb));
+            }
             GS_CHECK(hipEventRecord(sl->evM[k], sb));
             prev = k;
         } else {
@@ -870,6 +892,7 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->hres) (void)hipHostFree(sl->hres);
         for (auto ev : sl->evP) (void)hipEventDestroy(ev);
         for (auto ev : sl->evM) (void)hipEventDestroy(ev);
+        for (auto ev : sl->evA) (void)hipEventDestroy(ev);
         if (sl->evFork) (void)hipEventDestroy(sl->evFork);
         for (int k = 0; k < 4; ++k)
             if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
@@ -965,6 +988,8 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
     else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
     else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value != 0;
+    else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;
+    else if (!strcmp(name, "chain_prefetch")) ctx->chain_prefetch = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);

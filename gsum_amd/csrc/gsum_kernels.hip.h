@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "gsum_hip.h"
 
 #define GS_NB 128
@@ -1612,7 +1613,11 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
 // In-place use (C == A, TRSM against an explicit inverse) is safe when one tile spans all N = K
 // columns: every global load of the tile's rows is finished before the epilogue stores.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false>
+// PF: operand chunks requested ahead of the one being multiplied.  1 = the next chunk only (one memory latency per 16
+// columns of K: fine when several workgroups share a CU, 1.3-1.5 us per chunk for the lone 32 x 128 tiles of the
+// factorisation's chain -- sibling update 12.6 us, look-ahead update 21 us for 0.4 / 0.9 us of MFMA work per tile).
+// 4 = a ring of four register sets (K a multiple of 64): the same products in the same order, ~3x sooner.
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false, int PF = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
                                                      const double* B, int64_t ldb, int M, int N, int K,
                                                      int tri, int beta, double sign,
@@ -1670,30 +1675,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
             }
         }
 
-    gs_d2 ra[A_IT], rb[B_IT];
-    // one 16-B global load of the staging set: i < A_IT -> A tile, else B tile
-    auto gload_one = [&](int kc, int i) {
+    gs_d2 ra[PF][A_IT], rb[PF][B_IT];
+    // one 16-B global load of the staging set: i < A_IT -> A tile, else B tile; `slot` = register set (compile-time)
+    auto gload_one = [&](int kc, int i, auto slot) {
+        constexpr int S = decltype(slot)::value;
         if (i < A_IT) {
             const int vv = t + i * NT;
             if (vv < A_VECS) {
                 int row = m0 + (vv >> 3);
                 row = row < M ? row : M - 1;
-                ra[i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)row * lda + kc * GS_KC + 2 * (vv & 7));
+                ra[S][i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)row * lda + kc * GS_KC + 2 * (vv & 7));
             }
         } else {
             const int vv = t + (i - A_IT) * NT;
             if (vv < B_VECS) {
                 int row = n0 + (vv >> 3);
                 row = row < N ? row : N - 1;
-                rb[i - A_IT] = *reinterpret_cast<const gs_d2*>(B + (int64_t)row * ldb + kc * GS_KC + 2 * (vv & 7));
+                rb[S][i - A_IT] = *reinterpret_cast<const gs_d2*>(B + (int64_t)row * ldb + kc * GS_KC + 2 * (vv & 7));
             }
         }
     };
-    auto gload = [&](int kc) {
+    auto gload = [&](int kc, auto slot) {
 #pragma unroll
-        for (int i = 0; i < A_IT + B_IT; ++i) gload_one(kc, i);
+        for (int i = 0; i < A_IT + B_IT; ++i) gload_one(kc, i, slot);
     };
-    auto swrite = [&](int stage) {
+    auto swrite = [&](int stage, auto slot) {
+        constexpr int S = decltype(slot)::value;
         double* sA = lds + stage * (BM + BN) * GS_LSTR;
         double* sB = sA + BM * GS_LSTR;
 #pragma unroll
@@ -1701,8 +1708,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
             const int vv = t + it * NT;
             if (vv < A_VECS) {          // rows are only 8-B aligned at an odd stride: two 8-byte stores
                 double* q = sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-                q[0] = ra[it][0] * sign;
-                q[1] = ra[it][1] * sign;
+                q[0] = ra[S][it][0] * sign;
+                q[1] = ra[S][it][1] * sign;
             }
         }
 #pragma unroll
@@ -1710,11 +1717,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
             const int vv = t + it * NT;
             if (vv < B_VECS) {
                 double* q = sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-                q[0] = rb[it][0];
-                q[1] = rb[it][1];
+                q[0] = rb[S][it][0];
+                q[1] = rb[S][it][1];
             }
         }
     };
+    auto multiply = [&](int stage) {
+        const double* sA = lds + stage * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
+        const double* sB = lds + stage * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
+#pragma unroll
+        for (int ks = 0; ks < GS_KC / 4; ++ks) {
+            double af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 16 * GS_LSTR + ks * 4];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 16 * GS_LSTR + ks * 4];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
 
     const int nk = K / GS_KC;
     // STAMP build only (diagnostics, separate instantiation): shader-cycle sums of the loop phases
@@ -1729,37 +1754,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
             tq = now;
         }
     };
-    stamp(-1);
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    stamp(0);                                   // prologue: C loads issued, first chunk staged
-    for (int c = 0; c < nk; ++c) {
-        // Next chunk's operands: issued in one burst ahead of the MFMAs.  (Spreading them over the k-steps
-        // was measured and is no better: under load each load instruction blocks in-order issue for ~300
-        // cycles wherever it sits; the CU's vector-memory path, ~7-10 B/clk, is the ceiling for this tile.)
-        if (c + 1 < nk) gload(c + 1);
-        stamp(1);                               // global load issue
-        const double* sA = lds + (c & 1) * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
-        const double* sB = lds + (c & 1) * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 4; ++ks) {
-            double af[WM], bf[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 16 * GS_LSTR + ks * 4];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 16 * GS_LSTR + ks * 4];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        stamp(2);                               // fragment reads + MFMAs
-        if (c + 1 < nk) swrite((c + 1) & 1);
-        stamp(3);                               // wait for the global loads, LDS stores
+    if constexpr (PF == 1) {
+        stamp(-1);
+        gload(0, I0{});
+        swrite(0, I0{});
         __syncthreads();
-        stamp(4);                               // barrier
+        stamp(0);                                   // prologue: C loads issued, first chunk staged
+        for (int c = 0; c < nk; ++c) {
+            // Next chunk's operands: issued in one burst ahead of the MFMAs.  (Spreading them over the k-steps
+            // was measured and is no better: under load each load instruction blocks in-order issue for ~300
+            // cycles wherever it sits; the CU's vector-memory path, ~7-10 B/clk, is the ceiling for this tile.)
+            if (c + 1 < nk) gload(c + 1, I0{});
+            stamp(1);                               // global load issue
+            multiply(c & 1);
+            stamp(2);                               // fragment reads + MFMAs
+            if (c + 1 < nk) swrite((c + 1) & 1, I0{});
+            stamp(3);                               // wait for the global loads, LDS stores
+            __syncthreads();
+            stamp(4);                               // barrier
+        }
+    } else {
+        static_assert(PF == 1 || PF == 4, "ring of four register sets");
+        using I1 = std::integral_constant<int, 1 % PF>;
+        using I2 = std::integral_constant<int, 2 % PF>;
+        using I3 = std::integral_constant<int, 3 % PF>;
+        // nk is a multiple of 4 (the launcher checks K % 64 == 0).  Branch-free body: loads past the end re-read the last
+        // chunk and the last LDS store goes to the stage nobody reads again -- a branch around a load makes the
+        // compiler's wait-count bookkeeping drain every outstanding load at the join.
+        auto clampk = [&](int kc) { return kc < nk ? kc : nk - 1; };
+        gload(0, I0{});
+        gload(clampk(1), I1{});
+        gload(clampk(2), I2{});
+        gload(clampk(3), I3{});
+        swrite(0, I0{});
+        __syncthreads();
+        auto iter = [&](int c, auto slot, auto next) {
+            gload(clampk(c + 4), slot);             // this set went to LDS in the previous iteration
+            multiply(c & 1);
+            swrite((c + 1) & 1, next);              // requested three iterations ago
+            __syncthreads();
+        };
+        for (int c = 0; c < nk; c += 4) {
+            iter(c, I0{}, I1{});
+            iter(c + 1, I1{}, I2{});
+            iter(c + 2, I2{}, I3{});
+            iter(c + 3, I3{}, I0{});
+        }
     }
     if (STAMP && stamps && lane == 0) {
         unsigned long long* o = stamps + ((int64_t)blockIdx.x * (NT / 64) + w) * 5;

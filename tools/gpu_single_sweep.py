@@ -28,16 +28,15 @@ def run(label):
     print(f"{label:40s} potrf ms min {min(ts):.3f} median {sorted(ts)[3]:.3f}", flush=True)
 
 
-for rep in range(2):
-    for fused in (1, 0):
-        ctx.set_option("chain_fused", fused)
-        for win in (1, 0):
-            ctx.set_option("chain_window", win)
-            for R in (0, 2):
-                ctx.set_option("reserve_cus", R)
-                run(f"fused={fused} window={win} reserve_cus={R}")
-ctx.set_option("chain_fused", 1)
-ctx.set_option("chain_window", 1)
+ctx.set_option("chain_fused", 0)
+ctx.set_option("chain_window", 0)
+for rep in range(3):
+    for pf in (1, 0):
+        ctx.set_option("chain_prefetch", pf)
+        for R in (0, 2):
+            ctx.set_option("reserve_cus", R)
+            run(f"chain_prefetch={pf} reserve_cus={R}")
+ctx.set_option("chain_prefetch", 1)
 ctx.set_option("bulk_lds_pad", 0)
 ctx.set_option("reserve_cus", 0)
 ctx.set_option("bulk_cfg", 7)
