@@ -53,6 +53,17 @@ def last(agg, name):
 for sub, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_single", "single_eval_n2048_n8192_kernel_stats.csv"),
                   ("prof_predict", "predict_kernel_stats.csv"), ("prof_grad", "grad_n8192_kernel_stats.csv")):
     copy(newest(sub, "*kernel_stats.csv"), name)
+# the single-evaluation kernel trace itself (start / end of every dispatch) and the per-step timeline derived from it
+tr = newest("prof_single", "*kernel_trace.csv")
+if tr:
+    copy(tr, "single_eval_kernel_trace.csv")
+    import subprocess
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_timeline.py"), tr, "60"], capture_output=True, text=True).stdout
+    open(os.path.join(OUT, f"{TAG}_single_eval_timeline.txt"), "w").write(
+        "Last n = 8192 factorisation of `rocprofv3 --kernel-trace -- python3 tools/prof_eval.py 2048 8192` (look-ahead schedule, one\n"
+        "evaluation in flight); columns: start us, end us, duration us, kernel, stream, grid.  Then the start-to-start period of the\n"
+        "bulk launches (= duration of an outer step of 256 columns) and the bulk launches' own durations.\n\n" + txt)
+    print("wrote", f"{TAG}_single_eval_timeline.txt")
 json_line("bench.log", "bench_default.jsonl")
 json_line("rocprof_bench.log", "bench_under_rocprof.jsonl")
 json_line("plain_n1.log", "plain_n1.jsonl")
