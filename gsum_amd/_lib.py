@@ -129,6 +129,8 @@ PROTOTYPES = {
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_resident_shape": (C.c_int, [_p, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
+    "gsum_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _ip, _ip]),
+    "gsum_lml_resident_shard": (C.c_int, [_p, _kp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _ip, _ip, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
     "gsum_debug_diag_stamps": (C.c_int, [_p, _ip]),
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
@@ -442,6 +444,23 @@ class HipContext:
                                                 info.ctypes.data_as(_ip)))
         self._warn_if_probe_fell_back()
         return G, sld, info
+
+    def lml_resident_shard(self, descs, nugget: float, rank: int, world: int):
+        """This rank's slice of ``descs`` (gsum_shard_range), written to its positions of full-length arrays (NaN / -1
+        elsewhere): ready for an in-place all-gather.  Returns (G, sld, info, lo, hi)."""
+        k = self.resident_shape()[2]
+        if k == 0:
+            raise ValueError("gsum_set_inputs has not been called")
+        nk = len(descs)
+        G = np.full((nk, k, k), np.nan)
+        sld = np.full(nk, np.nan)
+        info = np.full(nk, -1, dtype=np.int64)
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        arr = self._desc_array(descs)
+        self._check(self._lib.gsum_lml_resident_shard(self._h, arr, nk, int(rank), int(world), float(nugget), _ptr(G), _ptr(sld),
+                                                      info.ctypes.data_as(_ip), C.byref(lo), C.byref(hi)))
+        self._warn_if_probe_fell_back()
+        return G, sld, info, int(lo.value), int(hi.value)
 
     def _warn_if_probe_fell_back(self):
         if getattr(self, "_probe_warned", False):

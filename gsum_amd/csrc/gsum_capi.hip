@@ -1579,6 +1579,30 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
     return gs_lml_on(ctx, &ctx->res, kernels, n_kernels, nugget, G_out, sld_out, info_out);
 }
 
+int gsum_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return -2;
+    const int64_t chunk = (total + world - 1) / world;
+    *lo = std::min<int64_t>(total, (int64_t)rank * chunk);
+    *hi = std::min<int64_t>(total, *lo + chunk);
+    return 0;
+}
+
+int gsum_lml_resident_shard(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, int32_t rank, int32_t world,
+                            double nugget, double* G_out, double* sld_out, int64_t* info_out, int64_t* lo, int64_t* hi) {
+    if (!ctx) return -2;
+    if (!kernels || !G_out || !sld_out || !info_out || !lo || !hi || n_kernels < 0) {
+        ctx->err = "gsum_lml_resident_shard: null argument";
+        return -2;
+    }
+    if (gsum_shard_range(n_kernels, rank, world, lo, hi)) {
+        ctx->err = "gsum_lml_resident_shard: bad rank / world";
+        return -2;
+    }
+    if (*hi == *lo) return 0;                       // more ranks than grid points: nothing for this one
+    const int64_t kk = (int64_t)ctx->res.k * ctx->res.k;
+    return gs_lml_on(ctx, &ctx->res, kernels + *lo, (int32_t)(*hi - *lo), nugget, G_out + *lo * kk, sld_out + *lo, info_out + *lo);
+}
+
 int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n,
                    int32_t d, const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out,
                    int64_t* info_out) {

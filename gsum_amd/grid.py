@@ -13,12 +13,15 @@ __all__ = ["shard_range", "gather_flat", "lml_grid_distributed", "predict_distri
 
 
 def shard_range(total: int, rank: int = 0, world: int = 1):
-    """Contiguous slice [lo, hi) of ``range(total)`` owned by ``rank`` (ceil-sized blocks)."""
-    if world < 1 or not (0 <= rank < world):
+    """Contiguous slice [lo, hi) of ``range(total)`` owned by ``rank`` (ceil-sized blocks): the partition the C ABI
+    defines (``gsum_shard_range``, include/gsum_hip.h), asked of the library itself so that a C host and this layer can
+    never disagree.  (The function is host arithmetic; calling it needs the built library but no GPU.)"""
+    import ctypes as C
+    from ._lib import load_library
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    if load_library().gsum_shard_range(int(total), int(rank), int(world), C.byref(lo), C.byref(hi)) != 0:
         raise ValueError("bad rank/world")
-    chunk = -(-total // world)
-    lo = min(total, rank * chunk)
-    return lo, min(total, lo + chunk)
+    return int(lo.value), int(hi.value)
 
 
 def _dist():

@@ -212,6 +212,21 @@ int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k);
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out);
 
+/* ---- multi-GPU: the grid partition inside the ABI ----------------------------------------------------------------
+ * One process per GPU, one context each; grid points (and new points of predict) are independent, so the flattened
+ * list is block-partitioned over `world` ranks with no data-path collective.  gsum_shard_range is THE partition (the
+ * Python layer, gsum_amd/grid.py, calls it too): rank r owns [lo, hi) = [min(total, r c), min(total, (r + 1) c)) with
+ * c = ceil(total / world).  gsum_lml_resident_shard evaluates this rank's descriptors only and writes them to THEIR
+ * positions of full-length output arrays (the other entries are left untouched), so that a host holding its own RCCL
+ * communicator all-gathers in place -- e.g. for the log-determinants, on buffers of world * c doubles:
+ *     ncclAllGather(sld + lo, sld, c, ncclDouble, comm, stream)
+ * (INTEGRATION.md).  The library itself opens no communicator: which ranks form the group and over which transport
+ * is the host's decision (the reference's Python host uses torch.distributed, backend "nccl" = RCCL over xGMI).
+ * Replaces: the nested Python loop over grid points, docs/notebooks/correlated_EFT_publication.ipynb:1457-1459. */
+int gsum_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+int gsum_lml_resident_shard(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, int32_t rank, int32_t world,
+                            double nugget, double* G_out, double* sld_out, int64_t* info_out, int64_t* lo, int64_t* hi);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event times (ms) of the last fused evaluation on the library's own streams:
  * ms[0] K build, ms[1] Cholesky (incl. fused forward solve), ms[2] finalize + D2H, ms[3] total.

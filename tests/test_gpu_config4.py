@@ -213,6 +213,35 @@ def test_resident_inputs_survive_other_calls(ctx):
     assert s0[0] == s1[0] and i0[0] == i1[0] == 0
 
 
+def test_lml_resident_shard_fills_exactly_its_slice(ctx):
+    """The C ABI's multi-GPU entry: rank r of `world` evaluates descriptors [lo, hi) of the list into THEIR positions of
+    full-length arrays; the ranks' slices together are the unsharded call, bit for bit (here the ranks run one after
+    the other on the one GPU: the all-gather is the host's)."""
+    rng = np.random.RandomState(11)
+    n, k = 700, 5
+    X = np.sort(rng.rand(n, 1), axis=0) * 50
+    Z = np.c_[rng.randn(n, k - 1), np.ones(n)]
+    descs = [gsum_amd.describe_kernel(RBF(ell), 1) for ell in np.linspace(0.4, 1.4, 11)]
+    ctx.set_inputs(X, Z)
+    G0, s0, i0 = ctx.lml_resident(descs, 1e-8)
+    for world in (1, 3, 4, 16):
+        G = np.full_like(G0, np.nan)
+        s = np.full_like(s0, np.nan)
+        seen = np.zeros(len(descs), dtype=int)
+        for rank in range(world):
+            Gr, sr, ir, lo, hi = ctx.lml_resident_shard(descs, 1e-8, rank, world)
+            assert (lo, hi) == gsum_amd.shard_range(len(descs), rank, world)
+            assert np.all(np.isnan(sr[:lo])) and np.all(np.isnan(sr[hi:])) and np.all(ir[:lo] == -1) and np.all(ir[hi:] == -1)
+            assert np.all(ir[lo:hi] == 0)
+            G[lo:hi], s[lo:hi] = Gr[lo:hi], sr[lo:hi]
+            seen[lo:hi] += 1
+        assert np.all(seen == 1)
+        np.testing.assert_array_equal(G, G0)
+        np.testing.assert_array_equal(s, s0)
+    with pytest.raises(ValueError):
+        ctx.lml_resident_shard(descs, 1e-8, 3, 3)
+
+
 def test_queue_probe_reports_real_concurrency(ctx):
     """Before trusting more than 4 evaluations in flight the library times its streams (gs_probe_queues).  Here the test
     process asked for 32 hardware queues before HIP initialised (tests/conftest.py), so the library's default of 16 in-flight

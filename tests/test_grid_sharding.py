@@ -22,6 +22,23 @@ def test_shard_range_partitions_everything():
         shard_range(10, 2, 2)
 
 
+def test_shard_range_is_the_c_abi_partition():
+    """gsum_amd.grid asks the library (gsum_shard_range); the statement of record is ceil-sized contiguous blocks."""
+    import ctypes as C
+    from gsum_amd._lib import load_library
+    lib = load_library()
+    for total in (0, 1, 5, 63, 64, 65, 4096, 4097):
+        for world in (1, 2, 3, 7, 8, 100):
+            chunk = -(-total // world)
+            for rank in range(world):
+                lo, hi = C.c_int64(-1), C.c_int64(-1)
+                assert lib.gsum_shard_range(total, rank, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == (min(total, rank * chunk), min(total, rank * chunk + chunk)) == shard_range(total, rank, world)
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    for bad in ((10, -1, 2), (10, 2, 2), (10, 0, 0), (-1, 0, 1)):
+        assert lib.gsum_shard_range(*bad, C.byref(lo), C.byref(hi)) != 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
