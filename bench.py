@@ -311,8 +311,11 @@ def main():
 
     # dominant kernel, exclusive: one SYRK launch of the step-0 shape alone on the GPU (device-resident random
     # operands), for the kernel-quality view next to the in-situ numbers
-    ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 2)           # warm-up (first launches read low)
-    excl_tflops, excl_us = ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 4)
+    # (200 back-to-back launches, 60 ms: the sustained rate.  A handful of launches after an idle gap read 20 % low
+    # while the clock ramps; under this kernel the package sits at its 1400 W cap with sclk ~2.34 GHz,
+    # profiles/r02_clock_power.log -- the 78.6 TFLOP/s peak assumes 2.4 GHz.)
+    ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 20)
+    excl_tflops, excl_us = ctx.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 200)
 
     reuse = ell_grid = pred = None
     if rank == 0 and world == 1 and args.extras:
@@ -411,6 +414,8 @@ def main():
                          "avg_concurrent_launches": gemm_ms * 1e-3 * (K / sampled) / prof_elapsed,
                          "per_launch_tflops_shared": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                          "exclusive_tflops": excl_tflops, "exclusive_frac": excl_tflops / FP64_MFMA_PEAK_TFLOPS,
+                         "exclusive_what": "the same kernel alone: 200 back-to-back SYRK launches of the first outer step's shape "
+                                           "(M = n - 256, K = 256) on device-resident random operands",
                          "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K (K = 256, or 512 for "
                                              "the lazily updated far region), lower trapezoid for the near-column updates"},
             "kernel_time_shares": {"classes": shares,
