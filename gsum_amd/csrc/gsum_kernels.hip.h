@@ -1007,10 +1007,42 @@ __device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - 
     return fail;
 }
 
+// the blocks of panel column K that wave W owns, from the matrix into the register image: a strictly lower block negated
+// in the standard image, a diagonal micro-block in the pair image, not negated, read from its lower triangle only
+template <int W, int K>
+__device__ __forceinline__ void gs_d2_load_col(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], const double* A, int64_t ld, int lane) {
+    constexpr int R0 = W, R1 = 7 - W;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int prow = gs_pair_row(lane);
+    if constexpr (K <= R0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if constexpr (K < R0) {
+                P0[K][x] = -A[(int64_t)(16 * R0 + fr) * ld + 16 * K + fq + 4 * x];
+            } else {
+                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
+                P0[K][x] = A[(int64_t)(16 * R0 + hi) * ld + 16 * R0 + lo];
+            }
+        }
+    }
+    if constexpr (K <= R1) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if constexpr (K < R1) {
+                P1[K][x] = -A[(int64_t)(16 * R1 + fr) * ld + 16 * K + fq + 4 * x];
+            } else {
+                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
+                P1[K][x] = A[(int64_t)(16 * R1 + hi) * ld + 16 * R1 + lo];
+            }
+        }
+    }
+}
+
 template <int W, int J, bool FULL>
 __device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
                                            int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, const double* thr, double* dbuf,
                                            int* fail_sh, int lane, unsigned long long* stamps) {
+    if constexpr (J < 7) gs_d2_load_col<W, J + 1>(P0, P1, A, ld, lane);       // next column's blocks: a step ahead of their use
     __syncthreads();                                          // D_J (and a failure flag) visible
     if (stamps && W == 0 && lane == 0) stamps[8 + 2 * J] = __builtin_amdgcn_s_memtime();       // diagnostics only
     if (*fail_sh >= 0) return false;
@@ -1034,32 +1066,15 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
     const int prow = gs_pair_row(lane);
 
 #pragma unroll
-    for (int k = 0; k <= R0; ++k) {
-        S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k <= R0; ++k) S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if (k < R0) {
-                P0[k][x] = -A[(int64_t)(16 * R0 + fr) * ld + 16 * k + fq + 4 * x];
-            } else {
-                // the diagonal micro-block: pair image, not negated, read from its lower triangle only (mirrored)
-                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
-                P0[k][x] = A[(int64_t)(16 * R0 + hi) * ld + 16 * R0 + lo];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k <= R1; ++k) {
-        S1[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if (k < R1) {
-                P1[k][x] = -A[(int64_t)(16 * R1 + fr) * ld + 16 * k + fq + 4 * x];
-            } else {
-                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
-                P1[k][x] = A[(int64_t)(16 * R1 + hi) * ld + 16 * R1 + lo];
-            }
-        }
-    }
+    for (int k = 0; k <= R1; ++k) S1[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
+    // Only panel column 0 is fetched here; column k + 1 is requested at the start of step k (gs_d2_step), a whole
+    // step (7-10 k cycles) ahead of its use.  A block of the matrix is needed exactly once -- when its column is solved
+    // (or, for a diagonal micro-block, factored) -- so holding all nine of a wave's blocks from the start only cost
+    // registers: 72 of them, which is what pushed the fused kernels (capped at 256 for two evaluations per CU) into
+    // scratch.  Nothing writes a block before it is read: stores go to columns already solved.
+    gs_d2_load_col<W, 0>(P0, P1, A, ld, lane);
     // pivot thresholds (d0 was requested before the block, so it is the oldest load in flight): waves 0 and 1 store 64
     // each.  No barrier: the first recurrence reads entries 0..15, which its own wave wrote (LDS operations of one wave
     // execute in order); every later reader is behind the barriers of step 0.
@@ -2239,7 +2254,12 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
     if (tri) {
-        // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1
+        // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1.
+        // (An XCD-aware order -- rows padded to multiples of 8 slots so that workgroup id and column tile agree modulo 8
+        // and each XCD's L2 keeps one eighth of the B-side panel -- was measured: rocprofv3 FETCH_SIZE of the exclusive
+        // M = 8192 launch 813 -> 610 MB, its rate unchanged (55.0 vs 55.6 TF/s), the 16-in-flight pipeline 3 % SLOWER
+        // (266.6 vs 274 evals/s: with sixteen queues dispatching at once workgroup ids no longer map to XCDs round-robin,
+        // and the padding slots cost launches).  The kernel is not fetch-bound; the plain order stays.)
         const int bid = blockIdx.x;
         bm = (int)((sqrt(4.0 * (double)bid + 1.0) - 1.0) * 0.5);
         while ((int64_t)(bm + 1) * (bm + 2) <= bid) ++bm;
