@@ -82,8 +82,12 @@ struct gsum_ctx {
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
     int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
     int la_depth2 = 0;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
-    int chain_fused = 0;             // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
-                                     // (k_panel256) instead of diag / panel / sibling update / diag / panel; 0 = the five launches
+    int chain_fused = -1;            // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
+                                     // (k_panel256) instead of diag / panel / sibling update / diag / panel: 1 = always, 0 = never,
+                                     // -1 (default) = in batches only.  The fused kernels are slower end to end (125 + 35 us against
+                                     // 31 + 12 + 11 + 31 + 12) but two launches instead of five and less CU time: with 16 evaluations
+                                     // in flight latency is hidden and the batch runs 1.8 % faster (279 vs 274 evals/s), one
+                                     // factorisation alone is 10-30 % slower with them
     int chain_window = 0;            // look-ahead schedule: 1 = windowed (only the rows the next panels need are on the chain's
                                      // stream, the rest of each panel trails on a stream of its own), 0 = whole panels on the chain
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
@@ -558,7 +562,7 @@ static int gs_potrf_window(gsum_ctx* ctx, gsum_mat* m, hipStream_t sb) {
     const bool masked = sb != sl->sm && sl->sc && sl->srm;
     hipStream_t sm = sl->sm, sp = masked ? sl->sc : sl->sp, sr = masked ? sl->srm : sl->sr;
     const int ccfg = 1;
-    const bool fused = ctx->chain_fused != 0;
+    const bool fused = ctx->chain_fused > 0;            // a look-ahead schedule: only when asked for
     auto EV = [&](int k, int which) { return sl->evW[(size_t)GS_EVW_N * k + which]; };
     int prev = -1, pending_new = -1, pending_far = -1;
     bool rest_used = false;
@@ -703,7 +707,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
         const int Kp = two ? 2 * GS_NB : GS_NB;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (two && ctx->chain_fused && m->have_ltab) {
+        if (two && m->have_ltab && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && !la))) {
             // both diagonal blocks in one launch, then both panels of the rows below in one
             if (gs_diag256(ctx, sp, m, k)) return -1;
             if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
@@ -857,7 +861,7 @@ int gsum_init(int device, gsum_ctx** out) {
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
     const char* cf = getenv("GSUM_CHAIN_FUSED");
-    if (cf) ctx->chain_fused = atoi(cf) != 0;
+    if (cf) ctx->chain_fused = atoi(cf) < 0 ? -1 : (atoi(cf) != 0);
     const char* cw = getenv("GSUM_CHAIN_WINDOW");
     if (cw) ctx->chain_window = atoi(cw) != 0;
     const char* rc = getenv("GSUM_RESERVE_CUS");
@@ -987,7 +991,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
     else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
-    else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value != 0;
+    else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;
     else if (!strcmp(name, "chain_prefetch")) ctx->chain_prefetch = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));

@@ -97,7 +97,8 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
  * a look-ahead factorisation runs; -1: 2 from order 6144 up), "lazy_far" (0/1: batches at n >= 8192 update the far trailing region every other panel with K = 512),
  * "chain_prefetch" (1, default: four operand chunks in flight in the 32x128 chain GEMM tile; 0: one), and three schedule
  * experiments that give bit-identical results and are off by default ("Chain experiments"): "chain_fused"
- * (two diagonal blocks per launch + both panels of the rows below in one), "chain_window" (look-ahead on a window of rows,
+ * (two diagonal blocks per launch + both panels of the rows below in one: 1 always, 0 never, -1 = default = in batches
+ * only, where it is 1.8 % faster; alone it is slower), "chain_window" (look-ahead on a window of rows,
  * the rest of each panel on a second stream), "la_depth2" (bulk update in two launches, the chain waits for the first),
  * "release_scratch" (any value: free the grown work buffers and the per-slot workspace matrices now).
  * <0 for an unknown name. */

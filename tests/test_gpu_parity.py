@@ -160,7 +160,7 @@ def test_potrf_matches_lapack(ctx, n, lookahead):
     np.testing.assert_allclose(ctx.forward_solve(M, Z), W, rtol=1e-8, atol=1e-10 * np.abs(W).max())
     M.free()
     ctx.set_option("lookahead", 1)
-    ctx.set_option("chain_fused", 0)
+    ctx.set_option("chain_fused", -1)
     ctx.set_option("chain_window", 0)
 
 
@@ -180,7 +180,7 @@ def test_potrf_info_matches_lapack(ctx, n, bad, fused):
     M = ctx.upload(A)
     assert ctx.potrf(M) == bad + 1
     M.free()
-    ctx.set_option("chain_fused", 0)
+    ctx.set_option("chain_fused", -1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -577,7 +577,7 @@ def test_full_size_properties_n8192():
         ctx.set_option("reserve_cus", reserve)
         ctx.set_option("lookahead", la)
         out[("chain", fused, window, reserve, la)] = ctx.lml_batch([desc], X, Z, 1e-10)
-    for name, v in (("chain_fused", 0), ("chain_window", 0), ("reserve_cus", 0), ("lookahead", 1)):
+    for name, v in (("chain_fused", -1), ("chain_window", 0), ("reserve_cus", 0), ("lookahead", 1)):
         ctx.set_option(name, v)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
