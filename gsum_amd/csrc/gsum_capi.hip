@@ -707,7 +707,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
         const int Kp = two ? 2 * GS_NB : GS_NB;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (two && m->have_ltab && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && !la))) {
+        if (two && m->have_ltab && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && ctx->batch_active >= 3))) {
             // both diagonal blocks in one launch, then both panels of the rows below in one
             if (gs_diag256(ctx, sp, m, k)) return -1;
             if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
