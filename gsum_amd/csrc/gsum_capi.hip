@@ -78,7 +78,12 @@ struct gsum_ctx {
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
                                      // (measured: 14.3 vs 8.5 ms); -1 = 2 from order 6144 up
     int build_lower_only = 1;
-    int bulk_lds_pad = 0;            // bytes of dynamic LDS the bulk kernel asks for in look-ahead schedules (0 = what it needs)
+    int bulk_pad_below = 0;          // > 0: apply bulk_lds_pad only to bulk launches with fewer rows than this (the outer steps
+                                     // where the chain, not the bulk update, sets the pace)
+    int bulk_lds_pad = 80 * 1024;    // bytes of dynamic LDS the bulk kernel asks for in the look-ahead schedule of a factorisation
+                                     // (0 = what it needs, 53 KB): at 80 KB two bulk workgroups share a CU instead of three and a
+                                     // retiring one leaves room for a chain workgroup at once -- one factorisation 6.85 -> 6.70 ms
+    bool bulk_pad_now = false;       // set around the bulk launches of gs_potrf's look-ahead branch only
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
     int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
     int la_depth2 = 0;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
@@ -218,7 +223,8 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
         size_t shmem = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
         // experiment knob: pad the request so that fewer bulk workgroups share a CU and chain kernels find LDS at once
-        if (ctx->bulk_lds_pad > 0 && ctx->batch_active < 3) shmem = std::max(shmem, (size_t)ctx->bulk_lds_pad);
+        if (ctx->bulk_pad_now && ctx->bulk_lds_pad > 0 && (ctx->bulk_pad_below <= 0 || M < ctx->bulk_pad_below))
+            shmem = std::max(shmem, (size_t)ctx->bulk_lds_pad);
         if (!ctx->lds_attr_done.count((const void*)k_gemm_ld3)) {
             GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             ctx->lds_attr_done.insert((const void*)k_gemm_ld3);
@@ -289,6 +295,16 @@ static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc
 }
 
 // ---- matrices ---------------------------------------------------------------------------------
+// bulk update of a look-ahead schedule: the one launch class that asks for `bulk_lds_pad` bytes of LDS (two workgroups per
+// CU, so that chain workgroups find room as soon as one retires); every other user of the bulk tile wants three per CU
+static int gs_bulk_la(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                      int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
+    ctx->bulk_pad_now = true;
+    const int rc = gs_gemm(ctx, s, cfg, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
+    ctx->bulk_pad_now = false;
+    return rc;
+}
+
 static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     if (n <= 0 || n > (1 << 20)) GS_FAIL("matrix order out of range");
     gsum_mat* m = new gsum_mat();
@@ -639,7 +655,7 @@ static int gs_potrf_window(gsum_ctx* ctx, gsum_mat* m, hipStream_t sb) {
                 }
             }
             double* P3 = A + r3 * ld + c0;
-            if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+            if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
             GS_CHECK(hipEventRecord(sl->evM[k], sb));
             prev = k;
         } else {
@@ -676,6 +692,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
+    ctx->bulk_pad_now = false;
     if (la && gs_panel_stream(ctx, sl)) return -1;
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm, sb = sl->sm;
@@ -772,13 +789,13 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t wa = std::min<int64_t>(2 * GS_NB, m->np - r3);
             if (ctx->la_depth2 && wa > 0 && m3 > wa) {
                 ctx->next_algo_flops = (double)Kp * (2.0 * (double)m3 * wa - (double)wa * (wa - 1));
-                if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, wa, Kp, 0, 1, -1.0)) return -1;
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, wa, Kp, 0, 1, -1.0)) return -1;
                 GS_CHECK(hipEventRecord(sl->evA[k], sb));
                 const int64_t r4 = r3 + wa, m4 = naug - r4;
                 double* P4 = A + r4 * ld + c0;
-                if (gs_gemm(ctx, sb, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, Kp, 1, 1, -1.0)) return -1;
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, Kp, 1, 1, -1.0)) return -1;
             } else {
-                if (gs_gemm(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
                 GS_CHECK(hipEventRecord(sl->evA[k], sb));
             }
             GS_CHECK(hipEventRecord(sl->evM[k], sb));
@@ -864,6 +881,8 @@ int gsum_init(int device, gsum_ctx** out) {
     if (cf) ctx->chain_fused = atoi(cf) < 0 ? -1 : (atoi(cf) != 0);
     const char* cw = getenv("GSUM_CHAIN_WINDOW");
     if (cw) ctx->chain_window = atoi(cw) != 0;
+    const char* bp = getenv("GSUM_BULK_LDS_PAD");
+    if (bp) ctx->bulk_lds_pad = std::max(0, std::min(80 * 1024, atoi(bp)));
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
@@ -990,6 +1009,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
     else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
     else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
+    else if (!strcmp(name, "bulk_pad_below")) ctx->bulk_pad_below = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
     else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;

@@ -88,8 +88,8 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
 /* knobs: "lookahead", "build_lower_only", "profile_gemm", "diag_stamps" (0/1), "batch_slots" (1..24; default 16 with
  * GPU_MAX_HW_QUEUES >= 16 in the environment, else 12 / 8 / 3 -- keep it at 16 or below in a process that also owns an
  * RCCL communicator: the device time-slices user compute queues beyond 24), "diag_algo" / "build_algo" (2 = the round-2
- * kernels, 1 = the round-1 ones, kept for A/B), "bulk_lds_pad" (bytes of LDS the bulk kernel requests in look-ahead
- * schedules, to leave room for chain workgroups),
+ * kernels, 1 = the round-1 ones, kept for A/B), "bulk_lds_pad" (bytes of LDS the bulk kernel requests in the look-ahead
+ * schedule of a factorisation, to leave room for chain workgroups; default 80 KB = two bulk workgroups per CU, 0 = three),
  * "small_path" (0/1: fused single-workgroup evaluation for n <= 128), "medium_path" (0/1) and "medium_min_batch"
  * (128 < n <= 4096: calls with at least that many evaluations -- <= 0: auto, max(4, n^1.45 / 985) -- run
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
