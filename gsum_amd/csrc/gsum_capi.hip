@@ -86,7 +86,8 @@ struct gsum_ctx {
     bool bulk_pad_now = false;       // set around the bulk launches of gs_potrf's look-ahead branch only
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
     int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
-    int la_depth2 = 0;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
+    int la_depth2 = 1;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
+                                     // (-1 % with the 80-KB bulk launches: 6.69 -> 6.62 ms; nothing without them)
     int chain_fused = -1;            // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
                                      // (k_panel256) instead of diag / panel / sibling update / diag / panel: 1 = always, 0 = never,
                                      // -1 (default) = in batches only.  The fused kernels are slower end to end (125 + 35 us against

@@ -95,11 +95,11 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
  * one workgroup per evaluation, 256 in flight), "stagger" (-1 auto, 0 off, n: de-phase co-resident workgroups by n x 2048 cycles),
  * "reserve_cus" (0 = off, the default; 1..8: CUs per XCD the bulk stream's CU mask leaves to the panel chain while
  * a look-ahead factorisation runs; -1: 2 from order 6144 up), "lazy_far" (0/1: batches at n >= 8192 update the far trailing region every other panel with K = 512),
- * "chain_prefetch" (1, default: four operand chunks in flight in the 32x128 chain GEMM tile; 0: one), and three schedule
- * experiments that give bit-identical results and are off by default ("Chain experiments"): "chain_fused"
+ * "chain_prefetch" (1, default: four operand chunks in flight in the 32x128 chain GEMM tile; 0: one), and schedule
+ * variants that give bit-identical results ("Chain experiments"): "chain_fused"
  * (two diagonal blocks per launch + both panels of the rows below in one: 1 always, 0 never, -1 = default = in batches
  * only, where it is 1.8 % faster; alone it is slower), "chain_window" (look-ahead on a window of rows,
- * the rest of each panel on a second stream), "la_depth2" (bulk update in two launches, the chain waits for the first),
+ * the rest of each panel on a second stream), "la_depth2" (1, default: bulk update in two launches, the chain waits for the first),
  * "release_scratch" (any value: free the grown work buffers and the per-slot workspace matrices now).
  * <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);

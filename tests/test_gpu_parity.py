@@ -579,6 +579,12 @@ def test_full_size_properties_n8192():
         out[("chain", fused, window, reserve, la)] = ctx.lml_batch([desc], X, Z, 1e-10)
     for name, v in (("chain_fused", -1), ("chain_window", 0), ("reserve_cus", 0), ("lookahead", 1)):
         ctx.set_option(name, v)
+    for depth2, pad in ((0, 0), (1, 0), (0, 80 * 1024)):        # bulk update in one / two launches, 3 / 2 workgroups per CU
+        ctx.set_option("la_depth2", depth2)
+        ctx.set_option("bulk_lds_pad", pad)
+        out[("bulk", depth2, pad)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    ctx.set_option("la_depth2", 1)
+    ctx.set_option("bulk_lds_pad", 80 * 1024)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     # evaluations in flight: 1, 3, 10 or 16 per call is scheduling only; so is the batch mode's lazy K = 512 update of the

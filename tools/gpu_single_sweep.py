@@ -31,12 +31,13 @@ def run(label):
 ctx.set_option("chain_fused", 0)
 ctx.set_option("chain_window", 0)
 for rep in range(3):
-    for pad, below in ((0, 0), (80 * 1024, 0), (80 * 1024, 6400), (80 * 1024, 5120), (80 * 1024, 3840), (56 * 1024, 5120)):
-        ctx.set_option("bulk_lds_pad", pad)
-        ctx.set_option("bulk_pad_below", below)
-        run(f"bulk_lds_pad={pad} below={below}")
-ctx.set_option("bulk_lds_pad", 0)
-ctx.set_option("bulk_pad_below", 0)
+    for R in (0, 1, 2):
+        for d2 in (0, 1):
+            ctx.set_option("reserve_cus", R)
+            ctx.set_option("la_depth2", d2)
+            run(f"(pad 80 KB) reserve_cus={R} la_depth2={d2}")
+ctx.set_option("reserve_cus", 0)
+ctx.set_option("la_depth2", 0)
 ctx.set_option("bulk_lds_pad", 0)
 ctx.set_option("reserve_cus", 0)
 ctx.set_option("bulk_cfg", 7)
