@@ -86,6 +86,9 @@ struct gsum_ctx {
     bool bulk_pad_now = false;       // set around the bulk launches of gs_potrf's look-ahead branch only
     int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
     int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
+    int la_split = 0;                // look-ahead schedule: while the trailing matrix has at least this many rows, only the next
+                                     // diagonal block's piece of the look-ahead update runs on the chain's stream (0 = never split,
+                                     // the default: measured 1 % slower at 1024 ... 4096 -- two more events on the chain's stream)
     int la_depth2 = 1;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
                                      // (-1 % with the 80-KB bulk launches: 6.69 -> 6.62 ms; nothing without them)
     int chain_fused = -1;            // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
@@ -702,6 +705,10 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         GS_CHECK(hipEventRecord(sl->evFork, sm));
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
         if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
+        if (ctx->la_split > 0 || (ctx->chain_window && m->have_ltab)) {
+            if (gs_window_streams(ctx, sl, T)) return -1;
+            GS_CHECK(hipStreamWaitEvent(sl->sr, sl->evFork, 0));
+        }
         if (ctx->chain_window && m->have_ltab) {
             if (gs_window_streams(ctx, sl, T)) return -1;
             GS_CHECK(hipStreamWaitEvent(sl->sr, sl->evFork, 0));
@@ -719,6 +726,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
     bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
+    int pending_lr = -1;                             // outer step whose split look-ahead update (rest part) is in flight
     for (int k = 0; k < T; k += 2) {
         const bool two = k + 1 < T;
         const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
@@ -728,10 +736,13 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         if (two && m->have_ltab && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && ctx->batch_active >= 3))) {
             // both diagonal blocks in one launch, then both panels of the rows below in one
             if (gs_diag256(ctx, sp, m, k)) return -1;
+            if (pending_lr >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evW[(size_t)GS_EVW_N * pending_lr + GS_EVW_FAR], 0));
             if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
         } else {
             // ---- sub-step a
             if (gs_diag(ctx, sp, m, k)) return -1;
+            // (split look-ahead update, below: the diagonal block only needed its own 128 x 128 piece)
+            if (pending_lr >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evW[(size_t)GS_EVW_N * pending_lr + GS_EVW_FAR], 0));
             if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
             if (two) {
                 // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
@@ -775,11 +786,24 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             continue;
         }
         GS_CHECK(hipEventRecord(sl->evP[k], sp));
+        pending_lr = -1;
         if (r2 < m->np) {
             const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
             // look-ahead columns: need the previous bulk update to have finished with THEM (evA: see below)
             if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evA[prev], 0));
-            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+            if (ctx->la_split > 0 && mrest >= ctx->la_split && wn == 2 * GS_NB && sl->sr) {
+                // Split: the next diagonal block needs only ITS 128 x 128 piece of this update -- on the chain's stream,
+                // four workgroups -- and the rest (all rows below, both block columns; the piece above the diagonal is never
+                // read) goes to a second stream beside the diagonal block; the next panel solve waits for it.  While the
+                // trailing matrix is large this update is 0.3-1 GF and took 60-90 us on the chain beside the bulk update.
+                if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, GS_NB, GS_NB, Kp, 0, 1, -1.0)) return -1;
+                hipStream_t sq = sl->sr;
+                GS_CHECK(hipStreamWaitEvent(sq, sl->evP[k], 0));
+                if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sq, sl->evA[prev], 0));
+                if (gs_gemm(ctx, sq, ccfg, A + (r2 + GS_NB) * ld + r2, ld, P + GS_NB * ld, ld, P, ld, mrest - GS_NB, wn, Kp, 0, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(sl->evW[(size_t)GS_EVW_N * k + GS_EVW_FAR], sq));
+                pending_lr = k;
+            } else if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
@@ -1014,6 +1038,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
     else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;
+    else if (!strcmp(name, "la_split")) ctx->la_split = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_prefetch")) ctx->chain_prefetch = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));

@@ -99,7 +99,8 @@ const char* gsum_last_error(gsum_ctx* ctx);            /* NULL ctx: error of a f
  * variants that give bit-identical results ("Chain experiments"): "chain_fused"
  * (two diagonal blocks per launch + both panels of the rows below in one: 1 always, 0 never, -1 = default = in batches
  * only, where it is 1.8 % faster; alone it is slower), "chain_window" (look-ahead on a window of rows,
- * the rest of each panel on a second stream), "la_depth2" (1, default: bulk update in two launches, the chain waits for the first),
+ * the rest of each panel on a second stream), "la_depth2" (1, default: bulk update in two launches, the chain waits for the first), "la_split" (rows; 0 = off, default:
+ * split the look-ahead update while the trailing matrix is at least that tall),
  * "release_scratch" (any value: free the grown work buffers and the per-slot workspace matrices now).
  * <0 for an unknown name. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);

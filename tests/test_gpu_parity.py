@@ -585,6 +585,10 @@ def test_full_size_properties_n8192():
         out[("bulk", depth2, pad)] = ctx.lml_batch([desc], X, Z, 1e-10)
     ctx.set_option("la_depth2", 1)
     ctx.set_option("bulk_lds_pad", 80 * 1024)
+    for split in (1024, 4096):                                 # look-ahead update split (default: whole on the chain's stream)
+        ctx.set_option("la_split", split)
+        out[("la_split", split)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    ctx.set_option("la_split", 0)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     # evaluations in flight: 1, 3, 10 or 16 per call is scheduling only; so is the batch mode's lazy K = 512 update of the

@@ -31,13 +31,10 @@ def run(label):
 ctx.set_option("chain_fused", 0)
 ctx.set_option("chain_window", 0)
 for rep in range(3):
-    for R in (0, 1, 2):
-        for d2 in (0, 1):
-            ctx.set_option("reserve_cus", R)
-            ctx.set_option("la_depth2", d2)
-            run(f"(pad 80 KB) reserve_cus={R} la_depth2={d2}")
-ctx.set_option("reserve_cus", 0)
-ctx.set_option("la_depth2", 0)
+    for split in (0, 1024, 2048, 3072, 4096):
+        ctx.set_option("la_split", split)
+        run(f"la_split={split}")
+ctx.set_option("la_split", 0)
 ctx.set_option("bulk_lds_pad", 0)
 ctx.set_option("reserve_cus", 0)
 ctx.set_option("bulk_cfg", 7)
