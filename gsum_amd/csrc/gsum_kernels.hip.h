@@ -1392,10 +1392,44 @@ __device__ __forceinline__ void gs_sib_update(gs_d4 (&P1)[8], const gs_d4 (&P0)[
     }
 }
 
+// the same with half-size buffers (k-blocks 0..3 / 4..7 of one micro-block row at a time): 64 registers of operands in
+// flight instead of 128.  For k_panel256, whose waves have to fit beside six bulk waves per SIMD (272 free registers) in a
+// batch: a wave that needs more than that keeps a whole bulk workgroup off its CU for as long as it waits for memory.
+template <int H>
+__device__ __forceinline__ void gs_sib_fetch_half(gs_d4 (&buf)[4], const double* Lsib, int c, int lane) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) buf[kb][x] = Lsib[((c * 8 + 4 * H + kb) * 4 + x) * 64 + lane];
+}
+
+template <int H>
+__device__ __forceinline__ void gs_sib_apply_half(gs_d4& acc, const gs_d4 (&buf)[4], const gs_d4 (&P0)[8]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[kb][x], P0[4 * H + kb][x], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void gs_sib_update_lean(gs_d4 (&P1)[8], const gs_d4 (&P0)[8], const double* Lsib, int lane) {
+    gs_d4 b0[4], b1[4];
+    gs_sib_fetch_half<0>(b0, Lsib, 0, lane);
+    gs_sib_fetch_half<1>(b1, Lsib, 0, lane);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        __builtin_amdgcn_sched_barrier(0);
+        gs_sib_apply_half<0>(P1[c], b0, P0);                    // ascending k: blocks 0..3, then 4..7
+        if (c + 1 < 8) gs_sib_fetch_half<0>(b0, Lsib, c + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        gs_sib_apply_half<1>(P1[c], b1, P0);
+        if (c + 1 < 8) gs_sib_fetch_half<1>(b1, Lsib, c + 1, lane);
+    }
+}
+
 // rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
-__global__ __launch_bounds__(64) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
+__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
                                                   const double* Ltab1) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
@@ -1404,10 +1438,12 @@ __global__ __launch_bounds__(64) void k_panel256(double* P, int64_t ld, int M, c
     double* rows = P + (int64_t)r0 * ld;
     gs_d4 P0[8], P1[8];
     gs_panel16_load(P0, rows, ld, M - r0, lane);
-    gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
     gs_panel16_solve_g(P0, Ltab0, lane);
     gs_panel16_store(P0, rows, ld, M - r0, lane);
-    gs_sib_update(P1, P0, Lsib, lane);
+    __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now: 64 registers less at the peak
+    gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
+    gs_sib_update_lean(P1, P0, Lsib, lane);
+    __builtin_amdgcn_sched_barrier(0);
     gs_panel16_solve_g(P1, Ltab1, lane);
     gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
 }
@@ -1446,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // Replaces diag / panel / sibling update / diag on the chain of a factorisation: four dependent launches, two of them
 // over all rows below, become one; the rows below go through k_panel256 afterwards.  L10 is also left in Lsib (operand
 // layout) for that kernel.  Tables of both blocks to Ltab[0], Ltab[GS_LTAB].
-__global__ __launch_bounds__(256) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
+__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
                                                        int col0, const double* diag0, unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
     if (*info != 0) return;
