@@ -1393,8 +1393,9 @@ __device__ __forceinline__ void gs_sib_update(gs_d4 (&P1)[8], const gs_d4 (&P0)[
 }
 
 // the same with half-size buffers (k-blocks 0..3 / 4..7 of one micro-block row at a time): 64 registers of operands in
-// flight instead of 128.  For k_panel256, whose waves have to fit beside six bulk waves per SIMD (272 free registers) in a
-// batch: a wave that needs more than that keeps a whole bulk workgroup off its CU for as long as it waits for memory.
+// flight instead of 128.  For k_panel256 in a batch: six bulk waves (72 registers each) leave 80 of a SIMD's 512 registers
+// free and every retiring bulk workgroup 144 more, so a wave of up to 224 registers starts where ONE bulk workgroup has
+// left; a bigger one needs two or three gone and keeps them away for as long as it waits for memory.
 template <int H>
 __device__ __forceinline__ void gs_sib_fetch_half(gs_d4 (&buf)[4], const double* Lsib, int c, int lane) {
 #pragma unroll
