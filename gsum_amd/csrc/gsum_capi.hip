@@ -466,10 +466,8 @@ static int gs_window_streams(gsum_ctx* ctx, gs_slot* sl, int T) {
 
 static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* out) {
     const int R = ctx->reserve_cus >= 0 ? ctx->reserve_cus : (np >= 6144 ? 2 : 0);
-    if (R <= 0) {
-        *out = sl->sm;
-        return 0;
-    }
+    // CU-masked streams are destroyed as soon as the option no longer asks for them: idle ones are not harmless (with three
+    // of them alive a schedule that uses a second chain stream ran 1.5-2x slower -- tools/gpu_single_sweep.py found it)
     if (sl->sb && sl->sb_reserve != R) {
         for (hipStream_t* q : {&sl->sb, &sl->sc, &sl->srm}) {
             if (!*q) continue;
@@ -477,6 +475,11 @@ static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* o
             GS_CHECK(hipStreamDestroy(*q));
             *q = nullptr;
         }
+        sl->sb_reserve = 0;
+    }
+    if (R <= 0) {
+        *out = sl->sm;
+        return 0;
     }
     if (!sl->sb) {
         hipDeviceProp_t prop;
@@ -486,8 +489,10 @@ static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* o
         std::vector<uint32_t> mask(words, 0u), rmask(words, 0u);
         for (int i = 0; i < ncu; ++i) (i < ncu - 8 * R ? mask : rmask)[i >> 5] |= 1u << (i & 31);
         GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sb, (uint32_t)words, mask.data()));
-        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->srm, (uint32_t)words, mask.data()));
-        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sc, (uint32_t)words, rmask.data()));
+        if (ctx->chain_window) {        // the windowed schedule's chain / rest streams: only when that schedule is selected
+            GS_CHECK(hipExtStreamCreateWithCUMask(&sl->srm, (uint32_t)words, mask.data()));
+            GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sc, (uint32_t)words, rmask.data()));
+        }
         sl->sb_reserve = R;
     }
     *out = sl->sb;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Single-factorisation latency at n = 8192 against the knobs that shape the look-ahead schedule."""
+"""Single-factorisation latency at n = 8192: the default look-ahead schedule and each option changed on its own."""
 import os
 import sys
 
@@ -30,13 +30,18 @@ def run(label):
 
 ctx.set_option("chain_fused", 0)
 ctx.set_option("chain_window", 0)
+DEFAULTS = {"bulk_lds_pad": 80 * 1024, "la_depth2": 1, "chain_prefetch": 1, "reserve_cus": 0, "la_split": 0, "chain_window": 0,
+            "chain_fused": -1}
+VARIANTS = [("defaults", {}), ("bulk_lds_pad=0 (three bulk workgroups per CU)", {"bulk_lds_pad": 0}), ("la_depth2=0", {"la_depth2": 0}),
+            ("bulk_lds_pad=0 la_depth2=0", {"bulk_lds_pad": 0, "la_depth2": 0}), ("chain_prefetch=0", {"chain_prefetch": 0}),
+            ("reserve_cus=2", {"reserve_cus": 2}), ("la_split=2048", {"la_split": 2048}), ("chain_window=1", {"chain_window": 1}),
+            ("chain_fused=1", {"chain_fused": 1}), ("chain_fused=1 chain_window=1", {"chain_fused": 1, "chain_window": 1})]
 for rep in range(3):
-    for split in (0, 1024, 2048, 3072, 4096):
-        ctx.set_option("la_split", split)
-        run(f"la_split={split}")
-ctx.set_option("la_split", 0)
-ctx.set_option("bulk_lds_pad", 0)
-ctx.set_option("reserve_cus", 0)
-ctx.set_option("bulk_cfg", 7)
+    for label, opts in VARIANTS:
+        for k, v in {**DEFAULTS, **opts}.items():
+            ctx.set_option(k, v)
+        run(label)
+for k, v in DEFAULTS.items():
+    ctx.set_option(k, v)
 ctx.set_option("lookahead", 0)
 run("lookahead=0")
