@@ -1554,7 +1554,8 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_lml_medium, dim3(cnt), dim3(256), shmem, s, ctx->in->X, (int)n, ctx->in->d, ctx->in->Z, k,
-                           (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res));
+                           (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res),
+                           ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));

@@ -298,6 +298,130 @@ __device__ __forceinline__ bool gs_base_is_zero(double s) {
     return s > 555500.0;                                          // sqrt(s) > 745.3
 }
 
+// run-time family, exp tables in LDS (the fused one-workgroup kernels: the family is uniform over the workgroup, and a table
+// in LDS costs an LDS read per entry where the __constant__ one of gs_exp_np costs a vector load from memory)
+__device__ __forceinline__ double gs_base_value_f(int family, double s, const double* th, const double* tl) {
+    if (family == GSUM_RBF) return gs_base_value_t<GSUM_RBF>(s, th, tl);
+    if (family == GSUM_MATERN52) return gs_base_value_t<GSUM_MATERN52>(s, th, tl);
+    if (family == GSUM_MATERN32) return gs_base_value_t<GSUM_MATERN32>(s, th, tl);
+    return gs_base_value_t<GSUM_MATERN12>(s, th, tl);
+}
+
+// One 128 x 128 tile of the kernel matrix for the fused one-workgroup kernels (256 threads; ui / uj: the scaled coordinates
+// of the tile's rows / columns in LDS; th / tl: the exp tables in LDS): k_build2's per-entry arithmetic and its short cuts
+// -- family and the one-dimensional case as template parameters, tiles that touch neither the diagonal nor the padding
+// without per-entry tests, two rows per pass -- instead of the round-1 loop (runtime family switch and dimension loop,
+// diagonal and padding tests on every entry: ~90 VALU instructions per entry, 17-21 % of k_lml_medium at n = 512 ... 1024).
+// Wave w takes rows w, w + 4, ... ; each lane two adjacent columns.  The diagonal's values also go to diag0.
+template <int FAM, bool D1>
+__device__ __forceinline__ void gs_build_tile128(double* A, int64_t ld, const double* ui, const double* uj, const double* th,
+                                                 const double* tl, int bi, int bj, int n, int d, const gsum_kernel_desc& desc,
+                                                 double diag_add, double* diag0, int w, int lane) {
+#pragma clang fp contract(off)
+    double vj0[D1 ? 1 : GSUM_MAX_D], vj1[D1 ? 1 : GSUM_MAX_D];
+    if (D1) {
+        vj0[0] = uj[2 * lane];
+        vj1[0] = uj[2 * lane + 1];
+    } else {
+#pragma unroll
+        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+            vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
+            vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
+        }
+    }
+    const int r0 = bi * 128, c0 = bj * 128, gj0 = c0 + 2 * lane;
+    const bool plain = bi != bj && r0 + 128 <= n && c0 + 128 <= n;
+    const double amp = desc.amplitude, addc = desc.additive_const;
+#pragma unroll 1
+    for (int rp = w; rp < 128; rp += 8) {
+        double s[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = rp + 4 * h;
+            if (D1) {
+                const double xi = ui[rr];
+                const double e0 = xi - vj0[0], e1 = xi - vj1[0];
+                s[h][0] = e0 * e0;
+                s[h][1] = e1 * e1;
+            } else {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
+                    if (dd < d) {
+                        const double xi = ui[rr * d + dd];
+                        const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
+                        s0 = s0 + e0 * e0;
+                        s1 = s1 + e1 * e1;
+                    }
+                }
+                s[h][0] = s0;
+                s[h][1] = s1;
+            }
+        }
+        double v[2][2];
+        if (plain) {
+            const bool nz = !(gs_base_is_zero<FAM>(s[0][0]) && gs_base_is_zero<FAM>(s[0][1]) && gs_base_is_zero<FAM>(s[1][0]) &&
+                              gs_base_is_zero<FAM>(s[1][1]));
+            if (__builtin_amdgcn_ballot_w64(nz) == 0) {
+                const double z = amp * 0.0 + addc;
+                v[0][0] = v[0][1] = v[1][0] = v[1][1] = z;
+            } else {
+                bool slow[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) v[h][c] = amp * gs_base_value_nb<FAM>(s[h][c], th, tl, slow[h][c]) + addc;
+                if (__builtin_amdgcn_ballot_w64(slow[0][0] || slow[0][1] || slow[1][0] || slow[1][1]) != 0) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (slow[h][c]) v[h][c] = amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int gi = r0 + rp + 4 * h, gj = gj0 + c;
+                    double val;
+                    if (gi >= n || gj >= n) {
+                        val = (gi == gj) ? 1.0 : 0.0;                 // identity padding up to a multiple of 128
+                    } else {
+                        const bool dg = gi == gj;
+                        const double b = dg ? 1.0 : gs_base_value_t<FAM>(s[h][c], th, tl);   // np.fill_diagonal(K, 1)
+                        val = amp * b;
+                        if (dg) val = val + desc.white_noise;
+                        val = val + addc;
+                        if (dg) val = val + diag_add;
+                    }
+                    if (gi == gj) diag0[gi] = val;
+                    v[h][c] = val;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const gs_d2 o = {v[h][0], v[h][1]};
+            *reinterpret_cast<gs_d2*>(A + (int64_t)(r0 + rp + 4 * h) * ld + gj0) = o;
+        }
+    }
+}
+
+// family and dimension are uniform over the workgroup: one scalar branch per tile
+__device__ __forceinline__ void gs_build_tile128_any(double* A, int64_t ld, const double* ui, const double* uj, const double* th,
+                                                     const double* tl, int bi, int bj, int n, int d, const gsum_kernel_desc& desc,
+                                                     double diag_add, double* diag0, int w, int lane) {
+#define GS_BT(F)                                                                                                       \
+    if (d == 1) gs_build_tile128<F, true>(A, ld, ui, uj, th, tl, bi, bj, n, d, desc, diag_add, diag0, w, lane);        \
+    else gs_build_tile128<F, false>(A, ld, ui, uj, th, tl, bi, bj, n, d, desc, diag_add, diag0, w, lane)
+    if (desc.family == GSUM_RBF) { GS_BT(GSUM_RBF); }
+    else if (desc.family == GSUM_MATERN52) { GS_BT(GSUM_MATERN52); }
+    else if (desc.family == GSUM_MATERN32) { GS_BT(GSUM_MATERN32); }
+    else { GS_BT(GSUM_MATERN12); }
+#undef GS_BT
+}
+
 #define GS_B2_ROWS 32
 // One 32 x 128 tile per 256-thread workgroup: wave w takes rows 8 w .. 8 w + 7, two at a time; each lane owns two adjacent
 // columns (one 16-B store per row, 1 KiB per wave-instruction).  Grid: CROSS or tri == 0: (prow / 32 rounded up) x (pcol /
@@ -1253,6 +1377,39 @@ __device__ __forceinline__ void gs_panel16_solve(gs_d4 (&P)[8], const double* ta
     }
 }
 
+// two 16-row groups against the same tables in one pass: every table block is read from LDS once and feeds two
+// independent MFMA chains (k_lml_medium's panel phase: 25-30 % of that kernel with one group at a time, each wave waiting
+// on its own LDS reads and dependent MFMAs).  Row for row the arithmetic of gs_panel16_solve.
+__device__ __forceinline__ void gs_panel16_solve2(gs_d4 (&P)[8], gs_d4 (&Q)[8], const double* tab, int lane) {
+    const double* Ls = tab + GS_D2_LS;
+    const double* Dv = tab + GS_D2_DV;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        gs_d4 SP = {0.0, 0.0, 0.0, 0.0}, SQ = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pp = 0; pp < j; ++pp) {
+            const double* blk = Ls + (j * (j - 1) / 2 + pp) * 256;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const double a = blk[x * 64 + lane];
+                SP = __builtin_amdgcn_mfma_f64_16x16x4f64(a, P[pp][x], SP, 0, 0, 0);
+                SQ = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Q[pp][x], SQ, 0, 0, 0);
+            }
+        }
+        const gs_d4 EP = P[j] + SP, EQ = Q[j] + SQ;
+        gs_d4 TP = {0.0, 0.0, 0.0, 0.0}, TQ = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const double dv = Dv[(j * 16 + fr) * GS_DV_STR + fq + 4 * x];
+            TP = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, EP[x], TP, 0, 0, 0);
+            TQ = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, EQ[x], TQ, 0, 0, 0);
+        }
+        P[j] = TP;
+        Q[j] = TQ;
+    }
+}
+
 __device__ __forceinline__ void gs_panel16_store(const gs_d4 (&P)[8], double* rows, int64_t ld, int nvalid, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     if (fr < nvalid) {
@@ -1562,6 +1719,9 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
     double* out = res + (int64_t)blockIdx.x * 258;
     // ---- kernel matrix (full symmetric 128x128 tile, identity padding beyond n)
+    double* etab = us + 128 * GSUM_MAX_D;                               // exp tables th[16] | tl[16]
+    if (t < 16) etab[t] = gs_exp_th[t];
+    else if (t < 32) etab[t] = gs_exp_tl[t - 16];
     for (int idx = t; idx < 128 * d; idx += 256) {
         const int r = idx / d, dd = idx - r * d;
         const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
@@ -1596,7 +1756,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
                     val = (gi == gj) ? 1.0 : 0.0;
                 } else {
                     const bool dg = gi == gj;
-                    const double bse = dg ? 1.0 : gs_base_value(desc.family, ss[c]);
+                    const double bse = dg ? 1.0 : gs_base_value_f(desc.family, ss[c], etab, etab + 16);
                     val = desc.amplitude * bse;
                     if (dg) val = val + desc.white_noise;
                     val = val + desc.additive_const;
@@ -1983,7 +2143,7 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
 
 __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
                                                      const gsum_kernel_desc* descs, double nugget, double* scratch,
-                                                     int64_t scratch_stride, double* res) {
+                                                     int64_t scratch_stride, double* res, unsigned long long* stamps = nullptr) {
     extern __shared__ double lds[];                 // max(GS_DIAG_WS, GS_TILE_LD_DOUBLES) doubles, lent in turn to the kernel
                                                     // build, the diagonal-block routine and the tile routine: 77.6 KB in
                                                     // all, so TWO evaluations share a CU
@@ -1999,11 +2159,26 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     double* diag0 = Ltab + (int64_t)T * 128 * 128;
     double* Wt = diag0 + np;                        // 16 x np, row-major
     double* out = res + (int64_t)blockIdx.x * 258;
+    // diagnostics (option "diag_stamps"): shader cycles of workgroup 0 per phase -> stamps[40..47] =
+    // {build, diagonal blocks, panel solves, sibling tiles, trailing tiles, W step, Gram + rest, total}
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0, tstart = 0;
+    const bool stamping = stamps != nullptr && blockIdx.x == 0 && t == 0;
+    auto phase = [&](int i) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (i >= 0) ph[i] += now - tq; else tstart = now;
+            tq = now;
+        }
+    };
+    phase(-1);
     // ---- kernel matrix: lower 128x128 tiles, identity padding (k_build's arithmetic)
     {
 #pragma clang fp contract(off)
         double* ui = lds;
         double* uj = lds + 128 * GSUM_MAX_D;
+        double* etab = lds + 2 * 128 * GSUM_MAX_D;      // exp tables th[16] | tl[16] (first read behind the loop's barriers)
+        if (t < 16) etab[t] = gs_exp_th[t];
+        else if (t < 32) etab[t] = gs_exp_tl[t - 16];
         for (int bi = 0; bi < T; ++bi)
             for (int bj = 0; bj <= bi; ++bj) {
                 __syncthreads();
@@ -2015,51 +2190,13 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                     uj[idx] = gj < n ? X[(int64_t)gj * d + dd] / ls : 0.0;
                 }
                 __syncthreads();
-                double vj0[GSUM_MAX_D], vj1[GSUM_MAX_D];
-#pragma unroll
-                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-                    vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
-                    vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
-                }
-                for (int rr = w; rr < 128; rr += 4) {
-                    const int gi = bi * 128 + rr;
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-                        if (dd < d) {
-                            const double xi = ui[rr * d + dd];
-                            const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
-                            s0 = s0 + e0 * e0;
-                            s1 = s1 + e1 * e1;
-                        }
-                    }
-                    const double ss[2] = {s0, s1};
-                    double v[2];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int gj = bj * 128 + 2 * lane + c;
-                        double val;
-                        if (gi >= n || gj >= n) {
-                            val = (gi == gj) ? 1.0 : 0.0;
-                        } else {
-                            const bool dg = gi == gj;
-                            const double bse = dg ? 1.0 : gs_base_value(desc.family, ss[c]);
-                            val = desc.amplitude * bse;
-                            if (dg) val = val + desc.white_noise;
-                            val = val + desc.additive_const;
-                            if (dg) val = val + nugget;
-                        }
-                        if (gi == gj) diag0[gi] = val;
-                        v[c] = val;
-                    }
-                    const gs_d2 o = {v[0], v[1]};
-                    *reinterpret_cast<gs_d2*>(A + (int64_t)gi * ld + bj * 128 + 2 * lane) = o;
-                }
+                gs_build_tile128_any(A, ld, ui, uj, etab, etab + 16, bi, bj, n, d, desc, nugget, diag0, w, lane);
             }
     }
     if (t == 0) ldet_sum = 0.0;
     __threadfence_block();
     __syncthreads();
+    phase(0);
     // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
     // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
     for (int b = 0; b < T; b += 2) {
@@ -2078,21 +2215,42 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
             if (t == 0) ldet_sum += ldet_blk;
             __threadfence_block();
             __syncthreads();
+            phase(1);
             // panel: rows below <- rows * L_cc^-T by blocked substitution against the tables gs_diag_block left in lds,
             // 16 rows per wave at a time
-            for (int br = w; br < (T - c - 1) * 8; br += 4)
-                gs_panel16(A + ((int64_t)(c + 1) * 128 + 16 * br) * ld + c * 128, ld, 16, lds, lane);
+            {
+                const int ngr = (T - c - 1) * 8;        // 16-row groups below the block: two per wave and pass
+                double* pan = A + ((int64_t)(c + 1) * 128) * ld + c * 128;
+                for (int br = w; br < ngr; br += 8) {
+                    double* ra = pan + (int64_t)(16 * br) * ld;
+                    if (br + 4 < ngr) {
+                        double* rb = pan + (int64_t)(16 * (br + 4)) * ld;
+                        gs_d4 Pg[8], Qg[8];
+                        gs_panel16_load(Pg, ra, ld, 16, lane);
+                        gs_panel16_load(Qg, rb, ld, 16, lane);
+                        gs_panel16_solve2(Pg, Qg, lds, lane);
+                        gs_panel16_store(Pg, ra, ld, 16, lane);
+                        gs_panel16_store(Qg, rb, ld, 16, lane);
+                    } else {
+                        gs_panel16(ra, ld, 16, lds, lane);
+                    }
+                }
+            }
             __threadfence_block();
+            if (stamping || stamps) __syncthreads();        // (diagnostic runs only: a barrier so that the phases separate)
+            phase(2);
             if (s == 0 && two)                      // sibling block column b + 1: the first panel only (K = 128)
                 for (int i = b + 1; i < T; ++i)
                     gs_tile128(A + (int64_t)i * 128 * ld + (b + 1) * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
                                A + (int64_t)(b + 1) * 128 * ld + b * 128, ld, 128, 128, 128, 1, -1.0, lds);
+            phase(3);
         }
         const int Kp = two ? 256 : 128, first = b + (two ? 2 : 1);
         for (int i = first; i < T; ++i)             // trailing lower tiles: both panels in one pass
             for (int j = first; j <= i; ++j)
                 gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
                            A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
+        phase(4);
     }
     // ---- W^T = Z^T L^-T, block column by block column (left-looking on the 16 right-hand-side rows), on the matrix
     // cores straight from global memory: wave w owns point-columns [32 w, 32 w + 32) of each 128-column block.
@@ -2130,6 +2288,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
         __threadfence_block();
         __syncthreads();
     }
+    phase(5);
     // ---- Gram matrix G = W^T W by wave 0 (ascending k), log-det, info
     if (w == 0) {
         gs_d4 g = {0.0, 0.0, 0.0, 0.0};
@@ -2143,6 +2302,11 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
             out[256] = ldet_sum;
             out[257] = 0.0;
         }
+    }
+    phase(6);
+    if (stamping) {
+        for (int i = 0; i < 7; ++i) stamps[40 + i] = ph[i];
+        stamps[47] = tq - tstart;
     }
 }
 
