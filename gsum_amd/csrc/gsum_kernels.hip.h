@@ -2266,16 +2266,27 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                 acc[h][x] = (rr < k && pc < n) ? Z[(int64_t)pc * k + rr] : 0.0;
             }
         }
-        for (int c = 0; c < b; ++c)                                // minus W^T[:, c] L[b, c]^T, ascending k
-            for (int s4 = 0; s4 < 32; ++s4) {
-                const int kk = c * 128 + 4 * s4 + fq;
-                const double av = -Wt[(int64_t)fr * np + kk];
+        // minus W^T[:, c] L[b, c]^T, ascending k.  Operands straight from global memory, eight k-steps requested at a time
+        // before their MFMAs (one step at a time the loop waited for a memory round trip per 2 MFMAs: 11-14 % of the kernel)
+        {
+            const double* wrow = Wt + (int64_t)fr * np + fq;
+            const double* l0 = A + (int64_t)(b * 128 + (2 * w) * 16 + fr) * ld + fq;
+            const double* l1 = l0 + (int64_t)16 * ld;
+            for (int kk0 = 0; kk0 < b * 128; kk0 += 32) {
+                double av[8], bv0[8], bv1[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double bv = A[(int64_t)(b * 128 + (2 * w + h) * 16 + fr) * ld + kk];
-                    acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[h], 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = -wrow[kk0 + 4 * u];
+                    bv0[u] = l0[kk0 + 4 * u];
+                    bv1[u] = l1[kk0 + 4 * u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv0[u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv1[u], acc[1], 0, 0, 0);
                 }
             }
+        }
         // the updated rows go to W^T, then one wave solves them against block b's tables
 #pragma unroll
         for (int h = 0; h < 2; ++h)
