@@ -1728,47 +1728,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
         us[idx] = r < n ? X[(int64_t)r * d + dd] / ls : 0.0;
     }
     __syncthreads();
-    {
-        double vj0[GSUM_MAX_D], vj1[GSUM_MAX_D];
-#pragma unroll
-        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-            vj0[dd] = dd < d ? us[(2 * lane) * d + dd] : 0.0;
-            vj1[dd] = dd < d ? us[(2 * lane + 1) * d + dd] : 0.0;
-        }
-        for (int gi = w; gi < 128; gi += 4) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-                if (dd < d) {
-                    const double xi = us[gi * d + dd];
-                    const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
-                    s0 = s0 + e0 * e0;
-                    s1 = s1 + e1 * e1;
-                }
-            }
-            const double ss[2] = {s0, s1};
-            double v[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int gj = 2 * lane + c;
-                double val;
-                if (gi >= n || gj >= n) {
-                    val = (gi == gj) ? 1.0 : 0.0;
-                } else {
-                    const bool dg = gi == gj;
-                    const double bse = dg ? 1.0 : gs_base_value_f(desc.family, ss[c], etab, etab + 16);
-                    val = desc.amplitude * bse;
-                    if (dg) val = val + desc.white_noise;
-                    val = val + desc.additive_const;
-                    if (dg) val = val + nugget;
-                }
-                if (gi == gj) dg0[gi] = val;
-                v[c] = val;
-            }
-            gs_d2 o = {v[0], v[1]};
-            *reinterpret_cast<gs_d2*>(A + gi * 128 + 2 * lane) = o;
-        }
-    }
+    // (the one tile is a diagonal tile: rows and columns are the same points; family / dimension as template parameters)
+    gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
     __threadfence_block();
     __syncthreads();
     // ---- Cholesky of the block; its substitution tables stay in wsd
