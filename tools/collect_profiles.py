@@ -69,7 +69,7 @@ json_line("rocprof_bench.log", "bench_under_rocprof.jsonl")
 json_line("plain_n1.log", "plain_n1.jsonl")
 json_line("bench_predict.log", "bench_predict.jsonl")
 for log in ("rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
-            "single_sweep.log", "slots_sweep.log", "clock_power.log"):
+            "single_sweep.log", "slots_sweep.log", "clock_power.log", "medium_phases.log"):
     path = os.path.join(SRC, log)
     if os.path.exists(path):
         text = open(path, errors="replace").read().splitlines()
