@@ -2158,6 +2158,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     __threadfence_block();
     __syncthreads();
     phase(0);
+    const int fr = lane & 15, fq = lane >> 4;
     // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
     // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
     for (int b = 0; b < T; b += 2) {
@@ -2177,23 +2178,67 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
             __threadfence_block();
             __syncthreads();
             phase(1);
-            // panel: rows below <- rows * L_cc^-T by blocked substitution against the tables gs_diag_block left in lds,
-            // 16 rows per wave at a time
+            // The 16 right-hand-side rows are rows of the bordered matrix: block column c of W^T = Z^T L^-T is brought up to
+            // date here (left-looking over the columns already done, on the matrix cores straight from global memory: wave w
+            // owns point-columns [32 w, 32 w + 32) of the block) and then SOLVED WITH THE PANEL below, against the tables
+            // gs_diag_block has just left in LDS.  As a separate sweep after the factorisation every block cost a reload of its
+            // 73-KB table, two barriers and a lone wave solving while three waited: 12-15 % of the kernel at n <= 1024.
             {
-                const int ngr = (T - c - 1) * 8;        // 16-row groups below the block: two per wave and pass
+                gs_d4 acc[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pc = c * 128 + (2 * w + h) * 16 + fr;        // accumulator column = point index
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int rr = fq + 4 * x;                         // accumulator row = right-hand side
+                        acc[h][x] = (rr < k && pc < n) ? Z[(int64_t)pc * k + rr] : 0.0;
+                    }
+                }
+                // minus W^T[:, c'] L[c, c']^T, ascending k; eight k-steps requested at a time before their MFMAs
+                const double* wrow = Wt + (int64_t)fr * np + fq;
+                const double* l0 = A + (int64_t)(c * 128 + (2 * w) * 16 + fr) * ld + fq;
+                const double* l1 = l0 + (int64_t)16 * ld;
+                for (int kk0 = 0; kk0 < c * 128; kk0 += 32) {
+                    double av[8], bv0[8], bv1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        av[u] = -wrow[kk0 + 4 * u];
+                        bv0[u] = l0[kk0 + 4 * u];
+                        bv1[u] = l1[kk0 + 4 * u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv0[u], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv1[u], acc[1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + c * 128 + (2 * w + h) * 16 + fr] = acc[h][x];
+            }
+            __threadfence_block();
+            __syncthreads();
+            phase(5);
+            // panel: rows below <- rows * L_cc^-T by blocked substitution against the tables in lds, two 16-row groups per
+            // wave and pass; the last group is the right-hand-side rows
+            {
+                const int ngr = (T - c - 1) * 8;        // 16-row groups of the matrix below the block; group ngr = W^T[:, c]
                 double* pan = A + ((int64_t)(c + 1) * 128) * ld + c * 128;
-                for (int br = w; br < ngr; br += 8) {
-                    double* ra = pan + (int64_t)(16 * br) * ld;
-                    if (br + 4 < ngr) {
-                        double* rb = pan + (int64_t)(16 * (br + 4)) * ld;
+                for (int br = w; br <= ngr; br += 8) {
+                    double* ra = br < ngr ? pan + (int64_t)(16 * br) * ld : Wt + c * 128;
+                    const int64_t lda_ = br < ngr ? ld : np;
+                    if (br + 4 <= ngr) {
+                        double* rb = br + 4 < ngr ? pan + (int64_t)(16 * (br + 4)) * ld : Wt + c * 128;
+                        const int64_t ldb_ = br + 4 < ngr ? ld : np;
                         gs_d4 Pg[8], Qg[8];
-                        gs_panel16_load(Pg, ra, ld, 16, lane);
-                        gs_panel16_load(Qg, rb, ld, 16, lane);
+                        gs_panel16_load(Pg, ra, lda_, 16, lane);
+                        gs_panel16_load(Qg, rb, ldb_, 16, lane);
                         gs_panel16_solve2(Pg, Qg, lds, lane);
-                        gs_panel16_store(Pg, ra, ld, 16, lane);
-                        gs_panel16_store(Qg, rb, ld, 16, lane);
+                        gs_panel16_store(Pg, ra, lda_, 16, lane);
+                        gs_panel16_store(Qg, rb, ldb_, 16, lane);
                     } else {
-                        gs_panel16(ra, ld, 16, lds, lane);
+                        gs_panel16(ra, lda_, 16, lds, lane);
                     }
                 }
             }
@@ -2213,54 +2258,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                            A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
         phase(4);
     }
-    // ---- W^T = Z^T L^-T, block column by block column (left-looking on the 16 right-hand-side rows), on the matrix
-    // cores straight from global memory: wave w owns point-columns [32 w, 32 w + 32) of each 128-column block.
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int b = 0; b < T; ++b) {
-        gs_d4 acc[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pc = b * 128 + (2 * w + h) * 16 + fr;        // accumulator column = point index
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int rr = fq + 4 * x;                         // accumulator row = right-hand side
-                acc[h][x] = (rr < k && pc < n) ? Z[(int64_t)pc * k + rr] : 0.0;
-            }
-        }
-        // minus W^T[:, c] L[b, c]^T, ascending k.  Operands straight from global memory, eight k-steps requested at a time
-        // before their MFMAs (one step at a time the loop waited for a memory round trip per 2 MFMAs: 11-14 % of the kernel)
-        {
-            const double* wrow = Wt + (int64_t)fr * np + fq;
-            const double* l0 = A + (int64_t)(b * 128 + (2 * w) * 16 + fr) * ld + fq;
-            const double* l1 = l0 + (int64_t)16 * ld;
-            for (int kk0 = 0; kk0 < b * 128; kk0 += 32) {
-                double av[8], bv0[8], bv1[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    av[u] = -wrow[kk0 + 4 * u];
-                    bv0[u] = l0[kk0 + 4 * u];
-                    bv1[u] = l1[kk0 + 4 * u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv0[u], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv1[u], acc[1], 0, 0, 0);
-                }
-            }
-        }
-        // the updated rows go to W^T, then one wave solves them against block b's tables
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + b * 128 + (2 * w + h) * 16 + fr] = acc[h][x];
-        __threadfence_block();
-        __syncthreads();
-        gs_load_ltab(lds, Ltab + (int64_t)b * GS_LTAB);
-        if (w == 0) gs_panel16(Wt + b * 128, np, 16, lds, lane);
-        __threadfence_block();
-        __syncthreads();
-    }
-    phase(5);
+    __threadfence_block();
+    __syncthreads();                               // W^T complete (its last block was solved by whichever wave had the group)
     // ---- Gram matrix G = W^T W by wave 0 (ascending k), log-det, info
     if (w == 0) {
         gs_d4 g = {0.0, 0.0, 0.0, 0.0};
