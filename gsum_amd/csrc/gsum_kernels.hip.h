@@ -2116,8 +2116,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     const int np = (n + 127) / 128 * 128, T = np / 128;
     const int64_t ld = np + GS_BORDER;
     double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
-    double* Ltab = A + (int64_t)np * ld;            // T x GS_LTAB substitution tables (in a T x 128 x 128 slot)
-    double* diag0 = Ltab + (int64_t)T * 128 * 128;
+    double* diag0 = A + (int64_t)np * ld + (int64_t)T * 128 * 128;     // (the T x 128 x 128 slot before it held exported tables
+                                                                       // while the right-hand sides had a sweep of their own)
     double* Wt = diag0 + np;                        // 16 x np, row-major
     double* out = res + (int64_t)blockIdx.x * 258;
     // diagnostics (option "diag_stamps"): shader cycles of workgroup 0 per phase -> stamps[40..47] =
@@ -2165,7 +2165,9 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
         const bool two = b + 1 < T;
         for (int s = 0; s < (two ? 2 : 1); ++s) {
             const int c = b + s;
-            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, (double*)nullptr, Ltab + (int64_t)c * GS_LTAB,
+            // (no table export: every consumer of block c's tables -- the panel below, right-hand-side rows included -- reads
+            // them from LDS before the next block overwrites them)
+            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, (double*)nullptr, (double*)nullptr,
                                           &ldet_blk, diag0 + c * 128, nullptr, lds);
             if (bad) {
                 if (t == 0) {

@@ -18,7 +18,7 @@ for n in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048]:
     r = 6
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
-    descs = [gsum_amd.describe_kernel(RBF(0.2 + 0.0001 * i), 1) for i in range(512)]
+    descs = [gsum_amd.describe_kernel(RBF(0.2 + 0.0001 * i), 1) for i in range(int(os.environ.get("MEDIUM_EVALS", "512")))]
     ctx.set_inputs(X, Z)
     ctx.set_option("medium_min_batch", 1)
     ctx.lml_resident(descs, 1e-10)
