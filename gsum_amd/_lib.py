@@ -384,10 +384,13 @@ class HipContext:
     # -- fused hot path ------------------------------------------------------
     @staticmethod
     def _desc_array(descs):
-        arr = (KernelDesc * len(descs))()
-        for i, dsc in enumerate(descs):
-            C.memmove(C.byref(arr[i]), C.byref(dsc), C.sizeof(KernelDesc))
-        return arr
+        """Contiguous ``gsum_kernel_desc[]`` for the C ABI.  An array built earlier (``HipContext.desc_array``) passes through:
+        for the fused small-n path the marshalling of thousands of descriptors was more than half of the call."""
+        if isinstance(descs, C.Array) and getattr(descs, "_type_", None) is KernelDesc:
+            return descs
+        return (KernelDesc * len(descs)).from_buffer_copy(b"".join(map(bytes, descs)))
+
+    desc_array = _desc_array
 
     def lml_batch(self, descs, X, rhs, nugget: float):
         """K build + Cholesky + Gram/log-det for each descriptor (host inputs)."""

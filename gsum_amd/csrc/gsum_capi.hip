@@ -106,6 +106,7 @@ struct gsum_ctx {
     gs_inputs op, res;
     gs_inputs* in = &res;
     double* scratch = nullptr; size_t scratch_cap = 0;
+    double* hbatch = nullptr; size_t hbatch_cap = 0;   // pinned host buffer for the fused paths' result blocks (258 doubles each)
     double* gws = nullptr; size_t gws_cap = 0;     // gradient path: U = L^-T, R^-1, V^T, per-parameter partials
     double timers[4] = {0, 0, 0, 0};
     unsigned long long* dstamps = nullptr;   // 8 u64: phase stamps of the last diagonal-block kernel
@@ -965,6 +966,7 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (I->Z) (void)hipFree(I->Z);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->hbatch) (void)hipHostFree(ctx->hbatch);
     if (ctx->gws) (void)hipFree(ctx->gws);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
     for (auto ev : ctx->prof_pool) (void)hipEventDestroy(ev);
@@ -1496,25 +1498,39 @@ static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sl
 }
 
 // n <= 128: one fused workgroup per evaluation (k_lml_small), up to 512 evaluations per launch
+static int gs_reserve_pinned(gsum_ctx* ctx, size_t bytes) {
+    if (ctx->hbatch_cap >= bytes) return 0;
+    if (ctx->hbatch) (void)hipHostFree(ctx->hbatch);
+    ctx->hbatch = nullptr;
+    ctx->hbatch_cap = 0;
+    GS_CHECK(hipHostMalloc((void**)&ctx->hbatch, bytes, hipHostMallocDefault));
+    ctx->hbatch_cap = bytes;
+    return 0;
+}
+
 static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out,
                         double* sld_out, int64_t* info_out) {
-    const int k = ctx->in->k, CH = 512;
+    // Evaluations per launch: up to 4096 (eight rounds of the 512 resident workgroups; 256 KB of scratch each).  With 512 per
+    // launch, a synchronisation, a pageable read-back and the host-side unpacking sat between every two rounds of a kernel
+    // that runs ~0.2 ms per round.
+    const int k = ctx->in->k, CH = std::min(4096, (n_kernels + 511) / 512 * 512);
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * GS_SMALL_SCRATCH * 8)) return -1;
     char* base = (char*)ctx->scratch;
-    std::vector<double> hres((size_t)CH * 258);
+    if (gs_reserve_pinned(ctx, (size_t)CH * 258 * 8)) return -1;
+    double* hres = ctx->hbatch;
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_lml_small, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n, ctx->in->d, ctx->in->Z, k,
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), (double*)(base + o_res));
         GS_CHECK(hipGetLastError());
-        GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));
         for (int e = 0; e < cnt; ++e) {
-            const double* r = hres.data() + (size_t)e * 258;
+            const double* r = hres + (size_t)e * 258;
             for (int a = 0; a < k; ++a)
                 for (int b = 0; b < k; ++b) G_out[(size_t)(lo + e) * k * k + a * k + b] = r[a * 16 + b];
             sld_out[lo + e] = r[256];
@@ -1549,7 +1565,8 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
         GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         ctx->lds_attr_done.insert((const void*)k_lml_medium);
     }
-    std::vector<double> hres((size_t)CH * 258);
+    if (gs_reserve_pinned(ctx, (size_t)CH * 258 * 8)) return -1;
+    double* hres = ctx->hbatch;
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
@@ -1557,10 +1574,10 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res),
                            ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
         GS_CHECK(hipGetLastError());
-        GS_CHECK(hipMemcpyAsync(hres.data(), base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));
         for (int e = 0; e < cnt; ++e) {
-            const double* r = hres.data() + (size_t)e * 258;
+            const double* r = hres + (size_t)e * 258;
             for (int a = 0; a < k; ++a)
                 for (int b = 0; b < k; ++b) G_out[(size_t)(lo + e) * k * k + a * k + b] = r[a * 16 + b];
             sld_out[lo + e] = r[256];
