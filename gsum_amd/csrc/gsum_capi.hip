@@ -1371,16 +1371,20 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                                (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
-    hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
-    GS_CHECK(hipGetLastError());
-    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     std::vector<double> vw;
     if (k > 0) {
+        // row sums of squares and V^T W in ONE pass over V^T (k_rowsumsq_vw)
         if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
-        if (gs_gemm(ctx, ctx->cur->sm, 1, dVW, 16, Bt, ldb, L->A + np * ld, ld, m, 16, (int)np, 0, 0, 1.0)) return -1;
+        hipLaunchKernelGGL(k_rowsumsq_vw, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np,
+                           L->A + np * ld, ld, dSS, dVW);
+        GS_CHECK(hipGetLastError());
         vw.resize((size_t)m * 16);
         GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
+    } else {
+        hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
+        GS_CHECK(hipGetLastError());
     }
+    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
     if (cov_out) {
         // V^T V is symmetric: lower tiles only (half the flops of the square product), then mirrored in place
         if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 1, 0, 1.0)) return -1;
