@@ -1375,7 +1375,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     if (k > 0) {
         // row sums of squares and V^T W in ONE pass over V^T (k_rowsumsq_vw)
         if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
-        hipLaunchKernelGGL(k_rowsumsq_vw, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np,
+        hipLaunchKernelGGL(k_rowsumsq_vw, dim3((unsigned)((m + 4 * GS_VW_ROWS - 1) / (4 * GS_VW_ROWS))), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np,
                            L->A + np * ld, ld, dSS, dVW);
         GS_CHECK(hipGetLastError());
         vw.resize((size_t)m * 16);

@@ -2556,35 +2556,39 @@ __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, i
 //   ss[row] = sum_j B[row][j]^2,   vw[row * 16 + c] = sum_j B[row][j] W[c][j].
 // predict reads V^T (m x n, 268 MB at m = 2048, n = 16384) for both: as k_rowsumsq + a 16-column GEMM on the 32 x 128 tile
 // (64 workgroups looping over K = n: 0.79 ms, latency-bound) that was two passes and 0.9 ms; this is one streaming pass.
-// One wave per FOUR rows (W -- 2 MB, L2-resident -- is re-read once per wave, not once per row), sixteen rows per workgroup.
+// One wave per GS_VW_ROWS rows (W -- 2 MB, L2-resident -- is re-read once per wave, not once per row).
+#define GS_VW_ROWS 2
 __global__ __launch_bounds__(256) void k_rowsumsq_vw(const double* B, int64_t ldb, int nrows, int ncols, const double* W, int64_t ldw,
                                                      double* ss, double* vw) {
+    constexpr int R = GS_VW_ROWS;
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= nrows) return;
-    const double* p[4];
+    const double* p[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = B + (int64_t)(row0 + r < nrows ? row0 + r : nrows - 1) * ldb;
-    double s[4] = {0.0, 0.0, 0.0, 0.0}, acc[4][16];
+    for (int r = 0; r < R; ++r) p[r] = B + (int64_t)(row0 + r < nrows ? row0 + r : nrows - 1) * ldb;
+    double s[R], acc[R][16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.0;
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
+    }
     for (int j = lane; j < ncols; j += 64) {
-        double b[4], wv[16];
+        double b[R], wv[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = p[r][j];
+        for (int r = 0; r < R; ++r) b[r] = p[r][j];
 #pragma unroll
         for (int c = 0; c < 16; ++c) wv[c] = W[(int64_t)c * ldw + j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
             s[r] += b[r] * b[r];
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[r][c] += b[r] * wv[c];
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_down(s[r], off, 64);
 #pragma unroll
