@@ -20,7 +20,7 @@ def configure_runtime(hw_queues: int = 32) -> bool:
     """Ask the HIP runtime for ``hw_queues`` hardware queues (environment variable ``GPU_MAX_HW_QUEUES``).
 
     The runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline of ``lml_resident`` keeps up
-    to 20 independent evaluations in flight on their own streams and wants a queue each (267 instead of 180
+    to 16 independent evaluations in flight on their own streams and wants a queue each (270-286 instead of 180-205
     evaluations per second at n = 8192).  The runtime reads the variable once, when it initialises, so call this
     before ANYTHING in the process touches the GPU (torch.cuda included).  Importing gsum_amd does not change the
     environment by itself: an application decides this for its whole process.  Returns False, and leaves a value the
@@ -133,6 +133,7 @@ PROTOTYPES = {
     "gsum_lml_resident_shard": (C.c_int, [_p, _kp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _ip, _ip, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
     "gsum_debug_diag_stamps": (C.c_int, [_p, _ip]),
+    "gsum_debug_chain_stamps": (C.c_int, [_p, _dp, C.c_int32, C.POINTER(C.c_int32)]),
     "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -251,7 +252,7 @@ class HipContext:
 
     def get_option(self, name: str) -> int:
         v = int(self._lib.gsum_get_option(self._h, name.encode()))
-        if v < 0 and name not in ("reserve_cus",):
+        if v < 0 and name not in ("reserve_cus", "chain_persist", "chain_probe"):
             raise ValueError(f"unknown option: {name}")
         return v
 
@@ -435,10 +436,11 @@ class HipContext:
         return int(n.value), int(d.value), int(k.value)
 
     def lml_resident(self, descs, nugget: float):
-        k = self.resident_shape()[2]          # the library's own record, not a cached copy
-        if k == 0:
+        n, _, k = self.resident_shape()       # the library's own record, not a cached copy
+        if n == 0:
             raise ValueError("gsum_set_inputs has not been called")
         nk = len(descs)
+        self._note_default_queues(nk)
         G = np.empty((nk, k, k))
         sld = np.empty(nk)
         info = np.zeros(nk, dtype=np.int64)
@@ -450,20 +452,36 @@ class HipContext:
 
     def lml_resident_shard(self, descs, nugget: float, rank: int, world: int):
         """This rank's slice of ``descs`` (gsum_shard_range), written to its positions of full-length arrays (NaN / -1
-        elsewhere): ready for an in-place all-gather.  Returns (G, sld, info, lo, hi)."""
-        k = self.resident_shape()[2]
-        if k == 0:
+        elsewhere).  Returns (G, sld, info, lo, hi); the arrays are views of length ``len(descs)`` into buffers of
+        ``world * ceil(len(descs) / world)`` leading entries, which is what an equal-chunk in-place all-gather
+        (``ncclAllGather(buf + lo, buf, chunk, ...)``, include/gsum_hip.h) reads and writes: ``G.base`` etc. are those
+        buffers."""
+        n, _, k = self.resident_shape()
+        if n == 0:
             raise ValueError("gsum_set_inputs has not been called")
         nk = len(descs)
-        G = np.full((nk, k, k), np.nan)
-        sld = np.full(nk, np.nan)
-        info = np.full(nk, -1, dtype=np.int64)
+        padded = int(world) * (-(-nk // int(world))) if world > 0 else nk
+        G = np.full((padded, k, k), np.nan)[:nk]
+        sld = np.full(padded, np.nan)[:nk]
+        info = np.full(padded, -1, dtype=np.int64)[:nk]
         lo, hi = C.c_int64(0), C.c_int64(0)
         arr = self._desc_array(descs)
         self._check(self._lib.gsum_lml_resident_shard(self._h, arr, nk, int(rank), int(world), float(nugget), _ptr(G), _ptr(sld),
                                                       info.ctypes.data_as(_ip), C.byref(lo), C.byref(hi)))
         self._warn_if_probe_fell_back()
         return G, sld, info, int(lo.value), int(hi.value)
+
+    def _note_default_queues(self, n_kernels):
+        """One-time note when a batch runs on the runtime's default 4 hardware queues (3 evaluations in flight) only
+        because nobody asked for more: importing gsum_amd leaves the environment alone (configure_runtime)."""
+        if n_kernels <= 4 or getattr(self, "_queues_noted", False) or "GPU_MAX_HW_QUEUES" in os.environ:
+            return
+        self._queues_noted = True
+        if int(self._lib.gsum_get_option(self._h, b"batch_slots")) <= 3:
+            warnings.warn("gsum_amd: GPU_MAX_HW_QUEUES is not set, so batches keep 3 evaluations in flight on the HIP "
+                          "runtime's default 4 hardware queues (about two thirds of the throughput at n = 8192); call "
+                          "gsum_amd.configure_runtime() before anything touches the GPU to get 16 in flight",
+                          RuntimeWarning, stacklevel=3)
 
     def _warn_if_probe_fell_back(self):
         if getattr(self, "_probe_warned", False):
@@ -502,6 +520,15 @@ class HipContext:
         v = np.zeros(64, dtype=np.int64)
         self._check(self._lib.gsum_debug_diag_stamps(self._h, v.ctypes.data_as(_ip)))
         return v
+
+    def chain_stamps(self, max_steps: int = 512):
+        """(steps, 16) array of the last persistent-chain factorisation's realtime stamps in microseconds from its
+        start (NaN: not written); needs ``set_option("chain_stamps", 1)``.  Column meaning: include/gsum_hip.h."""
+        out = np.zeros((max_steps, 16))
+        steps = C.c_int32(0)
+        self._check(self._lib.gsum_debug_chain_stamps(self._h, _ptr(out), max_steps, C.byref(steps)))
+        out = out[: steps.value]
+        return np.where(out < 0, np.nan, out * 0.01)
 
     def gemm_profile(self):
         """(total ms, total algorithmic flops, launches) of the profiled big-tile GEMM launches; resets."""

@@ -25,6 +25,10 @@ struct gsum_mat {
     int solved_k = -1;                  // hold (-1: none): a repeated predict / forward_gram with the same RHS skips the solve
     double* logdet = nullptr;  // T per-block sums of log L_ii
     double* diag0 = nullptr;   // np original diagonal entries (pivot-cancellation test)
+    // persistent-chain schedule (allocated the first time a factorisation of this matrix uses it)
+    unsigned* cflags = nullptr;            // gs_fl_count(T / 2) words, zeroed before every factorisation
+    double* cdump = nullptr;               // 2 x GS_CH_GMAX x 16 x 256 doubles: operand images of the window's rows
+    unsigned long long* cstamps = nullptr; // T / 2 x GS_CH_STAMPS realtime stamps (option "chain_stamps")
     bool factored = false;
 };
 
@@ -40,6 +44,8 @@ struct gs_slot {
     hipStream_t sc = nullptr, srm = nullptr;   // windowed schedule with reserve_cus > 0: the chain on the reserved CUs ONLY,
                                                // the rest stream on the bulk stream's CUs
     hipStream_t sr = nullptr;        // windowed look-ahead schedule: the rows below the window (panel rest, far look-ahead columns)
+    hipStream_t sa = nullptr;        // persistent-chain schedule: the panel of the rows below the window and the near updates A, B
+    hipEvent_t evC = nullptr, evS = nullptr;     // ... its joins (chain kernel / stream sa -> main stream)
     std::vector<hipEvent_t> evP, evM, evA;
     std::vector<hipEvent_t> evW;     // windowed schedule: five events per outer step (GS_EVW_*)
     hipEvent_t evFork = nullptr, evR = nullptr;
@@ -48,6 +54,8 @@ struct gs_slot {
     double* hres = nullptr;          // pinned
     gsum_mat* ws = nullptr;          // workspace matrix of the fused path (reused across calls)
     int pending = -1;                // index of the evaluation in flight on this slot
+    gsum_kernel_desc last_desc;      // ... and what it was (a chain-schedule timeout re-runs it on the host-enqueued schedule)
+    double last_nugget = 0.0;
 };
 
 #define GS_MAX_SLOTS 24
@@ -99,6 +107,19 @@ struct gsum_ctx {
                                      // factorisation alone is 10-30 % slower with them
     int chain_window = 0;            // look-ahead schedule: 1 = windowed (only the rows the next panels need are on the chain's
                                      // stream, the rest of each panel trails on a stream of its own), 0 = whole panels on the chain
+    int chain_persist = -1;          // ONE factorisation alone: the dependent chain as a persistent kernel on CUs of its own (k_chain),
+                                     // the M-proportional work host-enqueued and gated on its flags.  -1 (default) = when the order
+                                     // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
+    int chain_min_np = 2048;
+    int chain_rows = 512;            // the chain's window: rows under the panel it solves and updates itself (256 or 512)
+    int chain_stamps = 0;            // record the chain kernel's per-step realtime stamps (gsum_debug_chain_stamps)
+    int chain_probe = 0;             // two-stream concurrency probe: 0 not run, 1 streams run side by side, -1 they do not (a
+                                     // profiler serialises dispatches): the chain schedule would deadlock until its timeout
+    int chain_events_needed = 0;     // the gradient path trails the factorisation by evP events: host-enqueued schedule only
+    int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
+    const unsigned* gate_ptr = nullptr;   // gate of the NEXT bulk (cfg 7) / k_panel256 launch; consumed by it
+    unsigned gate_want = 0;
+    unsigned* gate_flags = nullptr;
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
                                      // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
@@ -223,6 +244,7 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
     if (cfg == 6 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (cfg == 7 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
+    if (ctx->gate_ptr && cfg != 7) GS_FAIL("internal: only the cfg-7 bulk tile can be gated");
     if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
@@ -243,7 +265,8 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
             blocks = ((M + 127) / 128) * ((N + 63) / 64);
         }
         hipLaunchKernelGGL(k_gemm_ld3, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                           beta, sign);
+                           beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate_flags);
+        ctx->gate_ptr = nullptr;
         GS_CHECK(hipGetLastError());
         return 0;
     }
@@ -324,13 +347,10 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->logdet, (size_t)m->T * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->diag0, (size_t)m->np * sizeof(double));
     if (e != hipSuccess) {
-        if (m->A) (void)hipFree(m->A);
-        if (m->Linv) (void)hipFree(m->Linv);
-        if (m->Ltab) (void)hipFree(m->Ltab);
-    if (m->Lsib) (void)hipFree(m->Lsib);
-        if (m->Lsib) (void)hipFree(m->Lsib);
-        if (m->logdet) (void)hipFree(m->logdet);
-        if (m->diag0) (void)hipFree(m->diag0);
+        for (double** q : {&m->A, &m->Linv, &m->Ltab, &m->Lsib, &m->logdet, &m->diag0}) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
         delete m;
         ctx->err = std::string("hipMalloc(matrix) failed: ") + hipGetErrorString(e);
         return -1;
@@ -347,6 +367,9 @@ static void gs_mat_release(gsum_mat* m) {
     if (m->Lsib) (void)hipFree(m->Lsib);
     if (m->logdet) (void)hipFree(m->logdet);
     if (m->diag0) (void)hipFree(m->diag0);
+    if (m->cflags) (void)hipFree(m->cflags);
+    if (m->cdump) (void)hipFree(m->cdump);
+    if (m->cstamps) (void)hipFree(m->cstamps);
     delete m;
 }
 
@@ -547,7 +570,9 @@ static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, d
     if (M <= 0) return 0;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
     hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
-                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB);
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->gate_ptr, ctx->gate_want,
+                       ctx->gate_flags);
+    ctx->gate_ptr = nullptr;
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
@@ -683,6 +708,133 @@ static int gs_potrf_window(gsum_ctx* ctx, gsum_mat* m, hipStream_t sb) {
     return 0;
 }
 
+
+// ---- persistent-chain schedule (see k_chain) ------------------------------------------------------------------------
+// Do kernels of two streams of this process run side by side?  The chain kernel waits for flags that host-enqueued kernels
+// on other streams set, and they wait for its flags: under a tool that serialises dispatches (rocprofv3's kernel trace does)
+// that would stall until the in-kernel timeout.  One spinning wave on one stream, the word it waits for written from another;
+// 20 ms at most, once per context.
+static int gs_chain_probe(gsum_ctx* ctx, gs_slot* sl) {
+    if (ctx->chain_probe != 0) return 0;
+    unsigned* d = (unsigned*)ctx->dstamps + 64;                 // words 64.. of the 64 x u64 stamp buffer: unused by the stamps' 8 x u64
+    GS_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(unsigned), sl->sm));
+    GS_CHECK(hipEventRecord(sl->evFork, sl->sm));
+    GS_CHECK(hipStreamWaitEvent(sl->sa, sl->evFork, 0));
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, sl->sm, (const unsigned*)d, 2000000ull, d + 1);     // <= 20 ms
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sa, d, 1u);
+    GS_CHECK(hipGetLastError());
+    unsigned seen = 0;
+    GS_CHECK(hipMemcpyAsync(&seen, d + 1, sizeof(unsigned), hipMemcpyDeviceToHost, sl->sm));
+    GS_CHECK(hipStreamSynchronize(sl->sm));
+    GS_CHECK(hipStreamSynchronize(sl->sa));
+    ctx->chain_probe = seen ? 1 : -1;
+    return 0;
+}
+
+static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
+    if (!sl->sa) {
+        GS_CHECK(hipStreamCreateWithPriority(&sl->sa, hipStreamNonBlocking, ctx->prio_hi));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evC, hipEventDisableTiming));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evS, hipEventDisableTiming));
+    }
+    const int S = m->T / 2;
+    if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)gs_fl_count(S) * sizeof(unsigned)));
+    if (!m->cdump) GS_CHECK(hipMalloc((void**)&m->cdump, (size_t)2 * GS_CH_GMAX * 16 * 256 * sizeof(double)));
+    if (!m->cstamps) {
+        GS_CHECK(hipMalloc((void**)&m->cstamps, (size_t)S * GS_CH_STAMPS * sizeof(unsigned long long)));
+        GS_CHECK(hipMemset(m->cstamps, 0, (size_t)S * GS_CH_STAMPS * sizeof(unsigned long long)));
+    }
+    if (!ctx->lds_attr_done.count((const void*)k_chain)) {
+        GS_CHECK(hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(GS_CH_LDS_DOUBLES * sizeof(double))));
+        ctx->lds_attr_done.insert((const void*)k_chain);
+    }
+    return 0;
+}
+
+static bool gs_chain_wanted(const gsum_ctx* ctx, const gsum_mat* m) {
+    if (ctx->chain_persist == 0 || ctx->chain_events_needed || !m->have_ltab || ctx->bulk_cfg != 7) return false;
+    if (m->T < 4 || (m->T & 1)) return false;
+    return ctx->chain_persist > 0 || m->np >= ctx->chain_min_np;
+}
+
+// Outer step s (panel columns [c0, c0 + 256), trailing matrix from r2 = c0 + 256), K = 256 everywhere:
+//   k_chain            diagonal super-block, the window rows [r2, r2 + W) of the panel, C[window rows][r2, r2 + 256)
+//   sa: rest(s)        rows >= r2 + W of the panel (k_panel256, gated on T1[s])                       -> evP[s]
+//       A(s)           C[rows >= r2 + W][r2, r2 + 256)            gated on the window's first 16 row groups   -> FA[s]
+//       B(s)           C[rows >= r2 + 256][r2 + 256, r2 + 512)    gated on the whole window, after Far(s - 1) -> FB[s]
+//   sm: Far(s)         lower tiles of C[rows, columns >= r2 + 512], after rest(s)                     -> evM[s]
+static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
+    gs_slot* sl = ctx->cur;
+    const int T = m->T, S = T / 2;
+    const int W = ctx->chain_rows >= 512 ? 512 : 256;
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    unsigned* fl = m->cflags;
+    hipStream_t sm = sl->sm, sp = sl->sp, sa = sl->sa;
+    GS_CHECK(hipMemsetAsync(fl, 0, (size_t)gs_fl_count(S) * sizeof(unsigned), sm));
+    GS_CHECK(hipEventRecord(sl->evFork, sm));
+    GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
+    GS_CHECK(hipStreamWaitEvent(sa, sl->evFork, 0));
+    gs_chain_args ca;
+    ca.A = A; ca.ld = ld; ca.np = (int)m->np; ca.naug = (int)naug; ca.S = S; ca.W = W;
+    ca.Ltab = m->Ltab; ca.Lsib = m->Lsib; ca.logdet = m->logdet; ca.diag0 = m->diag0; ca.info = sl->dinfo;
+    ca.dump = m->cdump; ca.flags = fl; ca.stamps = ctx->chain_stamps ? m->cstamps : nullptr;
+    {
+        const int rec = gs_prof_begin(ctx, sp, GS_PROF_DIAG, (double)T * GS_NB * GS_NB * GS_NB / 3.0);
+        hipLaunchKernelGGL(k_chain, dim3((unsigned)(1 + W / 64)), dim3(256), GS_CH_LDS_DOUBLES * sizeof(double), sp, ca);
+        gs_prof_end(ctx, sp, rec);
+        GS_CHECK(hipGetLastError());
+    }
+    auto gate = [&](int kind, int s, unsigned want) {
+        ctx->gate_ptr = fl + gs_fl(kind, S, s);
+        ctx->gate_want = want;
+        ctx->gate_flags = fl;
+    };
+    int prev_far = -1;
+    for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
+        const int k = 2 * s;
+        const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
+        const int Gs = (int)((wend - r2) / 16);
+        if (mr > 0) {
+            gate(GS_FL_T1, s, 1u);
+            if (gs_panel256(ctx, sa, m, k, A + wend * ld + c0, ld, mr)) return -1;
+        }
+        GS_CHECK(hipEventRecord(sl->evP[s], sa));
+        if (mr > 0) {
+            gate(GS_FL_WTOP, s, (unsigned)std::min(16, Gs));
+            if (gs_gemm(ctx, sa, GS_BULK, A + wend * ld + r2, ld, A + wend * ld + c0, ld, A + r2 * ld + c0, ld, mr, 256, 256, 0, 1, -1.0)) return -1;
+        }
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FA, S, s), 1u);
+        const int64_t r3 = r2 + 256, m3 = naug - r3, wb = std::min<int64_t>(256, m3);
+        if (m3 > 0) {
+            if (prev_far >= 0) GS_CHECK(hipStreamWaitEvent(sa, sl->evM[prev_far], 0));
+            gate(GS_FL_WALL, s, (unsigned)Gs);
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * wb - (double)wb * (wb - 1));
+            if (gs_gemm(ctx, sa, GS_BULK, A + r3 * ld + r3, ld, A + r3 * ld + c0, ld, A + r3 * ld + c0, ld, m3, wb, 256, 0, 1, -1.0)) return -1;
+        }
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FB, S, s), 1u);
+        GS_CHECK(hipGetLastError());
+        const int64_t r4 = r3 + 256, m4 = naug - r4;
+        if (m4 > 0) {
+            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[s], 0));
+            if (W < 512) gate(GS_FL_WALL, s, (unsigned)Gs);      // (W = 512: every operand row of Far is below the window)
+            if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, A + r4 * ld + c0, ld, A + r4 * ld + c0, ld, m4, m4, 256, 1, 1, -1.0)) return -1;
+            GS_CHECK(hipEventRecord(sl->evM[s], sm));
+            prev_far = s;
+        }
+    }
+    GS_CHECK(hipEventRecord(sl->evC, sp));
+    GS_CHECK(hipEventRecord(sl->evS, sa));
+    GS_CHECK(hipStreamWaitEvent(sm, sl->evC, 0));
+    GS_CHECK(hipStreamWaitEvent(sm, sl->evS, 0));
+    // a chain that gave up (flags[0] == 1) reports through the info word: INT_MAX is no LAPACK index
+    hipLaunchKernelGGL(k_chain_status, dim3(1), dim3(64), 0, sm, (const unsigned*)fl, sl->dinfo);
+    GS_CHECK(hipGetLastError());
+    m->factored = true;
+    return 0;
+}
+
 static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int T = m->T;
     gs_slot* sl = ctx->cur;
@@ -704,6 +856,11 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
     ctx->bulk_pad_now = false;
     if (la && gs_panel_stream(ctx, sl)) return -1;
+    if (la && gs_chain_wanted(ctx, m)) {
+        if (gs_chain_resources(ctx, sl, m)) return -1;
+        if (gs_chain_probe(ctx, sl)) return -1;
+        if (ctx->chain_probe > 0) return gs_potrf_chain(ctx, m);
+    }
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm, sb = sl->sm;
     if (la) {
@@ -914,6 +1071,8 @@ int gsum_init(int device, gsum_ctx** out) {
     if (cw) ctx->chain_window = atoi(cw) != 0;
     const char* bp = getenv("GSUM_BULK_LDS_PAD");
     if (bp) ctx->bulk_lds_pad = std::max(0, std::min(80 * 1024, atoi(bp)));
+    const char* cp = getenv("GSUM_CHAIN_PERSIST");
+    if (cp) ctx->chain_persist = atoi(cp) < 0 ? -1 : (atoi(cp) != 0);
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
@@ -960,6 +1119,9 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->srm) (void)hipStreamDestroy(sl->srm);
         if (sl->su) (void)hipStreamDestroy(sl->su);
         if (sl->evU) (void)hipEventDestroy(sl->evU);
+        if (sl->sa) (void)hipStreamDestroy(sl->sa);
+        if (sl->evC) (void)hipEventDestroy(sl->evC);
+        if (sl->evS) (void)hipEventDestroy(sl->evS);
     }
     for (gs_inputs* I : {&ctx->op, &ctx->res}) {
         if (I->X) (void)hipFree(I->X);
@@ -983,6 +1145,10 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "queue_probe_fell_back")) return ctx->probe_fell_back;
     if (!strcmp(name, "lookahead")) return ctx->lookahead;
     if (!strcmp(name, "bulk_cfg")) return ctx->bulk_cfg;
+    if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
+    if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
+    if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
+    if (!strcmp(name, "chain_rows")) return ctx->chain_rows;
     return -1;
 }
 
@@ -1047,6 +1213,10 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;
     else if (!strcmp(name, "la_split")) ctx->la_split = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_prefetch")) ctx->chain_prefetch = value != 0;
+    else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
+    else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
+    else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else GS_FAIL(std::string("unknown option: ") + name);
@@ -1148,6 +1318,13 @@ int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
     if (gs_finalize(ctx, A)) return -1;
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     *info = (int64_t)ctx->cur->hres[257];
+    if (*info == GS_INFO_CHAIN_ABORT) {
+        ctx->chain_persist = 0;
+        ++ctx->chain_aborts;
+        A->factored = false;
+        GS_FAIL("the persistent chain schedule timed out (streams of this process do not run side by side); the matrix is "
+                "destroyed -- rebuild it and factorise again: the schedule is now switched off (option chain_persist = 0)");
+    }
     if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
     A->factored = (*info == 0);
     return 0;
@@ -1468,6 +1645,8 @@ static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double n
         if (gs_mat_alloc(ctx, ctx->in->n, &sl->ws)) return -1;
     }
     gsum_mat* m = sl->ws;
+    sl->last_desc = *desc;
+    sl->last_nugget = nugget;
     if (ctx->profile_gemm > 0) ctx->prof_this_eval = (ctx->prof_eval_count++ % ctx->profile_gemm) == 0;
     GS_CHECK(hipEventRecord(sl->tev[0], sl->sm));
     if (gs_build_into(ctx, sl->sm, m, desc, ctx->in->X, ctx->in->d, nugget, ctx->build_lower_only)) return -1;
@@ -1486,6 +1665,18 @@ static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sl
     const int i = sl->pending, k = ctx->in->k;
     if (i < 0) return 0;
     GS_CHECK(hipStreamSynchronize(sl->sm));
+    if ((int64_t)sl->hres[257] == GS_INFO_CHAIN_ABORT) {
+        // the persistent chain timed out (its streams did not run side by side): once more on the host-enqueued schedule
+        ctx->chain_persist = 0;
+        ++ctx->chain_aborts;
+        gs_slot* keep = ctx->cur;
+        ctx->cur = sl;
+        const gsum_kernel_desc d = sl->last_desc;
+        const int rc = gs_eval_enqueue(ctx, &d, sl->last_nugget);
+        ctx->cur = keep;
+        if (rc) return rc;
+        GS_CHECK(hipStreamSynchronize(sl->sm));
+    }
     for (int a = 0; a < k; ++a)
         for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = sl->hres[a * 16 + b];
     sld_out[i] = sl->hres[256];
@@ -1621,7 +1812,9 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     {
         // every slot owns a workspace matrix of the current order: keep the new ones within 80 % of the free memory
         const int64_t np = (ctx->in->n + GS_NB - 1) / GS_NB * GS_NB, ldw = np + GS_BORDER;
-        const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0;
+        const double Tw = (double)(np / GS_NB);
+        const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0      // A, Linv
+                                + Tw * GS_LTAB * 8.0 + (Tw / 2 + 1) * GS_LSIB * 8.0 + (double)np * 16.0;   // Ltab, Lsib, logdet + diag0
         int have = 0;
         for (int q = 0; q < std::min(S, ctx->n_slots_ready); ++q)
             if (ctx->slots[q].ws && ctx->slots[q].ws->n == ctx->in->n) ++have;
@@ -1712,7 +1905,10 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     gs_slot* sl = &ctx->slots[0];
     ctx->cur = sl;
     ctx->batch_active = 1;
-    if (gs_eval_enqueue(ctx, desc, nugget)) return -1;
+    ctx->chain_events_needed = 1;          // the sweep below trails the factorisation by its evP events (host-enqueued schedule)
+    const int rc_eval = gs_eval_enqueue(ctx, desc, nugget);
+    ctx->chain_events_needed = 0;
+    if (rc_eval) return -1;
     sl->pending = 0;
     gsum_mat* m = sl->ws;
     const int64_t np = m->np, ld = m->ld, ldg = np + GS_BORDER;
@@ -1798,6 +1994,26 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
         for (int i = 4; i < n && i < 9; ++i) ms[i] = (double)st[i - 4];
         if (n > 9) ms[9] = ctx->host_enqueue_ms;
     }
+    return 0;
+}
+
+// Realtime stamps (100 MHz ticks, relative to the first) of the last persistent-chain factorisation on slot 0's workspace
+// (option "chain_stamps" = 1): GS_CH_STAMPS = 16 per outer step -- D role 0 step begins, 1 its diagonal block is up to date,
+// 2 T0 set, 3 block row k + 1 up to date, 4 TL set, 5 sibling update done, 6 T1 set; P wave 0: 8 rows ready, 9 T0 seen,
+// 10 sibling update done, 11 T1 seen, 12 published, 13 first update task starts, 14 done.  Returns the steps written.
+int gsum_debug_chain_stamps(gsum_ctx* ctx, double* out, int32_t max_steps, int32_t* steps) {
+    if (!ctx || !out || !steps) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    gsum_mat* m = ctx->slots[0].ws;
+    *steps = 0;
+    if (!m || !m->cstamps) return 0;
+    const int S = std::min<int>(m->T / 2, max_steps);
+    std::vector<unsigned long long> h((size_t)S * GS_CH_STAMPS);
+    GS_CHECK(hipDeviceSynchronize());
+    GS_CHECK(hipMemcpy(h.data(), m->cstamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long t0 = h.empty() ? 0 : h[0];
+    for (size_t i = 0; i < h.size(); ++i) out[i] = h[i] ? (double)(long long)(h[i] - t0) : -1.0;
+    *steps = S;
     return 0;
 }
 

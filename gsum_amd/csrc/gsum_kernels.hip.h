@@ -1584,15 +1584,103 @@ __device__ __forceinline__ void gs_sib_update_lean(gs_d4 (&P1)[8], const gs_d4 (
     }
 }
 
+// ---- flags of the persistent-chain schedule (the schedule itself: after k_potrf_diag256, below) ----
+#define GS_CH_GMAX 32                       // window row groups at most (W = 512)
+#define GS_FL_ABORT 0                       // 0 running, 1 a wait timed out, 2 a pivot failed (info says where)
+#define GS_FL_BASE 16
+enum { GS_FL_T0 = 0, GS_FL_TL, GS_FL_T1, GS_FL_WTOP, GS_FL_WALL, GS_FL_UD0, GS_FL_UD1, GS_FL_UR, GS_FL_FA, GS_FL_FB, GS_FL_KINDS };
+__host__ __device__ inline int gs_fl(int kind, int S, int s) { return GS_FL_BASE + kind * S + s; }
+__host__ __device__ inline int gs_fl_wg(int S, int s, int g) { return GS_FL_BASE + GS_FL_KINDS * S + GS_CH_GMAX * s + g; }
+__host__ __device__ inline int gs_fl_count(int S) { return (GS_FL_BASE + (GS_FL_KINDS + GS_CH_GMAX) * S + 3) / 4 * 4; }
+#define GS_CH_TIMEOUT 100000000ull          // 1 s of s_memrealtime (100 MHz)
+#define GS_CH_STAMPS 16                     // u64 per outer step (diagnostics)
+#define GS_CH_LDS_DOUBLES GS_LSIB           // 128 KB: the L10 operand images (>= the diagonal routine's 75.8 KB workspace)
+
+#define GS_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ unsigned gs_flag_ld(const unsigned* f) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, GS_RLX_AGENT));
+}
+__device__ __forceinline__ void gs_flag_st(unsigned* f, unsigned v) { __hip_atomic_store(f, v, GS_RLX_AGENT); }
+__device__ __forceinline__ void gs_flag_add(unsigned* f) { (void)__hip_atomic_fetch_add(f, 1u, GS_RLX_AGENT); }
+__device__ __forceinline__ void gs_st_wt(double* p, double v) { __hip_atomic_store(p, v, GS_RLX_AGENT); }   // global_store_dwordx2 sc1
+__device__ __forceinline__ void gs_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One wave polls until *f >= want (every lane loads the same word: one request).  false: the chain was aborted.  No acquire.
+__device__ __forceinline__ bool gs_poll_ge(const unsigned* f, unsigned want, unsigned* flags) {
+    if (gs_flag_ld(f) < want) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(2);
+            if (gs_flag_ld(f) >= want) break;
+            if (gs_flag_ld(flags + GS_FL_ABORT)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > GS_CH_TIMEOUT) {
+                gs_flag_st(flags + GS_FL_ABORT, 1u);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+// ONE agent-scope acquire after the poll(s) have matched: this CU's L1 drops its lines; the wave's own later loads are ordered
+// behind the invalidate in its memory pipeline (other waves: s_waitcnt vmcnt(0) + barrier first, gs_wg_wait_ge)
+__device__ __forceinline__ void gs_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ bool gs_wait_ge(const unsigned* f, unsigned want, unsigned* flags) {
+    if (!gs_poll_ge(f, want, flags)) return false;
+    gs_acquire();
+    return true;
+}
+
+// the same for a whole workgroup: thread 0's wave polls and acquires, the others load behind the barrier.  `sh`: one int of LDS.
+__device__ __forceinline__ bool gs_wg_wait_ge(const unsigned* f, unsigned want, unsigned* flags, volatile int* sh) {
+    if (threadIdx.x < 64) {
+        const bool ok = gs_wait_ge(f, want, flags);
+        gs_drain();                              // the invalidate has completed before the barrier lets the other waves load
+        if (threadIdx.x == 0) *sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int ok = *sh;
+    __syncthreads();
+    return ok != 0;
+}
+
+// gate of a host-enqueued kernel (single-wave workgroups): proceed once the chain has set the flag
+__device__ __forceinline__ bool gs_gate_wave(const unsigned* gate, unsigned want, unsigned* flags) {
+    return gate == nullptr || gs_wait_ge(gate, want, flags);
+}
+
+__global__ void k_signal(unsigned* f, unsigned v) {
+    if (threadIdx.x == 0) gs_flag_st(f, v);
+}
+
+// end of a persistent-chain factorisation: a chain that gave up (a wait timed out) says so through the info word
+#define GS_INFO_CHAIN_ABORT 0x7fffffff
+__global__ void k_chain_status(const unsigned* flags, int* info) {
+    if (threadIdx.x == 0 && gs_flag_ld(flags + GS_FL_ABORT) == 1u) *info = GS_INFO_CHAIN_ABORT;
+}
+
+// two-stream probe of the chain schedule's one assumption: kernels of different streams of this process run side by side
+// (a profiler that serialises dispatches breaks it).  k_probe_wait spins until k_signal's word arrives or `ticks` pass.
+__global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned long long ticks, unsigned* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned seen = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        if (gs_flag_ld(f)) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (threadIdx.x == 0) *out = seen;
+}
+
 // rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
+// gate != NULL (persistent-chain schedule): the tables are the chain kernel's; wait for its flag first.
 __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1) {
+                                                  const double* Ltab1, const unsigned* gate, unsigned gate_want, unsigned* flags) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
     __builtin_amdgcn_s_setprio(3);
+    if (!gs_gate_wave(gate, gate_want, flags)) return;
     double* rows = P + (int64_t)r0 * ld;
     gs_d4 P0[8], P1[8];
     gs_panel16_load(P0, rows, ld, M - r0, lane);
@@ -1693,6 +1781,324 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld,
     __syncthreads();
     bad = gs_diag_block<false>(A11, ld, (double*)nullptr, Ltab + GS_LTAB, logdet + 1, diag0 + 128, nullptr, wsd);
     if (bad && t == 0) *info = col0 + 128 + bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT CHAIN (round 3): the dependent chain of ONE factorisation as one resident kernel on CUs of its own.
+//
+// One factorisation alone is bound by the chain diag -> panel -> sibling update -> diag -> panel -> look-ahead update of every
+// 256-column outer step, not by the bulk update: as host-enqueued launches every link queued behind bulk
+// workgroups for a CU slot, shared its SIMDs' matrix pipes with them (k_potrf_diag 43-96 us beside the bulk update, 31 alone)
+// and ran over ALL rows below the panel although the next diagonal blocks only need the rows just below it.  Here the chain
+// is cut down to a WINDOW of W rows under the panel and runs as ONE kernel of 1 + W / 64 workgroups that each hold a CU
+// alone (128 KB of LDS: no bulk workgroup fits beside them) and talk through flags in global memory:
+//   workgroup 0 (D role)       per outer step s (block columns k = 2 s, k + 1):  D(k) -> T0 | rows of block k + 1 solved
+//                              against it (tables in LDS) -> TL | A11 -= L10 L10^T | D(k + 1) -> T1
+//   workgroups 1.. (P role)    one wave per 16-row group of the window [r2, r2 + W): X_k = B_k L_kk^-T (after T0), sibling
+//                              update (after TL), X_k+1 (after T1), rows + operand images published; then the window's share of
+//                              the trailing update, C[window rows, next panel's columns] -= P P^T (K = 256), as 32 x 32 tasks
+//                              over the published images, the next diagonal block's tasks first (counters UD0 / UD1 / UR)
+// Everything M-proportional -- the panel of the rows below the window (k_panel256, gated on T1), the update of the next
+// panel's columns below the window (A), of the panel after it (B) and of the far region (Far) -- stays host-enqueued on two
+// streams and meets the chain through the same flags: gated kernels poll a flag the chain sets (gs_gate_*), one-thread
+// k_signal launches tell the chain that A(s) / B(s) have finished.  The regions are a partition of the trailing update of
+// the host-enqueued schedule and every element receives the same products in the same ascending order: results are
+// bit-identical to it (tests/test_gpu_parity.py).
+//
+// Hand-off discipline (MI355X_MICROARCH.md, inter-workgroup visibility): published bytes are stored write-through (relaxed
+// agent-scope atomic stores = global_store ... sc1), every storing wave drains vmcnt, (workgroup barrier,) ONE lane stores the
+// flag / adds to the counter; a consumer polls relaxed, then ONE agent-scope acquire, s_waitcnt vmcnt(0), (barrier,) plain loads.
+// Every spin is bounded (GS_CH_TIMEOUT): on expiry flags[GS_FL_ABORT] = 1 and every party leaves at its next wait.
+// ------------------------------------------------------------------------------------------------
+// a wave-uniform pointer made opaque to the optimiser, in SGPRs: inside the persistent loops LICM otherwise hoists hundreds of
+// per-lane 64-bit table addresses (base + lane + constant) out of the loop and spills them (1000 spilled VGPRs measured)
+template <class T>
+__device__ __forceinline__ T* gs_uniform_ptr(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+struct gs_chain_args {
+    double* A; int64_t ld; int np, naug, S, W;
+    double* Ltab; double* Lsib; double* logdet; const double* diag0; int* info;
+    double* dump;                  // [2][GS_CH_GMAX][16][4][64]: operand images of the window's solved rows, by step parity
+    unsigned* flags;               // gs_fl_count(S) words, zeroed before the launch
+    unsigned long long* stamps;    // S x GS_CH_STAMPS realtime stamps, or NULL
+};
+
+// window geometry of outer step s: Gs row groups [r2, r2 + 16 Gs), Gc column groups of the next panel
+__device__ __forceinline__ void gs_ch_geom(int np, int naug, int W, int s, int& r2, int& Gs, int& Gc) {
+    r2 = 256 * (s + 1);
+    const int wend = min(r2 + W, naug);
+    Gs = (wend - r2) / 16;
+    Gc = min(16, (naug - r2) / 16);
+}
+// number of 32 x 32 update tasks (I, J), J <= I, with Ilo <= I < Ihi, in a window of Gs row and Gc column groups
+__device__ __forceinline__ int gs_ch_ntasks(int Gs, int Gc, int Ilo, int Ihi) {
+    const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
+    int c = 0;
+    for (int I = Ilo; I < min(Ihi, NI); ++I) c += min(I + 1, NJ);
+    return c;
+}
+
+__device__ __forceinline__ void gs_panel16_store_wt(const gs_d4 (&P)[8], double* rows, int64_t ld, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) gs_st_wt(rows + (int64_t)fr * ld + 16 * k + fq + 4 * x, -P[k][x]);
+}
+__device__ __forceinline__ void gs_image_store_wt(const gs_d4 (&P)[8], double* img, int lane) {      // img: [kb][x][lane]
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) gs_st_wt(img + (k * 4 + x) * 64 + lane, P[k][x]);
+}
+
+// ---- D role: the 256 x 256 diagonal super-block of every outer step (k_potrf_diag256's arithmetic, tables kept in LDS)
+__device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, double* wsd, volatile int* sh) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int S = a.S;
+    unsigned* fl = a.flags;
+    for (int s = 0; s < S; ++s) {
+        const int k = 2 * s;
+        const int64_t c0 = 256 * (int64_t)s, ld = a.ld;
+        double* A00 = gs_uniform_ptr(a.A + c0 * ld + c0);
+        double* A10 = gs_uniform_ptr(A00 + 128 * ld);
+        double* A11 = gs_uniform_ptr(A10 + 128);
+        double* tab0 = gs_uniform_ptr(a.Ltab + (size_t)k * GS_LTAB);
+        double* tab1 = gs_uniform_ptr(tab0 + GS_LTAB);
+        double* sib = gs_uniform_ptr(a.Lsib + (size_t)s * GS_LSIB);
+        unsigned long long* st = a.stamps ? a.stamps + (size_t)s * GS_CH_STAMPS : nullptr;
+        int pr2 = 0, pGs = 0, pGc = 0;
+        if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
+        if (st && t == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+        if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD0, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 0, 4), fl, sh)) return;
+        if (st && t == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+        int bad = gs_diag_block<true>(A00, ld, (double*)nullptr, (double*)nullptr, a.logdet + k, a.diag0 + c0, nullptr, wsd);
+        if (bad) {                                  // uniform
+            if (t == 0) {
+                *a.info = (int)c0 + bad;
+                gs_flag_st(fl + GS_FL_ABORT, 2u);
+            }
+            return;
+        }
+        for (int i = t; i < GS_LTAB; i += 256) gs_st_wt(tab0 + i, wsd[i]);
+        gs_drain();
+        __syncthreads();
+        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T0, S, s), 1u);
+        if (st && t == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        // ---- L10: row groups w and 7 - w of block row k + 1 against the tables in LDS
+        if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD1, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 4, 8), fl, sh)) return;
+        if (st && t == 0) st[3] = __builtin_amdgcn_s_memrealtime();
+        const int g0 = w, g1 = 7 - w;
+        gs_d4 Pa[8], Pb[8];
+        gs_panel16_load(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
+        gs_panel16_load(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
+        gs_panel16_solve2(Pa, Pb, wsd, lane);
+        gs_panel16_store(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
+        gs_panel16_store(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
+        __syncthreads();                            // every wave is through with the tables: the LDS now takes the images of L10
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                wsd[((g0 * 8 + kb) * 4 + x) * 64 + lane] = Pa[kb][x];
+                wsd[((g1 * 8 + kb) * 4 + x) * 64 + lane] = Pb[kb][x];
+                gs_st_wt(sib + ((g0 * 8 + kb) * 4 + x) * 64 + lane, Pa[kb][x]);
+                gs_st_wt(sib + ((g1 * 8 + kb) * 4 + x) * 64 + lane, Pb[kb][x]);
+            }
+        gs_drain();
+        __syncthreads();
+        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_TL, S, s), 1u);
+        if (st && t == 0) st[4] = __builtin_amdgcn_s_memrealtime();
+        // ---- A11 -= L10 L10^T: micro-tiles (c, c') for c' in {g0, g1}, c >= c' (k_gemm_nt's arithmetic: -C + sum, ascending k)
+        auto tile = [&](int c, int cp, const gs_d4 (&Pq)[8]) {
+            gs_d4 acc;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = -A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wsd[((c * 8 + kb) * 4 + x) * 64 + lane], Pq[kb][x], acc, 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr] = -acc[x];
+        };
+        for (int c = g0; c < 8; ++c) tile(c, g0, Pa);
+        for (int c = g1; c < 8; ++c) tile(c, g1, Pb);
+        __syncthreads();
+        if (st && t == 0) st[5] = __builtin_amdgcn_s_memrealtime();
+        bad = gs_diag_block<true>(A11, ld, (double*)nullptr, (double*)nullptr, a.logdet + k + 1, a.diag0 + c0 + 128, nullptr, wsd);
+        if (bad) {
+            if (t == 0) {
+                *a.info = (int)c0 + 128 + bad;
+                gs_flag_st(fl + GS_FL_ABORT, 2u);
+            }
+            return;
+        }
+        for (int i = t; i < GS_LTAB; i += 256) gs_st_wt(tab1 + i, wsd[i]);
+        gs_drain();
+        __syncthreads();
+        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T1, S, s), 1u);
+        if (st && t == 0) st[6] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ---- P role: one wave = one 16-row group of the window per outer step, then its share of the window's update tasks
+__device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int pw, int NPW, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int S = a.S;
+    const int64_t ld = a.ld;
+    unsigned* fl = a.flags;
+    for (int s = 0; s < S; ++s) {
+        int r2, Gs, Gc;
+        gs_ch_geom(a.np, a.naug, a.W, s, r2, Gs, Gc);
+        const int64_t c0 = 256 * (int64_t)s;
+        const double* tab0_s = a.Ltab + (size_t)(2 * s) * GS_LTAB;
+        const double* sib_s = a.Lsib + (size_t)s * GS_LSIB;
+        double* dump = a.dump + (size_t)(s & 1) * GS_CH_GMAX * 16 * 256;
+        unsigned long long* st = (a.stamps && pw == 0) ? a.stamps + (size_t)s * GS_CH_STAMPS : nullptr;
+        int pr2 = 0, pGs = 0, pGc = 0;
+        if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
+        // ---- panel: X_k = B_k L_kk^-T;  B_k+1 -= X_k L(k+1, k)^T;  X_k+1 = B_k+1 L_k+1,k+1^-T   (k_panel256's arithmetic)
+#pragma unroll 1
+        for (int g = pw; g < Gs; g += NPW) {
+            double* rows = gs_uniform_ptr(a.A + (int64_t)(r2 + 16 * g) * ld + c0);
+            const double* tab0 = gs_uniform_ptr(tab0_s);
+            const double* tab1 = gs_uniform_ptr(tab0_s + GS_LTAB);
+            const double* sib = gs_uniform_ptr(sib_s);
+            double* img = gs_uniform_ptr(dump + (size_t)g * 16 * 256);
+            if (s > 0) {
+                // these rows' entries in panel s's columns: last updated by the window tasks of step s - 1 (rows that were
+                // in that window: its groups 16 ..) or by the host-enqueued update A(s - 1) (rows below it)
+                const bool in_prev = g + 16 < pGs;
+                const unsigned* f = in_prev ? fl + gs_fl(GS_FL_UR, S, s - 1) : fl + gs_fl(GS_FL_FA, S, s - 1);
+                const unsigned want = in_prev ? (unsigned)gs_ch_ntasks(pGs, pGc, 8, 1 << 20) : 1u;
+                if (!gs_wait_ge(f, want, fl)) return;
+            }
+            if (st) st[8] = __builtin_amdgcn_s_memrealtime();
+            gs_d4 P0[8], P1[8];
+            gs_panel16_load(P0, rows, ld, 16, lane);
+            if (!gs_wait_ge(fl + gs_fl(GS_FL_T0, S, s), 1u, fl)) return;
+            if (st) st[9] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+            gs_panel16_solve_g(P0, tab0, lane);
+            gs_panel16_store_wt(P0, rows, ld, lane);
+            gs_image_store_wt(P0, img, lane);
+            __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now (as k_panel256)
+            gs_panel16_load(P1, rows + 128, ld, 16, lane);
+            if (!gs_wait_ge(fl + gs_fl(GS_FL_TL, S, s), 1u, fl)) return;
+            gs_sib_update_lean(P1, P0, sib, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st) st[10] = __builtin_amdgcn_s_memrealtime();
+            if (!gs_wait_ge(fl + gs_fl(GS_FL_T1, S, s), 1u, fl)) return;
+            if (st) st[11] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+            gs_panel16_solve_g(P1, tab1, lane);
+            gs_panel16_store_wt(P1, rows + 128, ld, lane);
+            gs_image_store_wt(P1, img + 8 * 256, lane);
+            gs_drain();
+            if (lane == 0) {
+                gs_flag_st(fl + gs_fl_wg(S, s, g), 1u);
+                if (g < 16) gs_flag_add(fl + gs_fl(GS_FL_WTOP, S, s));
+                gs_flag_add(fl + gs_fl(GS_FL_WALL, S, s));
+            }
+            if (st) st[12] = __builtin_amdgcn_s_memrealtime();
+        }
+        // ---- the window's share of the trailing update: C[rows of groups 2I, 2I+1][columns of groups 2J, 2J+1] -= P P^T, K = 256,
+        // tasks in ascending I (the next diagonal block's first)
+        const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
+        const int ntask = gs_ch_ntasks(Gs, Gc, 0, 1 << 20);
+        bool first = true;
+        for (int tk = pw; tk < ntask; tk += NPW) {
+            int I = 0, J = 0, seen = 0;
+            for (I = 0; I < NI; ++I) {
+                const int c = min(I + 1, NJ);
+                if (tk < seen + c) { J = tk - seen; break; }
+                seen += c;
+            }
+            const int gi0 = 2 * I, gj0 = 2 * J;
+            const bool va1 = gi0 + 1 < Gs, vb1 = gj0 + 1 < Gc;
+            // the panel rows this task multiplies, and the last host-enqueued update of its C tile (B(s - 1))
+            if (!gs_poll_ge(fl + gs_fl_wg(S, s, gi0), 1u, fl)) return;
+            if (va1 && !gs_poll_ge(fl + gs_fl_wg(S, s, gi0 + 1), 1u, fl)) return;
+            if (!gs_poll_ge(fl + gs_fl_wg(S, s, gj0), 1u, fl)) return;
+            if (vb1 && !gs_poll_ge(fl + gs_fl_wg(S, s, gj0 + 1), 1u, fl)) return;
+            if (s > 0 && !gs_poll_ge(fl + gs_fl(GS_FL_FB, S, s - 1), 1u, fl)) return;
+            gs_acquire();
+            if (st && first) st[13] = __builtin_amdgcn_s_memrealtime();
+            // micro-tile (a, b): rows of group gi0 + a, columns of group gj0 + b; on the diagonal task only the lower ones
+            const bool v00 = true, v01 = vb1 && gi0 >= gj0 + 1, v10 = va1, v11 = va1 && vb1;
+            double* C0 = a.A + (int64_t)(r2 + 16 * gi0) * ld + r2 + 16 * gj0;
+            gs_d4 c00, c01, c10, c11;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
+                c00[x] = -C0[ro];
+                c01[x] = v01 ? -C0[ro + 16] : 0.0;
+                c10[x] = v10 ? -C0[ro + 16 * ld] : 0.0;
+                c11[x] = v11 ? -C0[ro + 16 * ld + 16] : 0.0;
+            }
+            const double* dA0 = dump + (size_t)gi0 * 16 * 256 + lane;
+            const double* dA1 = dump + (size_t)(va1 ? gi0 + 1 : gi0) * 16 * 256 + lane;
+            const double* dB0 = dump + (size_t)gj0 * 16 * 256 + lane;
+            const double* dB1 = dump + (size_t)(vb1 ? gj0 + 1 : gj0) * 16 * 256 + lane;
+            gs_d4 a0, a1, b0, b1, na0, na1, nb0, nb1;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                a0[x] = dA0[x * 64];
+                a1[x] = dA1[x * 64];
+                b0[x] = dB0[x * 64];
+                b1[x] = dB1[x * 64];
+            }
+#pragma unroll 1
+            for (int kb = 0; kb < 16; ++kb) {
+                const int kn = kb + 1 < 16 ? kb + 1 : kb;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    na0[x] = dA0[(kn * 4 + x) * 64];
+                    na1[x] = dA1[(kn * 4 + x) * 64];
+                    nb0[x] = dB0[(kn * 4 + x) * 64];
+                    nb1[x] = dB1[(kn * 4 + x) * 64];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[x], c00, 0, 0, 0);
+                    if (v01) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b1[x], c01, 0, 0, 0);
+                    if (v10) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b0[x], c10, 0, 0, 0);
+                    if (v11) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[x], c11, 0, 0, 0);
+                }
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
+                gs_st_wt(C0 + ro, -c00[x]);
+                if (v01) gs_st_wt(C0 + ro + 16, -c01[x]);
+                if (v10) gs_st_wt(C0 + ro + 16 * ld, -c10[x]);
+                if (v11) gs_st_wt(C0 + ro + 16 * ld + 16, -c11[x]);
+            }
+            gs_drain();
+            if (lane == 0) gs_flag_add(fl + gs_fl(I < 4 ? GS_FL_UD0 : (I < 8 ? GS_FL_UD1 : GS_FL_UR), S, s));
+            if (st && first) st[14] = __builtin_amdgcn_s_memrealtime();
+            first = false;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_chain(gs_chain_args a) {
+    extern __shared__ __attribute__((aligned(16))) double wsd[];
+    __shared__ int sh_ok;
+    __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x == 0) {
+        gs_chain_diag_role(a, wsd, &sh_ok);
+    } else {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gs_chain_panel_role(a, ((int)blockIdx.x - 1) * 4 + w, ((int)gridDim.x - 1) * 4, threadIdx.x & 63);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2417,14 +2823,29 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
 // 512).  Costs 50 % more operand loads per flop (served by L2).  Same staging layout and sign handling as k_gemm_ld;
 // results identical bit for bit.  Measured against k_gemm_ld in the same process: equal at M = 7936, +18 % at M = 4096
 // exclusive; -4 % time per pipelined evaluation, -6 % for one factorisation alone (n = 8192).
+// gate != NULL (persistent-chain schedule): the launch reads panel rows the chain kernel publishes; thread 0's wave polls the
+// chain's counter, acquires, and the workgroup starts behind a barrier (the flag rides in the not-yet-used staging LDS).
 __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign) {
+                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
+                                                      const unsigned* gate, unsigned gate_want, unsigned* flags) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
     extern __shared__ double lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (gate) {                                   // uniform
+        volatile int* okp = reinterpret_cast<volatile int*>(lds);
+        if (t < 64) {
+            const bool ok = gs_wait_ge(gate, gate_want, flags);
+            gs_drain();
+            if (t == 0) *okp = ok ? 1 : 0;
+        }
+        __syncthreads();
+        const int ok = *okp;
+        __syncthreads();
+        if (!ok) return;
+    }
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
     if (tri) {

@@ -48,25 +48,30 @@ def gather_flat(local: np.ndarray, total: int, group=None) -> np.ndarray:
     buf = torch.full((chunk,), float("nan"), dtype=torch.float64)
     buf[: hi - lo] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
     buf = buf.to(dev)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    full = torch.cat(outs).cpu().numpy()
+    full_t = torch.empty(world * chunk, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(full_t, buf, group=group)          # one collective, one output tensor
+    full = full_t.cpu().numpy()
     pieces = [full[r * chunk: r * chunk + (shard_range(total, r, world)[1] - shard_range(total, r, world)[0])]
               for r in range(world)]
     return np.concatenate(pieces)
 
 
-def lml_grid_distributed(evaluate, n_rows: int, n_cols: int, group=None) -> np.ndarray:
-    """Run ``evaluate(shard=(rank, world))`` -> (n_rows, n_cols) array with this rank's entries filled,
-    then gather every rank's slice.  ``evaluate`` is typically
-    ``functools.partial(TruncationGP.log_marginal_likelihood_grid, gp, thetas, ratios, mode=...)``.
+def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None = None, group=None) -> np.ndarray:
+    """Run ``evaluate(shard=(rank, world))`` -> array with this rank's entries filled (NaN elsewhere), then gather
+    every rank's slice.  ``evaluate`` is typically
+    ``functools.partial(TruncationGP.log_marginal_likelihood_grid, gp, thetas, ratios, mode=...)`` -- with or without
+    ``scales=``: the surface is gathered in whatever shape ``evaluate`` returns it ((rows, cols), or
+    (rows, cols, scales) for BASELINE config 4's (cbar, ratio) scan), flattened in C order, which is the order
+    ``log_marginal_likelihood_grid`` shards in.  ``n_rows`` / ``n_cols`` are optional and only checked.
     """
     dist = _dist()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
-    total = n_rows * n_cols
+    surface = np.asarray(evaluate(shard=(rank, world)), dtype=np.float64)
+    if n_rows is not None and n_cols is not None and tuple(surface.shape[:2]) != (n_rows, n_cols):
+        raise ValueError(f"evaluate returned a surface of shape {surface.shape}, expected ({n_rows}, {n_cols}[, scales])")
+    total = surface.size
     lo, hi = shard_range(total, rank, world)
-    local = np.asarray(evaluate(shard=(rank, world)), dtype=np.float64).reshape(-1)[lo:hi]
-    return gather_flat(local, total, group).reshape(n_rows, n_cols)
+    return gather_flat(surface.reshape(-1)[lo:hi], total, group).reshape(surface.shape)
 
 
 def predict_distributed(predict, Xnew, n_curves, group=None):

@@ -119,8 +119,10 @@ class TruncationGP:
         # working precision (cond >= 1e16) and still returns usable numbers.  A Cholesky factorisation of the same
         # matrix fails; rather than regress those workflows the conditioning is retried with a relative jitter on the
         # diagonal of the correlation matrix, smallest first, and says so.
+        # (relative to the kernel's own diagonal: amplitude + additive constant of the descriptor)
+        kdiag = float(desc.amplitude) + float(desc.additive_const)
         for jitter in (0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6):
-            K = ctx.kernel_matrix_dev(desc, Xc, diag_add=jitter)
+            K = ctx.kernel_matrix_dev(desc, Xc, diag_add=jitter * kdiag)
             try:
                 K.scale_series(sc, ref_c, ratio_c)
                 info = ctx.potrf(K)
@@ -136,6 +138,7 @@ class TruncationGP:
                     'conditions on it with LU and no jitter -- use fewer / better separated conditioning points' % info)
         else:
             raise np.linalg.LinAlgError('cov(Xc, Xc) is not positive definite even with a relative jitter of 1e-6')
+        self.conditioning_jitter_ = jitter          # what the last conditioning needed (0.0: none), for callers to check
         if jitter > 0.0:
             warnings.warn('cov(Xc, Xc) is singular to working precision: conditioned with a relative diagonal jitter of %g '
                           '(the reference solves this system with LU and no jitter; set strict_conditioning=True to get '

@@ -239,6 +239,14 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
  * round-2 kernel: [7] start, [8 + 2j], [9 + 2j] wave 0 behind the two barriers of micro-block column j, [24 + j] cycles
  * of the pivot recurrence of micro-block j). */
 int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64);
+/* diagnostic: per-outer-step realtime stamps of the last persistent-chain factorisation (options "chain_stamps" = 1,
+ * "chain_persist"; gsum_potrf_lower / a single fused evaluation on a matrix whose order is a multiple of 256): out holds
+ * 16 values per step in 100 MHz ticks relative to the first stamp (-1: not written).  Indices: D role 0 step begins, 1 its
+ * diagonal block is up to date, 2 first block's tables published, 3 block row k + 1 up to date, 4 L(k+1, k) published,
+ * 5 sibling update done, 6 second block's tables published; P wave 0: 8 its rows are up to date, 9 first tables seen,
+ * 10 sibling update done, 11 second tables seen, 12 rows published, 13 its first update task starts, 14 is done.
+ * This is the timeline evidence for numpy.linalg.cholesky at gsum/models.py:711, 809, 969 (one factorisation alone). */
+int gsum_debug_chain_stamps(gsum_ctx* ctx, double* out, int32_t max_steps, int32_t* steps);
 /* With option "profile_gemm" = N > 0 every kernel launch of every N-th fused evaluation (the 1st, N+1-th, ... since the
  * option was set; operator-level calls: every launch) is bracketed by HIP events on the stream it is launched on
  * (~230 launches per evaluation at n = 8192: N = 2 costs ~9 % of batch throughput).  This returns the summed durations

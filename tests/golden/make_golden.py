@@ -607,10 +607,70 @@ def gen_cbar_ratio_grid():
                 strip_argmax=[int(v) for v in np.unravel_index(np.argmax(strip), strip.shape)])
 
 
+def gen_s5_predict():
+    """BASELINE config 5 exactly as SURVEY.md 8(d) S5 states it: n = 16384 points in 2-D (the box bench.py uses: mean
+    nearest-neighbour spacing ~0.5 ell), Matern-5/2(ell = [0.7, 1.3]) + White(1e-6) fixed, 8 curves.  The reference's
+    fit -> log_marginal_likelihood -> predict(return_std) (models.py:671-738, 912-1039, 753-845) at the first 16 of the
+    m = 2048 new points bench.py's predict leg uses, so that leg can check itself against this file."""
+    n, r, m = 16384, 8, 2048
+    side = np.array([0.35, 0.65]) * np.sqrt(n)
+    X = np.random.RandomState(0).rand(n, 2) * side
+    Xs = np.random.RandomState(1).rand(m, 2) * side
+    y = np.random.RandomState(2).randn(n, r)
+    kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+    gp = gsum.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None)
+    import time
+    t0 = time.time()
+    gp.fit(X, y)
+    print("s5 fit", time.time() - t0, flush=True)
+    lml = float(gp.log_marginal_likelihood(theta=np.log([0.7, 1.3])))
+    print("s5 lml", lml, time.time() - t0, flush=True)
+    mean, std = gp.predict(Xs[:16], return_std=True)
+    print("s5 predict", time.time() - t0, flush=True)
+    mean_n, std_n = gp.predict(Xs[:16], return_std=True, pred_noise=True)
+    return dict(n=n, r=r, m=m, probes=16, side=L(side), length_scale=[0.7, 1.3], white=1e-6, nugget=1e-10,
+                recipe="X = RandomState(0).rand(n,2)*side; Xs = RandomState(1).rand(m,2)*side; y = RandomState(2).randn(n,r); "
+                       "side = [0.35, 0.65]*sqrt(n); ConjugateGaussianProcess(Matern([0.7,1.3],2.5)+White(1e-6,fixed), "
+                       "center=0, disp=0, df=1, scale=1, optimizer=None)",
+                lml=lml, cov_factor=float(gp.cov_factor_), scale=float(gp.scale_), df=float(gp.df_),
+                center=L(gp.center_), mean=L(mean), std=L(std), std_pred_noise=L(std_n),
+                y_checksum=float(np.sum(y * np.cos(np.arange(y.size).reshape(y.shape)))),
+                X_checksum=float(np.sum(X * np.cos(np.arange(X.size).reshape(X.shape)))))
+
+
+def gen_s1_plumbing():
+    """BASELINE config 1: X = linspace(0, 1, 128), 4 orders, RBF(0.2), ratio 0.5, ref 1, coefficients by
+    the recipe of datasets.py:65-71 (multivariate normal draw, nugget 1e-10, random_state 0); TruncationGP fit, lml at a few
+    (ell, ratio) points, predict at 9 new points.  cond(K) ~ 1e13 here: tests scale their tolerance by it."""
+    n, r = 128, 4
+    X = np.linspace(0, 1, n)[:, None]
+    kern = RBF(0.2)
+    y = gsum.make_gaussian_partial_sums(X, orders=r, kernel=kern, ratio=0.5, ref=1.0, nugget=1e-10, random_state=0)
+    gp = gsum.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y, orders=np.arange(r))
+    K = kern(X)
+    K[np.diag_indices_from(K)] += 1e-10
+    out = dict(n=n, r=r, y=L(y), length_scale=0.2, ratio=0.5, ref=1.0, nugget=1e-10, cond=float(np.linalg.cond(K)),
+               cov_factor=float(gp.coeffs_process.cov_factor_), scale=float(gp.coeffs_process.scale_),
+               df=float(gp.coeffs_process.df_), lml=[])
+    for ell in (0.2, 0.15, 0.3):
+        for q in (0.5, 0.4):
+            out["lml"].append(dict(ell=ell, ratio=q, value=float(gp.log_marginal_likelihood(theta=np.log([ell]), ratio=q))))
+    cgp = gsum.ConjugateGaussianProcess(kernel=RBF(0.2), center=0, disp=0, df=1, scale=1, optimizer=None)
+    c = gsum.coefficients(y, ratio=0.5, ref=1.0, orders=np.arange(r))
+    cgp.fit(X, c)
+    Xs = np.linspace(0.03, 0.97, 9)[:, None]
+    mean, std = cgp.predict(Xs, return_std=True)
+    out["cgp"] = dict(Xs=L(Xs), mean=L(mean), std=L(std), cov_factor=float(cgp.cov_factor_),
+                      lml=float(cgp.log_marginal_likelihood(theta=np.log([0.2]))))
+    return out
+
+
 def main():
     only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
     if only:
-        gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid)
+        gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid, s5_predict=gen_s5_predict,
+                    s1_plumbing=gen_s1_plumbing)
         for name in only:
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(gens[name](), f, indent=1)
@@ -642,6 +702,10 @@ def main():
         json.dump(gen_large(), f, indent=1)
     with open(os.path.join(HERE, "large_lml_gp_drawn.json"), "w") as f:
         json.dump(gen_large_gp_drawn(), f, indent=1)
+    with open(os.path.join(HERE, "s1_plumbing.json"), "w") as f:
+        json.dump(gen_s1_plumbing(), f, indent=1)
+    with open(os.path.join(HERE, "s5_predict.json"), "w") as f:      # ~10 minutes on 8 cores, ~15 GB
+        json.dump(gen_s5_predict(), f, indent=1)
     import sklearn, scipy
     with open(os.path.join(HERE, "VERSIONS.json"), "w") as f:
         json.dump(dict(numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__,

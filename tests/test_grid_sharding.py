@@ -95,6 +95,50 @@ def test_grid_gather_gloo(world, ni, nj):
     assert all(shape == (ni, nj) for _, _, shape in res)
 
 
+def _scales_worker(rank, world, port, q):
+    """A (rows, cols, scales) surface -- BASELINE config 4's (cbar, ratio) scan returns one -- through the gather helper:
+    every rank fills its C-order slice of ni * nj * ns flat points with a known function of the index."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ni, nj, ns = 3, 4, 5
+
+        def evaluate(shard):
+            out = np.full((ni, nj, ns), np.nan)
+            lo, hi = shard_range(ni * nj * ns, *shard)
+            out.reshape(-1)[lo:hi] = np.sqrt(np.arange(lo, hi) + 0.5)
+            return out
+
+        full = lml_grid_distributed(evaluate, ni, nj)
+        want = np.sqrt(np.arange(ni * nj * ns) + 0.5).reshape(ni, nj, ns)
+        bad_shape = False
+        try:
+            lml_grid_distributed(evaluate, nj, ni)
+        except ValueError:
+            bad_shape = True
+        q.put((rank, bool(np.array_equal(full, want)) and bad_shape, full.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grid_gather_with_scales_axis_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scales_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(shape == (3, 4, 5) for _, _, shape in res)
+
+
 def _predict_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

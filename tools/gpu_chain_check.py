@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Persistent-chain schedule against the host-enqueued look-ahead schedule: bit-identity of G / sum log L_ii / info for one
+evaluation alone at several orders and both window sizes, repeated (hand-off races show up as mismatches), the factor itself
+through the operator-level potrf, a non-positive-definite input, and the latency of each.  Usage: gpu_chain_check.py [reps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import gsum_amd  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+ctx = gsum_amd.default_context(0)
+ctx.set_option("batch_slots", 1)
+out = {"cases": []}
+bad = 0
+
+
+def evaluate(desc, nugget):
+    G, sld, info = ctx.lml_resident([desc], nugget)
+    return G[0].copy(), float(sld[0]), int(info[0]), ctx.timers()["potrf_ms"]
+
+
+for n, r, kern, d in ((1024, 4, RBF(0.2), 1), (2048, 4, RBF(0.2), 1), (2304, 3, Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2),
+                      (4096, 6, RBF(0.2), 1), (8192, 6, RBF(0.2), 1), (8192 - 256 + 40, 6, RBF(0.2), 1)):
+    rng = np.random.RandomState(n)
+    if d == 1:
+        X = 0.1 * np.arange(n)[:, None]
+    else:
+        X = rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    Z = np.concatenate([rng.randn(n, r), np.ones((n, 1))], axis=1)
+    desc = gsum_amd.describe_kernel(kern, d)
+    ctx.set_inputs(X, Z)
+    ctx.set_option("chain_persist", 0)
+    ref = evaluate(desc, 1e-10)
+    t_ref = min(evaluate(desc, 1e-10)[3] for _ in range(reps))
+    for W in (512, 256):
+        ctx.set_option("chain_persist", 1)
+        ctx.set_option("chain_rows", W)
+        same, ts = 0, []
+        for _ in range(reps):
+            G, sld, info, ms = evaluate(desc, 1e-10)
+            ok = np.array_equal(G, ref[0]) and sld == ref[1] and info == ref[2]
+            same += ok
+            ts.append(ms)
+        rec = dict(n=n, W=W, identical=same, reps=reps, potrf_ms_chain=min(ts), potrf_ms_chain_median=float(np.median(ts)),
+                   potrf_ms_host=t_ref, probe=ctx.get_option("chain_probe"), aborts=ctx.get_option("chain_aborts"),
+                   persist_now=ctx.get_option("chain_persist"), info=ref[2],
+                   maxdiff=float(np.max(np.abs(G - ref[0]))), sld_diff=sld - ref[1])
+        bad += same != reps
+        out["cases"].append(rec)
+        print(json.dumps(rec), flush=True)
+
+# the factor itself, operator level (gsum_potrf_lower -> L), n = 4096
+n = 4096
+X = 0.1 * np.arange(n)[:, None]
+desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+Ls = []
+for persist in (0, 1):
+    ctx.set_option("chain_persist", persist)
+    K = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+    info = ctx.potrf(K)
+    Ls.append((info, K.to_host()))
+    K.free()
+if Ls[0][1] is not None:
+    same = bool(np.array_equal(Ls[0][1], Ls[1][1]))
+    print("factor identical:", same, "info", Ls[0][0], Ls[1][0], flush=True)
+    out["factor_identical"] = same
+    bad += not same
+
+# not positive definite: duplicated points, no nugget -> same LAPACK info on both schedules
+n = 2048
+X = 0.1 * np.arange(n)[:, None]
+X[1500] = X[1499]
+Z = np.concatenate([np.random.RandomState(1).randn(n, 3), np.ones((n, 1))], axis=1)
+ctx.set_inputs(X, Z)
+infos = []
+for persist in (0, 1):
+    ctx.set_option("chain_persist", persist)
+    infos.append(evaluate(desc, 0.0)[2])
+print("non-PD info host / chain:", infos, flush=True)
+out["nonpd_info"] = infos
+bad += infos[0] != infos[1] or infos[0] == 0
+
+# timeline of one factorisation at n = 8192
+n, r = 8192, 6
+X = 0.1 * np.arange(n)[:, None]
+Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
+ctx.set_inputs(X, Z)
+ctx.set_option("chain_persist", 1)
+ctx.set_option("chain_rows", 512)
+ctx.set_option("chain_stamps", 1)
+for _ in range(3):
+    evaluate(desc, 1e-10)
+st = ctx.chain_stamps()
+np.set_printoptions(linewidth=250, precision=1, suppress=True)
+print("step: D[begin, diag ready, T0, row ready, TL, sib done, T1] | P0[rows ready, T0 seen, sib, T1 seen, published, task start, task done]  (us)")
+for s in range(st.shape[0]):
+    print(s, st[s, 0:7], "|", st[s, 8:15], flush=True)
+out["stamps_us"] = np.nan_to_num(st, nan=-1.0).tolist()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "chain_check.json"), "w") as f:
+    json.dump(out, f)
+print("FAILURES:", bad)
+sys.exit(1 if bad else 0)
