@@ -786,6 +786,10 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         gs_prof_end(ctx, sp, rec);
         GS_CHECK(hipGetLastError());
     }
+    // nothing of the other streams is dispatched before every workgroup of the chain is resident (see k_wait_flag); the main
+    // stream follows sa through evP[0]
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, sa, (const unsigned*)(fl + GS_FL_RESIDENT), (unsigned)(1 + W / 64), fl);
+    GS_CHECK(hipGetLastError());
     auto gate = [&](int kind, int s, unsigned want) {
         ctx->gate_ptr = fl + gs_fl(kind, S, s);
         ctx->gate_want = want;

@@ -1587,6 +1587,7 @@ __device__ __forceinline__ void gs_sib_update_lean(gs_d4 (&P1)[8], const gs_d4 (
 // ---- flags of the persistent-chain schedule (the schedule itself: after k_potrf_diag256, below) ----
 #define GS_CH_GMAX 32                       // window row groups at most (W = 512)
 #define GS_FL_ABORT 0                       // 0 running, 1 a wait timed out, 2 a pivot failed (info says where)
+#define GS_FL_RESIDENT 1                    // workgroups of k_chain that have started (k_wait_flag holds the other streams back)
 #define GS_FL_BASE 16
 enum { GS_FL_T0 = 0, GS_FL_TL, GS_FL_T1, GS_FL_WTOP, GS_FL_WALL, GS_FL_UD0, GS_FL_UD1, GS_FL_UR, GS_FL_FA, GS_FL_FB, GS_FL_KINDS };
 __host__ __device__ inline int gs_fl(int kind, int S, int s) { return GS_FL_BASE + kind * S + s; }
@@ -1609,13 +1610,17 @@ __device__ __forceinline__ void gs_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ bool gs_poll_ge(const unsigned* f, unsigned want, unsigned* flags) {
     if (gs_flag_ld(f) < want) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
+        for (unsigned spins = 0;; ++spins) {
+            // short naps first (a hand-off on the critical path), longer ones once the wait is clearly a long one (the chain
+            // idling behind the bulk update in the first third of a factorisation): polls are fabric traffic the bulk kernels pay for
+            if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
             if (gs_flag_ld(f) >= want) break;
-            if (gs_flag_ld(flags + GS_FL_ABORT)) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > GS_CH_TIMEOUT) {
-                gs_flag_st(flags + GS_FL_ABORT, 1u);
-                return false;
+            if ((spins & 15) == 15) {
+                if (gs_flag_ld(flags + GS_FL_ABORT)) return false;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > GS_CH_TIMEOUT) {
+                    gs_flag_st(flags + GS_FL_ABORT, 1u);
+                    return false;
+                }
             }
         }
     }
@@ -1650,6 +1655,14 @@ __device__ __forceinline__ bool gs_gate_wave(const unsigned* gate, unsigned want
 
 __global__ void k_signal(unsigned* f, unsigned v) {
     if (threadIdx.x == 0) gs_flag_st(f, v);
+}
+
+// one wave that waits for a chain flag in stream order: everything enqueued behind it on its stream starts only then.
+// Used once per factorisation: the gated kernels must not be dispatched before EVERY workgroup of k_chain is resident -- a
+// k_chain wave needs a whole SIMD's registers and its workgroup most of a CU's LDS, and gated waves that spin on a flag of a
+// chain workgroup that found no room would keep it out for good (seen: one factorisation in three timed out at n = 8192).
+__global__ __launch_bounds__(64) void k_wait_flag(const unsigned* f, unsigned want, unsigned* flags) {
+    (void)gs_wait_ge(f, want, flags);
 }
 
 // end of a persistent-chain factorisation: a chain that gave up (a wait timed out) says so through the info word
@@ -1885,11 +1898,9 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
             }
             return;
         }
+        // tables of block k to global memory, write-through; their flag goes out below, behind the row solves (the stores drain
+        // meanwhile: the P waves have the ~70 us until T1 for their first solve and sibling update)
         for (int i = t; i < GS_LTAB; i += 256) gs_st_wt(tab0 + i, wsd[i]);
-        gs_drain();
-        __syncthreads();
-        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T0, S, s), 1u);
-        if (st && t == 0) st[2] = __builtin_amdgcn_s_memrealtime();
         // ---- L10: row groups w and 7 - w of block row k + 1 against the tables in LDS
         if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD1, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 4, 8), fl, sh)) return;
         if (st && t == 0) st[3] = __builtin_amdgcn_s_memrealtime();
@@ -1900,7 +1911,10 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
         gs_panel16_solve2(Pa, Pb, wsd, lane);
         gs_panel16_store(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
         gs_panel16_store(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
-        __syncthreads();                            // every wave is through with the tables: the LDS now takes the images of L10
+        gs_drain();
+        __syncthreads();                            // tables published; every wave is through with them: the LDS takes the images of L10
+        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T0, S, s), 1u);
+        if (st && t == 0) st[2] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -1910,9 +1924,7 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
                 gs_st_wt(sib + ((g0 * 8 + kb) * 4 + x) * 64 + lane, Pa[kb][x]);
                 gs_st_wt(sib + ((g1 * 8 + kb) * 4 + x) * 64 + lane, Pb[kb][x]);
             }
-        gs_drain();
-        __syncthreads();
-        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_TL, S, s), 1u);
+        __syncthreads();                            // images in LDS (the copies for the other workgroups drain behind the update)
         if (st && t == 0) st[4] = __builtin_amdgcn_s_memrealtime();
         // ---- A11 -= L10 L10^T: micro-tiles (c, c') for c' in {g0, g1}, c >= c' (k_gemm_nt's arithmetic: -C + sum, ascending k)
         auto tile = [&](int c, int cp, const gs_d4 (&Pq)[8]) {
@@ -1929,7 +1941,9 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
         };
         for (int c = g0; c < 8; ++c) tile(c, g0, Pa);
         for (int c = g1; c < 8; ++c) tile(c, g1, Pb);
+        gs_drain();
         __syncthreads();
+        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_TL, S, s), 1u);
         if (st && t == 0) st[5] = __builtin_amdgcn_s_memrealtime();
         bad = gs_diag_block<true>(A11, ld, (double*)nullptr, (double*)nullptr, a.logdet + k + 1, a.diag0 + c0 + 128, nullptr, wsd);
         if (bad) {
@@ -2093,6 +2107,7 @@ __global__ __launch_bounds__(256, 1) void k_chain(gs_chain_args a) {
     extern __shared__ __attribute__((aligned(16))) double wsd[];
     __shared__ int sh_ok;
     __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) gs_flag_add(a.flags + GS_FL_RESIDENT);
     if (blockIdx.x == 0) {
         gs_chain_diag_role(a, wsd, &sh_ok);
     } else {
