@@ -522,9 +522,9 @@ class HipContext:
         return v
 
     def chain_stamps(self, max_steps: int = 512):
-        """(steps, 16) array of the last persistent-chain factorisation's realtime stamps in microseconds from its
+        """(steps, 24) array of the last persistent-chain factorisation's realtime stamps in microseconds from its
         start (NaN: not written); needs ``set_option("chain_stamps", 1)``.  Column meaning: include/gsum_hip.h."""
-        out = np.zeros((max_steps, 16))
+        out = np.zeros((max_steps, 24))
         steps = C.c_int32(0)
         self._check(self._lib.gsum_debug_chain_stamps(self._h, _ptr(out), max_steps, C.byref(steps)))
         out = out[: steps.value]

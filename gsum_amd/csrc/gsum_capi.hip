@@ -117,8 +117,13 @@ struct gsum_ctx {
                                      // profiler serialises dispatches): the chain schedule would deadlock until its timeout
     int chain_events_needed = 0;     // the gradient path trails the factorisation by evP events: host-enqueued schedule only
     int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
+    unsigned long long* kst_ptr = nullptr;   // diagnostics: start / end stamp pair of the NEXT bulk (cfg 7) / k_panel256 launch
     const unsigned* gate_ptr = nullptr;   // gate of the NEXT bulk (cfg 7) / k_panel256 launch; consumed by it
     unsigned gate_want = 0;
+    const unsigned* gate2_ptr = nullptr;  // ... a second counter the same launch waits for (cfg 7 only)
+    unsigned gate2_want = 0;
+    int first_tiles = 0;                  // ... tri launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
+    unsigned* first_done = nullptr;
     unsigned* gate_flags = nullptr;
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
                                      // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
@@ -265,8 +270,12 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
             blocks = ((M + 127) / 128) * ((N + 63) / 64);
         }
         hipLaunchKernelGGL(k_gemm_ld3, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                           beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate_flags);
-        ctx->gate_ptr = nullptr;
+                           beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
+                           tri == 1 ? ctx->first_tiles : 0, ctx->first_done);
+        ctx->gate_ptr = ctx->gate2_ptr = nullptr;
+        ctx->kst_ptr = nullptr;
+        ctx->first_tiles = 0;
+        ctx->first_done = nullptr;
         GS_CHECK(hipGetLastError());
         return 0;
     }
@@ -571,8 +580,9 @@ static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, d
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
     hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
                        m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->gate_ptr, ctx->gate_want,
-                       ctx->gate_flags);
+                       ctx->gate_flags, ctx->kst_ptr);
     ctx->gate_ptr = nullptr;
+    ctx->kst_ptr = nullptr;
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
@@ -740,9 +750,9 @@ static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
     const int S = m->T / 2;
     if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)gs_fl_count(S) * sizeof(unsigned)));
     if (!m->cdump) GS_CHECK(hipMalloc((void**)&m->cdump, (size_t)2 * GS_CH_GMAX * 16 * 256 * sizeof(double)));
-    if (!m->cstamps) {
-        GS_CHECK(hipMalloc((void**)&m->cstamps, (size_t)S * GS_CH_STAMPS * sizeof(unsigned long long)));
-        GS_CHECK(hipMemset(m->cstamps, 0, (size_t)S * GS_CH_STAMPS * sizeof(unsigned long long)));
+    if (!m->cstamps) {       // S x 16 chain stamps | S x 4 launch starts (preset to all ones: atomicMin) | S x 4 launch ends
+        GS_CHECK(hipMalloc((void**)&m->cstamps, (size_t)S * (GS_CH_STAMPS + GS_CH_KSTAMPS) * sizeof(unsigned long long)));
+        GS_CHECK(hipMemset(m->cstamps, 0, (size_t)S * (GS_CH_STAMPS + GS_CH_KSTAMPS) * sizeof(unsigned long long)));
     }
     if (!ctx->lds_attr_done.count((const void*)k_chain)) {
         GS_CHECK(hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -761,9 +771,9 @@ static bool gs_chain_wanted(const gsum_ctx* ctx, const gsum_mat* m) {
 // Outer step s (panel columns [c0, c0 + 256), trailing matrix from r2 = c0 + 256), K = 256 everywhere:
 //   k_chain            diagonal super-block, the window rows [r2, r2 + W) of the panel, C[window rows][r2, r2 + 256)
 //   sa: rest(s)        rows >= r2 + W of the panel (k_panel256, gated on T1[s])                       -> evP[s]
-//       A(s)           C[rows >= r2 + W][r2, r2 + 256)            gated on the window's first 16 row groups   -> FA[s]
-//       B(s)           C[rows >= r2 + 256][r2 + 256, r2 + 512)    gated on the whole window, after Far(s - 1) -> FB[s]
-//   sm: Far(s)         lower tiles of C[rows, columns >= r2 + 512], after rest(s)                     -> evM[s]
+//       A(s)           C[rows >= r2 + W][r2, r2 + 256)            gated on the window's first 16 row groups and on FB[s - 1]  -> FA[s]
+//   sm: B(s) + Far(s)  lower tiles of C[rows, columns >= r2 + 256] in one launch, gated on the whole window, after rest(s); the tiles
+//                      of its first 256 columns (B) first, counted in FB[s]
 static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     gs_slot* sl = ctx->cur;
     const int T = m->T, S = T / 2;
@@ -788,44 +798,61 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     }
     // nothing of the other streams is dispatched before every workgroup of the chain is resident (see k_wait_flag); the main
     // stream follows sa through evP[0]
-    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, sa, (const unsigned*)(fl + GS_FL_RESIDENT), (unsigned)(1 + W / 64), fl);
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, sa, (const unsigned*)(fl + GS_FL_RESIDENT), (unsigned)(1 + W / 64),
+                       (const unsigned*)nullptr, 0u, fl);
     GS_CHECK(hipGetLastError());
-    auto gate = [&](int kind, int s, unsigned want) {
-        ctx->gate_ptr = fl + gs_fl(kind, S, s);
-        ctx->gate_want = want;
-        ctx->gate_flags = fl;
+    // the stream waits for chain flags (one spinning wave; see k_wait_flag)
+    auto wait1 = [&](hipStream_t st, int kind, int s, unsigned want) {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want, (const unsigned*)nullptr, 0u, fl);
     };
-    int prev_far = -1;
+    auto wait2 = [&](hipStream_t st, int kind, int s, unsigned want, int kind2, int s2, unsigned want2) {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want,
+                           (const unsigned*)(fl + gs_fl(kind2, S, s2)), want2, fl);
+    };
+    unsigned long long* kst0 = nullptr;          // launch stamps (diagnostics): a (first start, last end) pair per launch, four per step
+    if (ctx->chain_stamps) {
+        // a launch writes kst[0] (atomicMin) and kst[1] (atomicMax): interleave (start, end) pairs, starts preset to all ones
+        kst0 = m->cstamps + (size_t)S * GS_CH_STAMPS;
+        std::vector<unsigned long long> init((size_t)S * GS_CH_KSTAMPS);
+        for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+        GS_CHECK(hipMemcpyAsync(kst0, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, sm));
+        GS_CHECK(hipStreamSynchronize(sm));      // (diagnostic mode only: the host vector goes out of scope)
+    }
+    auto kstamp = [&](int s, int which) { ctx->kst_ptr = kst0 ? kst0 + ((size_t)s * 4 + which) * 2 : nullptr; };
+    // B and Far are ONE launch on the main stream (k_gemm_ld3, nfirst): B's tiles take the first block ids, start on an empty chip
+    // the moment the previous trailing update ends, are stored write-through and counted in FB[s]; Far's tiles follow in the same
+    // grid.  sa keeps rest -> A, ~70 us per step.  (Measured on the way: rest / A / B on sa with B waiting for Far(s - 1) by event:
+    // the cycle rest -> A -> B -> rest, ~135 us, bound steps 11-20, 5.61 ms; the panel on a stream of its own with two more events
+    // per step made every cross-stream wait 60-90 us, 6.9 ms; B as its own launch in front of Far on the main stream idled the chip
+    // for ~45 us per step in the first third, 5.83 ms.)
     for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
         const int k = 2 * s;
         const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
         const int Gs = (int)((wend - r2) / 16);
         if (mr > 0) {
-            gate(GS_FL_T1, s, 1u);
+            wait1(sa, GS_FL_T1, s, 1u);
+            kstamp(s, 0);
             if (gs_panel256(ctx, sa, m, k, A + wend * ld + c0, ld, mr)) return -1;
         }
         GS_CHECK(hipEventRecord(sl->evP[s], sa));
         if (mr > 0) {
-            gate(GS_FL_WTOP, s, (unsigned)std::min(16, Gs));
+            // the window's first 16 row groups (this update's B operand) and B(s - 1) (the same region of C)
+            if (s > 0) wait2(sa, GS_FL_WTOP, s, (unsigned)std::min(16, Gs), GS_FL_FB, s - 1, gs_ch_nfirst((int)naug, s - 1));
+            else wait1(sa, GS_FL_WTOP, s, (unsigned)std::min(16, Gs));
+            kstamp(s, 1);
             if (gs_gemm(ctx, sa, GS_BULK, A + wend * ld + r2, ld, A + wend * ld + c0, ld, A + r2 * ld + c0, ld, mr, 256, 256, 0, 1, -1.0)) return -1;
         }
         hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FA, S, s), 1u);
-        const int64_t r3 = r2 + 256, m3 = naug - r3, wb = std::min<int64_t>(256, m3);
-        if (m3 > 0) {
-            if (prev_far >= 0) GS_CHECK(hipStreamWaitEvent(sa, sl->evM[prev_far], 0));
-            gate(GS_FL_WALL, s, (unsigned)Gs);
-            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * wb - (double)wb * (wb - 1));
-            if (gs_gemm(ctx, sa, GS_BULK, A + r3 * ld + r3, ld, A + r3 * ld + c0, ld, A + r3 * ld + c0, ld, m3, wb, 256, 0, 1, -1.0)) return -1;
-        }
-        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FB, S, s), 1u);
         GS_CHECK(hipGetLastError());
-        const int64_t r4 = r3 + 256, m4 = naug - r4;
-        if (m4 > 0) {
+        const int64_t r3 = r2 + 256, m3 = naug - r3;
+        if (m3 > 0) {
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[s], 0));
-            if (W < 512) gate(GS_FL_WALL, s, (unsigned)Gs);      // (W = 512: every operand row of Far is below the window)
-            if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, A + r4 * ld + c0, ld, A + r4 * ld + c0, ld, m4, m4, 256, 1, 1, -1.0)) return -1;
-            GS_CHECK(hipEventRecord(sl->evM[s], sm));
-            prev_far = s;
+            wait1(sm, GS_FL_WALL, s, (unsigned)Gs);
+            ctx->first_tiles = (int)gs_ch_nfirst((int)naug, s);
+            ctx->first_done = fl + gs_fl(GS_FL_FB, S, s);
+            ctx->gate_flags = fl;
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, A + r3 * ld + c0, ld, A + r3 * ld + c0, ld, m3, m3, 256, 1, 1, -1.0)) return -1;
         }
     }
     GS_CHECK(hipEventRecord(sl->evC, sp));
@@ -2011,12 +2038,22 @@ int gsum_debug_chain_stamps(gsum_ctx* ctx, double* out, int32_t max_steps, int32
     gsum_mat* m = ctx->slots[0].ws;
     *steps = 0;
     if (!m || !m->cstamps) return 0;
-    const int S = std::min<int>(m->T / 2, max_steps);
-    std::vector<unsigned long long> h((size_t)S * GS_CH_STAMPS);
+    const int Sall = m->T / 2, S = std::min<int>(Sall, max_steps);
+    std::vector<unsigned long long> h((size_t)Sall * (GS_CH_STAMPS + GS_CH_KSTAMPS));
     GS_CHECK(hipDeviceSynchronize());
     GS_CHECK(hipMemcpy(h.data(), m->cstamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const unsigned long long t0 = h.empty() ? 0 : h[0];
-    for (size_t i = 0; i < h.size(); ++i) out[i] = h[i] ? (double)(long long)(h[i] - t0) : -1.0;
+    const int WOUT = GS_CH_STAMPS + GS_CH_KSTAMPS;
+    for (int s = 0; s < S; ++s) {
+        for (int i = 0; i < GS_CH_STAMPS; ++i) {
+            const unsigned long long v = h[(size_t)s * GS_CH_STAMPS + i];
+            out[(size_t)s * WOUT + i] = v ? (double)(long long)(v - t0) : -1.0;
+        }
+        for (int i = 0; i < GS_CH_KSTAMPS; ++i) {
+            const unsigned long long v = h[(size_t)Sall * GS_CH_STAMPS + (size_t)s * GS_CH_KSTAMPS + i];
+            out[(size_t)s * WOUT + GS_CH_STAMPS + i] = (v && v != ~0ull) ? (double)(long long)(v - t0) : -1.0;
+        }
+    }
     *steps = S;
     return 0;
 }

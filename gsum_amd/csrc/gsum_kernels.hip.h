@@ -1595,6 +1595,7 @@ __host__ __device__ inline int gs_fl_wg(int S, int s, int g) { return GS_FL_BASE
 __host__ __device__ inline int gs_fl_count(int S) { return (GS_FL_BASE + (GS_FL_KINDS + GS_CH_GMAX) * S + 3) / 4 * 4; }
 #define GS_CH_TIMEOUT 100000000ull          // 1 s of s_memrealtime (100 MHz)
 #define GS_CH_STAMPS 16                     // u64 per outer step (diagnostics)
+#define GS_CH_KSTAMPS 8                     // ... and first start / last end of the step's four host-enqueued launches
 #define GS_CH_LDS_DOUBLES GS_LSIB           // 128 KB: the L10 operand images (>= the diagonal routine's 75.8 KB workspace)
 
 #define GS_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -1657,12 +1658,15 @@ __global__ void k_signal(unsigned* f, unsigned v) {
     if (threadIdx.x == 0) gs_flag_st(f, v);
 }
 
-// one wave that waits for a chain flag in stream order: everything enqueued behind it on its stream starts only then.
-// Used once per factorisation: the gated kernels must not be dispatched before EVERY workgroup of k_chain is resident -- a
-// k_chain wave needs a whole SIMD's registers and its workgroup most of a CU's LDS, and gated waves that spin on a flag of a
-// chain workgroup that found no room would keep it out for good (seen: one factorisation in three timed out at n = 8192).
-__global__ __launch_bounds__(64) void k_wait_flag(const unsigned* f, unsigned want, unsigned* flags) {
-    (void)gs_wait_ge(f, want, flags);
+// one wave that waits for chain flags in stream order: everything enqueued behind it on its stream starts only then (the
+// launch boundary is the acquire).  This is how the host-enqueued kernels of the schedule meet the chain: a poll + acquire +
+// two barriers in front of EVERY workgroup of a 3000-workgroup trailing update cost 24 us per outer step (measured), and
+// gated workgroups hold their slots while they spin; one spinning wave costs nothing.
+// Also once per factorisation: nothing is dispatched before EVERY workgroup of k_chain is resident -- a k_chain wave needs a whole
+// SIMD's registers and its workgroup most of a CU's LDS, and other streams' waves that wait for a chain workgroup that found no
+// room would keep it out for good (seen: one factorisation in three timed out at n = 8192).
+__global__ __launch_bounds__(64) void k_wait_flag(const unsigned* f, unsigned want, const unsigned* f2, unsigned want2, unsigned* flags) {
+    if (gs_poll_ge(f, want, flags) && f2) (void)gs_poll_ge(f2, want2, flags);
 }
 
 // end of a persistent-chain factorisation: a chain that gave up (a wait timed out) says so through the info word
@@ -1688,12 +1692,14 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
 // gate != NULL (persistent-chain schedule): the tables are the chain kernel's; wait for its flag first.
 __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, const unsigned* gate, unsigned gate_want, unsigned* flags) {
+                                                  const double* Ltab1, const unsigned* gate, unsigned gate_want, unsigned* flags,
+                                                  unsigned long long* kst) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
     __builtin_amdgcn_s_setprio(3);
     if (!gs_gate_wave(gate, gate_want, flags)) return;
+    if (kst && lane == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());          // diagnostics: first start / last end of the launch
     double* rows = P + (int64_t)r0 * ld;
     gs_d4 P0[8], P1[8];
     gs_panel16_load(P0, rows, ld, M - r0, lane);
@@ -1705,6 +1711,7 @@ __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M
     __builtin_amdgcn_sched_barrier(0);
     gs_panel16_solve_g(P1, Ltab1, lane);
     gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
+    if (kst && lane == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
@@ -1827,6 +1834,10 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld,
 // per-lane 64-bit table addresses (base + lane + constant) out of the loop and spills them (1000 spilled VGPRs measured)
 template <class T>
 __device__ __forceinline__ T* gs_uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;          // (readfirstlane: uniform by construction, whatever the
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);               // divergence analysis thinks)
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    p = (T*)(((unsigned long long)hi << 32) | lo);
     asm volatile("" : "+s"(p));
     return p;
 }
@@ -1845,6 +1856,11 @@ __device__ __forceinline__ void gs_ch_geom(int np, int naug, int W, int s, int& 
     const int wend = min(r2 + W, naug);
     Gs = (wend - r2) / 16;
     Gc = min(16, (naug - r2) / 16);
+}
+// tiles of the first 256 columns of outer step s's host-enqueued trailing update (k_gemm_ld3, nfirst): what FB[s] counts up to
+__host__ __device__ inline unsigned gs_ch_nfirst(int naug, int s) {
+    const int m3 = naug - 256 * (s + 2);
+    return m3 > 0 ? (unsigned)(4 * ((m3 + 127) / 128) - 2) : 0u;
 }
 // number of 32 x 32 update tasks (I, J), J <= I, with Ilo <= I < Ihi, in a window of Gs row and Gc column groups
 __device__ __forceinline__ int gs_ch_ntasks(int Gs, int Gc, int Ilo, int Ihi) {
@@ -1909,12 +1925,11 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
         gs_panel16_load(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
         gs_panel16_load(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
         gs_panel16_solve2(Pa, Pb, wsd, lane);
-        gs_panel16_store(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
-        gs_panel16_store(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
         gs_drain();
         __syncthreads();                            // tables published; every wave is through with them: the LDS takes the images of L10
         if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T0, S, s), 1u);
         if (st && t == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        // (L10's rows go back to the matrix from the published image, by P waves 0..7: gs_chain_panel_role)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -1961,9 +1976,117 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
     }
 }
 
-// ---- P role: one wave = one 16-row group of the window per outer step, then its share of the window's update tasks
-__device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int pw, int NPW, int lane) {
+// ---- P role: one wave = one 16-row group of the window per outer step, then its share of the window's update tasks.
+// A 32 x 32 update task (I, J): C[rows of groups 2I, 2I+1][columns of groups 2J, 2J+1] -= P P^T over the panel's 256 columns
+// (16 k-blocks of operand images); held in four accumulators that start as -C (the bulk tiles' arithmetic).
+struct gs_utask {
+    int I, J, gi0, gj0;
+    bool va1, vb1, v01, v10, v11;
+    double* C0;
+    const double *dA0, *dA1, *dB0, *dB1;
+    gs_d4 c00, c01, c10, c11;
+};
+
+__device__ __forceinline__ bool gs_utask_decode(gs_utask& u, int tk, int Gs, int Gc, double* A, int64_t ld, int r2, const double* dump,
+                                                int lane) {
+    const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
+    int I = 0, J = -1, seen = 0;
+    for (I = 0; I < NI; ++I) {
+        const int c = min(I + 1, NJ);
+        if (tk < seen + c) { J = tk - seen; break; }
+        seen += c;
+    }
+    if (J < 0) return false;
+    u.I = I; u.J = J; u.gi0 = 2 * I; u.gj0 = 2 * J;
+    u.va1 = u.gi0 + 1 < Gs;
+    u.vb1 = u.gj0 + 1 < Gc;
+    // micro-tile (a, b): rows of group gi0 + a, columns of group gj0 + b; on a diagonal task only the lower ones
+    u.v01 = u.vb1 && u.gi0 >= u.gj0 + 1;
+    u.v10 = u.va1;
+    u.v11 = u.va1 && u.vb1;
+    u.C0 = gs_uniform_ptr(A + (int64_t)(r2 + 16 * u.gi0) * ld + r2 + 16 * u.gj0);
+    u.dA0 = gs_uniform_ptr(dump + (size_t)u.gi0 * 16 * 256) + lane;
+    u.dA1 = gs_uniform_ptr(dump + (size_t)(u.va1 ? u.gi0 + 1 : u.gi0) * 16 * 256) + lane;
+    u.dB0 = gs_uniform_ptr(dump + (size_t)u.gj0 * 16 * 256) + lane;
+    u.dB1 = gs_uniform_ptr(dump + (size_t)(u.vb1 ? u.gj0 + 1 : u.gj0) * 16 * 256) + lane;
+    return true;
+}
+
+// the flags of the four row groups a task multiplies have reached `want` (1: first 128 panel columns published, 2: all 256)
+__device__ __forceinline__ bool gs_utask_poll(const gs_utask& u, unsigned* fl, int S, int s, unsigned want) {
+    if (!gs_poll_ge(fl + gs_fl_wg(S, s, u.gi0), want, fl)) return false;
+    if (u.va1 && !gs_poll_ge(fl + gs_fl_wg(S, s, u.gi0 + 1), want, fl)) return false;
+    if (!gs_poll_ge(fl + gs_fl_wg(S, s, u.gj0), want, fl)) return false;
+    if (u.vb1 && !gs_poll_ge(fl + gs_fl_wg(S, s, u.gj0 + 1), want, fl)) return false;
+    return true;
+}
+
+__device__ __forceinline__ void gs_utask_load(gs_utask& u, int64_t ld, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
+        u.c00[x] = -u.C0[ro];
+        u.c01[x] = u.v01 ? -u.C0[ro + 16] : 0.0;
+        u.c10[x] = u.v10 ? -u.C0[ro + 16 * ld] : 0.0;
+        u.c11[x] = u.v11 ? -u.C0[ro + 16 * ld + 16] : 0.0;
+    }
+}
+
+// k-blocks [kb0, kb1) in ascending order, operands one k-block ahead
+__device__ __forceinline__ void gs_utask_accumulate(gs_utask& u, int kb0, int kb1) {
+    gs_d4 a0, a1, b0, b1, na0, na1, nb0, nb1;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        a0[x] = u.dA0[(kb0 * 4 + x) * 64];
+        a1[x] = u.dA1[(kb0 * 4 + x) * 64];
+        b0[x] = u.dB0[(kb0 * 4 + x) * 64];
+        b1[x] = u.dB1[(kb0 * 4 + x) * 64];
+    }
+#pragma unroll 1
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int kn = kb + 1 < kb1 ? kb + 1 : kb;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            na0[x] = u.dA0[(kn * 4 + x) * 64];
+            na1[x] = u.dA1[(kn * 4 + x) * 64];
+            nb0[x] = u.dB0[(kn * 4 + x) * 64];
+            nb1[x] = u.dB1[(kn * 4 + x) * 64];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u.c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[x], u.c00, 0, 0, 0);
+            if (u.v01) u.c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b1[x], u.c01, 0, 0, 0);
+            if (u.v10) u.c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b0[x], u.c10, 0, 0, 0);
+            if (u.v11) u.c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[x], u.c11, 0, 0, 0);
+        }
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+
+__device__ __forceinline__ void gs_utask_store(const gs_utask& u, int64_t ld, unsigned* fl, int S, int s, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
+        gs_st_wt(u.C0 + ro, -u.c00[x]);
+        if (u.v01) gs_st_wt(u.C0 + ro + 16, -u.c01[x]);
+        if (u.v10) gs_st_wt(u.C0 + ro + 16 * ld, -u.c10[x]);
+        if (u.v11) gs_st_wt(u.C0 + ro + 16 * ld + 16, -u.c11[x]);
+    }
+    gs_drain();
+    if (lane == 0) gs_flag_add(fl + gs_fl(u.I < 4 ? GS_FL_UD0 : (u.I < 8 ? GS_FL_UD1 : GS_FL_UR), S, s));
+}
+
+// Per outer step, wave pw (its workgroup's four waves meet at two barriers: the second block's tables are staged in LDS once):
+//   rows ready -> [T0] X_k, published (group flag = 1) -> [TL] sibling update; L10's rows to the matrix (waves 0..7) ->
+//   FIRST HALF of its first update task (k-blocks 0..7 need only the X_k images; accumulators stay in registers) ->
+//   [T1] tables of block k + 1 into LDS (the four waves a quarter each) -> X_k+1, published (group flag = 2) ->
+//   second half of that task -> its other tasks in full.
+// What is left on the chain's critical path between T1 and the next diagonal block: one solve from LDS, one publish, 128 MFMAs.
+__device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int pw, int NPW, int lane, double* tabl) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wq = pw & 3;                       // wave within its workgroup
     const int S = a.S;
     const int64_t ld = a.ld;
     unsigned* fl = a.flags;
@@ -1971,20 +2094,20 @@ __device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int 
         int r2, Gs, Gc;
         gs_ch_geom(a.np, a.naug, a.W, s, r2, Gs, Gc);
         const int64_t c0 = 256 * (int64_t)s;
-        const double* tab0_s = a.Ltab + (size_t)(2 * s) * GS_LTAB;
-        const double* sib_s = a.Lsib + (size_t)s * GS_LSIB;
+        const double* tab0 = gs_uniform_ptr(a.Ltab + (size_t)(2 * s) * GS_LTAB);
+        const double* tab1 = gs_uniform_ptr(a.Ltab + (size_t)(2 * s + 1) * GS_LTAB);
+        const double* sib = gs_uniform_ptr(a.Lsib + (size_t)s * GS_LSIB);
         double* dump = a.dump + (size_t)(s & 1) * GS_CH_GMAX * 16 * 256;
         unsigned long long* st = (a.stamps && pw == 0) ? a.stamps + (size_t)s * GS_CH_STAMPS : nullptr;
         int pr2 = 0, pGs = 0, pGc = 0;
         if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
-        // ---- panel: X_k = B_k L_kk^-T;  B_k+1 -= X_k L(k+1, k)^T;  X_k+1 = B_k+1 L_k+1,k+1^-T   (k_panel256's arithmetic)
-#pragma unroll 1
-        for (int g = pw; g < Gs; g += NPW) {
-            double* rows = gs_uniform_ptr(a.A + (int64_t)(r2 + 16 * g) * ld + c0);
-            const double* tab0 = gs_uniform_ptr(tab0_s);
-            const double* tab1 = gs_uniform_ptr(tab0_s + GS_LTAB);
-            const double* sib = gs_uniform_ptr(sib_s);
-            double* img = gs_uniform_ptr(dump + (size_t)g * 16 * 256);
+        const int g = pw;
+        const bool has = g < Gs;                 // NPW = W / 16 >= Gs: a wave owns at most one row group
+        double* rows = gs_uniform_ptr(a.A + (int64_t)(r2 + 16 * (has ? g : 0)) * ld + c0);
+        double* img = gs_uniform_ptr(dump + (size_t)(has ? g : 0) * 16 * 256);
+        gs_d4 P0[8], P1[8];
+        // ---- X_k = B_k L_kk^-T  (k_panel256's arithmetic throughout)
+        if (has) {
             if (s > 0) {
                 // these rows' entries in panel s's columns: last updated by the window tasks of step s - 1 (rows that were
                 // in that window: its groups 16 ..) or by the host-enqueued update A(s - 1) (rows below it)
@@ -1994,7 +2117,6 @@ __device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int 
                 if (!gs_wait_ge(f, want, fl)) return;
             }
             if (st) st[8] = __builtin_amdgcn_s_memrealtime();
-            gs_d4 P0[8], P1[8];
             gs_panel16_load(P0, rows, ld, 16, lane);
             if (!gs_wait_ge(fl + gs_fl(GS_FL_T0, S, s), 1u, fl)) return;
             if (st) st[9] = __builtin_amdgcn_s_memrealtime();
@@ -2002,103 +2124,77 @@ __device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int 
             gs_panel16_solve_g(P0, tab0, lane);
             gs_panel16_store_wt(P0, rows, ld, lane);
             gs_image_store_wt(P0, img, lane);
+            gs_drain();
+            if (lane == 0) gs_flag_st(fl + gs_fl_wg(S, s, g), 1u);
             __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now (as k_panel256)
             gs_panel16_load(P1, rows + 128, ld, 16, lane);
+        }
+        if (has || pw < 8) {
             if (!gs_wait_ge(fl + gs_fl(GS_FL_TL, S, s), 1u, fl)) return;
+        }
+        if (has) {
             gs_sib_update_lean(P1, P0, sib, lane);
             __builtin_amdgcn_sched_barrier(0);
-            if (st) st[10] = __builtin_amdgcn_s_memrealtime();
-            if (!gs_wait_ge(fl + gs_fl(GS_FL_T1, S, s), 1u, fl)) return;
-            if (st) st[11] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-            gs_panel16_solve_g(P1, tab1, lane);
+        }
+        if (pw < 8) {
+            // L(k+1, k) back into the matrix, from its operand image (the diagonal workgroup only publishes the image: 128
+            // scattered stores per lane off its critical path); nobody reads these rows before the factorisation ends
+            double* l10 = gs_uniform_ptr(a.A + (c0 + 128 + 16 * pw) * ld + c0);
+            const double* im = gs_uniform_ptr(sib + (size_t)pw * 8 * 256) + lane;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) l10[(int64_t)fr * ld + 16 * kb + fq + 4 * x] = -im[(kb * 4 + x) * 64];
+        }
+        if (st) st[10] = __builtin_amdgcn_s_memrealtime();
+        // ---- first half of this wave's first update task, while the diagonal workgroup factors block k + 1
+        const int ntask = gs_ch_ntasks(Gs, Gc, 0, 1 << 20);
+        gs_utask u;
+        bool early = false;
+        const bool have_task = pw < ntask && gs_utask_decode(u, pw, Gs, Gc, a.A, ld, r2, dump, lane);
+        const unsigned fb_want = s > 0 ? gs_ch_nfirst(a.naug, s - 1) : 0u;     // B(s - 1): C's last host-enqueued update, counted per tile
+        if (have_task && gs_flag_ld(fl + gs_fl(GS_FL_FB, S, s > 0 ? s - 1 : 0)) >= fb_want) {      // (C is up to date already: else later, in full)
+            if (!gs_utask_poll(u, fl, S, s, 1u)) return;
+            gs_acquire();
+            gs_utask_load(u, ld, lane);
+            gs_utask_accumulate(u, 0, 8);
+            early = true;
+        }
+        // ---- tables of block k + 1 into LDS, X_k+1 = B_k+1 L_k+1,k+1^-T
+        if (!gs_wait_ge(fl + gs_fl(GS_FL_T1, S, s), 1u, fl)) return;
+        if (st) st[11] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();                             // the previous step's readers of the LDS tables are through
+        gs_load_ltab_direct(tabl, tab1, wq, lane);
+        gs_drain();
+        __syncthreads();
+        if (has) {
+            gs_panel16_solve(P1, tabl, lane);
             gs_panel16_store_wt(P1, rows + 128, ld, lane);
             gs_image_store_wt(P1, img + 8 * 256, lane);
             gs_drain();
             if (lane == 0) {
-                gs_flag_st(fl + gs_fl_wg(S, s, g), 1u);
+                gs_flag_st(fl + gs_fl_wg(S, s, g), 2u);
                 if (g < 16) gs_flag_add(fl + gs_fl(GS_FL_WTOP, S, s));
                 gs_flag_add(fl + gs_fl(GS_FL_WALL, S, s));
             }
-            if (st) st[12] = __builtin_amdgcn_s_memrealtime();
         }
-        // ---- the window's share of the trailing update: C[rows of groups 2I, 2I+1][columns of groups 2J, 2J+1] -= P P^T, K = 256,
-        // tasks in ascending I (the next diagonal block's first)
-        const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
-        const int ntask = gs_ch_ntasks(Gs, Gc, 0, 1 << 20);
-        bool first = true;
+        if (st) st[12] = __builtin_amdgcn_s_memrealtime();
+        // ---- the window's share of the trailing update, tasks in ascending I (the next diagonal block's first)
         for (int tk = pw; tk < ntask; tk += NPW) {
-            int I = 0, J = 0, seen = 0;
-            for (I = 0; I < NI; ++I) {
-                const int c = min(I + 1, NJ);
-                if (tk < seen + c) { J = tk - seen; break; }
-                seen += c;
-            }
-            const int gi0 = 2 * I, gj0 = 2 * J;
-            const bool va1 = gi0 + 1 < Gs, vb1 = gj0 + 1 < Gc;
-            // the panel rows this task multiplies, and the last host-enqueued update of its C tile (B(s - 1))
-            if (!gs_poll_ge(fl + gs_fl_wg(S, s, gi0), 1u, fl)) return;
-            if (va1 && !gs_poll_ge(fl + gs_fl_wg(S, s, gi0 + 1), 1u, fl)) return;
-            if (!gs_poll_ge(fl + gs_fl_wg(S, s, gj0), 1u, fl)) return;
-            if (vb1 && !gs_poll_ge(fl + gs_fl_wg(S, s, gj0 + 1), 1u, fl)) return;
-            if (s > 0 && !gs_poll_ge(fl + gs_fl(GS_FL_FB, S, s - 1), 1u, fl)) return;
+            const bool first = tk == pw;
+            if (!first && !gs_utask_decode(u, tk, Gs, Gc, a.A, ld, r2, dump, lane)) break;
+            if (!gs_utask_poll(u, fl, S, s, 2u)) return;
+            if (s > 0 && !gs_poll_ge(fl + gs_fl(GS_FL_FB, S, s - 1), fb_want, fl)) return;
             gs_acquire();
             if (st && first) st[13] = __builtin_amdgcn_s_memrealtime();
-            // micro-tile (a, b): rows of group gi0 + a, columns of group gj0 + b; on the diagonal task only the lower ones
-            const bool v00 = true, v01 = vb1 && gi0 >= gj0 + 1, v10 = va1, v11 = va1 && vb1;
-            double* C0 = a.A + (int64_t)(r2 + 16 * gi0) * ld + r2 + 16 * gj0;
-            gs_d4 c00, c01, c10, c11;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
-                c00[x] = -C0[ro];
-                c01[x] = v01 ? -C0[ro + 16] : 0.0;
-                c10[x] = v10 ? -C0[ro + 16 * ld] : 0.0;
-                c11[x] = v11 ? -C0[ro + 16 * ld + 16] : 0.0;
+            if (first && early) {
+                gs_utask_accumulate(u, 8, 16);
+            } else {
+                gs_utask_load(u, ld, lane);
+                gs_utask_accumulate(u, 0, 16);
             }
-            const double* dA0 = dump + (size_t)gi0 * 16 * 256 + lane;
-            const double* dA1 = dump + (size_t)(va1 ? gi0 + 1 : gi0) * 16 * 256 + lane;
-            const double* dB0 = dump + (size_t)gj0 * 16 * 256 + lane;
-            const double* dB1 = dump + (size_t)(vb1 ? gj0 + 1 : gj0) * 16 * 256 + lane;
-            gs_d4 a0, a1, b0, b1, na0, na1, nb0, nb1;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                a0[x] = dA0[x * 64];
-                a1[x] = dA1[x * 64];
-                b0[x] = dB0[x * 64];
-                b1[x] = dB1[x * 64];
-            }
-#pragma unroll 1
-            for (int kb = 0; kb < 16; ++kb) {
-                const int kn = kb + 1 < 16 ? kb + 1 : kb;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    na0[x] = dA0[(kn * 4 + x) * 64];
-                    na1[x] = dA1[(kn * 4 + x) * 64];
-                    nb0[x] = dB0[(kn * 4 + x) * 64];
-                    nb1[x] = dB1[(kn * 4 + x) * 64];
-                }
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[x], c00, 0, 0, 0);
-                    if (v01) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b1[x], c01, 0, 0, 0);
-                    if (v10) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b0[x], c10, 0, 0, 0);
-                    if (v11) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[x], c11, 0, 0, 0);
-                }
-                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
-                gs_st_wt(C0 + ro, -c00[x]);
-                if (v01) gs_st_wt(C0 + ro + 16, -c01[x]);
-                if (v10) gs_st_wt(C0 + ro + 16 * ld, -c10[x]);
-                if (v11) gs_st_wt(C0 + ro + 16 * ld + 16, -c11[x]);
-            }
-            gs_drain();
-            if (lane == 0) gs_flag_add(fl + gs_fl(I < 4 ? GS_FL_UD0 : (I < 8 ? GS_FL_UD1 : GS_FL_UR), S, s));
+            gs_utask_store(u, ld, fl, S, s, lane);
             if (st && first) st[14] = __builtin_amdgcn_s_memrealtime();
-            first = false;
         }
     }
 }
@@ -2112,7 +2208,7 @@ __global__ __launch_bounds__(256, 1) void k_chain(gs_chain_args a) {
         gs_chain_diag_role(a, wsd, &sh_ok);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        gs_chain_panel_role(a, ((int)blockIdx.x - 1) * 4 + w, ((int)gridDim.x - 1) * 4, threadIdx.x & 63);
+        gs_chain_panel_role(a, ((int)blockIdx.x - 1) * 4 + w, ((int)gridDim.x - 1) * 4, threadIdx.x & 63, wsd);
     }
 }
 
@@ -2838,11 +2934,17 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
 // 512).  Costs 50 % more operand loads per flop (served by L2).  Same staging layout and sign handling as k_gemm_ld;
 // results identical bit for bit.  Measured against k_gemm_ld in the same process: equal at M = 7936, +18 % at M = 4096
 // exclusive; -4 % time per pipelined evaluation, -6 % for one factorisation alone (n = 8192).
-// gate != NULL (persistent-chain schedule): the launch reads panel rows the chain kernel publishes; thread 0's wave polls the
-// chain's counter, acquires, and the workgroup starts behind a barrier (the flag rides in the not-yet-used staging LDS).
+// Persistent-chain schedule (gate != NULL): the launch reads panel rows the chain kernel publishes; thread 0's wave polls the
+// chain's counter(s), acquires, and the workgroup starts behind a barrier (the flag rides in the not-yet-used staging LDS).
+// nfirst > 0 (tri launches of that schedule): the tiles of the first 256 COLUMNS take the first nfirst block ids -- they
+// are dispatched first, stored write-through and counted in *first_done, because the chain's next-but-one outer step and the
+// next step's A update wait for exactly them ("B"), not for the rest of the trailing update ("Far") behind them in the same
+// launch.  One launch instead of two: B starts on an empty chip the moment the previous trailing update ends.
 __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                      const unsigned* gate, unsigned gate_want, unsigned* flags) {
+                                                      const unsigned* gate, unsigned gate_want, const unsigned* gate2,
+                                                      unsigned gate2_want, unsigned* flags, unsigned long long* kst, int nfirst,
+                                                      unsigned* first_done) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
@@ -2852,7 +2954,9 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
     if (gate) {                                   // uniform
         volatile int* okp = reinterpret_cast<volatile int*>(lds);
         if (t < 64) {
-            const bool ok = gs_wait_ge(gate, gate_want, flags);
+            bool ok = gs_poll_ge(gate, gate_want, flags);
+            if (ok && gate2) ok = gs_poll_ge(gate2, gate2_want, flags);
+            gs_acquire();
             gs_drain();
             if (t == 0) *okp = ok ? 1 : 0;
         }
@@ -2861,9 +2965,26 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
         __syncthreads();
         if (!ok) return;
     }
+    if (kst && t == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());             // diagnostics: first start / last end of the launch
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
-    if (tri) {
+    bool first_cols = false;
+    if (tri && nfirst > 0) {
+        // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
+        // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
+        const int bid = blockIdx.x;
+        if (bid < nfirst) {
+            if (bid < 2) { bm = 0; bn = bid; }
+            else { bm = 1 + (bid - 2) / 4; bn = (bid - 2) % 4; }
+            first_cols = true;
+        } else {
+            const int f = bid - nfirst;
+            bm = (int)((3.0 + sqrt(1.0 + 4.0 * (double)f)) * 0.5);
+            while ((int64_t)(bm - 1) * (bm - 2) > f) --bm;
+            while ((int64_t)bm * (bm - 1) <= f) ++bm;
+            bn = 4 + f - (bm - 1) * (bm - 2);
+        }
+    } else if (tri) {
         // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1.
         // (An XCD-aware order -- rows padded to multiples of 8 slots so that workgroup id and column tile agree modulo 8
         // and each XCD's L2 keeps one eighth of the B-side panel -- was measured: rocprofv3 FETCH_SIZE of the exclusive
@@ -2881,7 +3002,10 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
         bn = blockIdx.x / tm;
     }
     const int m0 = bm * BM, n0 = bn * BN;
-    if (n0 >= N) return;                      // tri: the last row of a ragged matrix may have one column tile too many
+    if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
+        if (first_cols && t == 0) gs_flag_add(first_done);
+        return;
+    }
     if (tri == 2) {
         A += m0;
         B += m0;
@@ -2967,9 +3091,19 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
+                if (row < M && col < N) {
+                    const double v = neg ? -acc[i][j][x] : acc[i][j][x];
+                    if (first_cols) gs_st_wt(C + (int64_t)row * ldc + col, v);
+                    else C[(int64_t)row * ldc + col] = v;
+                }
             }
         }
+    if (first_cols) {                         // published to the chain kernel: every wave drains, then one lane counts the tile
+        gs_drain();
+        __syncthreads();
+        if (t == 0) gs_flag_add(first_done);
+    }
+    if (kst && t == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
 }
 
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.

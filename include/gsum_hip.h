@@ -241,7 +241,8 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
 int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64);
 /* diagnostic: per-outer-step realtime stamps of the last persistent-chain factorisation (options "chain_stamps" = 1,
  * "chain_persist"; gsum_potrf_lower / a single fused evaluation on a matrix whose order is a multiple of 256): out holds
- * 16 values per step in 100 MHz ticks relative to the first stamp (-1: not written).  Indices: D role 0 step begins, 1 its
+ * 24 values per step in 100 MHz ticks relative to the first stamp (-1: not written); [16..23] = first start / last end of the
+ * step's four host-enqueued launches (panel of the rows below the window, updates A, B, Far).  Indices: D role 0 step begins, 1 its
  * diagonal block is up to date, 2 first block's tables published, 3 block row k + 1 up to date, 4 L(k+1, k) published,
  * 5 sibling update done, 6 second block's tables published; P wave 0: 8 its rows are up to date, 9 first tables seen,
  * 10 sibling update done, 11 second tables seen, 12 rows published, 13 its first update task starts, 14 is done.

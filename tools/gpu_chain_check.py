@@ -102,7 +102,7 @@ st = ctx.chain_stamps()
 np.set_printoptions(linewidth=250, precision=1, suppress=True)
 print("step: D[begin, diag ready, T0, row ready, TL, sib done, T1] | P0[rows ready, T0 seen, sib, T1 seen, published, task start, task done]  (us)")
 for s in range(st.shape[0]):
-    print(s, st[s, 0:7], "|", st[s, 8:15], flush=True)
+    print(s, st[s, 0:7], "|", st[s, 8:15], "| rest/A/B/Far", st[s, 16:24], flush=True)
 out["stamps_us"] = np.nan_to_num(st, nan=-1.0).tolist()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "chain_check.json"), "w") as f:
