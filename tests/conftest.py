@@ -44,6 +44,18 @@ def load_golden(name):
         return json.load(f)
 
 
+def s5_inputs(d):
+    """The S5 inputs by the fixture's recipe (bench.py's predict leg uses the same)."""
+    n, r = d["n"], d["r"]
+    side = np.array(d["side"])
+    X = np.random.RandomState(0).rand(n, 2) * side
+    Xs = np.random.RandomState(1).rand(d["m"], 2) * side
+    y = np.random.RandomState(2).randn(n, r)
+    assert float(np.sum(y * np.cos(np.arange(y.size).reshape(y.shape)))) == pytest.approx(d["y_checksum"], rel=1e-13)
+    assert float(np.sum(X * np.cos(np.arange(X.size).reshape(X.shape)))) == pytest.approx(d["X_checksum"], rel=1e-13)
+    return X, Xs[: d["probes"]], y
+
+
 def make_kernel(spec):
     """Rebuild a scikit-learn kernel from a golden-fixture kernel spec."""
     from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C

@@ -1,0 +1,158 @@
+"""GPU tests added in round 3 (``-m gpu``): BASELINE config 5 exactly as specified (S5, n = 16384) and config 1's workload
+(S1, n = 128) against reference-generated goldens; the persistent-chain schedule of one factorisation against the
+host-enqueued schedule (bit-identity, info codes, the operator-level factor, fall-back).  Everything goes through
+libgsum_hip.so; the oracle / the reference's numbers are the checker only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+import gsum_amd  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return gsum_amd.default_context(0)
+
+
+def test_config5_s5_as_specified_against_reference():
+    """BASELINE configs[4] / SURVEY.md 8(d) S5, nothing varied: n = 16384 points X = RandomState(0).rand(n, 2) * side, side =
+    [0.35, 0.65] sqrt(n), Matern-5/2(ell = [0.7, 1.3]) + White(1e-6) fixed, 8 curves, nugget 1e-10.  The reference's own
+    fit -> cov_factor_, log_marginal_likelihood and predict(return_std) at 16 probe points (models.py:671-738, 912-1039,
+    753-845; tests/golden/s5_predict.json, generated in the build container by make_golden.py) against the HIP path.
+    Tolerances: log-likelihood 1e-10 relative (north star); variance 1e-10 * cov_factor absolute (two valid
+    fp64 formulations already differ by 5e-11); mean 1e-9 of the largest mean (a sum of 16384 products at cond(K) ~ 1e6)."""
+    from conftest import s5_inputs
+    d = load_golden("s5_predict.json")
+    X, Xp, y = s5_inputs(d)
+    kern = Matern(length_scale=d["length_scale"], nu=2.5) + WhiteKernel(d["white"], noise_level_bounds="fixed")
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y)
+    assert gp.cov_factor_ == pytest.approx(d["cov_factor"], rel=1e-10)
+    assert gp.df_ == d["df"]
+    lml = gp.log_marginal_likelihood(theta=np.log(d["length_scale"]))
+    assert lml == pytest.approx(d["lml"], rel=1e-10)
+    mean, std = gp.predict(Xp, return_std=True)
+    want_mean, want_std = np.array(d["mean"]), np.array(d["std"])
+    assert mean.shape == want_mean.shape and std.shape == want_std.shape
+    np.testing.assert_allclose(mean, want_mean, rtol=0, atol=1e-9 * np.abs(want_mean).max())
+    np.testing.assert_allclose(std ** 2, want_std ** 2, rtol=0, atol=1e-10 * d["cov_factor"])
+    _, std_n = gp.predict(Xp, return_std=True, pred_noise=True)
+    np.testing.assert_allclose(std_n ** 2, np.array(d["std_pred_noise"]) ** 2, rtol=0, atol=1e-10 * d["cov_factor"])
+
+
+def test_config1_s1_workload_through_the_small_path():
+    """BASELINE configs[0]'s workload (S1: X = linspace(0, 1, 128), 4 orders, RBF(0.2), coefficients by datasets.py:65-71) --
+    the reference's own problem size -- through the one-workgroup-per-evaluation path (k_lml_small) against the reference's
+    numbers (tests/golden/s1_plumbing.json).  cond(K) = 5.6e11 (nugget 1e-10 on a grid 84 points per length scale): the bound is
+    1e-16 cond(K) relative, the class of the small golden cases; what is observed is printed."""
+    d = load_golden("s1_plumbing.json")
+    X = np.linspace(0, 1, d["n"])[:, None]
+    y, orders = np.array(d["y"]), np.arange(d["r"])
+    tol = max(1e-10, 1e-16 * d["cond"])
+    gp = gsum_amd.TruncationGP(kernel=RBF(d["length_scale"]), ratio=d["ratio"], ref=d["ref"], center=0, disp=0, df=1, scale=1,
+                               optimizer=None)
+    gp.fit(X, y, orders=orders)
+    assert gp.coeffs_process.cov_factor_ == pytest.approx(d["cov_factor"], rel=tol)
+    worst = 0.0
+    for e in d["lml"]:
+        got = gp.log_marginal_likelihood(theta=np.log([e["ell"]]), ratio=e["ratio"])
+        worst = max(worst, abs(got - e["value"]) / abs(e["value"]))
+        assert got == pytest.approx(e["value"], rel=tol)
+    print("S1 worst relative lml error vs reference:", worst, "bound", tol)
+    cgp = gsum_amd.ConjugateGaussianProcess(kernel=RBF(d["length_scale"]), center=0, disp=0, df=1, scale=1, optimizer=None)
+    cgp.fit(X, gsum_amd.coefficients(y, ratio=d["ratio"], ref=d["ref"], orders=orders))
+    mean, std = cgp.predict(np.array(d["cgp"]["Xs"]), return_std=True)
+    np.testing.assert_allclose(mean, d["cgp"]["mean"], rtol=tol, atol=tol * np.abs(d["cgp"]["mean"]).max())
+    np.testing.assert_allclose(std ** 2, np.array(d["cgp"]["std"]) ** 2, rtol=0, atol=tol * d["cgp"]["cov_factor"])
+
+
+def _inputs(n, r, d, seed):
+    rng = np.random.RandomState(seed)
+    X = 0.1 * np.arange(n)[:, None] if d == 1 else rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    return X, np.concatenate([rng.randn(n, r), np.ones((n, 1))], axis=1)
+
+
+@pytest.mark.parametrize("n,kern,d", [(1024, RBF(0.2), 1), (2048, RBF(0.2), 1),
+                                      (2304, Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2), (4096, RBF(0.2), 1)])
+def test_persistent_chain_schedule_is_bit_identical(ctx, n, kern, d):
+    """One factorisation alone: the persistent chain kernel + gated host-enqueued updates (k_chain) against
+    the host-enqueued look-ahead schedule -- G, sum log L_ii and info array_equal, both window sizes, several runs each (a
+    hand-off race would show as a mismatch on some run), no time-outs, and the schedule really ran (chain_probe = 1)."""
+    X, Z = _inputs(n, 4, d, n)
+    desc = gsum_amd.describe_kernel(kern, d)
+    old_slots = ctx.get_option("batch_slots")
+    ctx.set_option("batch_slots", 1)
+    ctx.set_inputs(X, Z)
+    try:
+        ctx.set_option("chain_persist", 0)
+        G0, s0, i0 = ctx.lml_resident([desc], 1e-10)
+        assert i0[0] == 0
+        aborts = ctx.get_option("chain_aborts")
+        for W in (512, 256):
+            ctx.set_option("chain_persist", 1)
+            ctx.set_option("chain_rows", W)
+            for _ in range(4):
+                G, s, i = ctx.lml_resident([desc], 1e-10)
+                np.testing.assert_array_equal(G, G0)
+                np.testing.assert_array_equal(s, s0)
+                np.testing.assert_array_equal(i, i0)
+        assert ctx.get_option("chain_probe") == 1
+        assert ctx.get_option("chain_aborts") == aborts
+        assert ctx.get_option("chain_persist") == 1
+    finally:
+        ctx.set_option("chain_persist", -1)
+        ctx.set_option("chain_rows", 512)
+        ctx.set_option("batch_slots", old_slots)
+
+
+def test_persistent_chain_factor_and_info_codes(ctx):
+    """The factor itself through the operator-level entry (gsum_potrf_lower -> L, array_equal between the schedules), and a
+    matrix that is not positive definite: the same LAPACK info (1-based first failing column) from both, -inf upstream."""
+    n = 2048
+    X = 0.1 * np.arange(n)[:, None]
+    desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+    Ls = []
+    try:
+        for persist in (0, 1):
+            ctx.set_option("chain_persist", persist)
+            K = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+            assert ctx.potrf(K) == 0
+            Ls.append(K.to_host())
+            K.free()
+        np.testing.assert_array_equal(Ls[0], Ls[1])
+        Xd = X.copy()
+        Xd[1500] = Xd[1499]                        # duplicated point, no nugget: singular to working precision
+        infos = []
+        for persist in (0, 1):
+            ctx.set_option("chain_persist", persist)
+            K = ctx.kernel_matrix_dev(desc, Xd, diag_add=0.0)
+            infos.append(ctx.potrf(K))
+            K.free()
+        assert infos[0] == infos[1] == 1501
+    finally:
+        ctx.set_option("chain_persist", -1)
+
+
+def test_persistent_chain_full_size_n8192(ctx):
+    """BASELINE config 3's factorisation on the new schedule: bit-identical to the host-enqueued schedule at n = 8192 and the
+    known answer of SURVEY.md 8(c) (reference value, tests/golden/large_lml.json) at 1e-10."""
+    g = [c for c in load_golden("large_lml.json") if c["n"] == 8192][0]
+    n, r = g["n"], g["r"]
+    X = g["dx"] * np.arange(n)[:, None]
+    c = np.random.RandomState(g["seed"]).randn(n, r)
+    y = gsum_amd.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+    gp = gsum_amd.TruncationGP(kernel=RBF(g["length_scale"]), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y, orders=np.arange(r))
+    vals = {}
+    try:
+        for persist in (0, 1):
+            ctx.set_option("chain_persist", persist)
+            vals[persist] = gp.log_marginal_likelihood(theta=np.log([g["length_scale"]]), ratio=0.5)
+        assert vals[0] == vals[1]
+        assert vals[1] == pytest.approx(g["lml"]["0.5"], rel=1e-10)
+    finally:
+        ctx.set_option("chain_persist", -1)

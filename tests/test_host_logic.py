@@ -306,3 +306,22 @@ def test_importing_the_package_leaves_the_environment_alone():
             "assert os.environ['GPU_MAX_HW_QUEUES'] == '16'; assert not gsum_amd.configure_runtime(32); "
             "assert os.environ['GPU_MAX_HW_QUEUES'] == '16'")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_bench_launch_command_is_the_contracts_and_needs_no_gpu():
+    """`python bench.py --gpus N` starts its N ranks through exactly the launcher line the driver uses (one process per GPU,
+    rendezvous on 127.0.0.1); building that command is host logic and touches no GPU (importing bench does not import torch)."""
+    import importlib
+    import sys as _sys
+    had_torch = "torch" in _sys.modules
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(8, 29555, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert had_torch or "torch" not in _sys.modules
+    assert bench.PARITY_BOUND == 1e-10
+    assert bench.golden_lml(8192, 6) == -212339.01508125057 and bench.golden_lml(2048, 4) == -41135.57871678863
+    assert bench.golden_lml(8192, 5) is None

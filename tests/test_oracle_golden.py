@@ -3,10 +3,12 @@
 The golden files were produced by tests/golden/make_golden.py, which imports
 buqeye/gsum read-only in the build container.  CPU-only; no GPU needed.
 """
+import os
+
 import numpy as np
 import pytest
 
-from conftest import make_kernel, prior_kwargs
+from conftest import load_golden, make_kernel, prior_kwargs, s5_inputs
 from oracle import gsum_oracle as orc
 
 RTOL = 1e-12
@@ -317,3 +319,46 @@ def test_cbar_ratio_grid_against_reference():
     strip = np.array([[orc.trunc_lml(RBF(0.2), np.log([e]), X, y, orders, ratio=q) for e in g["ells"]] for q in g["ratios"]])
     np.testing.assert_allclose(strip, np.array(g["strip_ratio_by_ell"]), rtol=1e-10)
     assert list(np.unravel_index(np.argmax(strip), strip.shape)) == g["strip_argmax"]
+
+
+def test_oracle_s1_plumbing_golden():
+    """BASELINE config 1 (X = linspace(0, 1, 128), 4 orders, RBF(0.2), coefficients drawn by the recipe of
+    datasets.py:65-71): the oracle against the reference's own TruncationGP / ConjugateGaussianProcess outputs
+    (tests/golden/s1_plumbing.json, written by make_golden.py from /root/reference).  cond(K) = 5.6e11 here, so this
+    also says the restatement issues the same LAPACK calls on the same matrix: the values agree to the last bit."""
+    from sklearn.gaussian_process.kernels import RBF
+    d = load_golden("s1_plumbing.json")
+    X = np.linspace(0, 1, d["n"])[:, None]
+    y, orders = np.array(d["y"]), np.arange(d["r"])
+    for e in d["lml"]:
+        got = orc.trunc_lml(RBF(e["ell"]), np.log([e["ell"]]), X, y, orders, ratio=e["ratio"], ref=d["ref"])
+        assert got == pytest.approx(e["value"], rel=1e-12)
+    c = orc.coefficients(y, d["ratio"], d["ref"], orders)
+    fit = orc.cgp_fit(RBF(d["length_scale"]), X, c)
+    assert fit["cov_factor"] == pytest.approx(d["cgp"]["cov_factor"], rel=1e-12)
+    mean, std = orc.cgp_predict(fit, np.array(d["cgp"]["Xs"]), return_std=True)
+    np.testing.assert_allclose(mean, d["cgp"]["mean"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(std, d["cgp"]["std"], rtol=1e-9)          # sqrt of a difference of O(1) numbers at 1e-11
+    assert orc.cgp_lml(RBF(d["length_scale"]), np.log([d["length_scale"]]), X, c) == pytest.approx(d["cgp"]["lml"], rel=1e-12)
+
+
+@pytest.mark.skipif(os.environ.get("GSUM_RUN_SLOW") != "1",
+                    reason="n = 16384 on the CPU: ~4 minutes and ~12 GB; run with GSUM_RUN_SLOW=1 (log of the last run: "
+                           "profiles/r03_oracle_s5_check.log)")
+def test_oracle_s5_predict_golden_slow():
+    """BASELINE config 5 exactly as specified (S5: n = 16384 2-D points, Matern-5/2(ell = [0.7, 1.3]) + White(1e-6), 8 curves):
+    the oracle's fit / log-likelihood / predictive mean and standard deviation at 16 probe points against the reference's
+    (tests/golden/s5_predict.json; models.py:671-738, 912-1039, 753-845).  Pins the oracle at the largest BASELINE size."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    d = load_golden("s5_predict.json")
+    X, Xp, y = s5_inputs(d)
+    kern = Matern(length_scale=d["length_scale"], nu=2.5) + WhiteKernel(d["white"], noise_level_bounds="fixed")
+    fit = orc.cgp_fit(kern, X, y)
+    assert fit["cov_factor"] == pytest.approx(d["cov_factor"], rel=1e-12)
+    mean, std = orc.cgp_predict(fit, Xp, return_std=True)
+    np.testing.assert_allclose(mean, d["mean"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(std ** 2, np.array(d["std"]) ** 2, rtol=1e-10, atol=1e-10 * d["cov_factor"])
+    lml = orc.cgp_lml(kern, np.log(d["length_scale"]), X, y)
+    assert lml == pytest.approx(d["lml"], rel=1e-12)
+    print("oracle vs reference at S5: lml rel", abs(lml - d["lml"]) / abs(d["lml"]), "mean max abs", np.abs(mean - d["mean"]).max(),
+          "var max abs / cov_factor", np.abs(std ** 2 - np.array(d["std"]) ** 2).max() / d["cov_factor"])
