@@ -2940,11 +2940,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
 // are dispatched first, stored write-through and counted in *first_done, because the chain's next-but-one outer step and the
 // next step's A update wait for exactly them ("B"), not for the rest of the trailing update ("Far") behind them in the same
 // launch.  One launch instead of two: B starts on an empty chip the moment the previous trailing update ends.
-__global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+template <int NST>
+__global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
                                                       const unsigned* gate, unsigned gate_want, const unsigned* gate2,
                                                       unsigned gate2_want, unsigned* flags, unsigned long long* kst, int nfirst,
-                                                      unsigned* first_done) {
+                                                      unsigned* first_done, int stagger) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
@@ -2966,6 +2967,15 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
         if (!ok) return;
     }
     if (kst && t == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());             // diagnostics: first start / last end of the launch
+    // De-phasing of the workgroups that share a CU.  The first 768 workgroups of a launch start together, three per CU, and
+    // tiles take the same time: all three read their C tiles together, multiply together, store together -- the C traffic
+    // (2 x 64 KB per tile) is then never hidden behind another workgroup's MFMAs.  K = 256 against K = 512 launches say so:
+    // t = a + b K with the K loop at 65 TF/s and a = 92 us = the launch's whole C traffic at HBM speed.  The second and third
+    // workgroup of a CU sleep one and two thirds of a tile time once; every later workgroup inherits the offset.
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {
+        const int naps = (blockIdx.x >= 512 ? 2 : 1) * stagger;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
     bool first_cols = false;
@@ -3060,13 +3070,19 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
 #pragma unroll
     for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
     const int nk = K / GS_KC;
+    // NST stages of LDS: chunk c + NST - 1 is requested while chunk c is multiplied.  Every wave issues exactly three
+    // LDS-direct loads per stage, so "all but the newest NST - 2 stages have landed" is vmcnt(3 (NST - 2)).
+    // (NST = 3: 74 KB per workgroup, two per CU; the operands of a K = 256 trailing update mostly MISS the L2 -- the panel is
+    // 16 MB, FETCH_SIZE ~ the operand bytes -- and come from the Infinity Cache in 1-2 us, more than one chunk of a shared CU.)
     stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST == 3 && nk > 1) stage_load(1, 1);
+    if (NST == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < nk; ++c) {
-        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
-        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rselA;
-        const double* sB = lds + (c & 1) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
+        if (c + NST - 1 < nk) stage_load(c + NST - 1, (c + NST - 1) % NST);
+        const double* sA = lds + (c % NST) * STAGE + wm * WM * 8 * GS_KC + rselA;
+        const double* sB = lds + (c % NST) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
 #pragma unroll
         for (int ks = 0; ks < GS_KC / 4; ++ks) {
             double af[WM], bf[WN];
@@ -3080,8 +3096,13 @@ __global__ __launch_bounds__(512, 6) void k_gemm_ld3(double* C, int64_t ldc, con
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NST == 3 && c + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk c + 1 has landed; c + 2 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (stagger == -1) {                      // DEBUG (timing experiments only): no C store -- one value per workgroup keeps the loop alive
+        if (t == 0) C[(int64_t)m0 * ldc + n0] = acc[0][0][0] + acc[1][1][3];
+        return;
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
