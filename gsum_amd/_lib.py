@@ -126,6 +126,8 @@ PROTOTYPES = {
                                  _dp, _dp, _ip]),
     "gsum_lml_grad": (C.c_int, [_p, _kp, C.POINTER(GradParam), C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32,
                                 C.c_double, _dp, _dp, _ip, _dp, _dp]),
+    "gsum_lml_grad_batch": (C.c_int, [_p, _kp, C.c_int32, C.POINTER(GradParam), C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32,
+                                C.c_double, _dp, _dp, _ip, _dp, _dp]),
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_resident_shape": (C.c_int, [_p, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
@@ -424,6 +426,32 @@ class HipContext:
         self._check(self._lib.gsum_lml_grad(self._h, C.byref(desc), arr, P, _ptr(X), n, d, _ptr(rhs), k, float(nugget),
                                             _ptr(G), _ptr(sld), info.ctypes.data_as(_ip), _ptr(trace), _ptr(H)))
         return G, float(sld[0]), int(info[0]), trace, H
+
+    def lml_grad_batch(self, descs, params, X, rhs, nugget: float):
+        """Value + gradient pieces of several kernels with one hyperparameter structure on one set of inputs, pipelined on
+        the device (gsum_lml_grad_batch): G (m, k, k), sld (m,), info (m,), trace (m, P), H (m, P, k, k).  ``params`` is a
+        list of m parameter lists (``describe_gradient`` of every kernel: the weights depend on the hyperparameter values)."""
+        X, rhs = _f64(X), _f64(rhs)
+        n, d = X.shape
+        k = rhs.shape[1]
+        m = len(descs)
+        if len(params) != m:
+            raise ValueError("one parameter list per kernel")
+        P = len(params[0])
+        arr = (GradParam * (P * m))()
+        for j, plist in enumerate(params):
+            if len(plist) != P:
+                raise ValueError("every kernel must have the same hyperparameter structure")
+            for i, pr in enumerate(plist):
+                arr[j * P + i].code, arr[j * P + i].dim, arr[j * P + i].weight = pr.code, pr.dim, pr.weight
+        G = np.empty((m, k, k))
+        sld = np.empty(m)
+        info = np.empty(m, dtype=np.int64)
+        trace = np.empty((m, P))
+        H = np.empty((m, P, k, k))
+        self._check(self._lib.gsum_lml_grad_batch(self._h, self._desc_array(descs), m, arr, P, _ptr(X), n, d, _ptr(rhs), k,
+                                                  float(nugget), _ptr(G), _ptr(sld), info.ctypes.data_as(_ip), _ptr(trace), _ptr(H)))
+        return G, sld, info, trace, H
 
     def set_inputs(self, X, rhs):
         X, rhs = _f64(X), _f64(rhs)

@@ -270,6 +270,7 @@ class ConjugateGaussianProcess:
         self.basis = lambda X: np.ones((np.shape(X)[0], 1))
         self.basis_train_ = None
         self.device = device
+        self.batch_restarts = True   # multi-start fits advance in lock step, objective evaluations batched on the device
         self._ctx = None
         self._L_dev = None          # device-resident Cholesky factor of kernel_(X_train_) + nugget
         self._corr = None
@@ -519,9 +520,96 @@ class ConjugateGaussianProcess:
             raise ValueError("Unknown optimizer %s." % self.optimizer)
         return theta_opt, func_min
 
+    def log_marginal_likelihood_batch(self, thetas, X=None, y=None):
+        """``log_marginal_likelihood(theta, eval_gradient=True)`` for several ``theta`` at once: [(lml, grad), ...].  The
+        evaluations are independent and go to the device as one pipelined batch (gsum_lml_grad_batch); every entry equals
+        the single call's result bit for bit."""
+        self._check_decomposition()
+        base = self._active_kernel()
+        X = np.asarray(self.X_train_ if X is None else X, dtype=float)
+        y = self.y_train_ if y is None else y
+        Z = self._rhs(X, y)
+        kernels = [base.clone_with_theta(np.asarray(t, dtype=float)) for t in thetas]
+        params = [describe_gradient(kk, X.shape[1]) for kk in kernels]     # the weights carry hyperparameter values: per kernel
+        if not params[0] or len(kernels) == 1:
+            return [self.log_marginal_likelihood(t, eval_gradient=True, X=X, y=y) for t in thetas]
+        descs = [describe_kernel(kk, X.shape[1]) for kk in kernels]
+        G, sld, info, trace, H = self._context().lml_grad_batch(descs, params, X, Z, self.nugget)
+        out = []
+        for i, kk in enumerate(kernels):
+            if info[i] != 0:
+                out.append((-np.inf, np.zeros_like(kk.theta)))                       # models.py:970-972
+            else:
+                out.append(self._lml_grad_gram(G[i], sld[i], trace[i], H[i], X.shape[0]))
+        return out
+
+    def _lockstep_restarts(self, starts, bounds):
+        """All starts of a multi-start fit (models.py:641-662) advanced together: every start runs its own L-BFGS in a thread,
+        the objective calls of one sweep meet in ``log_marginal_likelihood_batch`` and are evaluated on the device as ONE
+        pipelined batch.  Each start sees exactly the values the sequential loop would give it, so the optima are the same."""
+        import threading
+        n = len(starts)
+        cond = threading.Condition()
+        pending, results, alive = {}, {}, set(range(n))
+        state = {"error": None}
+
+        def flush():                       # called with the lock held: every live start has asked
+            ids = sorted(pending)
+            try:
+                vals = self.log_marginal_likelihood_batch([pending[i] for i in ids])
+            except BaseException as exc:   # noqa: BLE001 -- handed to every waiting thread
+                state["error"] = exc
+                vals = [(np.nan, None)] * len(ids)
+            for i, v in zip(ids, vals):
+                results[i] = v
+            pending.clear()
+            cond.notify_all()
+
+        def make_obj(i):
+            def obj(theta, eval_gradient=True):
+                with cond:
+                    pending[i] = np.array(theta, dtype=float)
+                    if len(pending) == len(alive):
+                        flush()
+                    else:
+                        while i not in results and state["error"] is None:
+                            cond.wait()
+                    if state["error"] is not None:
+                        raise state["error"]
+                    lml, grad = results.pop(i)
+                return -lml, -grad
+            return obj
+
+        optima = [None] * n
+
+        def run(i):
+            try:
+                optima[i] = self._constrained_optimization(make_obj(i), starts[i], bounds)
+            except BaseException as exc:   # noqa: BLE001
+                with cond:
+                    if state["error"] is None:
+                        state["error"] = exc
+                    cond.notify_all()
+            finally:
+                with cond:
+                    alive.discard(i)
+                    if pending and len(pending) == len(alive):
+                        flush()
+
+        threads = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if state["error"] is not None:
+            raise state["error"]
+        return optima
+
     def _calibrate_kernel(self):
         """models.py:630-669, with the intended argmin over restarts (the reference's ragged
-        ``np.array(optima)`` at :664 raises on numpy >= 1.24)."""
+        ``np.array(optima)`` at :664 raises on numpy >= 1.24).  With ``n_restarts_optimizer > 0`` and the default optimiser all
+        starts advance in lock step, their objective evaluations batched on the device (``_lockstep_restarts``); the random
+        initial points are drawn in the reference's order, so the starts -- and the optima -- are the sequential loop's."""
         if self.optimizer is not None and self.kernel_.n_dims > 0:
             def obj_func(theta, eval_gradient=True):                                   # models.py:634-640
                 if eval_gradient:
@@ -529,15 +617,18 @@ class ConjugateGaussianProcess:
                     return -lml, -grad
                 return -self.log_marginal_likelihood(theta)
 
-            optima = [self._constrained_optimization(obj_func, self.kernel_.theta, self.kernel_.bounds)]
+            starts = [np.array(self.kernel_.theta, dtype=float)]
+            bounds = self.kernel_.bounds
             if self.n_restarts_optimizer > 0:
                 if not np.isfinite(self.kernel_.bounds).all():
                     raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) "
                                      "requires that all bounds are finite.")
-                bounds = self.kernel_.bounds
                 for _ in range(self.n_restarts_optimizer):
-                    theta_initial = self._rng.uniform(bounds[:, 0], bounds[:, 1])
-                    optima.append(self._constrained_optimization(obj_func, theta_initial, bounds))
+                    starts.append(self._rng.uniform(bounds[:, 0], bounds[:, 1]))
+            if len(starts) > 1 and self.optimizer == "fmin_l_bfgs_b" and self.batch_restarts:
+                optima = self._lockstep_restarts(starts, bounds)
+            else:
+                optima = [self._constrained_optimization(obj_func, st, bounds) for st in starts]
             values = [o[1] for o in optima]
             best = int(np.argmin(values))
             self.kernel_.theta = optima[best][0]

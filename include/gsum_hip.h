@@ -197,6 +197,14 @@ int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_ker
 int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_param* params, int32_t n_params,
                   const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget, double* G_out,
                   double* sld_out, int64_t* info_out, double* trace_out, double* H_out);
+/* The same for n_desc kernels of ONE hyperparameter structure on one set of inputs: the current points of all restarts of a
+ * multi-start fit (gsum/models.py:641-662 runs them one after the other), or a grid of gradients.  Independent evaluations,
+ * pipelined over the library's slots (up to 8 in flight; each owns a workspace matrix, U = L^-T and R^-1: 3 n^2 doubles).
+ * params holds n_desc x n_params entries (codes and dims equal across kernels, the weights -- hyperparameter values -- per kernel).
+ * Outputs are gsum_lml_grad's, stacked: G (n_desc, k, k), sld (n_desc), info (n_desc), trace (n_desc, P), H (n_desc, P, k, k). */
+int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_desc, const gsum_grad_param* params,
+                        int32_t n_params, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget,
+                        double* G_out, double* sld_out, int64_t* info_out, double* trace_out, double* H_out);
 
 /* Same, with inputs already resident in HBM: gsum_set_inputs uploads X and RHS once,
  * gsum_lml_resident evaluates descriptors against them (what bench.py times).  The evaluations of one

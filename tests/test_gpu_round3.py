@@ -156,3 +156,49 @@ def test_persistent_chain_full_size_n8192(ctx):
         assert vals[1] == pytest.approx(g["lml"]["0.5"], rel=1e-10)
     finally:
         ctx.set_option("chain_persist", -1)
+
+
+def test_lml_grad_batch_equals_single_calls():
+    """gsum_lml_grad_batch (value + gradient of several kernels, pipelined over slots, each on one stream) against the
+    single-evaluation entry (look-ahead schedule, trailing U sweep): every piece array_equal -- the two differ in schedule only."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C
+    from gsum_amd.kernels import describe_kernel, describe_gradient
+    ctx = gsum_amd.default_context(0)
+    n, r = 1500, 3
+    rng = np.random.RandomState(11)
+    X = np.sort(rng.rand(n))[:, None] * 150.0
+    Z = np.concatenate([rng.randn(n, r), np.ones((n, 1))], axis=1)
+    base = C(1.3) * RBF(0.8) + WhiteKernel(1e-4)
+    thetas = [base.theta + d for d in (0.0, 0.1, -0.2, 0.05, 0.3)]
+    kernels = [base.clone_with_theta(t) for t in thetas]
+    params = [describe_gradient(k, 1) for k in kernels]
+    descs = [describe_kernel(k, 1) for k in kernels]
+    G, sld, info, trace, H = ctx.lml_grad_batch(descs, params, X, Z, 1e-10)
+    assert np.all(info == 0)
+    for i, d in enumerate(descs):
+        g1, s1, i1, t1, h1 = ctx.lml_grad(d, params[i], X, Z, 1e-10)
+        np.testing.assert_array_equal(G[i], g1)
+        assert sld[i] == s1 and i1 == 0
+        np.testing.assert_array_equal(trace[i], t1)
+        np.testing.assert_array_equal(H[i], h1)
+
+
+def test_multi_start_fit_in_lock_step_equals_the_sequential_loop():
+    """fit with n_restarts_optimizer > 0 (models.py:641-662): the starts advanced together with their objective evaluations
+    batched on the device give the optimum the one-after-the-other loop gives -- same starts (the random draws come in the
+    reference's order), same objective values, same theta."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C
+    rng = np.random.RandomState(4)
+    n = 400
+    X = np.sort(rng.rand(n))[:, None] * 10.0
+    K = (C(2.0) * RBF(0.7))(X) + 1e-6 * np.eye(n)
+    y = np.linalg.cholesky(K) @ rng.randn(n, 3)
+    out = []
+    for lockstep in (True, False):
+        kern = C(1.0, (1e-2, 1e2)) * RBF(1.0, (1e-1, 1e1)) + WhiteKernel(1e-5, (1e-8, 1e-2))
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, n_restarts_optimizer=3, random_state=7)
+        gp.batch_restarts = lockstep
+        gp.fit(X, y)
+        out.append((gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
