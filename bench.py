@@ -198,9 +198,9 @@ def n2048_leg(ctx):
         tm = ctx.timers()
         cur = np.array([tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]])
         stage = cur if stage is None else np.minimum(stage, cur)
-    # 128 length scales x 8 ratios: a ratio row shares its right-hand sides and goes out as one batch of 128 evaluations
-    # (above the fused path's break-even of 67 at this order)
-    ells, ratios = np.linspace(0.15, 0.25, 128), np.linspace(0.3, 0.7, 8)
+    # 512 length scales x 2 ratios: a ratio row shares its right-hand sides and goes out as one batch of 512 evaluations =
+    # one launch of the fused path with every CU holding two evaluations
+    ells, ratios = np.linspace(0.15, 0.25, 512), np.linspace(0.45, 0.55, 2)
     thetas = [np.log([e]) for e in ells]
     gp.log_marginal_likelihood_grid(thetas, list(ratios[:1]), mode="full")        # workspaces
     t0 = time.perf_counter()
@@ -214,7 +214,7 @@ def n2048_leg(ctx):
                            "cholesky_tflops": flops / (stage[1] * 1e-3) / 1e12,
                            "cholesky_frac_of_fp64_mfma_peak": flops / (stage[1] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                            "note": "one evaluation alone is latency-bound: 8 outer steps of the dependent chain"},
-           "grid_1024": {"what": "128 x 8 (ell in linspace(0.15, 0.25), ratio in linspace(0.3, 0.7)) full-recompute scan, "
+           "grid_1024": {"what": "512 x 2 (ell in linspace(0.15, 0.25), ratio in {0.45, 0.55}) full-recompute scan, "
                                  "log_marginal_likelihood_grid(mode='full'): one workgroup per evaluation (k_lml_medium)",
                          "seconds": dt, "evals_per_s": grid.size / dt, "cholesky_tflops": flops * grid.size / dt / 1e12,
                          "cholesky_frac_of_fp64_mfma_peak": flops * grid.size / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,

@@ -83,8 +83,6 @@ struct gsum_ctx {
     int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
-    int bench_beta = 1;              // gsum_bench_gemm_nt: accumulate into C (0: timing experiments without the C read)
-    int bulk_stagger = 0;            // k_gemm_ld3: s_sleep(127) naps (3.4 us each) per third of a tile time for the second / third workgroup of a CU, per K = 256
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
     int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
                                      // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
@@ -279,11 +277,11 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         if (nst == 3)
             hipLaunchKernelGGL(k_gemm_ld3<3>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
                                beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
-                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done, ctx->bulk_stagger < 0 ? -1 : ctx->bulk_stagger * (K / 256));
+                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done);
         else
             hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
                                beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
-                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done, ctx->bulk_stagger < 0 ? -1 : ctx->bulk_stagger * (K / 256));
+                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done);
         ctx->gate_ptr = ctx->gate2_ptr = nullptr;
         ctx->kst_ptr = nullptr;
         ctx->first_tiles = 0;
@@ -1249,8 +1247,6 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
-    else if (!strcmp(name, "bulk_stagger")) ctx->bulk_stagger = (int)std::max<int64_t>(-1, std::min<int64_t>(64, value));
-    else if (!strcmp(name, "bench_beta")) ctx->bench_beta = value != 0;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "bulk_lds_pad")) ctx->bulk_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(80 * 1024, value));
@@ -2326,7 +2322,7 @@ int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64
     if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, 1, -1.0)) return -1;   // warm-up
     GS_CHECK(hipEventRecord(ctx->cur->tev[0], s));
     for (int r = 0; r < reps; ++r)
-        if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, ctx->bench_beta, -1.0)) return -1;
+        if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, 1, -1.0)) return -1;
     GS_CHECK(hipEventRecord(ctx->cur->tev[1], s));
     GS_CHECK(hipStreamSynchronize(s));
     float ms = 0.f;

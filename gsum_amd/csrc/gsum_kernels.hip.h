@@ -2945,7 +2945,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
                                                       const unsigned* gate, unsigned gate_want, const unsigned* gate2,
                                                       unsigned gate2_want, unsigned* flags, unsigned long long* kst, int nfirst,
-                                                      unsigned* first_done, int stagger) {
+                                                      unsigned* first_done) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
@@ -2967,15 +2967,10 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
         if (!ok) return;
     }
     if (kst && t == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());             // diagnostics: first start / last end of the launch
-    // De-phasing of the workgroups that share a CU.  The first 768 workgroups of a launch start together, three per CU, and
-    // tiles take the same time: all three read their C tiles together, multiply together, store together -- the C traffic
-    // (2 x 64 KB per tile) is then never hidden behind another workgroup's MFMAs.  K = 256 against K = 512 launches say so:
-    // t = a + b K with the K loop at 65 TF/s and a = 92 us = the launch's whole C traffic at HBM speed.  The second and third
-    // workgroup of a CU sleep one and two thirds of a tile time once; every later workgroup inherits the offset.
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {
-        const int naps = (blockIdx.x >= 512 ? 2 : 1) * stagger;
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    // (Tried in round 3, measured, not kept: de-phasing naps for the second and third workgroup of a CU -- no gain, the
+    // co-resident workgroups are not in lock step; three LDS stages with two workgroups per CU -- 3 % slower alone, 7 % slower
+    // pipelined.  A K = 256 launch at M = 7936 spends ~30-45 us on its C reads and ~25 us on its C stores of ~300; the K loop alone
+    // runs at 66 TF/s, the clock-limited rate under this kernel: profiles/r03_bulk_cphase.log.)
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
     bool first_cols = false;
@@ -3100,25 +3095,31 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (stagger == -1) {                      // DEBUG (timing experiments only): no C store -- one value per workgroup keeps the loop alive
-        if (t == 0) C[(int64_t)m0 * ldc + n0] = acc[0][0][0] + acc[1][1][3];
-        return;
-    }
+    if (!first_cols) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + (wn * WN + j) * 16 + fr;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) {
-                    const double v = neg ? -acc[i][j][x] : acc[i][j][x];
-                    if (first_cols) gs_st_wt(C + (int64_t)row * ldc + col, v);
-                    else C[(int64_t)row * ldc + col] = v;
+                for (int x = 0; x < 4; ++x) {
+                    const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                    if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
                 }
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                    if (row < M && col < N) gs_st_wt(C + (int64_t)row * ldc + col, neg ? -acc[i][j][x] : acc[i][j][x]);
+                }
+            }
+    }
     if (first_cols) {                         // published to the chain kernel: every wave drains, then one lane counts the tile
         gs_drain();
         __syncthreads();

@@ -325,3 +325,46 @@ def test_bench_launch_command_is_the_contracts_and_needs_no_gpu():
     assert bench.PARITY_BOUND == 1e-10
     assert bench.golden_lml(8192, 6) == -212339.01508125057 and bench.golden_lml(2048, 4) == -41135.57871678863
     assert bench.golden_lml(8192, 5) is None
+
+
+def test_kernel_register_budgets():
+    """The schedules count on what a wave of each kernel allocates: six bulk waves (<= 72 VGPRs each, allocated in eights) leave
+    room on a SIMD for ONE chain / panel wave (<= 224) as soon as a bulk workgroup retires; with 80 the panel of the rows below
+    the window took 270 us instead of 80 beside the trailing update (found in round 3 after an innocent-looking edit).  Compiles
+    the device code once with -Rpass-analysis=kernel-resource-usage (hipcc cross-compiles without a GPU; ~30 s)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = os.path.join(ROOT, "gsum_amd", "csrc", "gsum_capi.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c",
+                              "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "gsum_amd", "csrc"),
+                              "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(tmp, "dev.o"), src],
+                             capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    usage, name = {}, None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        for key in ("VGPRs", "AGPRs", "ScratchSize \\[bytes/lane\\]"):
+            m = re.search(r"remark:\s+" + key + r": (\d+)", line)
+            if m and name:
+                usage[name][key[:7]] = int(m.group(1))
+
+    def find(prefix):
+        hits = [v for k, v in usage.items() if prefix in k]
+        assert hits, prefix
+        return hits[0]
+
+    bulk = find("k_gemm_ld3ILi2E")
+    assert bulk["VGPRs"] <= 72 and bulk["Scratch"] == 0, bulk
+    assert find("10k_panel256")["VGPRs"] <= 224 and find("10k_panel256")["Scratch"] == 0
+    assert find("7k_panelP")["VGPRs"] <= 224
+    assert find("12k_potrf_diagILi2E")["VGPRs"] <= 224
+    chain = find("7k_chain")
+    assert chain["VGPRs"] <= 256 and chain["Scratch"] <= 64, chain        # one wave per SIMD, a CU of its own: no spills to memory

@@ -51,11 +51,12 @@ def last(agg, name):
 
 
 for sub, name in (("prof_bench", "bench_kernel_stats.csv"), ("prof_single", "single_eval_n2048_n8192_kernel_stats.csv"),
+                  ("prof_single_host", "single_eval_n8192_host_enqueued_kernel_stats.csv"),
                   ("prof_predict", "predict_kernel_stats.csv"), ("prof_grad", "grad_n8192_kernel_stats.csv")):
     copy(newest(sub, "*kernel_stats.csv"), name)
 # the single-evaluation kernel trace itself (start / end of every dispatch) and the per-step timeline derived from it
 tr = newest("prof_single", "*kernel_trace.csv")
-if tr:
+if tr and not os.path.exists(os.path.join(SRC, "single_eval_chain_timeline.txt")):
     copy(tr, "single_eval_kernel_trace.csv")
     import subprocess
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_timeline.py"), tr, "60"], capture_output=True, text=True).stdout
@@ -68,7 +69,8 @@ json_line("bench.log", "bench_default.jsonl")
 json_line("rocprof_bench.log", "bench_under_rocprof.jsonl")
 json_line("plain_n1.log", "plain_n1.jsonl")
 json_line("bench_predict.log", "bench_predict.jsonl")
-for log in ("rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
+copy(os.path.join(SRC, "single_eval_chain_timeline.txt"), "single_eval_timeline.txt")       # round 3: the chain kernel's own stamps
+for log in ("chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages.log", "rocprof_single.log", "rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
             "single_sweep.log", "slots_sweep.log", "clock_power.log", "medium_phases.log"):
     path = os.path.join(SRC, log)
     if os.path.exists(path):
@@ -82,12 +84,13 @@ copy(os.path.join(SRC, "r2_kernels.json"), "kernels_ab.json")
 # ---- PMC: bulk GEMM (exclusive launch M = 8192, K = 256) and kernel build (n = 8192)
 g = {}
 for sub in ("pmc_gemm1", "pmc_gemm2", "pmc_gemm3", "pmc_gemm4"):
+    g.update(counters(sub, "void k_gemm_ld3"))
     g.update(counters(sub, "k_gemm_ld3"))
 if g:
     fetch, write = last(g, "FETCH_SIZE"), last(g, "WRITE_SIZE")
     dur_ns = g["GRBM_GUI_ACTIVE"][-1][1] if "GRBM_GUI_ACTIVE" in g else None
     busy, gui = last(g, "SQ_VALU_MFMA_BUSY_CYCLES"), last(g, "GRBM_GUI_ACTIVE")
-    rec = {"kernel": "k_gemm_ld3", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_gemm.py 7 8192 256 1 3 (one pass per counter group; tools/gpu_r2_profiles.sh)",
+    rec = {"kernel": "k_gemm_ld3", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_gemm.py 7 8192 256 1 3 (one pass per counter group; tools/gpu_r3_profiles.sh)",
            "shape": {"M": 8192, "N": 8192, "K": 256, "tri": 1, "tiles": 4160},
            "counters": {k: v[-1][0] for k, v in g.items()}, "duration_us_profiled": dur_ns / 1e3 if dur_ns else None,
            "derived": {"hbm_read_bytes": fetch * 2048 if fetch else None, "hbm_write_bytes": write * 1024 if write else None,

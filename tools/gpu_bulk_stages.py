@@ -23,8 +23,8 @@ ctx.set_inputs(X, Z)
 ctx.lml_resident([desc] * 16, 1e-10)
 ref = None
 for rnd in range(3):
-    for st in (0, 3, 5, 8):
-        ctx.set_option("bulk_stagger", st)
+    for st in (2, 3):
+        ctx.set_option("bulk_stages", st)
         res = {}
         for name, args in (("syrk8k", (7, 7936, 7936, 256, True, 8208)), ("syrk8k_k512", (7, 7936, 7936, 512, True, 8208)),
                            ("syrk4k", (7, 4096, 4096, 256, True, 8208)), ("syrk2k", (7, 2048, 2048, 256, True, 8208))):
@@ -43,4 +43,4 @@ for rnd in range(3):
         key = (float(sld[0]).hex(), float(G[0, 0, 0]).hex())
         ref = ref or key
         res["identical"] = key == ref
-        print("stagger", st, res, flush=True)
+        print("stages", st, res, flush=True)

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Timeline of ONE factorisation on the persistent-chain schedule, from the chain kernel's own realtime stamps (a profiler sees
+one k_chain dispatch; what happens inside it only the kernel can say) and the first-start / last-end stamps of the step's three
+host-enqueued launches.  Writes gpurun_out/single_eval_chain_timeline.txt.   gpu_chain_timeline.py [n] [window rows]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import gsum_amd  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+r = 6
+ctx = gsum_amd.default_context(0)
+ctx.set_option("batch_slots", 1)
+X = 0.1 * np.arange(n)[:, None]
+Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
+desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+ctx.set_inputs(X, Z)
+ctx.set_option("chain_rows", W)
+plain = []
+for _ in range(6):
+    ctx.lml_resident([desc], 1e-10)
+    plain.append(ctx.timers()["potrf_ms"])
+ctx.set_option("chain_stamps", 1)
+for _ in range(3):
+    ctx.lml_resident([desc], 1e-10)
+stamped = ctx.timers()["potrf_ms"]
+st = ctx.chain_stamps()
+lines = []
+w = lines.append
+w(f"One factorisation alone, n = {n}, persistent-chain schedule (window {W} rows), potrf {min(plain):.3f} ms without stamps "
+  f"(best of 6; median {np.median(plain):.3f}), {stamped:.3f} ms with them.  chain_probe = {ctx.get_option('chain_probe')}, "
+  f"time-outs = {ctx.get_option('chain_aborts')}.")
+w("All times in microseconds from the chain kernel's first stamp.  Per outer step s (256 columns):")
+w("  D role (workgroup 0): begin | wait = until the diagonal block is up to date (update tasks of step s - 1) | D(k) = first 128 x 128 "
+  "block | L10 = rows of block k + 1 solved (tables in LDS) | sib = A11 -= L10 L10^T | D(k+1) = second block, tables published (T1)")
+w("  P wave 0: T1->pub = second tables seen -> its 16 rows solved and published | task = its first update task (second half) | "
+  "hand-off = T1 -> next step's diagonal block ready")
+w("  host-enqueued launches: rest = panel of the rows below the window (k_panel256), A = near update, B+Far = trailing update "
+  "(one launch, first-256-column tiles first): [first workgroup start, last workgroup end]")
+w("")
+w(" s |   begin   wait   D(k)    L10    sib  D(k+1) |  T1->pub  task  hand-off |  step || rest              A                 B+Far")
+for s in range(st.shape[0]):
+    d = st[s]
+    nxt = st[s + 1] if s + 1 < st.shape[0] else None
+    begin, ready, t0f, rowready, img, sibdone, t1 = d[0], d[1], d[2], d[3], d[4], d[5], d[6]
+    hand = (nxt[1] - t1) if nxt is not None else np.nan
+    step = (nxt[0] - begin) if nxt is not None else (t1 - begin)
+
+    def rng(a, b):
+        return "      -         " if np.isnan(a) or np.isnan(b) else f"[{a:7.1f},{b:7.1f}]"
+
+    w(f"{s:2d} | {begin:7.1f} {ready - begin:6.1f} {rowready - ready:6.1f} {img - rowready:6.1f} {sibdone - img:6.1f} {t1 - sibdone:6.1f} |"
+      f"  {d[12] - d[11]:6.1f} {d[14] - d[13]:6.1f}  {hand:7.1f} | {step:6.1f} || {rng(d[16], d[17])} {rng(d[18], d[19])} {rng(d[22], d[23])}")
+S = st.shape[0]
+late = [st[s + 1, 0] - st[s, 0] for s in range(S - 9, S - 1)]
+dk = [st[s, 3] - st[s, 1] for s in range(1, S)]
+w("")
+w(f"last 8 full steps: {np.mean(late):.1f} us per 256 columns on average; D(k) {np.min(dk):.1f} .. {np.max(dk):.1f} us (median {np.median(dk):.1f}) -- "
+  "on a CU of its own the diagonal block takes the same time whatever the bulk update does beside it")
+txt = "\n".join(lines) + "\n"
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+open(os.path.join(ROOT, "gpurun_out", "single_eval_chain_timeline.txt"), "w").write(txt)
+print(txt)
