@@ -26,7 +26,8 @@ struct gsum_mat {
     double* logdet = nullptr;  // T per-block sums of log L_ii
     double* diag0 = nullptr;   // np original diagonal entries (pivot-cancellation test)
     // persistent-chain schedule (allocated the first time a factorisation of this matrix uses it)
-    unsigned* cflags = nullptr;            // gs_fl_count(T / 2) words, zeroed before every factorisation
+    unsigned* cflags = nullptr;            // gs_fl_count(T / 2) words, zeroed before every factorisation; then T / 2 words "fbwant"
+    int fbwant_key = -1;                   // what fbwant was last computed for (window rows x 2 + lazy): uploaded only when it changes
     double* cdump = nullptr;               // 2 x GS_CH_GMAX x 16 x 256 doubles: operand images of the window's rows
     unsigned long long* cstamps = nullptr; // T / 2 x GS_CH_STAMPS realtime stamps (option "chain_stamps")
     bool factored = false;
@@ -114,6 +115,7 @@ struct gsum_ctx {
                                      // the M-proportional work host-enqueued and gated on its flags.  -1 (default) = when the order
                                      // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
     int chain_min_np = 2048;
+    int chain_lazy = 0;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
     int chain_rows = 512;            // the chain's window: rows under the panel it solves and updates itself (256 or 512)
     int chain_stamps = 0;            // record the chain kernel's per-step realtime stamps (gsum_debug_chain_stamps)
     int chain_probe = 0;             // two-stream concurrency probe: 0 not run, 1 streams run side by side, -1 they do not (a
@@ -277,11 +279,11 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         if (nst == 3)
             hipLaunchKernelGGL(k_gemm_ld3<3>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
                                beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
-                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done);
+                               tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
         else
             hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
                                beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
-                               tri == 1 ? ctx->first_tiles : 0, ctx->first_done);
+                               tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
         ctx->gate_ptr = ctx->gate2_ptr = nullptr;
         ctx->kst_ptr = nullptr;
         ctx->first_tiles = 0;
@@ -758,7 +760,7 @@ static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
         GS_CHECK(hipEventCreateWithFlags(&sl->evS, hipEventDisableTiming));
     }
     const int S = m->T / 2;
-    if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)gs_fl_count(S) * sizeof(unsigned)));
+    if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)(gs_fl_count(S) + S + 4) * sizeof(unsigned)));    // flags | fbwant[S]
     if (!m->cdump) GS_CHECK(hipMalloc((void**)&m->cdump, (size_t)2 * GS_CH_GMAX * 16 * 256 * sizeof(double)));
     if (!m->cstamps) {       // S x 16 chain stamps | S x 4 launch starts (preset to all ones: atomicMin) | S x 4 launch ends
         GS_CHECK(hipMalloc((void**)&m->cstamps, (size_t)S * (GS_CH_STAMPS + GS_CH_KSTAMPS) * sizeof(unsigned long long)));
@@ -799,7 +801,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     gs_chain_args ca;
     ca.A = A; ca.ld = ld; ca.np = (int)m->np; ca.naug = (int)naug; ca.S = S; ca.W = W;
     ca.Ltab = m->Ltab; ca.Lsib = m->Lsib; ca.logdet = m->logdet; ca.diag0 = m->diag0; ca.info = sl->dinfo;
-    ca.dump = m->cdump; ca.flags = fl; ca.stamps = ctx->chain_stamps ? m->cstamps : nullptr;
+    ca.dump = m->cdump; ca.flags = fl; ca.fbwant = fl + gs_fl_count(S); ca.stamps = ctx->chain_stamps ? m->cstamps : nullptr;
     {
         const int rec = gs_prof_begin(ctx, sp, GS_PROF_DIAG, (double)T * GS_NB * GS_NB * GS_NB / 3.0);
         hipLaunchKernelGGL(k_chain, dim3((unsigned)(1 + W / 64)), dim3(256), GS_CH_LDS_DOUBLES * sizeof(double), sp, ca);
@@ -835,6 +837,38 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // the cycle rest -> A -> B -> rest, ~135 us, bound steps 11-20, 5.61 ms; the panel on a stream of its own with two more events
     // per step made every cross-stream wait 60-90 us, 6.9 ms; B as its own launch in front of Far on the main stream idled the chip
     // for ~45 us per step in the first third, 5.83 ms.)
+    // LAZY FAR UPDATES (chain_lazy; the batch schedule's idea, worth far more here): one factorisation alone runs its trailing
+    // updates exclusively, and an exclusive K = 256 launch spends 15-20 % of its time on C reads and stores nothing else hides
+    // (47.5 TF/s at M = 7936 against 55 at K = 512: profiles/r03_bulk_cphase.log).  So even steps update only the 512 columns the
+    // next two panels live in ("near", K = 256, rectangular) and the following odd step applies both panels to everything right of
+    // them in ONE K = 512 pass after its own B columns.  Per element the same products in the same order: bit-identical.
+    struct Plan { int kind; unsigned fb; };          // kind 0: B + Far merged (tri), 1: near-512 (even), 2: B then Far K = 512 (odd)
+    std::vector<Plan> plan((size_t)S, Plan{0, 0u});
+    {
+        bool deferred = false;
+        for (int s = 0; s + 1 < S; ++s) {
+            const int64_t r3 = 256 * (int64_t)(s + 2), m3 = naug - r3;
+            if (m3 <= 0) continue;
+            const unsigned tm = (unsigned)((m3 + 127) / 128);
+            if (deferred) {
+                plan[s] = Plan{2, 4u * tm};
+                deferred = false;
+            } else if (ctx->chain_lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
+                plan[s] = Plan{1, 4u * tm};
+                deferred = true;
+            } else {
+                plan[s] = Plan{0, 4u * tm - 2u};
+            }
+        }
+    }
+    unsigned* fbw = fl + gs_fl_count(S);
+    const int fb_key = W * 2 + (ctx->chain_lazy ? 1 : 0);
+    if (m->fbwant_key != fb_key) {
+        std::vector<unsigned> h((size_t)S);
+        for (int s = 0; s < S; ++s) h[s] = plan[s].fb;
+        GS_CHECK(hipMemcpy(fbw, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        m->fbwant_key = fb_key;
+    }
     for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
         const int k = 2 * s;
         const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
@@ -844,11 +878,11 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             kstamp(s, 0);
             if (gs_panel256(ctx, sa, m, k, A + wend * ld + c0, ld, mr)) return -1;
         }
+        // the whole window solved (operands of the trailing update, and of A) and, for A, B(s - 1) (the same region of C)
+        if (s > 0) wait2(sa, GS_FL_WALL, s, (unsigned)Gs, GS_FL_FB, s - 1, plan[s - 1].fb);
+        else wait1(sa, GS_FL_WALL, s, (unsigned)Gs);
         GS_CHECK(hipEventRecord(sl->evP[s], sa));
         if (mr > 0) {
-            // the window's first 16 row groups (this update's B operand) and B(s - 1) (the same region of C)
-            if (s > 0) wait2(sa, GS_FL_WTOP, s, (unsigned)std::min(16, Gs), GS_FL_FB, s - 1, gs_ch_nfirst((int)naug, s - 1));
-            else wait1(sa, GS_FL_WTOP, s, (unsigned)std::min(16, Gs));
             kstamp(s, 1);
             if (gs_gemm(ctx, sa, GS_BULK, A + wend * ld + r2, ld, A + wend * ld + c0, ld, A + r2 * ld + c0, ld, mr, 256, 256, 0, 1, -1.0)) return -1;
         }
@@ -857,12 +891,31 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         const int64_t r3 = r2 + 256, m3 = naug - r3;
         if (m3 > 0) {
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[s], 0));
-            wait1(sm, GS_FL_WALL, s, (unsigned)Gs);
-            ctx->first_tiles = (int)gs_ch_nfirst((int)naug, s);
+            ctx->first_tiles = (int)plan[s].fb;
             ctx->first_done = fl + gs_fl(GS_FL_FB, S, s);
             ctx->gate_flags = fl;
-            kstamp(s, 3);
-            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, A + r3 * ld + c0, ld, A + r3 * ld + c0, ld, m3, m3, 256, 1, 1, -1.0)) return -1;
+            double* P3 = A + r3 * ld + c0;               // panel rows r3.., this step's 256 columns
+            if (plan[s].kind == 0) {
+                kstamp(s, 3);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, 256, 1, 1, -1.0)) return -1;
+            } else if (plan[s].kind == 1) {
+                // near region only: rows >= r3, columns [r3, r3 + 512); algorithmic work = the lower trapezoid
+                ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 512.0 - 512.0 * 511.0);
+                kstamp(s, 3);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, 512, 256, 0, 1, -1.0)) return -1;
+            } else {
+                // columns [r3, r3 + 256): this panel only (they had the previous one as "near") ...
+                ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 256.0 - 256.0 * 255.0);
+                kstamp(s, 2);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, std::min<int64_t>(256, m3), 256, 0, 1, -1.0)) return -1;
+                // ... everything right of them: the previous panel and this one together (512 contiguous panel columns)
+                const int64_t r4 = r3 + 256, m4 = naug - r4;
+                if (m4 > 0) {
+                    double* P4 = A + r4 * ld + (c0 - 256);
+                    kstamp(s, 3);
+                    if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, 512, 1, 1, -1.0)) return -1;
+                }
+            }
         }
     }
     GS_CHECK(hipEventRecord(sl->evC, sp));
@@ -1263,6 +1316,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
+    else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value != 0;
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));

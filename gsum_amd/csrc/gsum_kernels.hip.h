@@ -1847,6 +1847,7 @@ struct gs_chain_args {
     double* Ltab; double* Lsib; double* logdet; const double* diag0; int* info;
     double* dump;                  // [2][GS_CH_GMAX][16][4][64]: operand images of the window's solved rows, by step parity
     unsigned* flags;               // gs_fl_count(S) words, zeroed before the launch
+    const unsigned* fbwant;        // S words: how many first-256-column tiles the host-enqueued trailing update of step s counts in FB[s]
     unsigned long long* stamps;    // S x GS_CH_STAMPS realtime stamps, or NULL
 };
 
@@ -2152,7 +2153,7 @@ __device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int 
         gs_utask u;
         bool early = false;
         const bool have_task = pw < ntask && gs_utask_decode(u, pw, Gs, Gc, a.A, ld, r2, dump, lane);
-        const unsigned fb_want = s > 0 ? gs_ch_nfirst(a.naug, s - 1) : 0u;     // B(s - 1): C's last host-enqueued update, counted per tile
+        const unsigned fb_want = s > 0 ? a.fbwant[s - 1] : 0u;     // B(s - 1): C's last host-enqueued update, counted per tile
         if (have_task && gs_flag_ld(fl + gs_fl(GS_FL_FB, S, s > 0 ? s - 1 : 0)) >= fb_want) {      // (C is up to date already: else later, in full)
             if (!gs_utask_poll(u, fl, S, s, 1u)) return;
             gs_acquire();
@@ -3005,6 +3006,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
         const int tm = (M + BM - 1) / BM;
         bm = blockIdx.x % tm;
         bn = blockIdx.x / tm;
+        first_cols = (int)blockIdx.x < nfirst;        // column-major tile order: the first 4 tm ids are the first 256 columns
     }
     const int m0 = bm * BM, n0 = bn * BN;
     if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
