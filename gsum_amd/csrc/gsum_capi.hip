@@ -45,6 +45,8 @@ struct gs_slot {
     hipStream_t sc = nullptr, srm = nullptr;   // windowed schedule with reserve_cus > 0: the chain on the reserved CUs ONLY,
                                                // the rest stream on the bulk stream's CUs
     hipStream_t sr = nullptr;        // windowed look-ahead schedule: the rows below the window (panel rest, far look-ahead columns)
+    hipStream_t sband[4] = {nullptr, nullptr, nullptr, nullptr};   // persistent-chain schedule: row bands 1.. of the trailing update (band 0: sm)
+    hipEvent_t evBand[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t sa = nullptr;        // persistent-chain schedule: the panel of the rows below the window and the near updates A, B
     hipEvent_t evC = nullptr, evS = nullptr;     // ... its joins (chain kernel / stream sa -> main stream)
     std::vector<hipEvent_t> evP, evM, evA;
@@ -116,6 +118,12 @@ struct gsum_ctx {
                                      // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
     int chain_min_np = 2048;
     int chain_lazy = 0;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
+    int chain_bands = 1;             // persistent-chain schedule: the trailing update in this many row bands (fixed absolute boundaries, equal
+                                     // areas), each on a stream of its own: a band's tiles depend on their own previous version and the panel
+                                     // only, so band p of step s + 1 starts when band p of step s is done -- no chip-wide barrier per step.
+                                     // Measured (profiles/r03_chain_check.log): 2 / 3 / 4 bands 5.84 / 5.87 / 6.79 ms against 5.45 with one at
+                                     // n = 8192, 2.45-2.84 against 2.00 at 4096 -- B's tiles of a step then queue behind the other bands'
+                                     // previous launches instead of starting on an empty chip, and the chain waits for ALL of them.  Off.
     int chain_rows = 512;            // the chain's window: rows under the panel it solves and updates itself (256 or 512)
     int chain_stamps = 0;            // record the chain kernel's per-step realtime stamps (gsum_debug_chain_stamps)
     int chain_probe = 0;             // two-stream concurrency probe: 0 not run, 1 streams run side by side, -1 they do not (a
@@ -842,8 +850,30 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // (47.5 TF/s at M = 7936 against 55 at K = 512: profiles/r03_bulk_cphase.log).  So even steps update only the 512 columns the
     // next two panels live in ("near", K = 256, rectangular) and the following odd step applies both panels to everything right of
     // them in ONE K = 512 pass after its own B columns.  Per element the same products in the same order: bit-identical.
-    struct Plan { int kind; unsigned fb; };          // kind 0: B + Far merged (tri), 1: near-512 (even), 2: B then Far K = 512 (odd)
+    // ROW BANDS (chain_bands): the trailing update B + Far of a step is cut into row bands with boundaries fixed in absolute
+    // coordinates (equal areas of the whole triangle: X_p = n sqrt(p / NB), rounded to 256), band p on stream p.  A tile of the
+    // trailing matrix depends on its own previous version and on the panel only, so band p of step s + 1 may start when band p
+    // of step s is done, whatever the other bands do: the launches of one step no longer end at a chip-wide barrier, and one
+    // band's tail overlaps another's bulk -- what sixteen evaluations in flight do for a batch (52 TF/s of Cholesky flops there
+    // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
+    struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
     std::vector<Plan> plan((size_t)S, Plan{0, 0u});
+    const int NB = ctx->chain_lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
+    int64_t bound[6];
+    bound[0] = 0;
+    for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
+    bound[NB] = naug;
+    auto first_tiles_of = [&](int s) {               // tiles of the first 256 trailing columns over all bands of step s
+        const int64_t r3 = 256 * (int64_t)(s + 2);
+        unsigned cnt = 0;
+        for (int p = 0; p < NB; ++p) {
+            const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
+            if (lo >= hi) continue;
+            if (lo > r3) cnt += 4u * (unsigned)((hi - lo + 127) / 128);               // rectangle: all its first four column tiles
+            else cnt += 4u * (unsigned)((hi - lo + 127) / 128) - 2u;                   // the triangle that starts at r3
+        }
+        return cnt;
+    };
     {
         bool deferred = false;
         for (int s = 0; s + 1 < S; ++s) {
@@ -857,17 +887,26 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
                 plan[s] = Plan{1, 4u * tm};
                 deferred = true;
             } else {
-                plan[s] = Plan{0, 4u * tm - 2u};
+                plan[s] = Plan{0, first_tiles_of(s)};
             }
         }
     }
     unsigned* fbw = fl + gs_fl_count(S);
-    const int fb_key = W * 2 + (ctx->chain_lazy ? 1 : 0);
+    const int fb_key = (W * 2 + (ctx->chain_lazy ? 1 : 0)) * 8 + NB;
     if (m->fbwant_key != fb_key) {
         std::vector<unsigned> h((size_t)S);
         for (int s = 0; s < S; ++s) h[s] = plan[s].fb;
         GS_CHECK(hipMemcpy(fbw, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         m->fbwant_key = fb_key;
+    }
+    hipStream_t sbd[4] = {sm, nullptr, nullptr, nullptr};
+    for (int p = 1; p < NB; ++p) {
+        if (!sl->sband[p]) {
+            GS_CHECK(hipStreamCreateWithPriority(&sl->sband[p], hipStreamNonBlocking, ctx->prio_lo));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evBand[p], hipEventDisableTiming));
+        }
+        sbd[p] = sl->sband[p];
+        GS_CHECK(hipStreamWaitEvent(sbd[p], sl->evFork, 0));
     }
     for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
         const int k = 2 * s;
@@ -878,45 +917,73 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             kstamp(s, 0);
             if (gs_panel256(ctx, sa, m, k, A + wend * ld + c0, ld, mr)) return -1;
         }
-        // the whole window solved (operands of the trailing update, and of A) and, for A, B(s - 1) (the same region of C)
-        if (s > 0) wait2(sa, GS_FL_WALL, s, (unsigned)Gs, GS_FL_FB, s - 1, plan[s - 1].fb);
-        else wait1(sa, GS_FL_WALL, s, (unsigned)Gs);
-        GS_CHECK(hipEventRecord(sl->evP[s], sa));
+        // the whole window solved (operands of the trailing update, and of A): the panel of step s is complete ...
+        wait1(sa, GS_FL_WALL, s, (unsigned)Gs);
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_RP, S, s), 1u);
+        // ... and, for A, B(s - 1) (the same region of C)
         if (mr > 0) {
+            if (s > 0) wait1(sa, GS_FL_FB, s - 1, plan[s - 1].fb);
             kstamp(s, 1);
             if (gs_gemm(ctx, sa, GS_BULK, A + wend * ld + r2, ld, A + wend * ld + c0, ld, A + r2 * ld + c0, ld, mr, 256, 256, 0, 1, -1.0)) return -1;
         }
         hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FA, S, s), 1u);
         GS_CHECK(hipGetLastError());
         const int64_t r3 = r2 + 256, m3 = naug - r3;
-        if (m3 > 0) {
-            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[s], 0));
-            ctx->first_tiles = (int)plan[s].fb;
-            ctx->first_done = fl + gs_fl(GS_FL_FB, S, s);
-            ctx->gate_flags = fl;
-            double* P3 = A + r3 * ld + c0;               // panel rows r3.., this step's 256 columns
-            if (plan[s].kind == 0) {
-                kstamp(s, 3);
-                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, 256, 1, 1, -1.0)) return -1;
-            } else if (plan[s].kind == 1) {
-                // near region only: rows >= r3, columns [r3, r3 + 512); algorithmic work = the lower trapezoid
-                ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 512.0 - 512.0 * 511.0);
-                kstamp(s, 3);
-                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, 512, 256, 0, 1, -1.0)) return -1;
-            } else {
-                // columns [r3, r3 + 256): this panel only (they had the previous one as "near") ...
-                ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 256.0 - 256.0 * 255.0);
-                kstamp(s, 2);
-                if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, std::min<int64_t>(256, m3), 256, 0, 1, -1.0)) return -1;
-                // ... everything right of them: the previous panel and this one together (512 contiguous panel columns)
-                const int64_t r4 = r3 + 256, m4 = naug - r4;
-                if (m4 > 0) {
-                    double* P4 = A + r4 * ld + (c0 - 256);
-                    kstamp(s, 3);
-                    if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, 512, 1, 1, -1.0)) return -1;
+        if (m3 <= 0) continue;
+        unsigned* fbp = fl + gs_fl(GS_FL_FB, S, s);
+        double* P3 = A + r3 * ld + c0;               // panel rows r3.., this step's 256 columns
+        if (plan[s].kind == 0) {
+            for (int p = 0; p < NB; ++p) {
+                const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
+                if (lo >= hi) continue;
+                hipStream_t sb = sbd[p];
+                wait1(sb, GS_FL_RP, s, 1u);
+                double* Plo = A + lo * ld + c0;          // panel rows of this band
+                if (lo > r3) {
+                    // rectangle: rows [lo, hi) x columns [r3, lo); its first 256 columns are B's
+                    ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128));
+                    ctx->first_done = fbp;
+                    ctx->gate_flags = fl;
+                    if (p == NB - 1) kstamp(s, 3);
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + r3, ld, Plo, ld, P3, ld, hi - lo, lo - r3, 256, 0, 1, -1.0)) return -1;
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
+                } else {
+                    // the band the trailing matrix starts in: a triangle from r3, first-256-column tiles first
+                    ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128) - 2);
+                    ctx->first_done = fbp;
+                    ctx->gate_flags = fl;
+                    if (p == NB - 1) kstamp(s, 3); else kstamp(s, 2);
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
                 }
             }
+            continue;
         }
+        wait1(sm, GS_FL_RP, s, 1u);
+        ctx->first_tiles = (int)plan[s].fb;
+        ctx->first_done = fbp;
+        ctx->gate_flags = fl;
+        if (plan[s].kind == 1) {
+            // near region only: rows >= r3, columns [r3, r3 + 512); algorithmic work = the lower trapezoid
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 512.0 - 512.0 * 511.0);
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, 512, 256, 0, 1, -1.0)) return -1;
+        } else {
+            // columns [r3, r3 + 256): this panel only (they had the previous one as "near") ...
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 256.0 - 256.0 * 255.0);
+            kstamp(s, 2);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, std::min<int64_t>(256, m3), 256, 0, 1, -1.0)) return -1;
+            // ... everything right of them: the previous panel and this one together (512 contiguous panel columns)
+            const int64_t r4 = r3 + 256, m4 = naug - r4;
+            if (m4 > 0) {
+                double* P4 = A + r4 * ld + (c0 - 256);
+                kstamp(s, 3);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, 512, 1, 1, -1.0)) return -1;
+            }
+        }
+    }
+    for (int p = 1; p < NB; ++p) {
+        GS_CHECK(hipEventRecord(sl->evBand[p], sbd[p]));
+        GS_CHECK(hipStreamWaitEvent(sm, sl->evBand[p], 0));
     }
     GS_CHECK(hipEventRecord(sl->evC, sp));
     GS_CHECK(hipEventRecord(sl->evS, sa));
@@ -1213,6 +1280,10 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->srm) (void)hipStreamDestroy(sl->srm);
         if (sl->su) (void)hipStreamDestroy(sl->su);
         if (sl->evU) (void)hipEventDestroy(sl->evU);
+        for (int q = 0; q < 4; ++q) {
+            if (sl->sband[q]) (void)hipStreamDestroy(sl->sband[q]);
+            if (sl->evBand[q]) (void)hipEventDestroy(sl->evBand[q]);
+        }
         if (sl->gws) (void)hipFree(sl->gws);
         if (sl->hgrad) (void)hipHostFree(sl->hgrad);
         if (sl->sa) (void)hipStreamDestroy(sl->sa);
@@ -1317,6 +1388,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
     else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value != 0;
+    else if (!strcmp(name, "chain_bands")) ctx->chain_bands = (int)std::max<int64_t>(1, std::min<int64_t>(4, value));
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));

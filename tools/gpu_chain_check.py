@@ -40,17 +40,18 @@ for n, r, kern, d in ((1024, 4, RBF(0.2), 1), (2048, 4, RBF(0.2), 1), (2304, 3, 
     ctx.set_option("chain_persist", 0)
     ref = evaluate(desc, 1e-10)
     t_ref = min(evaluate(desc, 1e-10)[3] for _ in range(reps))
-    for W, lazy in ((512, 1), (512, 0), (256, 1)):
+    for W, lazy, bands in ((512, 0, 1), (256, 0, 1), (512, 1, 1), (512, 0, 3)):
         ctx.set_option("chain_persist", 1)
         ctx.set_option("chain_rows", W)
         ctx.set_option("chain_lazy", lazy)
+        ctx.set_option("chain_bands", bands)
         same, ts = 0, []
         for _ in range(reps):
             G, sld, info, ms = evaluate(desc, 1e-10)
             ok = np.array_equal(G, ref[0]) and sld == ref[1] and info == ref[2]
             same += ok
             ts.append(ms)
-        rec = dict(n=n, W=W, lazy=lazy, identical=same, reps=reps, potrf_ms_chain=min(ts), potrf_ms_chain_median=float(np.median(ts)),
+        rec = dict(n=n, W=W, lazy=lazy, bands=bands, identical=same, reps=reps, potrf_ms_chain=min(ts), potrf_ms_chain_median=float(np.median(ts)),
                    potrf_ms_host=t_ref, probe=ctx.get_option("chain_probe"), aborts=ctx.get_option("chain_aborts"),
                    persist_now=ctx.get_option("chain_persist"), info=ref[2],
                    maxdiff=float(np.max(np.abs(G - ref[0]))), sld_diff=sld - ref[1])
@@ -96,7 +97,8 @@ Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis
 ctx.set_inputs(X, Z)
 ctx.set_option("chain_persist", 1)
 ctx.set_option("chain_rows", 512)
-ctx.set_option("chain_lazy", 1)
+ctx.set_option("chain_lazy", 0)
+ctx.set_option("chain_bands", 1)
 ctx.set_option("chain_stamps", 1)
 for _ in range(3):
     evaluate(desc, 1e-10)
