@@ -1232,6 +1232,11 @@ int gsum_init(int device, gsum_ctx** out) {
     if (cw) ctx->chain_window = atoi(cw) != 0;
     const char* bp = getenv("GSUM_BULK_LDS_PAD");
     if (bp) ctx->bulk_lds_pad = std::max(0, std::min(80 * 1024, atoi(bp)));
+    const char* pg = getenv("GSUM_PIVOT_GUARD_ULPS");
+    if (pg) {
+        const double g = (double)std::max(0, std::min(1024, atoi(pg))) * 2.220446049250313e-16;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gs_pivot_guard), &g, sizeof g);
+    }
     const char* cp = getenv("GSUM_CHAIN_PERSIST");
     if (cp) ctx->chain_persist = atoi(cp) < 0 ? -1 : (atoi(cp) != 0);
     const char* rc = getenv("GSUM_RESERVE_CUS");
@@ -1388,6 +1393,12 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
     else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value != 0;
+    else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
+        const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_pivot_guard), &g, sizeof g));
+    }
     else if (!strcmp(name, "chain_bands")) ctx->chain_bands = (int)std::max<int64_t>(1, std::min<int64_t>(4, value));
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));

@@ -26,6 +26,13 @@
 #include "gsum_hip.h"
 
 #define GS_NB 128
+// pivot test: LAPACK's dpotf2 rule (p <= 0 or NaN -> info) with a guard of 2 eps: a pivot p of column j also counts as not positive
+// when p <= gs_pivot_guard * A_jj (the original diagonal entry).  Rounds 1-2 shipped 8 eps.  Measured in round 3
+// (tools/gpu_info_sweep.py, the duplicated-point cases of the test suite): with 0 an exactly singular matrix (n = 2048 Matern-5/2,
+// one point duplicated, no nugget) factorises on the device with a pivot of +1e-17 where numpy.linalg.cholesky raises; with 4 eps
+// and more the device refuses 2-D Matern-5/2 matrices that are singular to working precision and that LAPACK still factorises;
+// 1 and 2 eps reproduce LAPACK's outcome on all of them.  Option "pivot_guard_ulps" / GSUM_PIVOT_GUARD_ULPS.
+__device__ double gs_pivot_guard = 2.0 * 2.220446049250313e-16;
 #define GS_BORDER 16
 #define GS_KC 16                  // K chunk staged through LDS (16 doubles = one 128-B line per row)
 #define GS_LSTR (GS_KC + 1)       // odd LDS row stride (17 doubles): the compiler pairs fragment reads into
@@ -810,7 +817,7 @@ __device__ __forceinline__ int gs_diag_block_v1(double* A, int64_t ld, double* L
     }
     if (t < 128) {
         const double d0 = diag0[t];
-        thr[t] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
+        thr[t] = d0 > 0.0 ? d0 * gs_pivot_guard : 0.0;
     }
     const int tr = t >> 4, tc = t & 15;
     double a[8][8], vd[8];
@@ -1202,7 +1209,7 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
     // pivot thresholds (d0 was requested before the block, so it is the oldest load in flight): waves 0 and 1 store 64
     // each.  No barrier: the first recurrence reads entries 0..15, which its own wave wrote (LDS operations of one wave
     // execute in order); every later reader is behind the barriers of step 0.
-    if constexpr (W < 2) thr[threadIdx.x] = d0 > 0.0 ? d0 * (8.0 * 2.220446049250313e-16) : 0.0;
+    if constexpr (W < 2) thr[threadIdx.x] = d0 > 0.0 ? d0 * gs_pivot_guard : 0.0;
     if constexpr (W == 0) {
         gs_wave_lds_sync();
         const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);

@@ -202,3 +202,41 @@ def test_multi_start_fit_in_lock_step_equals_the_sequential_loop():
         out.append((gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_))
     np.testing.assert_array_equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1]
+
+
+def test_info_pattern_matern_and_2d(ctx):
+    """Which near-singular matrices factorise is part of 'bit-exact on indices'.  Beyond the S0 class (test_gpu_config4.py): RBF
+    (isotropic / anisotropic) and Matern-5/2 on random 2-D points must give numpy.linalg.cholesky's success / failure pattern over
+    48 length scales; on 1-D Matern-5/2 inputs that are singular to working precision (cond > 1e16) the two summation orders leave
+    pivots of opposite sign at 1e-17 A_jj: there the device may only be stricter (never a factor where LAPACK raises), and only in a
+    band of at most 6 adjacent length scales at the edge of the feasible region."""
+    n = 512
+    X1 = np.linspace(0, 1, n)[:, None]
+    X2 = np.random.RandomState(0).rand(n, 2)
+    ctx.set_option("medium_path", 0)
+    try:
+        for name, X, kern_of, ells, nug, exact in (
+                ("rbf 2-D", X2, lambda e: RBF(length_scale=e), np.geomspace(0.05, 2, 48), 1e-12, True),
+                ("rbf 2-D aniso", X2, lambda e: RBF(length_scale=[e, 2 * e]), np.geomspace(0.05, 2, 48), 1e-11, True),
+                ("matern52 2-D", X2, lambda e: Matern(length_scale=e, nu=2.5), np.geomspace(0.3, 100, 48), 0.0, True),
+                ("matern52 1-D", X1, lambda e: Matern(length_scale=e, nu=2.5), np.geomspace(0.5, 200, 48), 1e-14, False)):
+            want = []
+            for e in ells:
+                K = kern_of(float(e))(X)
+                K[np.diag_indices_from(K)] += nug
+                try:
+                    np.linalg.cholesky(K)
+                    want.append(True)
+                except np.linalg.LinAlgError:
+                    want.append(False)
+            descs = [gsum_amd.describe_kernel(kern_of(float(e)), X.shape[1]) for e in ells]
+            _, _, info = ctx.lml_batch(descs, X, np.ones((n, 1)), nug)
+            got = [int(i) == 0 for i in info]
+            diff = [i for i, (g, w) in enumerate(zip(got, want)) if g != w]
+            if exact:
+                assert not diff, (name, [(float(ells[i]), got[i], want[i]) for i in diff])
+            else:
+                assert all(want[i] and not got[i] for i in diff), name          # one-sided
+                assert len(diff) <= 6 and (not diff or diff[-1] - diff[0] == len(diff) - 1), (name, diff)
+    finally:
+        ctx.set_option("medium_path", 1)
