@@ -503,8 +503,10 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, "
-                                   f"{r} orders (BASELINE configs[2], S3)", "n": n, "orders": r,
+            "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, {r} orders"
+                                   + (" (BASELINE configs[2], S3)" if (n, r) == (8192, 6) else
+                                      " (BASELINE configs[1], S2)" if (n, r) == (2048, 4) else " (not a BASELINE size: rehearsal)"),
+                       "n": n, "orders": r,
                        "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": slots},
             "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)",
                         "ms_per_step_median": elapsed / K * 1e3, "ms_per_step_min": min(all_elapsed) / K * 1e3,

@@ -63,7 +63,8 @@ late = [st[s + 1, 0] - st[s, 0] for s in range(S - 9, S - 1)]
 dk = [st[s, 3] - st[s, 1] for s in range(1, S)]
 w("")
 w(f"last 8 full steps: {np.mean(late):.1f} us per 256 columns on average; D(k) {np.min(dk):.1f} .. {np.max(dk):.1f} us (median {np.median(dk):.1f}) -- "
-  "on a CU of its own the diagonal block takes the same time whatever the bulk update does beside it")
+  "on a CU of its own the diagonal block no longer queues behind or shares a SIMD with bulk waves; the slow ones are the first steps, "
+  "whose loads compete for HBM with the trailing update at full size")
 txt = "\n".join(lines) + "\n"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "single_eval_chain_timeline.txt"), "w").write(txt)
