@@ -208,6 +208,15 @@ def n2048_leg(ctx):
     dt = time.perf_counter() - t0
     flops = n ** 3 / 3.0
     ref = golden_lml(n, r)
+    # the same 1024 evaluations at the C ABI (gsum_set_inputs + gsum_lml_resident with the descriptors marshalled once): what the
+    # device path delivers without the host's per-theta kernel cloning (~15 ms per call of the grid method, in scikit-learn)
+    c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
+    ctx.set_inputs(X, np.concatenate([c, np.ones((n, 1))], axis=1))
+    darr = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.15, 0.25, 1024)])
+    ctx.lml_resident(darr, 1e-10)
+    t0 = time.perf_counter()
+    _, _, info_abi = ctx.lml_resident(darr, 1e-10)
+    dt_abi = time.perf_counter() - t0
     out = {"workload": f"n={n} 1-D RBF(0.2) dx=0.5ell, nugget 1e-10, {r} orders (BASELINE configs[1], S2)",
            "single_eval": {"host_ms_best": min(ts) * 1e3, "gpu_stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1],
                                                                           "finalize_d2h": stage[2], "gpu_total": stage[3]},
@@ -219,6 +228,10 @@ def n2048_leg(ctx):
                          "seconds": dt, "evals_per_s": grid.size / dt, "cholesky_tflops": flops * grid.size / dt / 1e12,
                          "cholesky_frac_of_fp64_mfma_peak": flops * grid.size / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                          "n_neg_inf": int(np.isneginf(grid).sum())},
+           "c_abi_1024": {"what": "1024 evaluations (ell in linspace(0.15, 0.25)) through gsum_lml_resident, descriptors marshalled once",
+                          "seconds": dt_abi, "evals_per_s": 1024 / dt_abi, "cholesky_tflops": flops * 1024 / dt_abi / 1e12,
+                          "cholesky_frac_of_fp64_mfma_peak": flops * 1024 / dt_abi / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                          "n_failed": int(np.count_nonzero(info_abi))},
            "parity": {"gpu": got, "reference": ref, "rel": None if ref is None else abs(got - ref) / abs(ref), "bound": PARITY_BOUND,
                       "what": "TruncationGP.log_marginal_likelihood(log 0.2, ratio=0.5) vs the reference's value, "
                               "tests/golden/large_lml.json (n = 2048)"}}

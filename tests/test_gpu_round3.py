@@ -240,3 +240,28 @@ def test_info_pattern_matern_and_2d(ctx):
                 assert len(diff) <= 6 and (not diff or diff[-1] - diff[0] == len(diff) - 1), (name, diff)
     finally:
         ctx.set_option("medium_path", 1)
+
+
+@pytest.mark.parametrize("n,n_theta,world", [(600, 11, 3), (2048, 8, 8)])
+def test_c_host_sharded_scan_equals_unsharded(n, n_theta, world):
+    """The multi-GPU recipe of INTEGRATION.md from a real C host (tests/c_host/shard_host.c, C99, the public header only): every rank of
+    a world evaluates its slice with gsum_lml_resident_shard into its own padded buffers, the blocks are stitched the way an in-place
+    all-gather does, and the result is bit-identical to one unsharded gsum_lml_resident call.  (The ranks run one after the other on
+    this box's single GPU; what is tested is the partition, the padded-buffer contract and the C boundary.)"""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not found")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "shard_host")
+        subprocess.run([gcc, "-std=c99", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_host", "shard_host.c"),
+                        "-o", exe, "-L" + os.path.join(ROOT, "gsum_amd"), "-lgsum_hip", "-Wl,-rpath," + os.path.join(ROOT, "gsum_amd")],
+                       check=True)
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="32")
+        res = subprocess.run([exe, str(n), str(n_theta), str(world)], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "gathered == unsharded: yes" in res.stdout

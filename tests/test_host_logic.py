@@ -368,3 +368,23 @@ def test_kernel_register_budgets():
     assert find("12k_potrf_diagILi2E")["VGPRs"] <= 224
     chain = find("7k_chain")
     assert chain["VGPRs"] <= 256 and chain["Scratch"] <= 64, chain        # one wave per SIMD, a CU of its own: no spills to memory
+
+
+def test_c_host_of_the_sharded_scan_compiles_as_c99():
+    """include/gsum_hip.h is a C header (no C++ in the boundary) and the C host of INTEGRATION.md's multi-GPU recipe,
+    tests/c_host/shard_host.c, compiles against it with -std=c99 -Wall -Wextra -Werror and links against the library (every symbol
+    it uses is exported).  It RUNS on the GPU box: tests/test_gpu_round3.py::test_c_host_sharded_scan_equals_unsharded."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not found")
+    src = os.path.join(ROOT, "tests", "c_host", "shard_host.c")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "shard_host")
+        res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                              "-L" + os.path.join(ROOT, "gsum_amd"), "-lgsum_hip", "-Wl,-rpath," + os.path.join(ROOT, "gsum_amd")],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        assert os.path.exists(exe)
