@@ -362,11 +362,21 @@ static int gs_bulk_la(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t 
     return rc;
 }
 
+// Padded order of a matrix (identity padding: exact zeros in every product, so results do not depend on it).  128 is the block
+// size; where the persistent-chain schedule applies the order goes to the next multiple of 256 instead -- an even number of block
+// columns -- so that schedule serves every order, not only multiples of 256 (n = 7976: 8192 instead of 8064 rows, +1.6 % work for a
+// factorisation that is 15 % faster).
+static int64_t gs_padded_order(const gsum_ctx* ctx, int64_t n) {
+    const int64_t p128 = (n + GS_NB - 1) / GS_NB * GS_NB, p256 = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB);
+    if (ctx->chain_persist != 0 && ctx->diag_algo == 2 && p256 >= ctx->chain_min_np) return p256;
+    return p128;
+}
+
 static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     if (n <= 0 || n > (1 << 20)) GS_FAIL("matrix order out of range");
     gsum_mat* m = new gsum_mat();
     m->n = n;
-    m->np = (n + GS_NB - 1) / GS_NB * GS_NB;
+    m->np = gs_padded_order(ctx, n);
     m->ld = m->np + GS_BORDER;          // row stride 64 KiB + 128 B at n = 8192: no channel aliasing
     m->T = (int)(m->np / GS_NB);
     hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
@@ -1995,7 +2005,7 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
     {
         // every slot owns a workspace matrix of the current order: keep the new ones within 80 % of the free memory
-        const int64_t np = (ctx->in->n + GS_NB - 1) / GS_NB * GS_NB, ldw = np + GS_BORDER;
+        const int64_t np = gs_padded_order(ctx, ctx->in->n), ldw = np + GS_BORDER;
         const double Tw = (double)(np / GS_NB);
         const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0      // A, Linv
                                 + Tw * GS_LTAB * 8.0 + (Tw / 2 + 1) * GS_LSIB * 8.0 + (double)np * 16.0;   // Ltab, Lsib, logdet + diag0
@@ -2228,7 +2238,7 @@ int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_
         return gs_grad_harvest(ctx, sl, n_params, G_out, sld_out, info_out, trace_out, H_out);
     }
     // slots: every one owns a workspace matrix and U, R^-1 (3 n^2 doubles in all): within 70 % of the free memory, 8 at most
-    const int64_t np = (n + GS_NB - 1) / GS_NB * GS_NB;
+    const int64_t np = gs_padded_order(ctx, n);
     size_t free_b = 0, total_b = 0;
     GS_CHECK(hipMemGetInfo(&free_b, &total_b));
     const double per_slot = 3.2 * (double)(np + GS_BORDER) * (double)(np + GS_BORDER) * 8.0;
