@@ -131,13 +131,8 @@ struct gsum_ctx {
     int chain_events_needed = 0;     // the gradient path trails the factorisation by evP events: host-enqueued schedule only
     int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
     unsigned long long* kst_ptr = nullptr;   // diagnostics: start / end stamp pair of the NEXT bulk (cfg 7) / k_panel256 launch
-    const unsigned* gate_ptr = nullptr;   // gate of the NEXT bulk (cfg 7) / k_panel256 launch; consumed by it
-    unsigned gate_want = 0;
-    const unsigned* gate2_ptr = nullptr;  // ... a second counter the same launch waits for (cfg 7 only)
-    unsigned gate2_want = 0;
-    int first_tiles = 0;                  // ... tri launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
+    int first_tiles = 0;                  // the NEXT bulk (cfg 7) launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
     unsigned* first_done = nullptr;
-    unsigned* gate_flags = nullptr;
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
                                      // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
@@ -262,7 +257,7 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
     if (cfg == 6 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (cfg == 7 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
-    if (ctx->gate_ptr && cfg != 7) GS_FAIL("internal: only the cfg-7 bulk tile can be gated");
+    if (ctx->first_tiles && cfg != 7) GS_FAIL("internal: only the cfg-7 bulk tile counts first-column tiles");
     if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
@@ -286,13 +281,12 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         }
         if (nst == 3)
             hipLaunchKernelGGL(k_gemm_ld3<3>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                               beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
+                               beta, sign, ctx->kst_ptr,
                                tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
         else
             hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                               beta, sign, ctx->gate_ptr, ctx->gate_want, ctx->gate2_ptr, ctx->gate2_want, ctx->gate_flags, ctx->kst_ptr,
+                               beta, sign, ctx->kst_ptr,
                                tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
-        ctx->gate_ptr = ctx->gate2_ptr = nullptr;
         ctx->kst_ptr = nullptr;
         ctx->first_tiles = 0;
         ctx->first_done = nullptr;
@@ -609,9 +603,7 @@ static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, d
     if (M <= 0) return 0;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
     hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
-                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->gate_ptr, ctx->gate_want,
-                       ctx->gate_flags, ctx->kst_ptr);
-    ctx->gate_ptr = nullptr;
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr);
     ctx->kst_ptr = nullptr;
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
@@ -953,7 +945,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
                     // rectangle: rows [lo, hi) x columns [r3, lo); its first 256 columns are B's
                     ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128));
                     ctx->first_done = fbp;
-                    ctx->gate_flags = fl;
                     if (p == NB - 1) kstamp(s, 3);
                     if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + r3, ld, Plo, ld, P3, ld, hi - lo, lo - r3, 256, 0, 1, -1.0)) return -1;
                     if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
@@ -961,7 +952,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
                     // the band the trailing matrix starts in: a triangle from r3, first-256-column tiles first
                     ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128) - 2);
                     ctx->first_done = fbp;
-                    ctx->gate_flags = fl;
                     if (p == NB - 1) kstamp(s, 3); else kstamp(s, 2);
                     if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
                 }
@@ -971,7 +961,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         wait1(sm, GS_FL_RP, s, 1u);
         ctx->first_tiles = (int)plan[s].fb;
         ctx->first_done = fbp;
-        ctx->gate_flags = fl;
         if (plan[s].kind == 1) {
             // near region only: rows >= r3, columns [r3, r3 + 512); algorithmic work = the lower trapezoid
             ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 512.0 - 512.0 * 511.0);

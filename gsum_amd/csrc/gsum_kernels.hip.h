@@ -1656,11 +1656,6 @@ __device__ __forceinline__ bool gs_wg_wait_ge(const unsigned* f, unsigned want, 
     return ok != 0;
 }
 
-// gate of a host-enqueued kernel (single-wave workgroups): proceed once the chain has set the flag
-__device__ __forceinline__ bool gs_gate_wave(const unsigned* gate, unsigned want, unsigned* flags) {
-    return gate == nullptr || gs_wait_ge(gate, want, flags);
-}
-
 __global__ void k_signal(unsigned* f, unsigned v) {
     if (threadIdx.x == 0) gs_flag_st(f, v);
 }
@@ -1697,15 +1692,12 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 // rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
-// gate != NULL (persistent-chain schedule): the tables are the chain kernel's; wait for its flag first.
 __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, const unsigned* gate, unsigned gate_want, unsigned* flags,
-                                                  unsigned long long* kst) {
+                                                  const double* Ltab1, unsigned long long* kst) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
     __builtin_amdgcn_s_setprio(3);
-    if (!gs_gate_wave(gate, gate_want, flags)) return;
     if (kst && lane == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());          // diagnostics: first start / last end of the launch
     double* rows = P + (int64_t)r0 * ld;
     gs_d4 P0[8], P1[8];
@@ -1827,7 +1819,7 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld,
 //                              over the published images, the next diagonal block's tasks first (counters UD0 / UD1 / UR)
 // Everything M-proportional -- the panel of the rows below the window (k_panel256, gated on T1), the update of the next
 // panel's columns below the window (A), of the panel after it (B) and of the far region (Far) -- stays host-enqueued on two
-// streams and meets the chain through the same flags: gated kernels poll a flag the chain sets (gs_gate_*), one-thread
+// streams and meets the chain through the same flags: a one-wave k_wait_flag in front of a launch holds its stream until the chain has set the flag, one-thread
 // k_signal launches tell the chain that A(s) / B(s) have finished.  The regions are a partition of the trailing update of
 // the host-enqueued schedule and every element receives the same products in the same ascending order: results are
 // bit-identical to it (tests/test_gpu_parity.py).
@@ -2942,38 +2934,22 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
 // 512).  Costs 50 % more operand loads per flop (served by L2).  Same staging layout and sign handling as k_gemm_ld;
 // results identical bit for bit.  Measured against k_gemm_ld in the same process: equal at M = 7936, +18 % at M = 4096
 // exclusive; -4 % time per pipelined evaluation, -6 % for one factorisation alone (n = 8192).
-// Persistent-chain schedule (gate != NULL): the launch reads panel rows the chain kernel publishes; thread 0's wave polls the
-// chain's counter(s), acquires, and the workgroup starts behind a barrier (the flag rides in the not-yet-used staging LDS).
+// Persistent-chain schedule: the launch is held back by a k_wait_flag in front of it on its stream until the chain has published the
+// panel rows it reads (per-workgroup polling was measured: 24 us per outer step).
 // nfirst > 0 (tri launches of that schedule): the tiles of the first 256 COLUMNS take the first nfirst block ids -- they
 // are dispatched first, stored write-through and counted in *first_done, because the chain's next-but-one outer step and the
 // next step's A update wait for exactly them ("B"), not for the rest of the trailing update ("Far") behind them in the same
 // launch.  One launch instead of two: B starts on an empty chip the moment the previous trailing update ends.
 template <int NST>
-__global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+__global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                      const unsigned* gate, unsigned gate_want, const unsigned* gate2,
-                                                      unsigned gate2_want, unsigned* flags, unsigned long long* kst, int nfirst,
-                                                      unsigned* first_done) {
+                                                      unsigned long long* kst, int nfirst, unsigned* first_done) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
     extern __shared__ double lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (gate) {                                   // uniform
-        volatile int* okp = reinterpret_cast<volatile int*>(lds);
-        if (t < 64) {
-            bool ok = gs_poll_ge(gate, gate_want, flags);
-            if (ok && gate2) ok = gs_poll_ge(gate2, gate2_want, flags);
-            gs_acquire();
-            gs_drain();
-            if (t == 0) *okp = ok ? 1 : 0;
-        }
-        __syncthreads();
-        const int ok = *okp;
-        __syncthreads();
-        if (!ok) return;
-    }
     if (kst && t == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());             // diagnostics: first start / last end of the launch
     // (Tried in round 3, measured, not kept: de-phasing naps for the second and third workgroup of a CU -- no gain, the
     // co-resident workgroups are not in lock step; three LDS stages with two workgroups per CU -- 3 % slower alone, 7 % slower
@@ -3104,15 +3080,22 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    // The store addresses are re-derived from the thread index HERE, behind an opaque copy of it: computed once in the prologue they
+    // stay live across the K loop, and this kernel must fit 72 VGPRs -- six bulk waves then leave a SIMD exactly the room in which one
+    // chain / panel wave (224) fits as soon as ONE bulk workgroup retires (tests/test_host_logic.py::test_kernel_register_budgets).
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int lane2 = t2 & 63, w2 = t2 >> 6;
+    const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
     if (!first_cols) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int col = n0 + (wn * WN + j) * 16 + fr;
+                const int col = n0 + (wn2 * WN + j) * 16 + fr2;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                    const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
                     if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
                 }
             }
@@ -3121,10 +3104,10 @@ __global__ __launch_bounds__(512, NST == 2 ? 6 : 4) void k_gemm_ld3(double* C, i
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int col = n0 + (wn * WN + j) * 16 + fr;
+                const int col = n0 + (wn2 * WN + j) * 16 + fr2;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
+                    const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
                     if (row < M && col < N) gs_st_wt(C + (int64_t)row * ldc + col, neg ? -acc[i][j][x] : acc[i][j][x]);
                 }
             }
