@@ -130,6 +130,7 @@ struct gsum_ctx {
                                      // profiler serialises dispatches): the chain schedule would deadlock until its timeout
     int chain_events_needed = 0;     // the gradient path trails the factorisation by evP events: host-enqueued schedule only
     int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
+    int chain_test_abort = 0;        // test hook: the chain gives up at this outer step of its NEXT factorisation (one shot)
     unsigned long long* kst_ptr = nullptr;   // diagnostics: start / end stamp pair of the NEXT bulk (cfg 7) / k_panel256 launch
     int first_tiles = 0;                  // the NEXT bulk (cfg 7) launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
     unsigned* first_done = nullptr;
@@ -812,6 +813,8 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     ca.A = A; ca.ld = ld; ca.np = (int)m->np; ca.naug = (int)naug; ca.S = S; ca.W = W;
     ca.Ltab = m->Ltab; ca.Lsib = m->Lsib; ca.logdet = m->logdet; ca.diag0 = m->diag0; ca.info = sl->dinfo;
     ca.dump = m->cdump; ca.flags = fl; ca.fbwant = fl + gs_fl_count(S); ca.stamps = ctx->chain_stamps ? m->cstamps : nullptr;
+    ca.test_abort = ctx->chain_test_abort;
+    ctx->chain_test_abort = 0;
     {
         const int rec = gs_prof_begin(ctx, sp, GS_PROF_DIAG, (double)T * GS_NB * GS_NB * GS_NB / 3.0);
         hipLaunchKernelGGL(k_chain, dim3((unsigned)(1 + W / 64)), dim3(256), GS_CH_LDS_DOUBLES * sizeof(double), sp, ca);
@@ -1392,6 +1395,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
     else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value != 0;
+    else if (!strcmp(name, "chain_test_abort")) ctx->chain_test_abort = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
         const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
         GS_CHECK(hipSetDevice(ctx->device));
@@ -1505,8 +1509,9 @@ int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
         ctx->chain_persist = 0;
         ++ctx->chain_aborts;
         A->factored = false;
-        GS_FAIL("the persistent chain schedule timed out (streams of this process do not run side by side); the matrix is "
-                "destroyed -- rebuild it and factorise again: the schedule is now switched off (option chain_persist = 0)");
+        ctx->err = "the persistent chain schedule timed out (streams of this process do not run side by side); the matrix is "
+                   "destroyed -- rebuild it and factorise again: the schedule is now switched off (option chain_persist = 0)";
+        return -1;                          // a runtime failure, not a bad argument
     }
     if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
     A->factored = (*info == 0);

@@ -1847,6 +1847,7 @@ struct gs_chain_args {
     double* dump;                  // [2][GS_CH_GMAX][16][4][64]: operand images of the window's solved rows, by step parity
     unsigned* flags;               // gs_fl_count(S) words, zeroed before the launch
     const unsigned* fbwant;        // S words: how many first-256-column tiles the host-enqueued trailing update of step s counts in FB[s]
+    int test_abort;                // test hook (option "chain_test_abort"): the D role gives up at this outer step as if a wait had timed out
     unsigned long long* stamps;    // S x GS_CH_STAMPS realtime stamps, or NULL
 };
 
@@ -1904,6 +1905,10 @@ __device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, doubl
         int pr2 = 0, pGs = 0, pGc = 0;
         if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
         if (st && t == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+        if (a.test_abort > 0 && s == a.test_abort) {          // (tests only: exercise the give-up path of every party and of the host)
+            if (t == 0) gs_flag_st(fl + GS_FL_ABORT, 1u);
+            return;
+        }
         if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD0, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 0, 4), fl, sh)) return;
         if (st && t == 0) st[1] = __builtin_amdgcn_s_memrealtime();
         int bad = gs_diag_block<true>(A00, ld, (double*)nullptr, (double*)nullptr, a.logdet + k, a.diag0 + c0, nullptr, wsd);

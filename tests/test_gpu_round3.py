@@ -269,3 +269,41 @@ def test_c_host_sharded_scan_equals_unsharded(n, n_theta, world):
         res = subprocess.run([exe, str(n), str(n_theta), str(world)], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "gathered == unsharded: yes" in res.stdout
+
+
+def test_chain_give_up_path_falls_back_to_the_host_enqueued_schedule(ctx):
+    """Every spin of the persistent-chain schedule is bounded; when one expires every party leaves at its next wait, the info word says
+    so and the evaluation is re-run on the host-enqueued schedule, which is then kept (chain_persist = 0).  The test hook
+    chain_test_abort makes the D role give up at outer step 2 exactly as a time-out would: the result must equal the normal one bit
+    for bit, chain_aborts counts it, and an in-place factorisation (gsum_potrf_lower: the matrix is destroyed) reports an error."""
+    n = 2048
+    X, Z = _inputs(n, 4, 1, 7)
+    desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+    old_slots = ctx.get_option("batch_slots")
+    ctx.set_option("batch_slots", 1)
+    ctx.set_inputs(X, Z)
+    try:
+        ctx.set_option("chain_persist", 1)
+        want = ctx.lml_resident([desc], 1e-10)
+        aborts = ctx.get_option("chain_aborts")
+        ctx.set_option("chain_test_abort", 2)
+        got = ctx.lml_resident([desc], 1e-10)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        assert ctx.get_option("chain_aborts") == aborts + 1
+        assert ctx.get_option("chain_persist") == 0                   # switched off after a give-up
+        ctx.set_option("chain_persist", 1)
+        K = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+        ctx.set_option("chain_test_abort", 3)
+        with pytest.raises(RuntimeError, match="timed out"):
+            ctx.potrf(K)
+        K.free()
+        assert ctx.get_option("chain_aborts") == aborts + 2
+        ctx.set_option("chain_persist", 1)
+        again = ctx.lml_resident([desc], 1e-10)                       # and the schedule works again when asked for
+        for a, b in zip(again, want):
+            np.testing.assert_array_equal(a, b)
+        assert ctx.get_option("chain_aborts") == aborts + 2
+    finally:
+        ctx.set_option("chain_persist", -1)
+        ctx.set_option("batch_slots", old_slots)
