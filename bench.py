@@ -181,7 +181,7 @@ def golden_lml(n, r):
 
 def n2048_leg(ctx):
     """BASELINE configs[1]: n = 2048 1-D RBF, 4 orders -- K build + Cholesky + logpdf on one MI355X.
-    One evaluation alone (the multi-kernel path with the persistent chain) and 1024 evaluations of a 32 x 32 (ell, ratio)
+    One evaluation alone (the multi-kernel path with the persistent chain) and 1024 evaluations of a 512 x 2 (ell, ratio)
     scan through TruncationGP.log_marginal_likelihood_grid(mode="full") (one workgroup per evaluation, k_lml_medium)."""
     import gsum_amd
     from sklearn.gaussian_process.kernels import RBF
@@ -209,7 +209,7 @@ def n2048_leg(ctx):
     flops = n ** 3 / 3.0
     ref = golden_lml(n, r)
     # the same 1024 evaluations at the C ABI (gsum_set_inputs + gsum_lml_resident with the descriptors marshalled once): what the
-    # device path delivers without the host's per-theta kernel cloning (~15 ms per call of the grid method, in scikit-learn)
+    # device path delivers without the grid method's host work (right-hand sides per ratio row, descriptors, the O(k^2) algebra)
     c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
     ctx.set_inputs(X, np.concatenate([c, np.ones((n, 1))], axis=1))
     darr = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.15, 0.25, 1024)])

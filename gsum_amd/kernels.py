@@ -7,8 +7,9 @@ own tests, notebooks and defaults use:
     [ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5}))  [+ WhiteKernel] [+ ConstantKernel]
 
 with isotropic or anisotropic ``length_scale``.  Anything else raises ``NotImplementedError`` —
-there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) stays with
-scikit-learn: callers use ``kernel.clone_with_theta(theta)`` and then describe the clone.
+there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's:
+callers use ``kernel.clone_with_theta(theta)`` and describe the clone, or, for a stack of thetas,
+:func:`describe_thetas`, which reproduces the setter's values without the per-theta clone.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Produ
 
 from ._lib import FAMILY, GSUM_MAX_D, GradParam, KernelDesc
 
-__all__ = ["describe_kernel", "describe_gradient", "default_kernel"]
+__all__ = ["describe_kernel", "describe_thetas", "describe_gradient", "default_kernel"]
 
 
 def default_kernel():
@@ -37,8 +38,43 @@ def _product_factors(k):
     return [k]
 
 
-def describe_kernel(kernel, n_features: int) -> KernelDesc:
-    """Flatten ``kernel`` into a :class:`KernelDesc` for inputs with ``n_features`` columns."""
+class _Leaf:
+    """One leaf of a kernel tree: its class, the value of its only hyperparameter, where that value sits in theta (None if fixed)."""
+    __slots__ = ("kind", "value", "offset", "n_elements", "nu", "shown")
+
+    def __init__(self, k, offset):
+        if isinstance(k, WhiteKernel):
+            self.kind, self.value, hyper = "white", k.noise_level, k.hyperparameter_noise_level
+        elif isinstance(k, ConstantKernel):
+            self.kind, self.value, hyper = "const", k.constant_value, k.hyperparameter_constant_value
+        elif isinstance(k, (RBF, Matern)):
+            self.kind, self.value, hyper = "stationary", k.length_scale, k.hyperparameter_length_scale
+        else:
+            self.kind, self.value, hyper = "unsupported", None, None
+        self.shown = k
+        self.nu = float(k.nu) if isinstance(k, Matern) else None          # Matern subclasses RBF: nu tells them apart
+        free = hyper is not None and not hyper.fixed
+        self.n_elements = hyper.n_elements if free else 0
+        self.offset = offset if free else None
+
+
+def _flatten(kernel):
+    """Sum terms -> product factors -> leaves, left to right: the order in which scikit-learn lays theta out (KernelOperator.theta
+    splits at k1.n_dims; every leaf of the supported family has exactly one hyperparameter)."""
+    offset = 0
+    terms = []
+    for term in _sum_terms(kernel):
+        leaves = []
+        for f in _product_factors(term):
+            leaf = _Leaf(f, offset)
+            offset += leaf.n_elements
+            leaves.append(leaf)
+        terms.append(leaves)
+    return terms, offset
+
+
+def _describe(terms, values, n_features, shown) -> KernelDesc:
+    """``values(leaf)`` -> the leaf's hyperparameter; ``shown`` only feeds error messages."""
     if n_features < 1 or n_features > GSUM_MAX_D:
         raise ValueError(f"number of features must be 1..{GSUM_MAX_D}, got {n_features}")
     desc = KernelDesc()
@@ -46,39 +82,38 @@ def describe_kernel(kernel, n_features: int) -> KernelDesc:
     desc.additive_const = 0.0
     desc.white_noise = 0.0
     base = None
-    for term in _sum_terms(kernel):
-        if isinstance(term, WhiteKernel):
-            desc.white_noise += float(term.noise_level)
+    for factors in terms:
+        if len(factors) == 1 and factors[0].kind == "white":
+            desc.white_noise += float(values(factors[0]))
             continue
-        if isinstance(term, ConstantKernel):
-            desc.additive_const += float(term.constant_value)
+        if len(factors) == 1 and factors[0].kind == "const":
+            desc.additive_const += float(values(factors[0]))
             continue
-        factors = _product_factors(term)
-        if all(isinstance(f, ConstantKernel) for f in factors):
+        if all(f.kind == "const" for f in factors):
             # a product of constants is one additive constant (C(2) * C(3) adds 6 everywhere): no stationary part
-            desc.additive_const += float(np.prod([f.constant_value for f in factors]))
+            desc.additive_const += float(np.prod([values(f) for f in factors]))
             continue
         if base is not None:
-            raise NotImplementedError(f"sum of two stationary kernels is not supported on the device: {kernel}")
+            raise NotImplementedError(f"sum of two stationary kernels is not supported on the device: {shown}")
         amp = 1.0
         for f in factors:
-            if isinstance(f, ConstantKernel):
-                amp *= float(f.constant_value)
-            elif isinstance(f, (RBF, Matern)) and base is None:
+            if f.kind == "const":
+                amp *= float(values(f))
+            elif f.kind == "stationary" and base is None:
                 base = f
             else:
-                raise NotImplementedError(f"kernel factor {f!r} is not supported on the device (in {kernel})")
+                raise NotImplementedError(f"kernel factor {f.shown!r} is not supported on the device (in {shown})")
         desc.amplitude = amp                 # only the term that supplied the stationary base sets the amplitude
     if base is None:
-        raise NotImplementedError(f"kernel {kernel} has no RBF/Matern part")
-    if isinstance(base, Matern):        # Matern subclasses RBF: test it first
-        fam = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}.get(float(base.nu))
+        raise NotImplementedError(f"kernel {shown} has no RBF/Matern part")
+    if base.nu is not None:
+        fam = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}.get(base.nu)
         if fam is None:
             raise NotImplementedError(f"Matern nu={base.nu} is not supported on the device (0.5, 1.5, 2.5 are)")
     else:
         fam = "rbf"
     desc.family = FAMILY[fam]
-    ls = np.atleast_1d(np.asarray(base.length_scale, dtype=float))
+    ls = np.atleast_1d(np.asarray(values(base), dtype=float))
     if ls.size == 1:
         desc.anisotropic = 0
         desc.length_scale[0] = float(ls[0])
@@ -89,6 +124,35 @@ def describe_kernel(kernel, n_features: int) -> KernelDesc:
         for i, v in enumerate(ls):
             desc.length_scale[i] = float(v)
     return desc
+
+
+def describe_kernel(kernel, n_features: int) -> KernelDesc:
+    """Flatten ``kernel`` into a :class:`KernelDesc` for inputs with ``n_features`` columns."""
+    terms, _ = _flatten(kernel)
+    return _describe(terms, lambda leaf: leaf.value, n_features, kernel)
+
+
+def describe_thetas(kernel, thetas, n_features: int):
+    """``[describe_kernel(kernel.clone_with_theta(t), n_features) for t in thetas]`` without the clones: scikit-learn's theta setter
+    costs 70-320 us per call (get_params / set_params over the tree), more than a batched n = 2048 evaluation takes on the device.
+    The values are formed exactly as the setter forms them (kernels.py Kernel.theta: ``np.exp(theta[i])`` for a scalar hyperparameter,
+    ``np.exp(theta[i:i+n])`` for a vector one), so the descriptors are equal byte for byte (tests/test_host_logic.py)."""
+    terms, n_dims = _flatten(kernel)
+    out = []
+    for theta in thetas:
+        theta = np.atleast_1d(np.asarray(theta, dtype=float))
+        if theta.ndim != 1 or theta.size != n_dims:
+            raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
+
+        def values(leaf, theta=theta):
+            if leaf.offset is None:
+                return leaf.value
+            if leaf.n_elements > 1:
+                return np.exp(theta[leaf.offset:leaf.offset + leaf.n_elements])
+            return np.exp(theta[leaf.offset])
+
+        out.append(_describe(terms, values, n_features, kernel))
+    return out
 
 
 def describe_gradient(kernel, n_features: int):

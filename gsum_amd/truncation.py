@@ -12,7 +12,7 @@ import warnings
 import numpy as np
 
 from .conjugate import ConjugateGaussianProcess, ConjugateStudentProcess
-from .kernels import describe_kernel
+from .kernels import describe_thetas
 from .series import coefficients, geometric_sum
 
 __all__ = ["TruncationGP", "TruncationTP"]
@@ -273,13 +273,10 @@ class TruncationGP:
                 return gp._lml_gram_batch(G, sld, n_pts)
             return gp._lml_gram_batch_sd(G, sld, n_pts, svals)
 
-        desc_of = {}                # one descriptor per theta (clone_with_theta is the slow host step)
-
-        def desc_for(j):
-            if j not in desc_of:
-                kern = base.clone_with_theta(np.atleast_1d(np.asarray(thetas[j], dtype=float)))
-                desc_of[j] = describe_kernel(kern, Xd.shape[1])
-            return desc_of[j]
+        # one descriptor per theta this rank touches, built in one go and without scikit-learn's per-theta clone
+        js = sorted({(flat // ns) % nj for flat in range(lo, hi)})
+        desc_of = dict(zip(js, describe_thetas(base, [thetas[j] for j in js], Xd.shape[1])))
+        desc_for = desc_of.__getitem__
 
         if mode == "full":
             # group this rank's points by ratio setting: they share the right-hand sides, so X and Z go to the

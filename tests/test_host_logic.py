@@ -388,3 +388,23 @@ def test_c_host_of_the_sharded_scan_compiles_as_c99():
                              capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
         assert os.path.exists(exe)
+
+
+def test_describe_thetas_equals_describing_the_clones():
+    """The grid's descriptors are built without scikit-learn's per-theta clone (kernels.describe_thetas); they must be the
+    clone's descriptors byte for byte -- values formed like Kernel.theta's setter forms them, theta laid out leaves left to right."""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C, Matern, WhiteKernel
+    from gsum_amd.kernels import describe_kernel, describe_thetas
+    rng = np.random.RandomState(0)
+    cases = [(C(1.0, "fixed") * RBF(0.2), 1), (RBF(0.2), 1), (C(2.0) * Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, "fixed"), 2),
+             (C(2.0) * Matern([0.7, 1.3], nu=1.5) + WhiteKernel(1e-6) + C(0.3), 2), (RBF([0.1, 0.2, 0.3]) * C(3.0) * C(0.5, "fixed"), 3),
+             (C(2.0) * C(3.0) + Matern(0.4, nu=0.5), 1), (WhiteKernel(0.1) + C(1.5) * RBF(0.3, "fixed"), 1)]
+    for kern, d in cases:
+        thetas = kern.theta + rng.randn(32, len(kern.theta))
+        got = describe_thetas(kern, thetas, d)
+        want = [describe_kernel(kern.clone_with_theta(t), d) for t in thetas]
+        assert all(bytes(a) == bytes(b) for a, b in zip(got, want)), kern
+    with pytest.raises(ValueError, match="correct number of entries"):
+        describe_thetas(RBF(0.2), [[0.1, 0.2]], 1)
+    with pytest.raises(NotImplementedError, match="not supported on the device"):
+        describe_thetas(RBF(0.1) * RBF(0.2), [[0.1, 0.2]], 1)
