@@ -26,7 +26,7 @@ from sklearn.exceptions import ConvergenceWarning
 from sklearn.utils import check_random_state
 
 from ._lib import GSUM_MAX_RHS, default_context
-from .kernels import default_kernel, describe_gradient, describe_kernel, describe_thetas
+from .kernels import default_kernel, describe_gradient, describe_gradients, describe_kernel, describe_thetas
 
 __all__ = ["ConjugateGaussianProcess", "ConjugateStudentProcess", "posterior_from_gram", "lml_from_gram",
            "lml_from_gram_batch", "student_lml_from_gram", "hyper_gradients_from_gram", "lml_grad_from_gram",
@@ -533,16 +533,17 @@ class ConjugateGaussianProcess:
         X = np.asarray(self.X_train_ if X is None else X, dtype=float)
         y = self.y_train_ if y is None else y
         Z = self._rhs(X, y)
-        kernels = [base.clone_with_theta(np.asarray(t, dtype=float)) for t in thetas]
-        params = [describe_gradient(kk, X.shape[1]) for kk in kernels]     # the weights carry hyperparameter values: per kernel
-        if not params[0] or len(kernels) == 1:
+        thetas = [np.atleast_1d(np.asarray(t, dtype=float)) for t in thetas]
+        # descriptors and gradient parameters straight from theta (kernels.describe_thetas): no scikit-learn clone per start
+        params = describe_gradients(base, thetas, X.shape[1])              # the weights carry hyperparameter values: per theta
+        if not thetas or not params[0] or len(thetas) == 1:
             return [self.log_marginal_likelihood(t, eval_gradient=True, X=X, y=y) for t in thetas]
-        descs = [describe_kernel(kk, X.shape[1]) for kk in kernels]
+        descs = describe_thetas(base, thetas, X.shape[1])
         G, sld, info, trace, H = self._context().lml_grad_batch(descs, params, X, Z, self.nugget)
         out = []
-        for i, kk in enumerate(kernels):
+        for i, t in enumerate(thetas):
             if info[i] != 0:
-                out.append((-np.inf, np.zeros_like(kk.theta)))                       # models.py:970-972
+                out.append((-np.inf, np.zeros_like(t)))                              # models.py:970-972
             else:
                 out.append(self._lml_grad_gram(G[i], sld[i], trace[i], H[i], X.shape[0]))
         return out

@@ -18,7 +18,7 @@ from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Produ
 
 from ._lib import FAMILY, GSUM_MAX_D, GradParam, KernelDesc
 
-__all__ = ["describe_kernel", "describe_thetas", "describe_gradient", "default_kernel"]
+__all__ = ["describe_kernel", "describe_thetas", "describe_gradient", "describe_gradients", "default_kernel"]
 
 
 def default_kernel():
@@ -155,11 +155,9 @@ def describe_thetas(kernel, thetas, n_features: int):
     return out
 
 
-def describe_gradient(kernel, n_features: int):
-    """One :class:`GradParam` per component of ``kernel.theta``, in scikit-learn's order (leaves left to right,
-    a leaf's free hyperparameters in alphabetical order; SURVEY.md quirk Q10): what ``kernel(X, eval_gradient=True)``
-    would put in ``K_gradient[:, :, p]``.  Same kernel family as :func:`describe_kernel`."""
-    describe_kernel(kernel, n_features)                       # same validation, same error messages
+def _gradient_params(terms, values, n_features):
+    """The gradient parameters of a flattened kernel whose leaf hyperparameters are ``values(leaf)``: one per FREE hyperparameter
+    element, leaves left to right (scikit-learn's theta order)."""
     out = []
 
     def gp(code, dim=0, weight=0.0):
@@ -167,30 +165,65 @@ def describe_gradient(kernel, n_features: int):
         g.code, g.dim, g.weight = code, dim, float(weight)
         return g
 
-    for term in _sum_terms(kernel):
-        if isinstance(term, WhiteKernel):
-            if not term.hyperparameter_noise_level.fixed:
-                out.append(gp(GradParam.WHITE, weight=term.noise_level))
+    for factors in terms:
+        if len(factors) == 1 and factors[0].kind == "white":
+            if factors[0].offset is not None:
+                out.append(gp(GradParam.WHITE, weight=values(factors[0])))
             continue
-        if isinstance(term, ConstantKernel):
-            if not term.hyperparameter_constant_value.fixed:
-                out.append(gp(GradParam.ADDITIVE, weight=term.constant_value))
+        if len(factors) == 1 and factors[0].kind == "const":
+            if factors[0].offset is not None:
+                out.append(gp(GradParam.ADDITIVE, weight=values(factors[0])))
             continue
-        factors = _product_factors(term)
-        if all(isinstance(f, ConstantKernel) for f in factors):
+        if all(f.kind == "const" for f in factors):
             # d (c1 c2 ...) / d log c_i = the whole product, for every free factor
-            value = float(np.prod([f.constant_value for f in factors]))
-            out.extend(gp(GradParam.ADDITIVE, weight=value) for f in factors if not f.hyperparameter_constant_value.fixed)
+            value = float(np.prod([values(f) for f in factors]))
+            out.extend(gp(GradParam.ADDITIVE, weight=value) for f in factors if f.offset is not None)
             continue
         for f in factors:
-            if isinstance(f, ConstantKernel):
-                if not f.hyperparameter_constant_value.fixed:
+            if f.kind == "const":
+                if f.offset is not None:
                     out.append(gp(GradParam.AMPLITUDE))
-            elif not f.hyperparameter_length_scale.fixed:      # RBF / Matern: length_scale is the only free one
-                if f.anisotropic:
+            elif f.offset is not None:                          # RBF / Matern: length_scale is the only free one
+                if f.n_elements > 1:
                     out.extend(gp(GradParam.LENGTH_DIM, dim=m) for m in range(n_features))
                 else:
                     out.append(gp(GradParam.LENGTH_ISO))
-    if len(out) != len(kernel.theta):
+    return out
+
+
+def describe_gradient(kernel, n_features: int):
+    """One :class:`GradParam` per component of ``kernel.theta``, in scikit-learn's order (leaves left to right,
+    a leaf's free hyperparameters in alphabetical order; SURVEY.md quirk Q10): what ``kernel(X, eval_gradient=True)``
+    would put in ``K_gradient[:, :, p]``.  Same kernel family as :func:`describe_kernel`."""
+    describe_kernel(kernel, n_features)                       # same validation, same error messages
+    terms, n_dims = _flatten(kernel)
+    out = _gradient_params(terms, lambda leaf: leaf.value, n_features)
+    if len(out) != n_dims or n_dims != len(kernel.theta):
         raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
+    return out
+
+
+def describe_gradients(kernel, thetas, n_features: int):
+    """``[describe_gradient(kernel.clone_with_theta(t), n_features) for t in thetas]`` without the clones (see
+    :func:`describe_thetas`): the weights of the additive / white parameters are the hyperparameter VALUES, so there is one list
+    per theta."""
+    describe_kernel(kernel, n_features)
+    terms, n_dims = _flatten(kernel)
+    out = []
+    for theta in thetas:
+        theta = np.atleast_1d(np.asarray(theta, dtype=float))
+        if theta.ndim != 1 or theta.size != n_dims:
+            raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
+
+        def values(leaf, theta=theta):
+            if leaf.offset is None:
+                return leaf.value
+            if leaf.n_elements > 1:
+                return np.exp(theta[leaf.offset:leaf.offset + leaf.n_elements])
+            return np.exp(theta[leaf.offset])
+
+        params = _gradient_params(terms, values, n_features)
+        if len(params) != n_dims:
+            raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
+        out.append(params)
     return out

@@ -408,3 +408,22 @@ def test_describe_thetas_equals_describing_the_clones():
         describe_thetas(RBF(0.2), [[0.1, 0.2]], 1)
     with pytest.raises(NotImplementedError, match="not supported on the device"):
         describe_thetas(RBF(0.1) * RBF(0.2), [[0.1, 0.2]], 1)
+
+
+def test_describe_gradients_equals_describing_the_clones():
+    """Gradient parameters (code, dim, weight) per theta without the clone: equal to describe_gradient of the clone byte for byte,
+    including the value-carrying weights of white / additive parameters and a kernel with nothing free."""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C, Matern, WhiteKernel
+    from gsum_amd.kernels import describe_gradient, describe_gradients
+    rng = np.random.RandomState(1)
+    cases = [(C(1.0, "fixed") * RBF(0.2), 1), (C(2.0) * Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, "fixed"), 2),
+             (C(2.0) * Matern([0.7, 1.3], nu=1.5) + WhiteKernel(1e-6) + C(0.3), 2), (RBF([0.1, 0.2, 0.3]) * C(3.0) * C(0.5, "fixed"), 3),
+             (C(2.0) * C(3.0) + Matern(0.4, nu=0.5), 1), (WhiteKernel(0.1) + C(1.5) * RBF(0.3, "fixed"), 1),
+             (C(1.0, "fixed") * RBF(0.2, "fixed"), 1)]
+    for kern, d in cases:
+        thetas = kern.theta + rng.randn(16, len(kern.theta))
+        got = describe_gradients(kern, thetas, d)
+        want = [describe_gradient(kern.clone_with_theta(t), d) for t in thetas]
+        for a, b in zip(got, want):
+            assert len(a) == len(b) == len(kern.theta)
+            assert all(bytes(x) == bytes(y) for x, y in zip(a, b)), kern
