@@ -666,11 +666,46 @@ def gen_s1_plumbing():
     return out
 
 
+def gen_underlying():
+    """BaseConjugateProcess.underlying_properties (models.py:740-749): mean(X) [, sqrt(diag(cov(X))) | cov(X)] of the process --
+    prior quantities before fit, center_ / cov_factor_-scaled after.  Inputs stored with the outputs."""
+    cases = []
+    for dim, kernels in ((1, KERNELS_1D[:2]), (2, KERNELS_2D[:1])):
+        rng = np.random.RandomState(300 + dim)
+        n, r = 20, 3
+        if dim == 1:
+            X = np.sort(rng.rand(n))[:, None] * 2.0
+            Xs = np.linspace(-0.1, 2.1, 5)[:, None]
+        else:
+            X = rng.rand(n, 2) * np.array([3.0, 5.0])
+            Xs = rng.rand(5, 2) * np.array([3.0, 5.0])
+        y = rng.randn(n, r) + 0.3
+        for ks in kernels:
+            for pr in PRIORS:
+                gp = gsum.ConjugateGaussianProcess(kernel=make_kernel(ks), optimizer=None, **prior_kwargs(pr))
+                prior = None
+                try:                                   # before fit: prior mean / covariance (center0, scale0 ...), if the reference allows it
+                    pm, pc = gp.underlying_properties(Xs, return_cov=True)
+                    prior = dict(mean=L(pm), cov=L(pc))
+                except Exception as exc:               # noqa: BLE001 -- recorded, not hidden
+                    prior = dict(error=type(exc).__name__)
+                gp.fit(X, y)
+                m0 = gp.underlying_properties(Xs)
+                m1, sd = gp.underlying_properties(Xs, return_std=True)
+                m2, cv = gp.underlying_properties(Xs, return_cov=True)
+                m3, cv_both = gp.underlying_properties(Xs, return_std=True, return_cov=True)     # return_cov wins (:742-744)
+                cases.append(dict(kernel=ks, prior=pr, X=L(X), y=L(y), Xs=L(Xs), unfitted=prior,
+                                  mean=L(m0), mean_std=L(m1), std=L(sd), mean_cov=L(m2), cov=L(cv),
+                                  both_returns_cov=bool(np.shape(cv_both) == np.shape(cv) and np.array_equal(cv_both, cv)),
+                                  cov_factor=float(gp.cov_factor_), center=L(gp.center_)))
+    return cases
+
+
 def main():
     only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
     if only:
         gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid, s5_predict=gen_s5_predict,
-                    s1_plumbing=gen_s1_plumbing)
+                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying)
         for name in only:
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(gens[name](), f, indent=1)
@@ -704,6 +739,8 @@ def main():
         json.dump(gen_large_gp_drawn(), f, indent=1)
     with open(os.path.join(HERE, "s1_plumbing.json"), "w") as f:
         json.dump(gen_s1_plumbing(), f, indent=1)
+    with open(os.path.join(HERE, "underlying.json"), "w") as f:
+        json.dump(gen_underlying(), f, indent=1)
     with open(os.path.join(HERE, "s5_predict.json"), "w") as f:      # ~10 minutes on 8 cores, ~15 GB
         json.dump(gen_s5_predict(), f, indent=1)
     import sklearn, scipy

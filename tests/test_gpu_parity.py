@@ -1020,3 +1020,38 @@ def test_integration_md_binding_runs():
     assert info == 0 and iw[0] == 0
     np.testing.assert_array_equal(G, Gw[0])
     assert sld == sw[0]
+
+
+def test_underlying_properties_golden():
+    """BaseConjugateProcess.underlying_properties (models.py:740-749) against the reference's outputs (tests/golden/underlying.json):
+    mean / std / cov after fit, the prior quantities before fit -- or the reference's exception type where it has none (df0 <= 2) --
+    and return_cov taking precedence over return_std."""
+    from conftest import load_golden
+    for case in load_golden("underlying.json"):
+        kern = make_kernel(case["kernel"])
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **prior_kwargs(case["prior"]))
+        un = case["unfitted"]
+        if "error" in un:
+            with pytest.raises(Exception) as exc:
+                gp.underlying_properties(Xs, return_cov=True)
+            assert type(exc.value).__name__ == un["error"], (case["prior"], exc.value)
+        else:
+            pm, pc = gp.underlying_properties(Xs, return_cov=True)
+            np.testing.assert_allclose(pm, un["mean"], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(pc, un["cov"], rtol=1e-12, atol=1e-15)           # scale0^2-factor times the kernel: no solve involved
+        gp.fit(X, y)
+        ptol = max(1e-9, 100 * lml_tol(kern(X) + 1e-10 * np.eye(len(X))))
+        vs = case["cov_factor"]
+        assert gp.cov_factor_ == pytest.approx(vs, rel=ptol)
+        mscale = max(np.abs(np.array(case["mean"])).max(), 1e-300)
+        m0 = gp.underlying_properties(Xs)
+        m1, sd = gp.underlying_properties(Xs, return_std=True)
+        m2, cv = gp.underlying_properties(Xs, return_cov=True)
+        for m, want in ((m0, case["mean"]), (m1, case["mean_std"]), (m2, case["mean_cov"])):
+            assert np.shape(m) == np.shape(want)
+            np.testing.assert_allclose(m, want, rtol=ptol, atol=ptol * mscale)
+        np.testing.assert_allclose(sd, case["std"], rtol=ptol)
+        np.testing.assert_allclose(cv, case["cov"], rtol=ptol, atol=1e-14 * vs)
+        m3, both = gp.underlying_properties(Xs, return_std=True, return_cov=True)
+        assert case["both_returns_cov"] and np.array_equal(both, cv)                    # return_cov wins (:742-744)

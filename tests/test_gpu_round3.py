@@ -10,7 +10,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 import gsum_amd  # noqa: E402
-from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel  # noqa: E402
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C, Matern, WhiteKernel  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -307,3 +307,40 @@ def test_chain_give_up_path_falls_back_to_the_host_enqueued_schedule(ctx):
     finally:
         ctx.set_option("chain_persist", -1)
         ctx.set_option("batch_slots", old_slots)
+
+
+@pytest.mark.parametrize("n,d,kern", [(256, 1, C(1.0) * RBF(0.2)), (300, 2, C(2.0) * Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6)),
+                                      (2048, 1, C(1.0) * RBF(0.2))])
+def test_lml_batch_method_equals_the_single_calls(n, d, kern):
+    """ConjugateGaussianProcess.log_marginal_likelihood_batch builds descriptors and gradient parameters from theta without cloning
+    the kernel (kernels.describe_thetas / describe_gradients); the single call clones (models.py:953).  Same bits, entry by entry --
+    including the per-theta weights of the white / additive parameters."""
+    rng = np.random.RandomState(n + d)
+    X = 0.1 * np.arange(n)[:, None] if d == 1 else rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    y = rng.randn(n, 3)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None, nugget=1e-8)
+    gp.fit(X, y)
+    thetas = [gp.kernel_.theta + 0.03 * i * np.linspace(-1.0, 1.0, len(gp.kernel_.theta)) for i in range(6)]
+    single = [gp.log_marginal_likelihood(t, eval_gradient=True) for t in thetas]
+    batch = gp.log_marginal_likelihood_batch(thetas)
+    assert len(batch) == len(single)
+    for (v0, g0), (v1, g1) in zip(single, batch):
+        assert np.isfinite(v0) and v0 == v1 and np.array_equal(g0, g1)
+    assert len({v for v, _ in batch}) == len(batch)            # six different thetas gave six different values: nothing was reused
+
+
+def test_lml_batch_method_reports_non_positive_definite_entries_like_the_single_call():
+    """models.py:970-972 per entry: a theta whose matrix is not positive definite gives (-inf, zeros) and leaves its neighbours alone."""
+    n = 200
+    X = 0.05 * np.arange(n)[:, None]
+    y = np.random.RandomState(3).randn(n, 2)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=C(1.0) * RBF(0.1), center=0, disp=0, df=1, scale=1, optimizer=None, nugget=0.0)
+    thetas = [np.log([1.0, 0.02]), np.log([1.0, 1e4]), np.log([1.5, 0.03]), np.log([1.0, 3e4])]
+    single = [gp.log_marginal_likelihood(t, eval_gradient=True, X=X, y=y) for t in thetas]
+    batch = gp.log_marginal_likelihood_batch(thetas, X=X, y=y)
+    kinds = [np.isneginf(v) for v, _ in single]
+    assert any(kinds) and not all(kinds), kinds               # both kinds present, or the test checks nothing
+    for (v0, g0), (v1, g1) in zip(single, batch):
+        assert v0 == v1 and np.array_equal(g0, g1)
+        if np.isneginf(v1):
+            assert not np.any(g1) and g1.shape == (2,)
