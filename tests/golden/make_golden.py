@@ -701,11 +701,34 @@ def gen_underlying():
     return cases
 
 
+def gen_sample_y():
+    """BaseConjugateProcess.sample_y (models.py:847-879), default path: rng.multivariate_normal on predict's / underlying_properties'
+    mean and covariance, one call per curve.  One curve (1-D mean) and three curves (stacked (m, r, n_samples))."""
+    cases = []
+    rng = np.random.RandomState(41)
+    n = 16
+    X = np.sort(rng.rand(n))[:, None] * 2.0
+    Xs = np.array([0.05, 0.37, 0.81, 1.33, 1.96, 2.4])[:, None]
+    for r in (1, 3):
+        y = np.sin(3.0 * X) * (1.0 + 0.2 * np.arange(r)) + 0.05 * rng.randn(n, r)
+        y_in = y[:, 0] if r == 1 else y
+        gp = gsum.ConjugateGaussianProcess(kernel=make_kernel(KERNELS_1D[0]), optimizer=None, center=0.1, disp=0, df=3, scale=1.5,
+                                           nugget=1e-8)
+        gp.fit(X, y_in)
+        _, cov_p = gp.predict(Xs, return_cov=True)
+        for underlying in (False, True):
+            ys = gp.sample_y(Xs, n_samples=4, random_state=11, underlying=underlying)
+            cases.append(dict(kernel=KERNELS_1D[0], X=L(X), y=L(y_in), Xs=L(Xs), r=r, underlying=underlying, n_samples=4, random_state=11,
+                              samples=L(ys), shape=list(np.shape(ys)), cov_factor=float(gp.cov_factor_),
+                              predict_cov_min_eig=float(np.linalg.eigvalsh(cov_p).min())))
+    return cases
+
+
 def main():
     only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
     if only:
         gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid, s5_predict=gen_s5_predict,
-                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying)
+                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying, sample_y=gen_sample_y)
         for name in only:
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(gens[name](), f, indent=1)
@@ -741,6 +764,8 @@ def main():
         json.dump(gen_s1_plumbing(), f, indent=1)
     with open(os.path.join(HERE, "underlying.json"), "w") as f:
         json.dump(gen_underlying(), f, indent=1)
+    with open(os.path.join(HERE, "sample_y.json"), "w") as f:
+        json.dump(gen_sample_y(), f, indent=1)
     with open(os.path.join(HERE, "s5_predict.json"), "w") as f:      # ~10 minutes on 8 cores, ~15 GB
         json.dump(gen_s5_predict(), f, indent=1)
     import sklearn, scipy

@@ -1055,3 +1055,22 @@ def test_underlying_properties_golden():
         np.testing.assert_allclose(cv, case["cov"], rtol=ptol, atol=1e-14 * vs)
         m3, both = gp.underlying_properties(Xs, return_std=True, return_cov=True)
         assert case["both_returns_cov"] and np.array_equal(both, cv)                    # return_cov wins (:742-744)
+
+
+def test_sample_y_default_path_reproduces_the_reference_draws():
+    """sample_y's default path (models.py:847-879) issues the reference's rng.multivariate_normal calls in the reference's order on
+    predict's / underlying_properties' mean and covariance: same seed, same draws, same shapes -- (m, n_samples) for one curve and for
+    underlying=True whatever the number of curves (the prior mean is one column), (m, r, n_samples) otherwise.  The draws inherit the
+    1e-9-level agreement of cov_factor_; observed 3e-10 ... 9e-10 of the largest draw (tests/golden/sample_y.json), bound 1e-7 of it."""
+    from conftest import load_golden
+    for case in load_golden("sample_y.json"):
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=make_kernel(case["kernel"]), optimizer=None, center=0.1, disp=0, df=3, scale=1.5,
+                                               nugget=1e-8)
+        gp.fit(X, y)
+        want = np.array(case["samples"])
+        got = gp.sample_y(Xs, n_samples=case["n_samples"], random_state=case["random_state"], underlying=case["underlying"])
+        assert list(got.shape) == case["shape"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-7 * np.abs(want).max())
+        other = gp.sample_y(Xs, n_samples=case["n_samples"], random_state=case["random_state"] + 1, underlying=case["underlying"])
+        assert np.abs(other - want).max() > 1e-3 * np.abs(want).max()          # the seed matters: the bound above is not vacuous
