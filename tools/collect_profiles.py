@@ -19,7 +19,26 @@ def newest(sub, pattern):
     return files[-1] if files else None
 
 
+def _reference_time():
+    """When the run being collected happened: the newest bench log under gpurun_out/."""
+    logs = [os.path.join(SRC, f) for f in ("bench.log", "rocprof_bench.log") if os.path.exists(os.path.join(SRC, f))]
+    return max(map(os.path.getmtime, logs)) if logs else None
+
+
+RUN_TIME = _reference_time()
+MAX_AGE_S = 2 * 3600.0
+
+
+def stale(src):
+    """gpurun_out/ is scratch that accumulates over a session: a file much older than the run being collected belongs to an earlier
+    run (or round) and must not be relabelled with this round's tag."""
+    return RUN_TIME is not None and os.path.getmtime(src) < RUN_TIME - MAX_AGE_S
+
+
 def copy(src, name):
+    if src and os.path.exists(src) and stale(src):
+        print("SKIPPED (older than this run):", os.path.relpath(src, ROOT), "->", f"{TAG}_{name}")
+        return
     if src and os.path.exists(src):
         shutil.copyfile(src, os.path.join(OUT, f"{TAG}_{name}"))
         print("wrote", f"{TAG}_{name}")
@@ -28,6 +47,9 @@ def copy(src, name):
 def json_line(log, name):
     path = os.path.join(SRC, log)
     if not os.path.exists(path):
+        return
+    if stale(path):
+        print("SKIPPED (older than this run):", os.path.relpath(path, ROOT), "->", f"{TAG}_{name}")
         return
     lines = [ln for ln in open(path) if ln.startswith("{")]
     if lines:
