@@ -87,7 +87,6 @@ struct gsum_ctx {
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
-    int panel_lean = 0;              // probe: k_panel256 held to 128 registers (spills) -- footprint against latency in a batch
     int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
                                      // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
@@ -604,8 +603,8 @@ static int gs_diag256(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
 static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
     if (M <= 0) return 0;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
-    hipLaunchKernelGGL(ctx->panel_lean ? k_panel256_lean : k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M,
-                       m->Ltab + (size_t)b * GS_LTAB, m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr);
+    hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr);
     ctx->kst_ptr = nullptr;
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
@@ -1378,7 +1377,6 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
-    else if (!strcmp(name, "panel_lean")) ctx->panel_lean = value != 0;
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;

@@ -1692,8 +1692,8 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 // rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
-__device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib, const double* Ltab1,
-                                                 unsigned long long* kst) {
+__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
+                                                  const double* Ltab1, unsigned long long* kst) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
@@ -1711,19 +1711,6 @@ __device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, c
     gs_panel16_solve_g(P1, Ltab1, lane);
     gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
     if (kst && lane == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
-}
-
-__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, unsigned long long* kst) {
-    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst);
-}
-
-// PROBE (option panel_lean, default off): the same code held to 128 registers (the rest spills to scratch).  In a batch the panel's
-// latency does not matter but its footprint might: a 224-register wave takes the place of three bulk waves on its SIMD, a 128-register
-// one of two.  Same arithmetic, same order: bit-identical.
-__global__ __launch_bounds__(64, 4) void k_panel256_lean(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                       const double* Ltab1, unsigned long long* kst) {
-    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst);
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
