@@ -87,7 +87,6 @@ struct gsum_ctx {
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
-    int diag256_wide = 0;            // probe: k_potrf_diag256 with the whole register file (no spills) -- wave speed against launch condition
     int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
                                      // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
@@ -594,7 +593,7 @@ static int gs_diag256(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
     const int64_t c = (int64_t)b * GS_NB;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
-    hipLaunchKernelGGL(ctx->diag256_wide ? k_potrf_diag256_wide : k_potrf_diag256, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB,
+    hipLaunchKernelGGL(k_potrf_diag256, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB,
                        m->Lsib + (size_t)(b / 2) * GS_LSIB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
@@ -1378,7 +1377,6 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
-    else if (!strcmp(name, "diag256_wide")) ctx->diag256_wide = value != 0;
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;

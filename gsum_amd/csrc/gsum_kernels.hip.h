@@ -1747,8 +1747,9 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // Replaces diag / panel / sibling update / diag on the chain of a factorisation: four dependent launches, two of them
 // over all rows below, become one; the rows below go through k_panel256 afterwards.  L10 is also left in Lsib (operand
 // layout) for that kernel.  Tables of both blocks to Ltab[0], Ltab[GS_LTAB].
-__device__ __forceinline__ void gs_potrf_diag256_body(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                      int col0, const double* diag0, unsigned long long* stamps, double* wsd) {
+__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
+                                                       int col0, const double* diag0, unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
     if (*info != 0) return;
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, lane = t & 63;
@@ -1799,20 +1800,6 @@ __device__ __forceinline__ void gs_potrf_diag256_body(double* A, int64_t ld, dou
     __syncthreads();
     bad = gs_diag_block<false>(A11, ld, (double*)nullptr, Ltab + GS_LTAB, logdet + 1, diag0 + 128, nullptr, wsd);
     if (bad && t == 0) *info = col0 + 128 + bad;
-}
-
-__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                       int col0, const double* diag0, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
-    gs_potrf_diag256_body(A, ld, Ltab, Lsib, logdet, info, col0, diag0, stamps, wsd);
-}
-
-// PROBE (option diag256_wide, default off): the same code allowed the whole register file (256 + 176 accumulation registers, no scratch)
-// instead of 256 registers with 224 B / lane of spills: a faster wave that needs an empty SIMD to start.  Bit-identical.
-__global__ __launch_bounds__(256, 1) void k_potrf_diag256_wide(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                            int col0, const double* diag0, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
-    gs_potrf_diag256_body(A, ld, Ltab, Lsib, logdet, info, col0, diag0, stamps, wsd);
 }
 
 // ------------------------------------------------------------------------------------------------
