@@ -87,6 +87,7 @@ struct gsum_ctx {
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
     int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
+    int bench_fill = 0;              // gsum_bench_gemm_nt operands: 0 random, 1 zeros (timing is value-independent, board power is not)
     int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
                                      // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
                                      // created after ~20 other streams exist made the same schedule 1.7x slower
@@ -1377,6 +1378,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
+    else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;
@@ -2459,6 +2461,11 @@ int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64
     hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dC, (int64_t)(cb / 8), 1u);
     hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dA, (int64_t)(ab / 8), 2u);
     hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dB, (int64_t)(bb / 8), 3u);
+    if (ctx->bench_fill == 1) {              // all-zero operands and C: what most of an RBF matrix's trailing update multiplies (power probe)
+        GS_CHECK(hipMemsetAsync(dC, 0, cb, s));
+        GS_CHECK(hipMemsetAsync(dA, 0, ab, s));
+        GS_CHECK(hipMemsetAsync(dB, 0, bb, s));
+    }
     const double* Bop = tri ? dA : dB;       // SYRK: both operands are the same panel
     if (gs_gemm(ctx, s, cfg, dC, N, dA, lda, Bop, lda, M, N, (int)K, tri, 1, -1.0)) return -1;   // warm-up
     GS_CHECK(hipEventRecord(ctx->cur->tev[0], s));
