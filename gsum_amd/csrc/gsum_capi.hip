@@ -1379,6 +1379,12 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
+    else if (!strcmp(name, "bulk_probe")) {
+        const int v = (int)value;
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_bulk_probe), &v, sizeof v));
+    }
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;
@@ -2450,8 +2456,30 @@ int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, dou
 
 int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int32_t reps, double* out2) {
-    if (!ctx || !out2 || M <= 0 || N <= 0 || K <= 0 || reps <= 0 || lda < K) return -2;
+    if (!ctx || !out2 || M <= 0 || N <= 0 || K <= 0 || reps <= 0 || (cfg != 99 && lda < K)) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
+    if (cfg == 99) {
+        // pure MFMA issue rate: M workgroups of N threads (N a multiple of 64, <= 512), K rounds of `lda` (4 or 8) independent MFMAs per wave
+        if (N % 64 || N > 512 || (lda != 4 && lda != 8)) return -2;
+        if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)M * N * 8)) return -1;
+        hipStream_t s = ctx->cur->sm;
+        auto launch = [&]() {
+            if (lda == 4) hipLaunchKernelGGL(k_mfma_peak<4>, dim3((unsigned)M), dim3((unsigned)N), 0, s, (double*)ctx->scratch, (int)K);
+            else hipLaunchKernelGGL(k_mfma_peak<8>, dim3((unsigned)M), dim3((unsigned)N), 0, s, (double*)ctx->scratch, (int)K);
+        };
+        launch();
+        GS_CHECK(hipEventRecord(ctx->cur->tev[0], s));
+        for (int r = 0; r < reps; ++r) launch();
+        GS_CHECK(hipEventRecord(ctx->cur->tev[1], s));
+        GS_CHECK(hipStreamSynchronize(s));
+        GS_CHECK(hipGetLastError());
+        float ms = 0.f;
+        GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
+        const double fl = (double)M * (double)(N / 64) * (double)K * (double)lda * 2048.0;      // 16 x 16 x 4 x 2 flops per MFMA
+        out2[0] = fl * reps / (ms * 1e-3) / 1e12;
+        out2[1] = ms * 1e3 / reps;
+        return 0;
+    }
     const size_t cb = (size_t)M * N * 8, ab = (size_t)M * lda * 8, bb = (size_t)N * lda * 8;
     const size_t oa = (cb + 255) / 256 * 256, ob = oa + (ab + 255) / 256 * 256;
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, ob + bb)) return -1;

@@ -2945,6 +2945,29 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, cons
 // are dispatched first, stored write-through and counted in *first_done, because the chain's next-but-one outer step and the
 // next step's A update wait for exactly them ("B"), not for the rest of the trailing update ("Far") behind them in the same
 // launch.  One launch instead of two: B starts on an empty chip the moment the previous trailing update ends.
+// What the fp64 matrix pipes sustain with NOTHING else going on: every wave issues `iters` rounds of NACC independent
+// v_mfma_f64_16x16x4_f64 on register operands (no LDS, no memory, no barrier).  gsum_bench_gemm_nt(cfg = 99): the ceiling a K loop can be
+// measured against on this part at the clock it holds.
+template <int NACC>
+__global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
+    gs_d4 acc[NACC];
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = gs_d4{0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sum == 1.2345e301) out[blockIdx.x * blockDim.x + threadIdx.x] = sum;          // keeps the chain alive
+}
+
+// PROBE (option bulk_probe, default 0; bench entry only): 1 = no C read, 2 = no C store, 4 = every tile fetches the operand rows of tile 0
+// (a 256-KB working set that stays in the L2: the K loop without its operand-fetch latency).  Results are then wrong by design.
+__device__ int gs_bulk_probe = 0;
+
 template <int NST>
 __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
@@ -3008,6 +3031,8 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     }
     const int fr = lane & 15, fq = lane >> 4;
     const bool neg = sign < 0.0;
+    const int probe = __builtin_amdgcn_readfirstlane(gs_bulk_probe);
+    if (probe & 1) beta = 0;
     gs_d4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -3017,8 +3042,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
-                acc[i][j][x] = neg ? -c : c;
+                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;      // sign applied below, behind the wait
             }
         }
     // staging: A has 16 eight-row slices (2 per wave: rows [16 w, 16 w + 16) by parity), B has 8 (1 per wave: wave w
@@ -3029,7 +3053,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     for (int h = 0; h < 2; ++h) {
         const int r = 16 * w + 2 * lrow + h;
         const int kp = lg ^ ((r >> 1) & 7);
-        int ra = m0 + r;
+        int ra = (probe & 4) ? r : m0 + r;
         ra = ra < M ? ra : M - 1;
         srcA[h] = A + (int64_t)ra * lda + 2 * kp;
     }
@@ -3038,7 +3062,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     {
         const int r = 16 * gb + 2 * lrow + hb;
         const int kp = lg ^ ((r >> 1) & 7);
-        int rb = n0 + r;
+        int rb = (probe & 4) ? r : n0 + r;
         rb = rb < N ? rb : N - 1;
         srcB = B + (int64_t)rb * ldb + 2 * kp;
     }
@@ -3061,8 +3085,20 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     // 16 MB, FETCH_SIZE ~ the operand bytes -- and come from the Infinity Cache in 1-2 us, more than one chunk of a shared CU.)
     stage_load(0, 0);
     if (NST == 3 && nk > 1) stage_load(1, 1);
+    // The C values were requested first and are used (negated) only from here on: with the negation next to the loads the compiler put its
+    // wait for them in front of the third LDS-direct load of stage 0, which then paid a memory latency of its own in every tile's prologue.
+    // (same-process A/B, profiles/r03_bulk_prologue_ab.log: +1 % on the kernel at K = 256, +0.2-0.3 % on the pipelined batch; bit-identical)
+    __builtin_amdgcn_sched_barrier(0);
     if (NST == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (neg) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[i][j][x] = -acc[i][j][x];
+    }
     __syncthreads();
     for (int c = 0; c < nk; ++c) {
         if (c + NST - 1 < nk) stage_load(c + NST - 1, (c + NST - 1) % NST);
@@ -3092,7 +3128,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     asm volatile("" : "+v"(t2));
     const int lane2 = t2 & 63, w2 = t2 >> 6;
     const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
-    if (!first_cols) {
+    if (probe & 2) {
+        if (acc[0][0][0] == 1.2345e301) C[t2] = acc[1][1][3] + acc[0][1][1] + acc[1][0][2];      // keeps the accumulators alive; never true in practice
+    } else if (!first_cols) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
