@@ -1379,12 +1379,6 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
-    else if (!strcmp(name, "bulk_probe")) {
-        const int v = (int)value;
-        GS_CHECK(hipSetDevice(ctx->device));
-        GS_CHECK(hipDeviceSynchronize());
-        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_bulk_probe), &v, sizeof v));
-    }
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;

@@ -2964,10 +2964,6 @@ __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
     if (sum == 1.2345e301) out[blockIdx.x * blockDim.x + threadIdx.x] = sum;          // keeps the chain alive
 }
 
-// PROBE (option bulk_probe, default 0; bench entry only): 1 = no C read, 2 = no C store, 4 = every tile fetches the operand rows of tile 0
-// (a 256-KB working set that stays in the L2: the K loop without its operand-fetch latency).  Results are then wrong by design.
-__device__ int gs_bulk_probe = 0;
-
 template <int NST>
 __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
@@ -3031,8 +3027,6 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     }
     const int fr = lane & 15, fq = lane >> 4;
     const bool neg = sign < 0.0;
-    const int probe = __builtin_amdgcn_readfirstlane(gs_bulk_probe);
-    if (probe & 1) beta = 0;
     gs_d4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -3053,7 +3047,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     for (int h = 0; h < 2; ++h) {
         const int r = 16 * w + 2 * lrow + h;
         const int kp = lg ^ ((r >> 1) & 7);
-        int ra = (probe & 4) ? r : m0 + r;
+        int ra = m0 + r;
         ra = ra < M ? ra : M - 1;
         srcA[h] = A + (int64_t)ra * lda + 2 * kp;
     }
@@ -3062,7 +3056,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     {
         const int r = 16 * gb + 2 * lrow + hb;
         const int kp = lg ^ ((r >> 1) & 7);
-        int rb = (probe & 4) ? r : n0 + r;
+        int rb = n0 + r;
         rb = rb < N ? rb : N - 1;
         srcB = B + (int64_t)rb * ldb + 2 * kp;
     }
@@ -3128,9 +3122,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     asm volatile("" : "+v"(t2));
     const int lane2 = t2 & 63, w2 = t2 >> 6;
     const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
-    if (probe & 2) {
-        if (acc[0][0][0] == 1.2345e301) C[t2] = acc[1][1][3] + acc[0][1][1] + acc[1][0][2];      // keeps the accumulators alive; never true in practice
-    } else if (!first_cols) {
+    if (!first_cols) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll

@@ -9,6 +9,4 @@ import gsum_amd  # noqa: E402
 
 cfg, M, K, tri, reps = (int(a) for a in (sys.argv[1:] + ["5", "8192", "256", "1", "3"])[:5])
 ctx = gsum_amd.default_context(0)
-if os.environ.get("GSUM_BULK_PROBE"):                 # probe builds only (option bulk_probe): 1 no C read, 2 no C store, 4 L2-hot operands
-    ctx.set_option("bulk_probe", int(os.environ["GSUM_BULK_PROBE"]))
 print(cfg, M, K, tri, ctx.bench_gemm_nt(cfg, M, M, K, bool(tri), 8208, reps), flush=True)
