@@ -133,6 +133,7 @@ struct gsum_ctx {
     int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
     int chain_test_abort = 0;        // test hook: the chain gives up at this outer step of its NEXT factorisation (one shot)
     unsigned long long* kst_ptr = nullptr;   // diagnostics: start / end stamp pair of the NEXT bulk (cfg 7) / k_panel256 launch
+    unsigned long long* panel_stats = nullptr;   // diagnostics (option panel_stats): {sum of wave lifetimes in 10-ns ticks, waves} of every k_panel256 launch
     int first_tiles = 0;                  // the NEXT bulk (cfg 7) launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
     unsigned* first_done = nullptr;
     int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
@@ -605,7 +606,7 @@ static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, d
     if (M <= 0) return 0;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
     hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
-                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr);
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr, ctx->panel_stats);
     ctx->kst_ptr = nullptr;
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
@@ -1324,6 +1325,13 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
     if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
     if (!strcmp(name, "chain_rows")) return ctx->chain_rows;
+    if (!strcmp(name, "panel_wave_ticks") || !strcmp(name, "panel_waves")) {         // read-back of option panel_stats (synchronises)
+        if (!ctx->panel_stats) return -1;
+        unsigned long long h[2] = {0, 0};
+        if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(h, ctx->panel_stats, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return (int64_t)h[!strcmp(name, "panel_wave_ticks") ? 0 : 1];
+    }
     return -1;
 }
 
@@ -1379,6 +1387,13 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
+    else if (!strcmp(name, "panel_stats")) {              // 1: (re)start accumulating wave lifetimes of k_panel256, 0: stop
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        if (value && !ctx->panel_stats) GS_CHECK(hipMalloc((void**)&ctx->panel_stats, 2 * sizeof(unsigned long long)));
+        if (value) GS_CHECK(hipMemset(ctx->panel_stats, 0, 2 * sizeof(unsigned long long)));
+        if (!value && ctx->panel_stats) { (void)hipFree(ctx->panel_stats); ctx->panel_stats = nullptr; }
+    }
     else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
     else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;

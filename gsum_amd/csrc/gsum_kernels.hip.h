@@ -1693,10 +1693,11 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
 __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, unsigned long long* kst) {
+                                                  const double* Ltab1, unsigned long long* kst, unsigned long long* wstat) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     if (r0 >= M) return;
+    const unsigned long long w_t0 = wstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);
     if (kst && lane == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());          // diagnostics: first start / last end of the launch
     double* rows = P + (int64_t)r0 * ld;
@@ -1711,6 +1712,10 @@ __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M
     gs_panel16_solve_g(P1, Ltab1, lane);
     gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
     if (kst && lane == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
+    if (wstat && lane == 0) {                                   // diagnostics (option panel_stats): how long the panel's waves are resident
+        atomicAdd(wstat, __builtin_amdgcn_s_memrealtime() - w_t0);
+        atomicAdd(wstat + 1, 1ull);
+    }
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still

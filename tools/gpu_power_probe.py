@@ -35,6 +35,10 @@ def find_sensors():
         cap = os.path.join(hw[0], "power1_cap")
         if os.path.exists(cap):
             out.setdefault(card, {})["cap"] = cap
+        for name in ("mem_busy_percent", "gpu_busy_percent"):
+            q = os.path.join(card, name)
+            if os.path.exists(q):
+                out.setdefault(card, {})[name] = q
     return out
 
 
@@ -68,7 +72,8 @@ def phase(name, work):
 
     def sample():
         while not stop.is_set():
-            rows.append([read(s.get("power", "")) for s in sensors.values()] + [read(s.get("sclk", "")) for s in sensors.values()])
+            rows.append([read(s.get("power", "")) for s in sensors.values()] + [read(s.get("sclk", "")) for s in sensors.values()]
+                        + [read(s.get("mem_busy_percent", "")) for s in sensors.values()] + [read(s.get("gpu_busy_percent", "")) for s in sensors.values()])
             time.sleep(0.01)
 
     th = threading.Thread(target=sample, daemon=True)
@@ -84,7 +89,8 @@ def phase(name, work):
     card = list(sensors)[busiest]
     cap = read(sensors[card].get("cap", "")) / 1e6
     print(f"{name:34s} {dt:5.2f} s  {rate}  power {np.nanmean(a[:, busiest]) / 1e6:7.1f} W (max {np.nanmax(a[:, busiest]) / 1e6:7.1f}, cap {cap:.0f})  "
-          f"sclk {np.nanmean(a[:, k + busiest]) / 1e6:6.0f} MHz (min {np.nanmin(a[:, k + busiest]) / 1e6:.0f})  [{len(a)} samples]", flush=True)
+          f"sclk {np.nanmean(a[:, k + busiest]) / 1e6:6.0f} MHz (min {np.nanmin(a[:, k + busiest]) / 1e6:.0f})  "
+          f"mem_busy {np.nanmean(a[:, 2 * k + busiest]):5.1f} %  gpu_busy {np.nanmean(a[:, 3 * k + busiest]):5.1f} %  [{len(a)} samples]", flush=True)
 
 
 def gemm(K, reps, fill=0):
