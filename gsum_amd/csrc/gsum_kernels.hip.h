@@ -3099,6 +3099,67 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
                 for (int x = 0; x < 4; ++x) acc[i][j][x] = -acc[i][j][x];
     }
     __syncthreads();
+    if constexpr (NST == 2) {
+        // Fragments one k-step ahead, in two register sets: the LDS reads of step ks + 1 are issued BEFORE the four MFMAs of step ks, and the last
+        // step of a chunk is multiplied behind the barrier, after the next chunk's loads and first reads have gone out -- a wave never sits between "MFMAs issued" and
+        // "next fragments arrived" with nothing to issue (the compiler's own schedule reused one register set: read, wait, multiply, four times per
+        // chunk).  Same products, same order per accumulator: bit-identical.  +7 registers (63 of the 72 this kernel may use).  Same-process A/B
+        // (profiles/r03_bulk_kloop_ab.log): pipelined batch +1.25 % (294.4-295.0 against 290.8-291.5 evals/s), K = 512 steady state +1.6 %, M = 4096 +1.2 %,
+        // one factorisation -0.9 % time; K = 256 at M = 7936 unchanged (that launch is held by its C phases).
+        static_assert(GS_KC == 16, "the pipelined K loop is written for four k-steps per chunk");
+        double afA[WM], bfA[WN], afB[WM], bfB[WN];
+        auto ldf = [&](double (&af)[WM], double (&bf)[WN], const double* sA, const double* sB, int ks) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
+        };
+        auto mm = [&](const double (&af)[WM], const double (&bf)[WN]) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        };
+        const double* sA = lds + wm * WM * 8 * GS_KC + rselA;
+        const double* sB = lds + OPA + wn * WN * 8 * GS_KC + rselB;
+        if (nk > 1) stage_load(1, 1);
+        if (nk > 0) ldf(afA, bfA, sA, sB, 0);
+        // `arrived` is an empty statement that reads a fragment set: the compiler's wait for that set lands THERE, i.e. before the next set's reads are
+        // issued -- placed in front of the MFMAs (its own choice) the wait came out as lgkmcnt(0) and covered the reads just issued as well.
+        auto arrived = [&](const double (&af)[WM], const double (&bf)[WN]) {
+            static_assert(WM == 2 && WN == 2, "two row and two column fragments per wave");
+            asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(bf[0]), "v"(bf[1]));
+        };
+        for (int c = 0; c < nk; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            arrived(afA, bfA);
+            ldf(afB, bfB, sA, sB, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            arrived(afB, bfB);
+            ldf(afA, bfA, sA, sB, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(afB, bfB);
+            __builtin_amdgcn_sched_barrier(0);
+            arrived(afA, bfA);
+            ldf(afB, bfB, sA, sB, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                // (waits for the LDS reads above too: this stage may be overwritten from here on)
+            if (c + 1 < nk) {                               // the next chunk's loads and first fragments go out BEFORE the last four MFMAs of this one
+                if (c + 2 < nk) stage_load(c + 2, c & 1);
+                sA = lds + ((c + 1) & 1) * STAGE + wm * WM * 8 * GS_KC + rselA;
+                sB = lds + ((c + 1) & 1) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
+                ldf(afA, bfA, sA, sB, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(afB, bfB);                                   // k-step 3 of chunk c
+        }
+    } else {
     for (int c = 0; c < nk; ++c) {
         if (c + NST - 1 < nk) stage_load(c + NST - 1, (c + NST - 1) % NST);
         const double* sA = lds + (c % NST) * STAGE + wm * WM * 8 * GS_KC + rselA;
@@ -3119,6 +3180,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
         if (NST == 3 && c + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk c + 1 has landed; c + 2 may be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
     }
     // The store addresses are re-derived from the thread index HERE, behind an opaque copy of it: computed once in the prologue they
     // stay live across the K loop, and this kernel must fit 72 VGPRs -- six bulk waves then leave a SIMD exactly the room in which one
