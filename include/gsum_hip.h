@@ -279,7 +279,11 @@ int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps);
 int gsum_probe_cu_mask(gsum_ctx* ctx, const uint32_t* mask, int32_t nwords, int32_t nblocks, int64_t* out);
 /* microbenchmark of the MFMA tile kernel on device-resident pseudo-random operands (leading dimension
  * lda >= K for A and B, as inside the factorisation): out2 = {algorithmic TFLOP/s, microseconds per launch}.
- * tri != 0: SYRK form (B = A, lower tiles only, M == N, flops counted as M(M+1)K). */
+ * tri != 0: SYRK form (B = A, lower tiles only, M == N, flops counted as M(M+1)K).
+ * Option "bench_fill" = 1 zeroes the operands first (timing is value-independent, board power is not: tools/gpu_power_probe.py).
+ * cfg = 99 is not a GEMM: the pure issue rate of v_mfma_f64_16x16x4_f64 on register operands -- M workgroups of N threads (a multiple
+ * of 64, <= 512), K rounds of lda (4 or 8) independent MFMAs per wave, tri ignored: what the matrix pipes sustain on this card
+ * (77.6 TFLOP/s measured, profiles/r03_mfma_peak.log), the ceiling the tile kernels are measured against. */
 int gsum_bench_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int32_t reps, double* out2);
 /* diagnostic build of the 128x128-tile kernel with s_memtime stamps around its loop phases (never used by
