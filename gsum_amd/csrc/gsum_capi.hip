@@ -1304,6 +1304,7 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (I->Z) (void)hipFree(I->Z);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->panel_stats) (void)hipFree(ctx->panel_stats);
     if (ctx->hbatch) (void)hipHostFree(ctx->hbatch);
     if (ctx->gws) (void)hipFree(ctx->gws);
     if (ctx->dstamps) (void)hipFree(ctx->dstamps);
