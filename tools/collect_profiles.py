@@ -62,6 +62,9 @@ def counters(sub, prefix):
     agg = {}
     if not f:
         return agg
+    if stale(f):
+        print("SKIPPED (older than this run):", os.path.relpath(f, ROOT))
+        return agg
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].startswith(prefix):
             agg.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
