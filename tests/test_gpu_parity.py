@@ -40,7 +40,8 @@ def lml_tol(R):
                                        (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32),
                                        (5, 128, 128, 128), (5, 300, 300, 256), (5, 130, 70, 64),
                                        (6, 128, 128, 128), (6, 300, 300, 256), (6, 130, 70, 64), (6, 1000, 257, 512),
-                                       (7, 128, 128, 128), (7, 300, 300, 256), (7, 130, 70, 64), (7, 1000, 257, 512)])
+                                       (7, 128, 128, 128), (7, 300, 300, 256), (7, 130, 70, 64), (7, 1000, 257, 512),
+                                       (7, 128, 128, 16), (7, 200, 100, 32), (7, 128, 64, 48), (7, 257, 129, 16)])     # one, two, three chunks: the pipelined K loop's edges
 def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
     """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
     swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
