@@ -3150,14 +3150,18 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                // (waits for the LDS reads above too: this stage may be overwritten from here on)
-            if (c + 1 < nk) {                               // the next chunk's loads and first fragments go out BEFORE the last four MFMAs of this one
-                if (c + 2 < nk) stage_load(c + 2, c & 1);
+            if (c + 1 < nk) {                               // the next chunk's first fragments are requested BEFORE the last four MFMAs of this one ...
                 sA = lds + ((c + 1) & 1) * STAGE + wm * WM * 8 * GS_KC + rselA;
                 sB = lds + ((c + 1) & 1) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
                 ldf(afA, bfA, sA, sB, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             mm(afB, bfB);                                   // k-step 3 of chunk c
+            // ... and the LDS-direct loads of chunk c + 2 behind them: their address arithmetic and M0 writes no longer stand between the barrier and
+            // the MFMAs (same-process A/B, profiles/r03_bulk_dma_order_ab.log: batch +0.7 %, M = 4096 +2.2 %, K = 256 / 512 steady state +1.5 / +0.7 %;
+            // one MFMA group later still is no better and costs M = 4096 1.7 %).
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nk) stage_load(c + 2, c & 1);
         }
     } else {
     for (int c = 0; c < nk; ++c) {
