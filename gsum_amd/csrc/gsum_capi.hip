@@ -86,7 +86,8 @@ struct gsum_ctx {
     int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
-    int lazy_far = 1;                // batch mode: K = 512 updates of the far trailing region every other panel
+    int lazy_far = 2;                // batch mode: K = 512 updates of the far trailing region every other panel (1: the next TWO panels' columns are "near",
+                                     // updated with K = 256 at every step; 2: only the next panel's, the one after it takes both updates in the K = 512 launch)
     int bench_fill = 0;              // gsum_bench_gemm_nt operands: 0 random, 1 zeros (timing is value-independent, board power is not)
     int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
                                      // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
@@ -1090,13 +1091,24 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             // traffic and launch overhead there).  Every element still subtracts the same products in the same
             // ascending-k order, so results do not change.
             const int64_t w2 = 2 * GS_NB;
-            // measured: -2.3 % per evaluation at n = 8192, neutral at 7000, +8 % (extra launches) at 4096 and below
+            // measured (lazy_far = 1 against none): -2.3 % per evaluation at n = 8192, neutral at 7000, +8 % (extra launches) at 4096 and below;
+            // lazy_far = 2 against 1 at n = 8192, same process: 303.4-303.8 against 297.6-298.7 evals/s (+1.9 %), profiles/r03_lazy_far2_ab.log
             const bool full_next = ctx->lazy_far && m->np >= 8192 && two && r2 + 2 * w2 <= m->np;   // a full panel follows, and one more
             if (!deferred && full_next) {
-                // near region only: rows >= r2, columns [r2, r2 + 512); algorithmic work = the lower trapezoid
-                ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * (2 * w2) - (double)(2 * w2) * (2 * w2 - 1));
-                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, 2 * w2, Kp, 0, 1, -1.0)) return -1;
+                // near region only: rows >= r2, columns [r2, r2 + 512) -- or, lazy_far = 2, just the next panel's 256 columns: the panel after that then
+                // takes both updates in the K = 512 launch below, which moves two thirds of the near region's flops out of skinny K = 256 launches and
+                // saves one launch per pair of steps; algorithmic work = the lower trapezoid
+                const int64_t wn = ctx->lazy_far == 2 ? w2 : 2 * w2;
+                ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * wn - (double)wn * (wn - 1));
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
                 deferred = true;
+                continue;
+            }
+            if (deferred && ctx->lazy_far == 2) {
+                // everything from column r2 on: the previous panel and this one together (contiguous 512 columns), lower triangle
+                double* P2 = A + r2 * ld + (c0 - w2);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P2, ld, P2, ld, mrest, mrest, (int)(w2 + Kp), 1, 1, -1.0)) return -1;
+                deferred = false;
                 continue;
             }
             if (deferred) {
