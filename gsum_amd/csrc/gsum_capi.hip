@@ -86,6 +86,8 @@ struct gsum_ctx {
     int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
+    int lazy_min_np = 4352;          // smallest padded order the lazy far updates are used at (profiles/r03_lazy_threshold.log, 20 in flight: +3 % at 4352,
+                                     // +3.7 / +4.8 / +5.3 / +6 / +6 % at 5120 / 6144 / 7168 / 8192 / 12288; neutral at 4096, -0.5 ... -3 % at 1536 ... 3072)
     int lazy_far = 2;                // batch mode: K = 512 updates of the far trailing region every other panel (1: the next TWO panels' columns are "near",
                                      // updated with K = 256 at every step; 2: only the next panel's, the one after it takes both updates in the K = 512 launch)
     int bench_fill = 0;              // gsum_bench_gemm_nt operands: 0 random, 1 zeros (timing is value-independent, board power is not)
@@ -1093,7 +1095,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t w2 = 2 * GS_NB;
             // measured (lazy_far = 1 against none): -2.3 % per evaluation at n = 8192, neutral at 7000, +8 % (extra launches) at 4096 and below;
             // lazy_far = 2 against 1 at n = 8192, same process: 303.4-303.8 against 297.6-298.7 evals/s (+1.9 %), profiles/r03_lazy_far2_ab.log
-            const bool full_next = ctx->lazy_far && m->np >= 8192 && two && r2 + 2 * w2 <= m->np;   // a full panel follows, and one more
+            const bool full_next = ctx->lazy_far && m->np >= ctx->lazy_min_np && two && r2 + 2 * w2 <= m->np;   // a full panel follows, and one more
             if (!deferred && full_next) {
                 // near region only: rows >= r2, columns [r2, r2 + 512) -- or, lazy_far = 2, just the next panel's 256 columns: the panel after that then
                 // takes both updates in the K = 512 launch below, which moves two thirds of the near region's flops out of skinny K = 256 launches and
@@ -1399,6 +1401,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
+    else if (!strcmp(name, "lazy_min_np")) ctx->lazy_min_np = (int)std::max<int64_t>(1024, value);
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
     else if (!strcmp(name, "panel_stats")) {              // 1: (re)start accumulating wave lifetimes of k_panel256, 0: stop
         GS_CHECK(hipSetDevice(ctx->device));
