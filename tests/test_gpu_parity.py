@@ -596,7 +596,7 @@ def test_full_size_properties_n8192():
     # far trailing region
     many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for slots, lazy in ((16, 1), (3, 1), (10, 0)):
+    for slots, lazy in ((16, 1), (3, 2), (10, 0), (16, 2)):
         ctx.set_option("batch_slots", slots)
         ctx.set_option("lazy_far", lazy)
         Gs, ss, infos = ctx.lml_resident(many, 1e-10)
@@ -604,7 +604,7 @@ def test_full_size_properties_n8192():
         for b in range(len(many)):
             np.testing.assert_array_equal(Gs[b], G0[0])
             assert ss[b] == s0[0]
-    ctx.set_option("lazy_far", 1)
+    ctx.set_option("lazy_far", 2)                              # the library's default
     ctx.set_option("batch_slots", 16)
     for key, (G, s, i) in out.items():
         np.testing.assert_array_equal(G, G0)
@@ -1075,3 +1075,30 @@ def test_sample_y_default_path_reproduces_the_reference_draws():
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-7 * np.abs(want).max())
         other = gp.sample_y(Xs, n_samples=case["n_samples"], random_state=case["random_state"] + 1, underlying=case["underlying"])
         assert np.abs(other - want).max() > 1e-3 * np.abs(want).max()          # the seed matters: the bound above is not vacuous
+
+
+@pytest.mark.parametrize("n", [4400, 5000, 7000])
+def test_batch_lazy_far_updates_are_scheduling_only_below_8192(ctx, n):
+    """The batch schedule's K = 512 far updates (lazy_far = 2) are used from padded order 4352 up: a batch evaluated with them, without them
+    and one evaluation at a time (the look-ahead / persistent-chain schedule) gives the same bits."""
+    from sklearn.gaussian_process.kernels import RBF
+    rng = np.random.RandomState(n)
+    X = 0.1 * np.arange(n)[:, None]
+    Z = np.concatenate([rng.randn(n, 4), np.ones((n, 1))], axis=1)
+    descs = [gsum_amd.describe_kernel(RBF(0.2 + 0.01 * i), 1) for i in range(6)]
+    ctx.set_inputs(X, Z)
+    old_slots = ctx.get_option("batch_slots")
+    try:
+        ctx.set_option("batch_slots", 1)
+        ref = ctx.lml_resident(descs, 1e-10)
+        assert np.all(ref[2] == 0)
+        for lazy in (2, 0, 1):
+            ctx.set_option("batch_slots", 6)
+            ctx.set_option("lazy_far", lazy)
+            G, sld, info = ctx.lml_resident(descs, 1e-10)
+            np.testing.assert_array_equal(G, ref[0])
+            np.testing.assert_array_equal(sld, ref[1])
+            np.testing.assert_array_equal(info, ref[2])
+    finally:
+        ctx.set_option("lazy_far", 2)
+        ctx.set_option("batch_slots", old_slots)
