@@ -86,6 +86,7 @@ struct gsum_ctx {
     int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
                                      // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
     int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
+    int predict_lazy = 1;            // the predictive sweep V^T = K* L^-T with the same pairing of trailing updates (K = 512 every other step)
     int lazy_min_np = 4352;          // smallest padded order the lazy far updates are used at (profiles/r03_lazy_threshold.log, 20 in flight: +3 % at 4352,
                                      // +3.7 / +4.8 / +5.3 / +6 / +6 % at 5120 / 6144 / 7168 / 8192 / 12288; neutral at 4096, -0.5 ... -3 % at 1536 ... 3072)
     int lazy_far = 2;                // batch mode: K = 512 updates of the far trailing region every other panel (1: the next TWO panels' columns are "near",
@@ -1401,6 +1402,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         }
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
+    else if (!strcmp(name, "predict_lazy")) ctx->predict_lazy = value != 0;
     else if (!strcmp(name, "lazy_min_np")) ctx->lazy_min_np = (int)std::max<int64_t>(1024, value);
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
     else if (!strcmp(name, "panel_stats")) {              // 1: (re)start accumulating wave lifetimes of k_panel256, 0: stop
@@ -1756,6 +1758,7 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     // factorisation: the trailing part of Bt is read and written once per 256 eliminated columns instead of once per 128
     // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work)
     const int sib_cfg = m >= 1024 ? GS_BULK : 1;
+    bool deferred = false;                               // the columns right of the next panel still owe the previous panel's update
     for (int c = 0; c < L->T; c += 2) {
         const bool two = c + 1 < L->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
@@ -1765,8 +1768,19 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                 return -1;
             if (gs_trsm_rows(ctx, ctx->cur->sm, L, c + 1, Bt + c1, ldb, m)) return -1;
         }
-        if (r2 < np && gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, np - r2,
-                               (int)(r2 - c0), 0, 1, -1.0))
+        if (r2 >= np) continue;
+        // The batch factorisation's lazy far updates (lazy_far = 2) applied to this sweep: after an even step only the next panel's 256 columns take
+        // this panel's update (K = 256); the step after it applies both panels to everything to its right in ONE K = 512 launch -- half as many passes
+        // over the trailing part of Bt, each at the tile kernel's better K = 512 rate.  Same products in the same ascending-k order per element.
+        const bool pair = ctx->predict_lazy && two && m >= 1024 && np >= ctx->lazy_min_np && c + 3 < L->T && r2 + 2 * GS_NB <= np;
+        if (!deferred && pair) {
+            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
+            deferred = true;
+        } else if (deferred) {
+            const int64_t cp = c0 - 2 * GS_NB;            // the previous panel's first column: [cp, r2) is 512 columns wide
+            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + cp, ldb, L->A + r2 * ld + cp, ld, m, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
+            deferred = false;
+        } else if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
     std::vector<double> vw;
