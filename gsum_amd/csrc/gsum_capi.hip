@@ -1403,6 +1403,12 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "predict_lazy")) ctx->predict_lazy = value != 0;
+    else if (!strcmp(name, "medium_lazy")) {            // (process-wide: a __device__ variable of the code object)
+        const int v = value != 0;
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_medium_lazy), &v, sizeof v));
+    }
     else if (!strcmp(name, "lazy_min_np")) ctx->lazy_min_np = (int)std::max<int64_t>(1024, value);
     else if (!strcmp(name, "bench_fill")) ctx->bench_fill = (int)value;
     else if (!strcmp(name, "panel_stats")) {              // 1: (re)start accumulating wave lifetimes of k_panel256, 0: stop

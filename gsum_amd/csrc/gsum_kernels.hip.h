@@ -2530,6 +2530,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 // Per-evaluation scratch: A (np x ld, ld = np + 16) | Linv (T x 128 x 128) | diag0 (np) | W^T (16 x np).
 // ------------------------------------------------------------------------------------------------
 #define GS_MEDIUM_MAX 4096
+__device__ int gs_medium_lazy = 1;                  // option "medium_lazy": the fused sweep's trailing updates paired (K = 512 every other outer step)
 
 // C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
 // 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld's layout: XOR-swizzled
@@ -2688,6 +2689,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     const int fr = lane & 15, fq = lane >> 4;
     // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
     // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
+    bool deferred = false;                          // the tiles right of the next panel still owe the previous panel's update
     for (int b = 0; b < T; b += 2) {
         const bool two = b + 1 < T;
         for (int s = 0; s < (two ? 2 : 1); ++s) {
@@ -2781,10 +2783,29 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
             phase(3);
         }
         const int Kp = two ? 256 : 128, first = b + (two ? 2 : 1);
+        // The batch factorisation's pairing of trailing updates (lazy_far = 2) inside this sweep: after an even outer step only the NEXT two block columns take
+        // this panel's update (K = 256); the step after it applies both panels to every tile right of them in one K = 512 pass -- the trailing tiles, which this
+        // HBM-resident sweep reads and writes once per update, are then touched half as often.  Same products in the same ascending-k order per element.
+        const bool pair = gs_medium_lazy && two && first + 1 < T;          // a full two-block panel follows
+        if (!deferred && pair) {
+            for (int i = first; i < T; ++i)
+                for (int j = first; j <= min(i, first + 1); ++j)
+                    gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
+                               A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
+            deferred = true;
+        } else if (deferred) {
+            const int bp = b - 2;                                          // the previous panel: block columns bp .. b + 1 are 512 contiguous columns
+            for (int i = first; i < T; ++i)
+                for (int j = first; j <= i; ++j)
+                    gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + bp * 128, ld,
+                               A + (int64_t)j * 128 * ld + bp * 128, ld, 128, 128, 256 + Kp, 1, -1.0, lds);
+            deferred = false;
+        } else {
         for (int i = first; i < T; ++i)             // trailing lower tiles: both panels in one pass
             for (int j = first; j <= i; ++j)
                 gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
                            A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
+        }
         phase(4);
     }
     __threadfence_block();

@@ -118,6 +118,24 @@ def single():
     return f"{(time.perf_counter() - t0) / 350 * 1e3:5.2f} ms each"
 
 
+def medium(nm, count):
+    def run():
+        Xm = 0.1 * np.arange(nm)[:, None]
+        Zm = np.concatenate([np.random.RandomState(0).randn(nm, 4), np.ones((nm, 1))], axis=1)
+        ctx.set_inputs(Xm, Zm)
+        darr = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.15, 0.25, count)])
+        ctx.lml_resident(darr, 1e-10)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            ctx.lml_resident(darr, 1e-10)
+            reps += 1
+        rate = reps * count / (time.perf_counter() - t0)
+        ctx.set_inputs(X, Z)
+        return f"{rate:8.0f} evals/s ({nm ** 3 / 3.0 * rate / 1e12:4.1f} TF/s)"
+    return run
+
+
 def idle():
     time.sleep(1.5)
     return "idle"
@@ -132,3 +150,6 @@ for rnd in range(2):
     phase("bulk tile K=512, ALL-ZERO data", gemm(512, 500, 1))
     phase("batch, 20 in flight", batch)
     phase("one factorisation at a time", single)
+    phase("fused path, n = 2048, 1024 evals", medium(2048, 1024))
+    phase("fused path, n = 4096, 512 evals", medium(4096, 512))
+    phase("fused path, n = 1024, 2048 evals", medium(1024, 2048))
