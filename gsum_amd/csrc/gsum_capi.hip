@@ -1022,7 +1022,11 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     GS_CHECK(hipGetLastError());
     // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
-    const bool la = ctx->lookahead != 0 && ctx->batch_active < 3;
+    // Only slot 0 ever runs a look-ahead schedule.  Those schedules create streams of their own (panel chain, near updates, row bands), and the HIP
+    // runtime stops running a process's streams side by side somewhere between 22 and 24 of them (tools/gpu_slots_sweep.py: 20 fine, 24 collapses):
+    // a call of exactly TWO evaluations used to give slot 1 its own set -- 24 streams with the 20 slot streams -- after which every later batch of the
+    // process ran 5-6 times slower (94 instead of 15 ms for 64 evaluations at n = 2048), and two persistent chains side by side were slow themselves.
+    const bool la = ctx->lookahead != 0 && ctx->batch_active < 3 && sl == &ctx->slots[0];
     ctx->bulk_pad_now = false;
     if (la && gs_panel_stream(ctx, sl)) return -1;
     if (la && gs_chain_wanted(ctx, m)) {
@@ -1404,7 +1408,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "predict_lazy")) ctx->predict_lazy = value != 0;
     else if (!strcmp(name, "medium_lazy")) {            // (process-wide: a __device__ variable of the code object)
-        const int v = value != 0;
+        const int v = (int)std::max<int64_t>(1, std::min<int64_t>(64, value));      // grouping depth: 1 none, 2 pairs, ..., >= 16: left-looking at n <= 4096
         GS_CHECK(hipSetDevice(ctx->device));
         GS_CHECK(hipDeviceSynchronize());
         GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_medium_lazy), &v, sizeof v));

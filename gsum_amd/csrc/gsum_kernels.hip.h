@@ -2530,7 +2530,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 // Per-evaluation scratch: A (np x ld, ld = np + 16) | Linv (T x 128 x 128) | diag0 (np) | W^T (16 x np).
 // ------------------------------------------------------------------------------------------------
 #define GS_MEDIUM_MAX 4096
-__device__ int gs_medium_lazy = 1;                  // option "medium_lazy": the fused sweep's trailing updates paired (K = 512 every other outer step)
+__device__ int gs_medium_lazy = 64;                 // option "medium_lazy": depth of the grouping of the fused sweep's trailing updates (1: one K = 256 update of every
+                                                    // trailing tile per outer step; 2: K = 512 every other step; >= 16: LEFT-LOOKING at n <= 4096 -- a tile is read and
+                                                    // written once, when its panel is next, with all the panels before it in one pass: the default, this sweep is HBM-bound)
 
 // C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
 // 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld's layout: XOR-swizzled
@@ -2689,7 +2691,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     const int fr = lane & 15, fq = lane >> 4;
     // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
     // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
-    bool deferred = false;                          // the tiles right of the next panel still owe the previous panel's update
+    int grp = 0;                                    // outer steps of the current group already applied to the NEXT panel's columns only
     for (int b = 0; b < T; b += 2) {
         const bool two = b + 1 < T;
         for (int s = 0; s < (two ? 2 : 1); ++s) {
@@ -2786,26 +2788,17 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
         // The batch factorisation's pairing of trailing updates (lazy_far = 2) inside this sweep: after an even outer step only the NEXT two block columns take
         // this panel's update (K = 256); the step after it applies both panels to every tile right of them in one K = 512 pass -- the trailing tiles, which this
         // HBM-resident sweep reads and writes once per update, are then touched half as often.  Same products in the same ascending-k order per element.
-        const bool pair = gs_medium_lazy && two && first + 1 < T;          // a full two-block panel follows
-        if (!deferred && pair) {
-            for (int i = first; i < T; ++i)
-                for (int j = first; j <= min(i, first + 1); ++j)
-                    gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
-                               A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
-            deferred = true;
-        } else if (deferred) {
-            const int bp = b - 2;                                          // the previous panel: block columns bp .. b + 1 are 512 contiguous columns
-            for (int i = first; i < T; ++i)
-                for (int j = first; j <= i; ++j)
-                    gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + bp * 128, ld,
-                               A + (int64_t)j * 128 * ld + bp * 128, ld, 128, 128, 256 + Kp, 1, -1.0, lds);
-            deferred = false;
-        } else {
-        for (int i = first; i < T; ++i)             // trailing lower tiles: both panels in one pass
-            for (int j = first; j <= i; ++j)
-                gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
-                           A + (int64_t)j * 128 * ld + b * 128, ld, 128, 128, Kp, 1, -1.0, lds);
-        }
+        // gs_medium_lazy = depth of the grouping (1: none, 2: pairs, d: the far tiles are touched once per d outer steps, with K = 256 d)
+        const int depth = gs_medium_lazy;
+        const bool more = depth > 1 && two && first + 1 < T && grp + 1 < depth;      // a full two-block panel follows and the group is not complete
+        const int gb = b - 2 * grp;                                                  // first block column of the group: [gb, b + 2) are (grp + 1) x 256 contiguous columns
+        const int Kg = 256 * grp + Kp;
+        const int jlast = more ? first + 1 : T - 1;                                  // near update: the next panel's two block columns only
+        for (int i = first; i < T; ++i)
+            for (int j = first; j <= min(i, jlast); ++j)
+                gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + gb * 128, ld,
+                           A + (int64_t)j * 128 * ld + gb * 128, ld, 128, 128, Kg, 1, -1.0, lds);
+        grp = more ? grp + 1 : 0;
         phase(4);
     }
     __threadfence_block();

@@ -14,7 +14,7 @@ import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 ctx = gsum_amd.default_context(0)
-LAZY = [int(a) for a in sys.argv[1:]] or [1]               # e.g. `gpu_medium_rate.py 0 1 0 1`: option medium_lazy alternated (same-process A/B)
+LAZY = [int(a) for a in sys.argv[1:]] or [64]              # e.g. `gpu_medium_rate.py 1 2 1 2`: option medium_lazy (grouping depth) alternated (same-process A/B)
 for n, count in [(n, c) for n, c in ((512, 2048), (1024, 2048), (1536, 1024), (2048, 1024), (3072, 512), (4096, 512)) for _ in LAZY]:
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([np.random.RandomState(0).randn(n, 4), np.ones((n, 1))], axis=1)
@@ -31,4 +31,4 @@ for n, count in [(n, c) for n, c in ((512, 2048), (1024, 2048), (1536, 1024), (2
     dt = min(ts)
     print(f"n={n:5d} medium_lazy={lazy}: {count / dt:9.1f} evals/s  {n ** 3 / 3.0 * count / dt / 1e12:6.2f} TF/s ({n ** 3 / 3.0 * count / dt / 1e12 / 78.6:5.3f} of 78.6)  "
           f"failed {int(np.count_nonzero(info))}  fingerprint {float(sld[7]).hex()} {float(G[-1, 1, 2]).hex()}", flush=True)
-ctx.set_option("medium_lazy", 1)
+ctx.set_option("medium_lazy", 64)
