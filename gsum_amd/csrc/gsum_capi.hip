@@ -2039,9 +2039,10 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    // break-even against the 20-slot pipelined path, measured at n = 256 ... 4096: 4, 9, 22, 67, 127, 175 evaluations
+    // break-even against the 20-slot pipelined path, re-measured at the end of round 3 (both paths had become faster; tools/gpu_medium_breakeven.py,
+    // profiles/r03_medium_breakeven.log): the fused path wins from 2, 8, ~23, ~45, ~78, ~140, ~180 evaluations at n = 256, 512, 1024, 1536, 2048, 3072, 4096
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
-                                                  : std::max(4, (int)(pow((double)ctx->in->n, 1.45) / 985.0));
+                                                  : std::max(4, (int)(pow((double)ctx->in->n, 1.55) / 2000.0));
     if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
