@@ -122,7 +122,8 @@ struct gsum_ctx {
                                      // the M-proportional work host-enqueued and gated on its flags.  -1 (default) = when the order
                                      // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
     int chain_min_np = 2048;
-    int chain_lazy = 0;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
+    int chain_lazy = -1;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
+                                     // -1 (default): on from padded order 10240 up, where it pays -- 13.6 -> 13.3 ms at n = 12288, 29.15 -> 28.13 ms at 16384, 5.28 -> 5.31 at 8192
     int chain_bands = 1;             // persistent-chain schedule: the trailing update in this many row bands (fixed absolute boundaries, equal
                                      // areas), each on a stream of its own: a band's tiles depend on their own previous version and the panel
                                      // only, so band p of step s + 1 starts when band p of step s is done -- no chip-wide barrier per step.
@@ -869,7 +870,8 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
     struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
     std::vector<Plan> plan((size_t)S, Plan{0, 0u});
-    const int NB = ctx->chain_lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
+    const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
+    const int NB = lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
     int64_t bound[6];
     bound[0] = 0;
     for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
@@ -894,7 +896,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             if (deferred) {
                 plan[s] = Plan{2, 4u * tm};
                 deferred = false;
-            } else if (ctx->chain_lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
+            } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
                 plan[s] = Plan{1, 4u * tm};
                 deferred = true;
             } else {
@@ -903,7 +905,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         }
     }
     unsigned* fbw = fl + gs_fl_count(S);
-    const int fb_key = (W * 2 + (ctx->chain_lazy ? 1 : 0)) * 8 + NB;
+    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB;
     if (m->fbwant_key != fb_key) {
         std::vector<unsigned> h((size_t)S);
         for (int s = 0; s < S; ++s) h[s] = plan[s].fb;
@@ -1439,7 +1441,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
-    else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value != 0;
+    else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "chain_test_abort")) ctx->chain_test_abort = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
         const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
