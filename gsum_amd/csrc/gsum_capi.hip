@@ -871,6 +871,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
     std::vector<Plan> plan((size_t)S, Plan{0, 0u});
     const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
+    const bool near256 = lazy && ctx->chain_lazy != 1;        // 2 / auto: only the next-but-one panel's 256 columns are "near" (the batch schedule's lazy_far = 2)
     const int NB = lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
     int64_t bound[6];
     bound[0] = 0;
@@ -894,7 +895,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             if (m3 <= 0) continue;
             const unsigned tm = (unsigned)((m3 + 127) / 128);
             if (deferred) {
-                plan[s] = Plan{2, 4u * tm};
+                plan[s] = Plan{2, near256 ? 4u * tm - 2u : 4u * tm};
                 deferred = false;
             } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
                 plan[s] = Plan{1, 4u * tm};
@@ -905,7 +906,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         }
     }
     unsigned* fbw = fl + gs_fl_count(S);
-    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB;
+    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0);
     if (m->fbwant_key != fb_key) {
         std::vector<unsigned> h((size_t)S);
         for (int s = 0; s < S; ++s) h[s] = plan[s].fb;
@@ -973,10 +974,16 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         ctx->first_tiles = (int)plan[s].fb;
         ctx->first_done = fbp;
         if (plan[s].kind == 1) {
-            // near region only: rows >= r3, columns [r3, r3 + 512); algorithmic work = the lower trapezoid
-            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 512.0 - 512.0 * 511.0);
+            // near region only: rows >= r3, columns [r3, r3 + 512) -- or just [r3, r3 + 256); algorithmic work = the lower trapezoid
+            const double wn = near256 ? 256.0 : 512.0;
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * wn - wn * (wn - 1.0));
             kstamp(s, 3);
-            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, 512, 256, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, near256 ? 256 : 512, 256, 0, 1, -1.0)) return -1;
+        } else if (near256) {
+            // everything from column r3 on takes the previous panel and this one together (512 contiguous panel columns), the tiles of its first 256 columns first
+            double* P4 = A + r3 * ld + (c0 - 256);
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P4, ld, P4, ld, m3, m3, 512, 1, 1, -1.0)) return -1;
         } else {
             // columns [r3, r3 + 256): this panel only (they had the previous one as "near") ...
             ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 256.0 - 256.0 * 255.0);
@@ -1441,7 +1448,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
-    else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value < 0 ? -1 : (int)std::min<int64_t>(2, value);
     else if (!strcmp(name, "chain_test_abort")) ctx->chain_test_abort = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
         const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
