@@ -65,6 +65,24 @@ struct gs_slot {
 
 #define GS_MAX_SLOTS 24
 
+// ---- grouped batch schedule ---------------------------------------------------------------------------------------------------------
+#define GS_WV_GROUPS 4
+struct gs_wave_group {
+    hipStream_t sc = nullptr;            // this group's chain stream (high priority): kernel builds, diagonal blocks, panels, read-out
+    hipEvent_t evChain = nullptr, evBulk = nullptr;
+    gs_wv_pool pool;                     // `cap` workspaces at fixed strides
+    int cap = 0;
+    int64_t n = 0;                       // order the pool was allocated for
+    // state inside a call
+    int cnt = 0, step = 0, first_eval = 0, start_tick = 0;
+    bool active = false;
+    gs_wave_group() { memset(&pool, 0, sizeof pool); }
+};
+struct gs_wave {
+    hipStream_t sb = nullptr;            // the bulk stream: the trailing updates of all groups, one launch after the other
+    gs_wave_group g[GS_WV_GROUPS];
+};
+
 struct gs_inputs {
     double* X = nullptr; int64_t n = 0; int d = 0; size_t X_cap = 0;     // n x d points
     double* Z = nullptr; int k = 0; size_t Z_cap = 0;                    // n x k right-hand sides
@@ -171,9 +189,18 @@ struct gsum_ctx {
     int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
     std::set<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this context's device
+    // grouped batch schedule (gs_lml_wave): the evaluations of a call advance in groups, one launch per kernel class and outer step
+    gs_wave wave;
+    int batch_mode = 1;              // 1 = grouped launches (default), 0 = one stream per evaluation (rounds 1-3; needs GPU_MAX_HW_QUEUES)
+    int wave_groups = 2;             // groups = chain streams; their bulk launches alternate on ONE bulk stream
+    int wave_size = 10;              // evaluations per group at most
+    int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
+    int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
+    int wave_near_on_chain = 1;      // the small "near" trailing updates (K = 256, the next panel's columns only) on the group's chain stream
 };
 
 static std::string g_init_error;
+static void gs_wave_release(gsum_ctx* ctx, bool streams);
 
 // kernel classes of the per-launch HIP-event profile (option "profile_gemm")
 enum { GS_PROF_BUILD = 0, GS_PROF_DIAG = 1, GS_PROF_PANEL = 2, GS_PROF_BULK = 3, GS_PROF_OTHER = 4, GS_PROF_CLASSES = 5 };
@@ -1327,6 +1354,7 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->evC) (void)hipEventDestroy(sl->evC);
         if (sl->evS) (void)hipEventDestroy(sl->evS);
     }
+    gs_wave_release(ctx, true);
     for (gs_inputs* I : {&ctx->op, &ctx->res}) {
         if (I->X) (void)hipFree(I->X);
         if (I->Z) (void)hipFree(I->Z);
@@ -1345,6 +1373,11 @@ const char* gsum_last_error(gsum_ctx* ctx) { return ctx ? ctx->err.c_str() : g_i
 int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!ctx || !name) return -1;
     if (!strcmp(name, "batch_slots")) return ctx->batch_slots;
+    if (!strcmp(name, "batch_mode")) return ctx->batch_mode;
+    if (!strcmp(name, "wave_groups")) return ctx->wave_groups;
+    if (!strcmp(name, "wave_size")) return ctx->wave_size;
+    if (!strcmp(name, "wave_shift")) return ctx->wave_shift;
+    if (!strcmp(name, "wave_min")) return ctx->wave_min;
     if (!strcmp(name, "queue_probe_streams")) return ctx->probe_streams;        // 0: the probe has not run
     if (!strcmp(name, "queue_probe_concurrency_x100")) return (int64_t)(ctx->probe_concurrency * 100.0 + 0.5);
     if (!strcmp(name, "queue_probe_fell_back")) return ctx->probe_fell_back;
@@ -1406,6 +1439,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         if (ctx->gws) GS_CHECK(hipFree(ctx->gws));
         ctx->scratch = ctx->gws = nullptr;
         ctx->scratch_cap = ctx->gws_cap = 0;
+        gs_wave_release(ctx, false);                           // the groups' workspaces (their streams stay)
         for (int i = 0; i < ctx->n_slots_ready; ++i) {         // and the per-slot workspace matrices of the fused path
             gs_mat_release(ctx->slots[i].ws);
             ctx->slots[i].ws = nullptr;
@@ -1460,6 +1494,12 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
+    else if (!strcmp(name, "batch_mode")) ctx->batch_mode = value != 0;
+    else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_GROUPS, value));
+    else if (!strcmp(name, "wave_size")) ctx->wave_size = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WVC_MAX, value));
+    else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
+    else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
+    else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
 }
@@ -2036,6 +2076,286 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     return 0;
 }
 
+// ---- grouped batch schedule ---------------------------------------------------------------------------------------------------------
+// The evaluations of one call are independent (a likelihood grid, gsum/models.py:958-1039 per grid point; the reference's loop is
+// docs/notebooks/correlated_EFT_publication.ipynb:1457-1459).  They are cut into groups of up to `wave_size`; the members of a group
+// advance through the outer steps of the blocked factorisation in lock step, and one launch per kernel class carries that step for
+// all of them (k_potrf_diag256g: a workgroup per member; k_panel256g: a wave per 16 rows of every member; k_gemm_ld3g: the tiles of
+// every member's trailing update).  Streams: one chain stream per group + ONE bulk stream; per group and step
+//     chain stream:  [bulk(g, s - 1) done]  diag(g, s)  panel(g, s)          -> evChain
+//     bulk stream:   [evChain]  bulk(g, s)                                     -> evBulk
+// and the host enqueues the groups round-robin, so that on the bulk stream the trailing updates of the groups alternate while the
+// latency-bound chain of one group runs beside the trailing update of the other(s).  Nothing depends on how many hardware queues the
+// runtime was started with (3 streams for two groups), a rank under torch.distributed.run runs the same schedule as a lone process,
+// and a per-launch profile IS the step time: the bulk launches do not overlap one another.
+// Per element of every matrix the same products are subtracted in the same order as in the one-stream-per-evaluation schedule
+// (same kernels' bodies, same K = 256 / K = 512 pairing of the trailing updates): G, sum log L_ii and info are bit-identical to it.
+static void gs_wave_free_group(gs_wave_group* g) {
+    for (void* q : {(void*)g->pool.A, (void*)g->pool.Ltab, (void*)g->pool.Lsib, (void*)g->pool.logdet, (void*)g->pool.diag0,
+                    (void*)g->pool.info, (void*)g->pool.res})
+        if (q) (void)hipFree(q);
+    memset(&g->pool, 0, sizeof g->pool);
+    g->cap = 0;
+    g->n = 0;
+}
+
+static void gs_wave_release(gsum_ctx* ctx, bool streams) {
+    for (int i = 0; i < GS_WV_GROUPS; ++i) {
+        gs_wave_group* g = &ctx->wave.g[i];
+        gs_wave_free_group(g);
+        if (!streams) continue;
+        if (g->sc) (void)hipStreamDestroy(g->sc);
+        if (g->evChain) (void)hipEventDestroy(g->evChain);
+        if (g->evBulk) (void)hipEventDestroy(g->evBulk);
+        g->sc = nullptr;
+        g->evChain = g->evBulk = nullptr;
+    }
+    if (streams && ctx->wave.sb) {
+        (void)hipStreamDestroy(ctx->wave.sb);
+        ctx->wave.sb = nullptr;
+    }
+}
+
+static double gs_wave_ws_bytes(int64_t np) {
+    const double T = (double)(np / GS_NB);
+    return (double)(np + GS_BORDER) * (double)(np + GS_BORDER) * 8.0 + T * GS_LTAB * 8.0 + (T / 2 + 1) * GS_LSIB * 8.0 +
+           (T + (double)np + 258.0) * 8.0 + 4.0;
+}
+
+static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
+    gs_wave* wv = &ctx->wave;
+    if (!wv->sb) GS_CHECK(hipStreamCreateWithPriority(&wv->sb, hipStreamNonBlocking, ctx->prio_lo));
+    const int T = (int)(np / GS_NB);
+    const int64_t ld = np + GS_BORDER;
+    for (int i = 0; i < G; ++i) {
+        gs_wave_group* g = &wv->g[i];
+        if (!g->sc) {
+            GS_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, ctx->prio_hi));
+            GS_CHECK(hipEventCreateWithFlags(&g->evChain, hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&g->evBulk, hipEventDisableTiming));
+        }
+        if (g->cap >= B && g->n == n) continue;
+        GS_CHECK(hipDeviceSynchronize());
+        gs_wave_free_group(g);
+        gs_wv_pool& p = g->pool;
+        p.strideA = (np + GS_BORDER) * ld;
+        p.ld = ld;
+        p.np = (int)np;
+        p.T = T;
+        hipError_t e = hipMalloc((void**)&p.A, (size_t)B * p.strideA * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.Ltab, (size_t)B * T * GS_LTAB * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.Lsib, (size_t)B * (T / 2 + 1) * GS_LSIB * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.logdet, (size_t)B * T * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.diag0, (size_t)B * np * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.info, (size_t)B * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&p.res, (size_t)B * 258 * sizeof(double));
+        if (e != hipSuccess) {
+            gs_wave_free_group(g);
+            ctx->err = std::string("hipMalloc(group workspaces) failed: ") + hipGetErrorString(e);
+            return -1;
+        }
+        g->cap = B;
+        g->n = n;
+    }
+    return 0;
+}
+
+// trailing update of outer step s in a batch (the pairing of gs_potrf's batch branch, lazy_far = 2): after an even step only the next
+// panel's 256 columns take the update (K = 256, rectangular); the step after it applies both panels to everything from its own first
+// trailing column on in ONE K = 512 pass; steps without a full next panel (or with the pairing off) update the whole lower triangle
+static void gs_wave_bulk_modes(int64_t np, bool lazy, std::vector<int>& mode) {
+    const int S = (int)(np / (2 * GS_NB));
+    mode.assign((size_t)S, 0);
+    bool deferred = false;
+    for (int s = 0; s < S; ++s) {
+        const int64_t r2 = 2 * GS_NB * (int64_t)(s + 1);
+        const bool full_next = lazy && r2 + 4 * GS_NB <= np;
+        if (!deferred && full_next) { mode[s] = 1; deferred = true; }
+        else if (deferred) { mode[s] = 2; deferred = false; }
+    }
+}
+
+static int gs_wave_fill_chain(const gs_wave_group* g, gs_wv_chain_args* a, bool panel_counts) {
+    a->p = g->pool;
+    a->n = g->cnt;
+    a->pad = 0;
+    const int naug = g->pool.np + GS_BORDER;
+    int run = 0;
+    for (int e = 0; e < g->cnt; ++e) {
+        a->q[e] = (short)e;
+        a->step[e] = (short)g->step;
+        if (panel_counts) run += (naug - 2 * GS_NB * (g->step + 1)) / 16;
+        a->end[e] = run;
+    }
+    return run;
+}
+
+static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out, double* sld_out,
+                       int64_t* info_out) {
+    const int64_t n = ctx->in->n, np = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB), ld = np + GS_BORDER, naug = np + GS_BORDER;
+    const int k = ctx->in->k, d = ctx->in->d, S = (int)(np / (2 * GS_NB));
+    int G = std::max(1, std::min(GS_WV_GROUPS, ctx->wave_groups));
+    int B = std::max(1, std::min(GS_WVC_MAX, ctx->wave_size));
+    if (n_kernels < G * B) {                      // a short call: every evaluation in flight at once, the groups equally full
+        G = std::min(G, n_kernels);
+        B = (n_kernels + G - 1) / G;
+    }
+    {
+        // group workspaces within 70 % of what is free (plus what the groups already hold)
+        size_t free_b = 0, total_b = 0;
+        GS_CHECK(hipMemGetInfo(&free_b, &total_b));
+        double held = 0.0;
+        for (int i = 0; i < GS_WV_GROUPS; ++i)
+            if (ctx->wave.g[i].cap && ctx->wave.g[i].n == n) held += ctx->wave.g[i].cap * gs_wave_ws_bytes(np);
+        const int fit = (int)std::min<double>(1e6, (0.7 * (double)free_b + held) / gs_wave_ws_bytes(np));
+        if (fit < 1) GS_FAIL("not enough device memory for one workspace matrix");
+        if (G * B > fit) {
+            G = std::max(1, std::min(G, fit));
+            B = std::max(1, fit / G);
+        }
+    }
+    if (gs_wave_prepare(ctx, G, B, n, np)) return -1;
+    if (gs_reserve_pinned(ctx, (size_t)n_kernels * 258 * sizeof(double))) return -1;
+    gs_wave* wv = &ctx->wave;
+    std::vector<int> mode;
+    gs_wave_bulk_modes(np, ctx->lazy_far != 0 && np >= ctx->lazy_min_np, mode);
+    const bool several_rounds = n_kernels > G * B;
+    // Groups out of phase in calls of several rounds (counted in sweeps of the loop below = macro-steps)?  Measured and left off:
+    // the groups' big updates alternate on one stream, so all groups advance at the same macro-step rate, and a group in its
+    // latency-bound last steps is paced by the other's 5-ms updates; 80 evaluations on 2 x 10: 315 evals/s in phase, 305 / 300
+    // with the second group 4 / 8 macro-steps behind (the chains of the first and last macro-steps then run with nothing beside them).
+    const int shift = !several_rounds ? 0 : (ctx->wave_shift > 0 ? std::min(ctx->wave_shift, S) : 0);
+    for (int i = 0; i < G; ++i) {
+        gs_wave_group* g = &wv->g[i];
+        g->active = false;
+        g->cnt = g->step = 0;
+        g->start_tick = i * shift;
+    }
+    const bool prof = ctx->profile_gemm > 0;
+    if (prof) ctx->prof_this_eval = true;
+    // everything of this call follows what the context's main stream has done so far (the resident inputs' upload)
+    hipStream_t s0 = ctx->slots[0].sm;
+    GS_CHECK(hipEventRecord(ctx->slots[0].evFork, s0));
+    GS_CHECK(hipStreamWaitEvent(wv->sb, ctx->slots[0].evFork, 0));
+    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamWaitEvent(wv->g[i].sc, ctx->slots[0].evFork, 0));
+    int next = 0, live = 0;
+    for (int tick = 0; next < n_kernels || live > 0; ++tick) {
+        for (int i = 0; i < G; ++i) {
+            gs_wave_group* g = &wv->g[i];
+            gs_wv_chain_args ca;
+            if (!g->active) {
+                if (next >= n_kernels || tick < g->start_tick) continue;
+                // ---- a new round of this group: its next evaluations enter (their workspaces are free: the read-out of the
+                // previous round is ahead of this on the chain stream)
+                g->cnt = std::min(B, n_kernels - next);
+                g->first_eval = next;
+                g->step = 0;
+                g->active = true;
+                ++live;
+                for (int e = 0; e < g->cnt; ++e) {
+                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_BUILD, 0.0);
+                    const int rc = gs_launch_build<false>(ctx, g->sc, g->pool.A + (int64_t)e * g->pool.strideA, ld, ctx->in->X, nullptr, n, n,
+                                                          np, np, d, &kernels[next + e], nugget, ctx->build_lower_only);
+                    gs_prof_end(ctx, g->sc, rec);
+                    if (rc) return rc;
+                }
+                next += g->cnt;
+                gs_wave_fill_chain(g, &ca, false);
+                const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_OTHER, 0.0);
+                hipLaunchKernelGGL(k_set_border_g, dim3((unsigned)((naug + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca, (int)n,
+                                   (const double*)ctx->in->Z, k);
+                hipLaunchKernelGGL(k_wave_begin, dim3((unsigned)((np + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca);
+                gs_prof_end(ctx, g->sc, rec);
+                GS_CHECK(hipGetLastError());
+            } else {
+                GS_CHECK(hipStreamWaitEvent(g->sc, g->evBulk, 0));            // the trailing update of the previous step
+            }
+            // ---- one macro-step: the chain of outer step g->step (diagonal super-blocks, then both panels of all rows below them) and
+            // its trailing update.  A "near" update (the next panel's 256 columns only, K = 256: ~1 GF per member) sits on the chain's
+            // critical path -- chain(s) -> near(s) -> chain(s + 1) -- and goes out on the CHAIN stream, followed at once by the next
+            // step's chain; only the big updates (whole lower triangle, K = 512 or 256) go to the bulk stream.  So between two of its
+            // big updates a group needs diag + panel + near + diag + panel (~0.8 ms) and the other groups' big updates cover it.
+            for (;;) {
+                {
+                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_DIAG, (double)g->cnt * 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
+                    gs_wave_fill_chain(g, &ca, false);
+                    hipLaunchKernelGGL(k_potrf_diag256g, dim3((unsigned)g->cnt), dim3(256), 0, g->sc, ca);
+                    gs_prof_end(ctx, g->sc, rec);
+                }
+                const int64_t c0 = 2 * GS_NB * (int64_t)g->step, r2 = c0 + 2 * GS_NB, mrest = naug - r2;
+                {
+                    const int groups = gs_wave_fill_chain(g, &ca, true);
+                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
+                    hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, g->sc, ca);
+                    gs_prof_end(ctx, g->sc, rec);
+                }
+                GS_CHECK(hipGetLastError());
+                const int md = mode[(size_t)g->step];
+                const bool near = md == 1 && ctx->wave_near_on_chain;
+                hipStream_t su = near ? g->sc : wv->sb;
+                if (!near) {
+                    GS_CHECK(hipEventRecord(g->evChain, g->sc));
+                    GS_CHECK(hipStreamWaitEvent(wv->sb, g->evChain, 0));
+                }
+                gs_wv_gemm_args ga;
+                ga.base = g->pool.A;
+                ga.strideA = g->pool.strideA;
+                ga.ld = ld;
+                ga.n = g->cnt;
+                ga.pad = 0;
+                gs_wv_gemm_entry en;
+                en.offC = r2 * ld + r2;
+                en.offA = en.offB = r2 * ld + (md == 2 ? c0 - 2 * GS_NB : c0);
+                en.M = (int)mrest;
+                en.N = md == 1 ? 2 * GS_NB : (int)mrest;
+                en.K = md == 2 ? 4 * GS_NB : 2 * GS_NB;
+                en.tri = md == 1 ? 0 : 1;
+                en.pad = 0;
+                const int64_t tm = (mrest + 127) / 128;
+                const int tiles = (int)(en.tri ? tm * (tm + 1) : tm * ((en.N + 63) / 64));
+                const double fl = en.tri ? (double)mrest * (double)(mrest + 1) * en.K
+                                         : (double)en.K * (2.0 * (double)mrest * en.N - (double)en.N * (en.N - 1));
+                int run = 0;
+                for (int e = 0; e < g->cnt; ++e) {
+                    en.q = e;
+                    ga.e[e] = en;
+                    run += tiles;
+                    ga.end[e] = run;
+                }
+                const int rec = gs_prof_begin(ctx, su, near ? GS_PROF_PANEL : GS_PROF_BULK, fl * g->cnt);
+                hipLaunchKernelGGL(k_gemm_ld3g, dim3((unsigned)run), dim3(512), 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double), su, ga);
+                gs_prof_end(ctx, su, rec);
+                GS_CHECK(hipGetLastError());
+                ++g->step;
+                if (!near) break;
+            }
+            GS_CHECK(hipEventRecord(g->evBulk, wv->sb));
+            if (g->step < S) continue;
+            // ---- the round is complete: read-out on the chain stream (the bulk stream goes on with the other groups)
+            GS_CHECK(hipStreamWaitEvent(g->sc, g->evBulk, 0));
+            gs_wave_fill_chain(g, &ca, false);
+            const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_OTHER, 0.0);
+            hipLaunchKernelGGL(k_finalize_g, dim3((unsigned)g->cnt), dim3(256), 0, g->sc, ca);
+            gs_prof_end(ctx, g->sc, rec);
+            GS_CHECK(hipGetLastError());
+            GS_CHECK(hipMemcpyAsync(ctx->hbatch + (size_t)g->first_eval * 258, g->pool.res, (size_t)g->cnt * 258 * sizeof(double),
+                                    hipMemcpyDeviceToHost, g->sc));
+            g->active = false;
+            --live;
+        }
+    }
+    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamSynchronize(wv->g[i].sc));
+    GS_CHECK(hipStreamSynchronize(wv->sb));
+    for (int i = 0; i < n_kernels; ++i) {
+        const double* r = ctx->hbatch + (size_t)i * 258;
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = r[a * 16 + b];
+        sld_out[i] = r[256];
+        info_out[i] = (int64_t)r[257];
+    }
+    return 0;
+}
+
 static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                      double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
@@ -2055,6 +2375,10 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    }
+    if (ctx->batch_mode == 1 && n_kernels >= ctx->wave_min && ctx->diag_algo == 2 && ctx->bulk_cfg == 7 && ctx->build_algo == 2) {
+        ctx->cur = &ctx->slots[0];
+        return gs_lml_wave(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
     if (ctx->batch_slots > 4 && n_kernels > 4 && ctx->probe_streams < ctx->batch_slots && !ctx->probe_fell_back) {
         if (gs_probe_queues(ctx, ctx->batch_slots)) return -1;

@@ -1692,10 +1692,10 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 // rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
-__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, unsigned long long* kst, unsigned long long* wstat) {
+__device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
+                                                 const double* Ltab1, unsigned long long* kst, unsigned long long* wstat, const int group) {
     const int lane = threadIdx.x;
-    const int r0 = blockIdx.x * 16;
+    const int r0 = group * 16;
     if (r0 >= M) return;
     const unsigned long long w_t0 = wstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);
@@ -1716,6 +1716,11 @@ __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M
         atomicAdd(wstat, __builtin_amdgcn_s_memrealtime() - w_t0);
         atomicAdd(wstat + 1, 1ull);
     }
+}
+
+__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
+                                                  const double* Ltab1, unsigned long long* kst, unsigned long long* wstat) {
+    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst, wstat, (int)blockIdx.x);
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
@@ -1752,9 +1757,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, doubl
 // Replaces diag / panel / sibling update / diag on the chain of a factorisation: four dependent launches, two of them
 // over all rows below, become one; the rows below go through k_panel256 afterwards.  L10 is also left in Lsib (operand
 // layout) for that kernel.  Tables of both blocks to Ltab[0], Ltab[GS_LTAB].
-__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                       int col0, const double* diag0, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
+__device__ __forceinline__ void gs_potrf_diag256_body(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
+                                                      int col0, const double* diag0, unsigned long long* stamps, double* wsd) {
     if (*info != 0) return;
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, lane = t & 63;
@@ -1805,6 +1809,70 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld,
     __syncthreads();
     bad = gs_diag_block<false>(A11, ld, (double*)nullptr, Ltab + GS_LTAB, logdet + 1, diag0 + 128, nullptr, wsd);
     if (bad && t == 0) *info = col0 + 128 + bad;
+}
+
+__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
+                                                       int col0, const double* diag0, unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
+    gs_potrf_diag256_body(A, ld, Ltab, Lsib, logdet, info, col0, diag0, stamps, wsd);
+}
+
+// ---- grouped chain kernels (see k_gemm_ld3g): outer step `step` of workspace `q` per entry, all workspaces of a group at fixed
+// strides from the first.  One workgroup per entry (diagonal super-block); one wave per 16 rows below it of every entry (panels).
+#define GS_WVC_MAX 24
+struct gs_wv_pool {
+    double* A; int64_t strideA, ld;          // augmented matrices, (np + 16) x ld each
+    double* Ltab; double* Lsib;              // T x GS_LTAB, (T / 2 + 1) x GS_LSIB per workspace
+    double* logdet; double* diag0;           // T, np per workspace
+    int* info;                               // 1 per workspace
+    double* res;                             // 258 per workspace (k_finalize_g)
+    int np, T;
+};
+struct gs_wv_chain_args {
+    gs_wv_pool p;
+    int n, pad;
+    short q[GS_WVC_MAX], step[GS_WVC_MAX];
+    int end[GS_WVC_MAX];                     // k_panel256g: running counts of 16-row groups
+};
+__global__ __launch_bounds__(256, 2) void k_potrf_diag256g(const gs_wv_chain_args a) {
+    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
+    const int e = (int)blockIdx.x;
+    const int64_t q = a.q[e];
+    const int b = 2 * a.step[e];
+    const int64_t c = (int64_t)b * GS_NB;
+    gs_potrf_diag256_body(a.p.A + q * a.p.strideA + c * a.p.ld + c, a.p.ld, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
+                          a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.logdet + q * a.p.T + b, a.p.info + q, (int)c,
+                          a.p.diag0 + q * a.p.np + c, (unsigned long long*)nullptr, wsd);
+}
+__global__ __launch_bounds__(64, 2) void k_panel256g(const gs_wv_chain_args a) {
+    const int bid = (int)blockIdx.x;
+    int e = 0;
+    while (e + 1 < a.n && bid >= a.end[e]) ++e;
+    const int first = e ? a.end[e - 1] : 0;
+    const int64_t q = a.q[e];
+    const int b = 2 * a.step[e];
+    const int64_t c0 = (int64_t)b * GS_NB, r2 = c0 + 2 * GS_NB;
+    const int M = a.p.np + GS_BORDER - (int)r2;
+    gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
+                     a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
+                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, bid - first);
+}
+// entering evaluations: border rows <- RHS^T (k_set_border), grid ((np + 16) / 256 rounded up, entries)
+__global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k) {
+    const int64_t q = a.q[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.p.np + GS_BORDER) return;
+    double* A = a.p.A + q * a.p.strideA;
+#pragma unroll
+    for (int c = 0; c < GS_BORDER; ++c)
+        A[(int64_t)(a.p.np + c) * a.p.ld + i] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
+}
+// entering evaluations: diag0 <- the diagonal before the factorisation touches it, info <- 0 (grid: (np / 256 rounded up, entries))
+__global__ __launch_bounds__(256) void k_wave_begin(const gs_wv_chain_args a) {
+    const int64_t q = a.q[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.p.np) a.p.diag0[q * a.p.np + i] = a.p.A[q * a.p.strideA + (int64_t)i * a.p.ld + i];
+    if (i == 0) a.p.info[q] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2983,10 +3051,12 @@ __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
     if (sum == 1.2345e301) out[blockIdx.x * blockDim.x + threadIdx.x] = sum;          // keeps the chain alive
 }
 
+// (body of k_gemm_ld3 / k_gemm_ld3g: `bid_in` is the tile's index within ITS product -- the workgroup id of a plain launch, the
+// offset into its entry's tile range for a grouped one)
 template <int NST>
-__global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                      unsigned long long* kst, int nfirst, unsigned* first_done) {
+__device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                                                 int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
+                                                 unsigned long long* kst, int nfirst, unsigned* first_done, const int bid_in) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
@@ -3004,7 +3074,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     if (tri && nfirst > 0) {
         // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
         // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
-        const int bid = blockIdx.x;
+        const int bid = bid_in;
         if (bid < nfirst) {
             if (bid < 2) { bm = 0; bn = bid; }
             else { bm = 1 + (bid - 2) / 4; bn = (bid - 2) % 4; }
@@ -3023,16 +3093,16 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
         // M = 8192 launch 813 -> 610 MB, its rate unchanged (55.0 vs 55.6 TF/s), the 16-in-flight pipeline 3 % SLOWER
         // (266.6 vs 274 evals/s: with sixteen queues dispatching at once workgroup ids no longer map to XCDs round-robin,
         // and the padding slots cost launches).  The kernel is not fetch-bound; the plain order stays.)
-        const int bid = blockIdx.x;
+        const int bid = bid_in;
         bm = (int)((sqrt(4.0 * (double)bid + 1.0) - 1.0) * 0.5);
         while ((int64_t)(bm + 1) * (bm + 2) <= bid) ++bm;
         while ((int64_t)bm * (bm + 1) > bid) --bm;
         bn = bid - (int)((int64_t)bm * (bm + 1));
     } else {
         const int tm = (M + BM - 1) / BM;
-        bm = blockIdx.x % tm;
-        bn = blockIdx.x / tm;
-        first_cols = (int)blockIdx.x < nfirst;        // column-major tile order: the first 4 tm ids are the first 256 columns
+        bm = bid_in % tm;
+        bn = bid_in / tm;
+        first_cols = bid_in < nfirst;        // column-major tile order: the first 4 tm ids are the first 256 columns
     }
     const int m0 = bm * BM, n0 = bn * BN;
     if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
@@ -3262,6 +3332,45 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     if (kst && t == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
 }
 
+
+template <int NST>
+__global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
+                                                      unsigned long long* kst, int nfirst, unsigned* first_done) {
+    gs_gemm_ld3_body<NST>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, nfirst, first_done, (int)blockIdx.x);
+}
+
+// ---- grouped launches: the same outer step of SEVERAL evaluations in one launch -------------------------------------------------
+// A batch of evaluations (a likelihood grid) used to run as up to 20 independent HIP streams, one evaluation each, and counted on
+// the runtime giving every stream a hardware queue of its own (GPU_MAX_HW_QUEUES) -- 24 live streams collapsed it, a process with an
+// RCCL communicator had to run a different policy, and no per-launch profile described the step.  Round 4: the evaluations of a
+// group advance in lock step and ONE launch carries the tiles of all of them.  An entry names its product by offsets from its
+// evaluation's workspace (all workspaces of a group are `strideA` doubles apart, same order, same leading dimension); the entry of a
+// workgroup is found from the running tile counts in the kernel arguments (scalar loads: the workgroup id is uniform).  The tile
+// arithmetic is gs_gemm_ld3_body's: results are bit-identical to the one-evaluation launches.
+#define GS_WV_MAX 24
+struct gs_wv_gemm_entry {
+    int64_t offC, offA, offB;      // doubles from the evaluation's workspace base
+    int M, N, K, tri;
+    int q, pad;                    // workspace index within the group
+};
+struct gs_wv_gemm_args {
+    double* base; int64_t strideA, ld;
+    int n, pad;
+    int end[GS_WV_MAX];            // running tile counts: entry e owns block ids [end[e - 1], end[e])
+    gs_wv_gemm_entry e[GS_WV_MAX];
+};
+__global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) {
+    const int bid = (int)blockIdx.x;
+    int e = 0;
+    while (e + 1 < a.n && bid >= a.end[e]) ++e;
+    const int first = e ? a.end[e - 1] : 0;
+    const gs_wv_gemm_entry& en = a.e[e];
+    double* W = a.base + (int64_t)en.q * a.strideA;
+    gs_gemm_ld3_body<2>(W + en.offC, a.ld, W + en.offA, a.ld, W + en.offB, a.ld, en.M, en.N, en.K, en.tri, 1, -1.0,
+                        (unsigned long long*)nullptr, 0, (unsigned*)nullptr, bid - first);
+}
+
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
 // res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
 __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, int np, const double* logdet,
@@ -3274,6 +3383,22 @@ __global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, i
         for (int i = 0; i < T; ++i) s += logdet[i];
         res[256] = s;
         res[257] = (double)(*info);
+    }
+}
+
+// the same for the finished evaluations of a group (one workgroup per entry)
+__global__ __launch_bounds__(256) void k_finalize_g(const gs_wv_chain_args a) {
+    const int64_t q = a.q[blockIdx.x];
+    const int t = threadIdx.x;
+    const int r = t >> 4, c = t & 15;
+    const double* A = a.p.A + q * a.p.strideA;
+    double* res = a.p.res + q * 258;
+    res[t] = -A[(int64_t)(a.p.np + r) * a.p.ld + a.p.np + c];
+    if (t == 0) {
+        double s = 0.0;
+        for (int i = 0; i < a.p.T; ++i) s += a.p.logdet[q * a.p.T + i];
+        res[256] = s;
+        res[257] = (double)a.p.info[q];
     }
 }
 
