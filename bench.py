@@ -32,12 +32,7 @@ import os
 import sys
 import time
 
-# Must precede the first GPU touch of the process (torch included): the HIP runtime reads it when it initialises.  One
-# hardware queue per in-flight evaluation instead of 4 shared ones (what gsum_amd.configure_runtime() does; bench.py is
-# an application of the library and makes that choice for its process).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -69,6 +64,17 @@ def available_cpus():
     except Exception:
         pass
     return max(1, n)
+
+
+def host_exp_is_svml():
+    """numpy's float64 exp on AVX-512 hosts is Intel SVML's __svml_exp8_ha, which is not correctly rounded (exp(-0.125) comes out one
+    ulp low); the device kernel-build restates THAT routine (gsum_kernels.hip.h, gs_exp_np) because the reference's own numbers were
+    made with it.  On a host whose numpy falls back to libm the CPU leg of this bench would differ from the GPU by ~6e-10 on the
+    uniform-grid workload through no fault of either: detected here (behaviour, not CPU flags) and the CPU comparison is then
+    labelled instead of failing the run; the committed reference value is the pin at every N either way."""
+    import math
+    xs = -0.125 * np.arange(0, 75) ** 2.0           # the S2 / S3 kernel arguments
+    return bool(np.any(np.exp(xs) != np.array([math.exp(v) for v in xs])) and np.exp(np.full(16, -0.125))[0] == float.fromhex("0x1.c3d6a24ed8221p-1"))
 
 
 def cpu_model():
@@ -299,9 +305,9 @@ def predict_leg(ctx, n, m, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32,
-                    help="evaluations per timed region (default: two full rounds of the 16 kept in flight; with a count that is "
-                         "not a multiple of it the last few run with the chip half empty: 247 instead of 269 evals/s at 20)")
+    ap.add_argument("--steps", type=int, default=20,
+                    help="evaluations per timed region = per call of the batch entry point (default: one round of the library's "
+                         "2 groups x 10 evaluations)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--points", dest="n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
@@ -309,9 +315,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=10,
                     help="the timed K-step region is run this many times back to back; value / ms_per_step are the "
                          "median region, min and max are reported beside it")
-    ap.add_argument("--slots", type=int, default=0,
-                    help="independent evaluations kept in flight per GPU (0 = library default, 16 with 32 hardware "
-                         "queues, 3 with the runtime's default 4 -- or fewer, in whole rounds, when --steps is not a multiple of it)")
+    ap.add_argument("--groups", type=int, default=0, help="groups of the batch schedule (0 = library default, 2)")
+    ap.add_argument("--group-size", type=int, default=0, help="evaluations per group (0 = library default, 10)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
     ap.add_argument("--config", default="lml", choices=["lml", "predict"],
@@ -366,35 +371,23 @@ def main():
     descs = [gsum_amd.describe_kernel(RBF(float(e)), 1) for e in mine]
 
     def evaluate(batch):
-        """K build + Cholesky + fused solve for every descriptor (the library keeps `slots` independent
-        evaluations in flight), then the O(k^2) host algebra per evaluation."""
+        """K build + Cholesky + fused solve for every descriptor (one call of the batch entry point: the library advances them in
+        groups, one launch per kernel class and outer step), then the O(k^2) host algebra per evaluation."""
         G, sld, info = ctx.lml_resident(batch, 1e-10)
         out = np.empty(len(batch))
         for i in range(len(batch)):
             out[i] = -np.inf if info[i] != 0 else lml_from_gram(G[i], sld[i], n, 0.0, 0.0, 1, 1)[0] - jac
         return out
 
-    if args.slots > 0:
-        ctx.set_option("batch_slots", args.slots)
-    else:
-        # A region whose K is not a multiple of the evaluations in flight ends with the chip part empty (K = 20 on 16 in
-        # flight: 264 evals/s against 285 at K = 32).  For such a K keep the same number of rounds but balance them: K = 20 ->
-        # 2 rounds of 10 (270 evals/s), K = 24 -> 12 (277 against 275), K = 40 -> 3 rounds of 14 (284 against 281).
-        smax = ctx.get_option("batch_slots")
-        if not use_dist and smax >= 16 and 16 < K <= 20:
-            # a process that owns the GPU alone (no communicator: no RCCL streams beside the library's) can keep 20 in flight
-            # -- round 1's setting, 3.69 ms per evaluation; with a communicator in the process 20 + its queues oversubscribe the
-            # device's 24 compute queues (DESIGN.md section 4), hence never under torch.distributed.run
-            ctx.set_option("batch_slots", K)
-        elif smax > 4 and K % smax:
-            rounds = -(-K // smax)
-            ctx.set_option("batch_slots", -(-K // rounds))
-    # set-up, not a step: the per-slot workspaces (0.5 GB each) are allocated on first use; do that here so that a
-    # small --warmup does not leave hipMalloc calls inside the timed region.  (The library also times its streams'
-    # real concurrency in this first call and would fall back to 3 in flight if the runtime had fewer queues.)
-    evaluate([descs[i % len(descs)] for i in range(max(args.slots, ctx.get_option("batch_slots")))])
-    slots = ctx.get_option("batch_slots")
-    probe = ctx.queue_probe()
+    if args.groups > 0:
+        ctx.set_option("wave_groups", args.groups)
+    if args.group_size > 0:
+        ctx.set_option("wave_size", args.group_size)
+    # set-up, not a step: the groups' workspaces (0.55 GB per evaluation in flight) are allocated on first use; do that here so
+    # that a small --warmup does not leave hipMalloc calls inside the timed region
+    evaluate([descs[i % len(descs)] for i in range(max(3, K))])
+    groups, gsize = ctx.get_option("wave_groups"), ctx.get_option("wave_size")
+    in_flight = min(K, groups * gsize)
     if W > 0:
         evaluate([descs[i % len(descs)] for i in range(W)])
     if use_dist:
@@ -419,20 +412,30 @@ def main():
         prof = ctx.kernel_profile()
         return el, allv, prof
 
-    # `repeats` plain timed regions (value = their median), then ONE more region with HIP events around every launch of
-    # every 2nd evaluation: the per-kernel time shares inside a timed region.  Bracketing ~230 launches per sampled
-    # evaluation costs throughput (10 % at every 4th evaluation), so the profiled region is reported, not counted.
+    # `repeats` plain timed regions (value = their median), then ONE more region with HIP events around every launch (a batch
+    # is ~170 launches since round 4: bracketing them all costs ~1 %): per-kernel times inside a timed region, each on the
+    # stream it is launched on.  The profiled region is reported, not counted.
     regions = [timed_region() for _ in range(max(1, args.repeats))]
-    PROFILE_EVERY = 2
-    prof_elapsed, _, prof = timed_region(PROFILE_EVERY)
+    prof_elapsed, _, prof = timed_region(1)
     ctx.set_option("profile_gemm", 0)
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, allvals, _ = regions[order[(len(order) - 1) // 2]]        # the median region (lower median)
     all_elapsed = [reg[0] for reg in regions]
     gemm_ms, gemm_flops, gemm_launches = (prof["bulk_update"][k] for k in ("ms", "flops", "launches"))
 
+    # every rank's first grid point, recomputed on rank 0 as a single evaluation (a different schedule: one factorisation alone):
+    # the gathered value must be that number bit for bit -- same code object, same inputs (N > 1: a rank that gathered garbage or
+    # another rank's slice fails here; N = 1: the batch against the single evaluation)
+    rank_check = None
+    if rank == 0:
+        firsts = [float(ells[rk * K]) for rk in range(world)]
+        redo = np.array([evaluate([gsum_amd.describe_kernel(RBF(e), 1)])[0] for e in firsts])
+        got_first = np.array([allvals[rk * K] for rk in range(world)])
+        rank_check = {"what": "grid point 0 of every rank: gathered value vs a single evaluation of the same descriptor on rank 0",
+                      "ranks": int(world), "bit_identical": bool(np.array_equal(redo, got_first)),
+                      "max_rel": float(np.max(np.abs(redo - got_first) / np.abs(redo)))}
+
     # single-evaluation stage times (one evaluation alone on the GPU), outside the timed region
-    ctx.set_option("batch_slots", 1)
     stage = None
     for i in range(3):
         ctx.lml_resident([descs[0]], 1e-10)
@@ -446,7 +449,6 @@ def main():
     ctx.set_option("profile_gemm", 0)
     # parity inside the run: the evaluation the CPU baseline times (ell = 0.2 exactly), on the GPU
     gpu_lml_02 = float(evaluate([gsum_amd.describe_kernel(RBF(0.2), 1)])[0])
-    ctx.set_option("batch_slots", slots)
 
     # dominant kernel, exclusive: one SYRK launch of the step-0 shape alone on the GPU (device-resident random
     # operands), for the kernel-quality view next to the in-situ numbers
@@ -491,7 +493,7 @@ def main():
         ctx.set_option("release_scratch", 1)
 
     pmc_traffic = pmc_file = None
-    for name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
+    for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc_traffic = json.load(f)["derived"]["hbm_traffic_bytes_per_launch"]
@@ -504,12 +506,12 @@ def main():
         potrf_flops = n ** 3 / 3.0
         chol_tflops = potrf_flops / (stage[1] * 1e-3) / 1e12
         # all ranks run the same launches; rank 0's record stands for one GPU
-        sampled = (K + PROFILE_EVERY - 1) // PROFILE_EVERY          # evaluations 0, 2, 4, ... of the profiled region
-        chip_tflops = gemm_flops * (K / sampled) / elapsed / 1e12     # every evaluation issues the same launches: the
-                                                                      # kernel's algorithmic flops per region / median region time
+        launch_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0    # algorithmic flops of the bulk launches / the sum
+                                                                                    # of their durations (they do not overlap one another)
+        region_tflops = gemm_flops / elapsed / 1e12                                   # ... / wall time of the median timed region
         bytes_written = 4.0 * n * n + 4.0 * n * 128
-        shares = {name: {"ms_per_eval": v["ms"] / sampled, "launches_per_eval": v["launches"] / sampled,
-                         "share_of_stream_time": v["ms"] * (K / sampled) / (slots * prof_elapsed * 1e3)}
+        shares = {name: {"ms_per_eval": v["ms"] / K, "launches_per_region": v["launches"],
+                         "share_of_region_time": v["ms"] * 1e-3 / prof_elapsed}
                   for name, v in prof.items()}
         out = {
             "metric": "lml_evals_per_sec", "value": total / elapsed, "unit": "evals/s",
@@ -520,12 +522,14 @@ def main():
                                    + (" (BASELINE configs[2], S3)" if (n, r) == (8192, 6) else
                                       " (BASELINE configs[1], S2)" if (n, r) == (2048, 4) else " (not a BASELINE size: rehearsal)"),
                        "n": n, "orders": r,
-                       "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": slots},
+                       "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": in_flight,
+                       "batch_schedule": f"{groups} groups x {gsize} evaluations, one launch per kernel class and outer step; "
+                                         f"{ctx.get_option('wave_streams')} streams; GPU_MAX_HW_QUEUES "
+                                         + ("unset" if "GPU_MAX_HW_QUEUES" not in os.environ else os.environ["GPU_MAX_HW_QUEUES"])},
             "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)",
                         "ms_per_step_median": elapsed / K * 1e3, "ms_per_step_min": min(all_elapsed) / K * 1e3,
                         "ms_per_step_max": max(all_elapsed) / K * 1e3,
                         "evals_per_s_all": [total / e for e in all_elapsed]},
-            "queue_probe": probe,
             "single_eval_stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1],
                                      "finalize_d2h": stage[2], "gpu_total": stage[3]},
             "single_eval_kernel_ms": {name: {"ms": v["ms"], "launches": v["launches"]} for name, v in single_prof.items()},
@@ -538,36 +542,40 @@ def main():
                              "frac_of_hbm_peak": bytes_written / (stage[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128): what the kernel stores",
                              "us": stage[0] * 1e3},
-            # dominant kernel: the fp64-MFMA SYRK of the trailing update.  `achieved` = algorithmic
-            # flops of ALL its launches in the timed region / wall time of the timed region, i.e. what this
-            # kernel delivers on the chip while `evals_in_flight` evaluations share it; per-launch averages
-            # (HIP events on the launch stream, what rocprofv3 --stats reports) and the exclusive rate follow.
-            "roofline": {"kernel": "k_gemm_ld3 (128x64-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, 3 workgroups "
-                                   "per CU, K=256/512, trailing update)",
-                         "bound": "mfma", "achieved": chip_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": chip_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic,
-                         "traffic_source": "HBM bytes of one M=8192, K=256 launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE) from "
+            # dominant kernel: the fp64-MFMA SYRK of the trailing update, k_gemm_ld3g.  Since round 4 a launch carries one outer step
+            # of all members of a group and the groups' launches follow one another on ONE stream: `achieved` is the prescribed
+            # per-launch figure -- algorithmic flops of the launches / the sum of their HIP-event durations on that stream -- and
+            # it is what `rocprofv3 --kernel-trace --stats` of this command reports for the kernel (profiles/).
+            "roofline": {"kernel": "k_gemm_ld3g (128x64-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, 3 workgroups "
+                                   "per CU; one launch = the trailing update (K = 512, or 256) of every evaluation of a group)",
+                         "bound": "mfma", "achieved": launch_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": launch_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic,
+                         "traffic_source": "HBM bytes of one M=8192, K=256 launch of this kernel's tile (FETCH_SIZE x 2 + WRITE_SIZE) from "
                                            f"the committed rocprofv3 --pmc passes, profiles/{pmc_file}; PMC cannot be "
                                            "collected inside bench.py; algorithmic bytes of that launch: 5.61e8",
                          "launches": gemm_launches,
-                         "launches_sampled": f"every {PROFILE_EVERY}nd evaluation of one extra, profiled K-step region "
+                         "launches_sampled": "every launch of one extra, profiled K-step region "
                                              f"({prof_elapsed / K * 1e3:.3f} ms per step with the events in place)",
                          "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches),
                          "avg_flops_per_launch": gemm_flops / max(1, gemm_launches),
-                         "avg_concurrent_launches": gemm_ms * 1e-3 * (K / sampled) / prof_elapsed,
-                         "per_launch_tflops_shared": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                         "sum_launch_ms": gemm_ms, "region_ms": elapsed * 1e3,
+                         "busy_share_of_region": gemm_ms * 1e-3 / prof_elapsed,
+                         "region_tflops": region_tflops, "region_frac": region_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "exclusive_tflops": excl_tflops, "exclusive_frac": excl_tflops / FP64_MFMA_PEAK_TFLOPS,
-                         "exclusive_what": "the same kernel alone: 200 back-to-back SYRK launches of the first outer step's shape "
+                         "exclusive_what": "the one-product form of the same tile alone: 200 back-to-back SYRK launches of the first outer step's shape "
                                            "(M = n - 256, K = 256) on device-resident random operands",
-                         "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K (K = 256, or 512 for "
-                                             "the lazily updated far region), lower trapezoid for the near-column updates"},
+                         "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K per member (K = 512 for "
+                                             "paired updates, 256 otherwise); the small near-column updates (lower trapezoid, K = 256) "
+                                             "run on the chain streams and are counted with the panel class"},
             "kernel_time_shares": {"classes": shares,
-                                   "note": "HIP-event duration of every launch of every 2nd evaluation inside one extra timed K-step "
-                                           "region (not counted in value), per kernel class, on the launch's own stream; share = class "
-                                           "time x (K / sampled) / (evals in flight x that region's wall time): the classes sum to <= 1, "
-                                           "the rest is stream idle time",
+                                   "note": "HIP-event duration of every launch inside one extra timed K-step region (not counted in "
+                                           "value), per kernel class, on the launch's own stream; share = class time / that region's "
+                                           "wall time.  The bulk class runs on one stream (its share is the fraction of the region "
+                                           "the trailing updates occupy the chip); diagonal blocks, panels and kernel builds run on "
+                                           "the groups' chain streams BESIDE it, so the shares add up to more than 1",
                                    "profiled_region_ms_per_step": prof_elapsed / K * 1e3,
-                                   "sum_of_shares": float(sum(v["share_of_stream_time"] for v in shares.values()))},
+                                   "sum_of_shares": float(sum(v["share_of_region_time"] for v in shares.values()))},
+            "rank_check": rank_check,
             "factor_reuse": reuse,
             "ell_ratio_grid": ell_grid,
             "predict": pred,
@@ -587,7 +595,13 @@ def main():
                              "rel_vs_reference": ref_rel, "reference_what": ref_what,
                              "what": "TruncationGP.log_marginal_likelihood(log 0.2, ratio=0.5) of the S3 workload: HIP path vs the "
                                      "CPU oracle evaluation that cpu_baseline times"}
-            if not rel <= PARITY_BOUND:
+            svml = host_exp_is_svml()
+            out["parity"]["host_exp_is_svml"] = svml
+            if not svml:
+                out["parity"]["cpu_note"] = ("this host's numpy exp is NOT the SVML routine the reference's numbers were made with and the "
+                                             "device kernel build restates: the CPU leg's kernel matrix differs by an ulp on whole diagonals "
+                                             "(~6e-10 on the log-likelihood); the CPU comparison is reported, the pin is rel_vs_reference")
+            elif not rel <= PARITY_BOUND:
                 rc = 3
         else:
             out["parity"] = {"gpu": gpu_lml_02, "cpu": None, "rel": ref_rel, "bound": PARITY_BOUND, "reference": ref_v,
@@ -603,6 +617,8 @@ def main():
         # N > 1: every rank's slice came through the all-gather; the gathered grid must be complete and finite
         out["gathered"] = {"length": int(len(allvals)), "expected": int(total), "finite": bool(np.isfinite(allvals).all())}
         if len(allvals) != total or not np.isfinite(allvals).all():
+            rc = 3
+        if rank_check is not None and not rank_check["bit_identical"]:
             rc = 3
         print(json.dumps(out), flush=True)
     if use_dist:

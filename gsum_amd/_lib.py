@@ -9,27 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
-import warnings
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def configure_runtime(hw_queues: int = 32) -> bool:
-    """Ask the HIP runtime for ``hw_queues`` hardware queues (environment variable ``GPU_MAX_HW_QUEUES``).
-
-    The runtime multiplexes streams onto 4 hardware queues by default; the batch pipeline of ``lml_resident`` keeps up
-    to 16 independent evaluations in flight on their own streams and wants a queue each (270-286 instead of 180-205
-    evaluations per second at n = 8192).  The runtime reads the variable once, when it initialises, so call this
-    before ANYTHING in the process touches the GPU (torch.cuda included).  Importing gsum_amd does not change the
-    environment by itself: an application decides this for its whole process.  Returns False, and leaves a value the
-    user already set untouched.  Whatever the environment says, the library times its streams' real concurrency
-    before it trusts more than 4 in-flight evaluations (``HipContext.queue_probe``)."""
-    if "GPU_MAX_HW_QUEUES" in os.environ:
-        return False
-    os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
-    return True
 
 
 LIB_PATH = os.environ.get("GSUM_HIP_LIBRARY") or os.path.join(_HERE, "libgsum_hip.so")
@@ -258,14 +241,6 @@ class HipContext:
             raise ValueError(f"unknown option: {name}")
         return v
 
-    def queue_probe(self):
-        """Result of the stream-concurrency probe that runs before the first batch wanting more than 4 evaluations in
-        flight: dict(streams, concurrency, fell_back_from, batch_slots); streams == 0 means it has not run."""
-        return dict(streams=self.get_option("queue_probe_streams"),
-                    concurrency=self.get_option("queue_probe_concurrency_x100") / 100.0,
-                    fell_back_from=self.get_option("queue_probe_fell_back"),
-                    batch_slots=self.get_option("batch_slots"))
-
     # -- operator level ------------------------------------------------------
     def kernel_matrix(self, desc: KernelDesc, X, Y=None, diag_add: float = 0.0) -> np.ndarray:
         X = _f64(X)
@@ -468,14 +443,12 @@ class HipContext:
         if n == 0:
             raise ValueError("gsum_set_inputs has not been called")
         nk = len(descs)
-        self._note_default_queues(nk)
         G = np.empty((nk, k, k))
         sld = np.empty(nk)
         info = np.zeros(nk, dtype=np.int64)
         arr = self._desc_array(descs)
         self._check(self._lib.gsum_lml_resident(self._h, arr, nk, float(nugget), _ptr(G), _ptr(sld),
                                                 info.ctypes.data_as(_ip)))
-        self._warn_if_probe_fell_back()
         return G, sld, info
 
     def lml_resident_shard(self, descs, nugget: float, rank: int, world: int):
@@ -496,33 +469,7 @@ class HipContext:
         arr = self._desc_array(descs)
         self._check(self._lib.gsum_lml_resident_shard(self._h, arr, nk, int(rank), int(world), float(nugget), _ptr(G), _ptr(sld),
                                                       info.ctypes.data_as(_ip), C.byref(lo), C.byref(hi)))
-        self._warn_if_probe_fell_back()
         return G, sld, info, int(lo.value), int(hi.value)
-
-    def _note_default_queues(self, n_kernels):
-        """One-time note when a batch runs on the runtime's default 4 hardware queues (3 evaluations in flight) only
-        because nobody asked for more: importing gsum_amd leaves the environment alone (configure_runtime)."""
-        if n_kernels <= 4 or getattr(self, "_queues_noted", False) or "GPU_MAX_HW_QUEUES" in os.environ:
-            return
-        self._queues_noted = True
-        if int(self._lib.gsum_get_option(self._h, b"batch_slots")) <= 3:
-            warnings.warn("gsum_amd: GPU_MAX_HW_QUEUES is not set, so batches keep 3 evaluations in flight on the HIP "
-                          "runtime's default 4 hardware queues (about two thirds of the throughput at n = 8192); call "
-                          "gsum_amd.configure_runtime() before anything touches the GPU to get 16 in flight",
-                          RuntimeWarning, stacklevel=3)
-
-    def _warn_if_probe_fell_back(self):
-        if getattr(self, "_probe_warned", False):
-            return
-        asked = int(self._lib.gsum_get_option(self._h, b"queue_probe_fell_back"))
-        if asked > 0:
-            self._probe_warned = True
-            conc = int(self._lib.gsum_get_option(self._h, b"queue_probe_concurrency_x100")) / 100.0
-            warnings.warn(
-                f"gsum_amd: {asked} evaluations in flight were configured but the HIP runtime runs only {conc:.1f} streams "
-                "side by side (GPU_MAX_HW_QUEUES was not in the environment when the runtime initialised -- call "
-                "gsum_amd.configure_runtime() before anything touches the GPU); the batch pipeline falls back to 3 in flight",
-                RuntimeWarning, stacklevel=3)
 
     # -- measurement ---------------------------------------------------------
     def timers(self):

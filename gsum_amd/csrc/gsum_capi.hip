@@ -93,9 +93,9 @@ struct gsum_ctx {
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
-    int batch_slots = 3;             // evaluations kept in flight by gsum_lml_resident: 3 is the measured optimum with
-                                     // the HIP runtime's default of 4 hardware queues; gsum_init raises it to 8 / 12 / 16
-                                     // when GPU_MAX_HW_QUEUES >= 8 / 12 / 16 is in the environment
+    int batch_slots = 3;             // gradient evaluations kept in flight by gsum_lml_grad_batch, one stream each: 3 is the measured
+                                     // optimum on the HIP runtime's default of 4 hardware queues (value-only batches do not use
+                                     // slots: gs_lml_wave)
     int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
@@ -179,9 +179,6 @@ struct gsum_ctx {
     struct ProfRec { int e0, e1; double flops; int cls; };     // cls: GS_PROF_* below
     std::vector<ProfRec> prof_recs;
     size_t prof_next = 0;
-    int probe_streams = 0;           // queue-concurrency probe (gs_probe_queues): streams timed, observed concurrency,
-    double probe_concurrency = 0.0;  // and whether batch_slots fell back to 3 because of it
-    int probe_fell_back = 0;
     int small_path = 1;              // n <= 128: fused one-workgroup-per-evaluation kernel
     int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
     int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n^1.45 / 985),
@@ -191,12 +188,16 @@ struct gsum_ctx {
     std::set<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this context's device
     // grouped batch schedule (gs_lml_wave): the evaluations of a call advance in groups, one launch per kernel class and outer step
     gs_wave wave;
-    int batch_mode = 1;              // 1 = grouped launches (default), 0 = one stream per evaluation (rounds 1-3; needs GPU_MAX_HW_QUEUES)
     int wave_groups = 2;             // groups = chain streams; their bulk launches alternate on ONE bulk stream
     int wave_size = 10;              // evaluations per group at most
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
     int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
+    int wave_last_streams = 0;
     int wave_near_on_chain = 1;      // the small "near" trailing updates (K = 256, the next panel's columns only) on the group's chain stream
+    int wave_depth = 3;              // panels per macro-step of the batch schedule: the far trailing region is updated once per `wave_depth`
+                                     // panels with K = 256 x wave_depth (2: the pairing of rounds 2-3).  n = 8192, 20 evaluations per call
+                                     // (tools/gpu_wave_check.py): 313.0 / 316.4 / 315.9 / 314.7 / 312.0 evals/s at depth 2 / 3 / 4 / 6 / 8
+    int wave_deep_rows = 3072;       // ... deeper than 2 only while the trailing matrix has at least this many rows
 };
 
 static std::string g_init_error;
@@ -1300,20 +1301,6 @@ int gsum_init(int device, gsum_ctx** out) {
     if (cp) ctx->chain_persist = atoi(cp) < 0 ? -1 : (atoi(cp) != 0);
     const char* rc = getenv("GSUM_RESERVE_CUS");
     if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
-    // Streams beyond the runtime's hardware-queue limit share queues (false serialisation between evaluations).
-    // With the limit raised (GPU_MAX_HW_QUEUES, read by the HIP runtime when it initialises) every in-flight evaluation
-    // owns a queue: 16 in flight run 3.7-3.8 ms per evaluation at n = 8192 against 4.9 for 3 in flight on the default 4
-    // queues.  Twenty in flight are 2-3 % faster still in a process that owns the GPU alone, but the device schedules at
-    // most 24 user compute queues without time-slicing them: with an RCCL communicator (or any other stream owner) in
-    // the process, 20 + its queues cross that line and throughput collapses to 148 evaluations per second (measured
-    // under torchrun, round 2; 16 in flight: 263).  Hence 16 by default; "batch_slots" / GSUM_BATCH_SLOTS override.
-    const char* hq = getenv("GPU_MAX_HW_QUEUES");
-    const int nq = hq ? atoi(hq) : 4;
-    if (nq >= 16) ctx->batch_slots = 16;
-    else if (nq >= 12) ctx->batch_slots = 12;
-    else if (nq >= 8) ctx->batch_slots = 8;
-    const char* bs = getenv("GSUM_BATCH_SLOTS");
-    if (bs) ctx->batch_slots = std::max(1, std::min(GS_MAX_SLOTS, atoi(bs)));
     *out = ctx;
     return 0;
 }
@@ -1373,14 +1360,14 @@ const char* gsum_last_error(gsum_ctx* ctx) { return ctx ? ctx->err.c_str() : g_i
 int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!ctx || !name) return -1;
     if (!strcmp(name, "batch_slots")) return ctx->batch_slots;
-    if (!strcmp(name, "batch_mode")) return ctx->batch_mode;
+    if (!strcmp(name, "wave_streams")) return ctx->wave_last_streams;     // streams the last batch call used (groups + 1; 0: none yet)
+    if (!strcmp(name, "wave_depth")) return ctx->wave_depth;
+    if (!strcmp(name, "wave_deep_rows")) return ctx->wave_deep_rows;
+    if (!strcmp(name, "wave_near_on_chain")) return ctx->wave_near_on_chain;
     if (!strcmp(name, "wave_groups")) return ctx->wave_groups;
     if (!strcmp(name, "wave_size")) return ctx->wave_size;
     if (!strcmp(name, "wave_shift")) return ctx->wave_shift;
     if (!strcmp(name, "wave_min")) return ctx->wave_min;
-    if (!strcmp(name, "queue_probe_streams")) return ctx->probe_streams;        // 0: the probe has not run
-    if (!strcmp(name, "queue_probe_concurrency_x100")) return (int64_t)(ctx->probe_concurrency * 100.0 + 0.5);
-    if (!strcmp(name, "queue_probe_fell_back")) return ctx->probe_fell_back;
     if (!strcmp(name, "lookahead")) return ctx->lookahead;
     if (!strcmp(name, "bulk_cfg")) return ctx->bulk_cfg;
     if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
@@ -1395,29 +1382,6 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
         return (int64_t)h[!strcmp(name, "panel_wave_ticks") ? 0 : 1];
     }
     return -1;
-}
-
-// Do S streams of this process really run side by side?  gsum_init can only read GPU_MAX_HW_QUEUES from the environment;
-// whether the HIP runtime read the same value depends on who initialised it (a process that touched the GPU before the
-// variable was set keeps the default 4 queues, and streams beyond the queue count share queues: the kernels of different
-// evaluations then serialise and 20 in flight are slower than 3).  So before the first batch that wants more than 4
-// slots, one spinning single-wave kernel per slot stream is timed: S x spin / elapsed is the observed concurrency.
-// Below 70 % of S the batch falls back to 3 slots (the optimum on 4 queues) and says so through gsum_get_option.
-static int gs_probe_queues(gsum_ctx* ctx, int S) {
-    if (gs_need_slots(ctx, S)) return -1;
-    GS_CHECK(hipDeviceSynchronize());
-    const unsigned long long ticks = 300000;                 // 3 ms of s_memrealtime (100 MHz): long against the ~0.2 ms it
-                                                             // takes the host to enqueue 20 launches
-    for (int rep = 0; rep < 2; ++rep) {                      // first round: code-object load, stream warm-up
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int q = 0; q < S; ++q) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, ctx->slots[q].sm, ticks);
-        GS_CHECK(hipGetLastError());
-        GS_CHECK(hipDeviceSynchronize());
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        ctx->probe_concurrency = (double)S * 3000.0 / us;
-    }
-    ctx->probe_streams = S;
-    return 0;
 }
 
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
@@ -1494,12 +1458,13 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
-    else if (!strcmp(name, "batch_mode")) ctx->batch_mode = value != 0;
     else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_GROUPS, value));
     else if (!strcmp(name, "wave_size")) ctx->wave_size = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WVC_MAX, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
+    else if (!strcmp(name, "wave_depth")) ctx->wave_depth = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
+    else if (!strcmp(name, "wave_deep_rows")) ctx->wave_deep_rows = (int)std::max<int64_t>(0, value);
     else GS_FAIL(std::string("unknown option: ") + name);
     return 0;
 }
@@ -2160,18 +2125,26 @@ static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
     return 0;
 }
 
-// trailing update of outer step s in a batch (the pairing of gs_potrf's batch branch, lazy_far = 2): after an even step only the next
-// panel's 256 columns take the update (K = 256, rectangular); the step after it applies both panels to everything from its own first
-// trailing column on in ONE K = 512 pass; steps without a full next panel (or with the pairing off) update the whole lower triangle
-static void gs_wave_bulk_modes(int64_t np, bool lazy, std::vector<int>& mode) {
+// Trailing updates of a batch, per outer step s (panel columns [256 s, 256 s + 256), trailing matrix from r2 = 256 (s + 1)).  Steps
+// are grouped into macro-steps of up to `depth` panels a .. a + L - 1 (L panels are grouped only while r2(a) + 256 L <= np):
+//   step a + i, i < L - 1   "near": only the NEXT panel's 256 columns are updated, with all panels of the macro-step so far at once
+//                           (rows r2.., rectangular, K = 256 (i + 1)) -- what the chain's next link needs;
+//   step a + L - 1          "far": everything from column r2 on, lower tiles, with all L panels in ONE pass (K = 256 L).
+// depth 1: a plain right-looking sweep (K = 256 everywhere); depth 2: the pairing of gs_potrf's batch branch (lazy_far = 2).  A deeper
+// grouping reads and writes the far region once per L panels -- the bulk tile's rate rises with K (C traffic per flop) -- at the
+// price of near updates with K up to 256 (L - 1).  Per element the same products are subtracted in the same ascending order whatever
+// the grouping (an accumulator that starts as C carries across launches exactly): results do not depend on it.
+struct gs_wave_step { int near; int K; int first; };        // first: the macro-step's first outer step (the operand's first panel)
+static void gs_wave_bulk_plan(int64_t np, int depth, int64_t deep_min_rows, std::vector<gs_wave_step>& plan) {
     const int S = (int)(np / (2 * GS_NB));
-    mode.assign((size_t)S, 0);
-    bool deferred = false;
-    for (int s = 0; s < S; ++s) {
-        const int64_t r2 = 2 * GS_NB * (int64_t)(s + 1);
-        const bool full_next = lazy && r2 + 4 * GS_NB <= np;
-        if (!deferred && full_next) { mode[s] = 1; deferred = true; }
-        else if (deferred) { mode[s] = 2; deferred = false; }
+    plan.assign((size_t)S, gs_wave_step{0, 2 * GS_NB, 0});
+    for (int a = 0; a < S;) {
+        const int64_t r2 = 2 * GS_NB * (int64_t)(a + 1);
+        int L = 1;
+        while (L < depth && r2 + 2 * GS_NB * (int64_t)(L + 1) <= np) ++L;
+        if (L > 2 && np + GS_BORDER - r2 < deep_min_rows) L = 2;          // deeper than pairs only while the trailing matrix is large
+        for (int i = 0; i < L; ++i) plan[(size_t)(a + i)] = gs_wave_step{i < L - 1 ? 1 : 0, 2 * GS_NB * (i + 1), a};
+        a += L;
     }
 }
 
@@ -2215,10 +2188,11 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
         }
     }
     if (gs_wave_prepare(ctx, G, B, n, np)) return -1;
+    ctx->wave_last_streams = G + 1;
     if (gs_reserve_pinned(ctx, (size_t)n_kernels * 258 * sizeof(double))) return -1;
     gs_wave* wv = &ctx->wave;
-    std::vector<int> mode;
-    gs_wave_bulk_modes(np, ctx->lazy_far != 0 && np >= ctx->lazy_min_np, mode);
+    std::vector<gs_wave_step> plan;
+    gs_wave_bulk_plan(np, (ctx->lazy_far != 0 && np >= ctx->lazy_min_np) ? std::max(2, ctx->wave_depth) : 1, ctx->wave_deep_rows, plan);
     const bool several_rounds = n_kernels > G * B;
     // Groups out of phase in calls of several rounds (counted in sweeps of the loop below = macro-steps)?  Measured and left off:
     // the groups' big updates alternate on one stream, so all groups advance at the same macro-step rate, and a group in its
@@ -2290,8 +2264,8 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     gs_prof_end(ctx, g->sc, rec);
                 }
                 GS_CHECK(hipGetLastError());
-                const int md = mode[(size_t)g->step];
-                const bool near = md == 1 && ctx->wave_near_on_chain;
+                const gs_wave_step st = plan[(size_t)g->step];
+                const bool near = st.near && ctx->wave_near_on_chain;
                 hipStream_t su = near ? g->sc : wv->sb;
                 if (!near) {
                     GS_CHECK(hipEventRecord(g->evChain, g->sc));
@@ -2305,11 +2279,11 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 ga.pad = 0;
                 gs_wv_gemm_entry en;
                 en.offC = r2 * ld + r2;
-                en.offA = en.offB = r2 * ld + (md == 2 ? c0 - 2 * GS_NB : c0);
+                en.offA = en.offB = r2 * ld + 2 * GS_NB * (int64_t)st.first;      // panels first .. step: K contiguous columns
                 en.M = (int)mrest;
-                en.N = md == 1 ? 2 * GS_NB : (int)mrest;
-                en.K = md == 2 ? 4 * GS_NB : 2 * GS_NB;
-                en.tri = md == 1 ? 0 : 1;
+                en.N = st.near ? 2 * GS_NB : (int)mrest;
+                en.K = st.K;
+                en.tri = st.near ? 0 : 1;
                 en.pad = 0;
                 const int64_t tm = (mrest + 127) / 128;
                 const int tiles = (int)(en.tri ? tm * (tm + 1) : tm * ((en.N + 63) / 64));
@@ -2376,49 +2350,21 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    if (ctx->batch_mode == 1 && n_kernels >= ctx->wave_min && ctx->diag_algo == 2 && ctx->bulk_cfg == 7 && ctx->build_algo == 2) {
+    if (n_kernels >= ctx->wave_min && ctx->diag_algo == 2 && ctx->bulk_cfg == 7 && ctx->build_algo == 2) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_wave(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    if (ctx->batch_slots > 4 && n_kernels > 4 && ctx->probe_streams < ctx->batch_slots && !ctx->probe_fell_back) {
-        if (gs_probe_queues(ctx, ctx->batch_slots)) return -1;
-        if (ctx->probe_concurrency < 0.7 * ctx->batch_slots) {
-            ctx->probe_fell_back = ctx->batch_slots;
-            ctx->batch_slots = 3;
-        }
-    }
-    int S = std::max(1, std::min(ctx->batch_slots, (int)n_kernels));
-    {
-        // every slot owns a workspace matrix of the current order: keep the new ones within 80 % of the free memory
-        const int64_t np = gs_padded_order(ctx, ctx->in->n), ldw = np + GS_BORDER;
-        const double Tw = (double)(np / GS_NB);
-        const double ws_bytes = (double)(np + GS_BORDER) * ldw * 8.0 + (double)np * GS_NB * 8.0      // A, Linv
-                                + Tw * GS_LTAB * 8.0 + (Tw / 2 + 1) * GS_LSIB * 8.0 + (double)np * 16.0;   // Ltab, Lsib, logdet + diag0
-        int have = 0;
-        for (int q = 0; q < std::min(S, ctx->n_slots_ready); ++q)
-            if (ctx->slots[q].ws && ctx->slots[q].ws->n == ctx->in->n) ++have;
-        size_t free_b = 0, total_b = 0;
-        GS_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const int can_add = (int)std::min<double>(1e6, 0.8 * (double)free_b / ws_bytes);
-        S = std::max(1, std::min(S, have + can_add));
-    }
-    if (gs_need_slots(ctx, S)) return -1;
-    ctx->batch_active = S;
+    // one or two evaluations (or a non-default kernel generation under test): one after the other, each with the schedule of a
+    // single factorisation (look-ahead / persistent chain) on the context's own streams
+    gs_slot* sl = &ctx->slots[0];
+    ctx->cur = sl;
+    ctx->batch_active = 1;
     int rc = 0;
     for (int i = 0; i < n_kernels && !rc; ++i) {
-        gs_slot* sl = &ctx->slots[i % S];
-        ctx->cur = sl;
-        rc = gs_eval_harvest(ctx, sl, G_out, sld_out, info_out);     // frees the slot (evaluation i - S)
-        if (!rc) rc = gs_eval_enqueue(ctx, &kernels[i], nugget);
+        rc = gs_eval_enqueue(ctx, &kernels[i], nugget);
         if (!rc) sl->pending = i;
+        if (!rc) rc = gs_eval_harvest(ctx, sl, G_out, sld_out, info_out);
     }
-    for (int s = 0; s < S; ++s) {
-        ctx->cur = &ctx->slots[s];
-        int r2 = gs_eval_harvest(ctx, ctx->cur, G_out, sld_out, info_out);
-        if (!rc) rc = r2;
-    }
-    ctx->cur = &ctx->slots[0];
-    ctx->batch_active = 1;
     return rc;
 }
 

@@ -10,7 +10,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -592,20 +592,24 @@ def test_full_size_properties_n8192():
     ctx.set_option("la_split", 0)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
-    # evaluations in flight: 1, 3, 10 or 16 per call is scheduling only; so is the batch mode's lazy K = 512 update of the
-    # far trailing region
+    # a batch (grouped launches, gs_lml_wave): the group layout is scheduling only; so is the batch schedule's pairing of trailing
+    # updates (K = 512 every other step) and the stream its small "near" updates go out on
     many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for slots, lazy in ((16, 1), (3, 2), (10, 0), (16, 2)):
-        ctx.set_option("batch_slots", slots)
+    for groups, size, lazy, near in ((2, 10, 2, 1), (1, 20, 2, 1), (3, 7, 0, 1), (2, 5, 2, 0), (4, 5, 2, 1)):
+        ctx.set_option("wave_groups", groups)
+        ctx.set_option("wave_size", size)
         ctx.set_option("lazy_far", lazy)
+        ctx.set_option("wave_near_on_chain", near)
         Gs, ss, infos = ctx.lml_resident(many, 1e-10)
         assert np.all(infos == 0)
         for b in range(len(many)):
             np.testing.assert_array_equal(Gs[b], G0[0])
             assert ss[b] == s0[0]
-    ctx.set_option("lazy_far", 2)                              # the library's default
-    ctx.set_option("batch_slots", 16)
+    ctx.set_option("lazy_far", 2)                              # the library's defaults
+    ctx.set_option("wave_groups", 2)
+    ctx.set_option("wave_size", 10)
+    ctx.set_option("wave_near_on_chain", 1)
     for key, (G, s, i) in out.items():
         np.testing.assert_array_equal(G, G0)
         np.testing.assert_array_equal(s, s0)
@@ -1087,13 +1091,12 @@ def test_batch_lazy_far_updates_are_scheduling_only_below_8192(ctx, n):
     Z = np.concatenate([rng.randn(n, 4), np.ones((n, 1))], axis=1)
     descs = [gsum_amd.describe_kernel(RBF(0.2 + 0.01 * i), 1) for i in range(6)]
     ctx.set_inputs(X, Z)
-    old_slots = ctx.get_option("batch_slots")
     try:
-        ctx.set_option("batch_slots", 1)
+        ctx.set_option("wave_min", 1000)                     # one evaluation after the other, each on the single-factorisation schedule
         ref = ctx.lml_resident(descs, 1e-10)
         assert np.all(ref[2] == 0)
-        for lazy in (2, 0, 1):
-            ctx.set_option("batch_slots", 6)
+        ctx.set_option("wave_min", 3)
+        for lazy in (2, 0):
             ctx.set_option("lazy_far", lazy)
             G, sld, info = ctx.lml_resident(descs, 1e-10)
             np.testing.assert_array_equal(G, ref[0])
@@ -1101,4 +1104,4 @@ def test_batch_lazy_far_updates_are_scheduling_only_below_8192(ctx, n):
             np.testing.assert_array_equal(info, ref[2])
     finally:
         ctx.set_option("lazy_far", 2)
-        ctx.set_option("batch_slots", old_slots)
+        ctx.set_option("wave_min", 3)

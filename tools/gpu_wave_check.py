@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Grouped batch schedule (gs_lml_wave, round 4) against the one-stream-per-evaluation schedule of rounds 1-3:
+"""Grouped batch schedule (gs_lml_wave, round 4) against single evaluations (rounds 1-3's one-stream-per-evaluation batch, which
+the first version of this script compared with -- bit-identical, 215 evals/s on default queues -- is gone):
 bit-identity of G / sum log L_ii / info on mixed batches (one non-positive-definite member), then throughput at
 n = 8192 for several group layouts.  GPU_MAX_HW_QUEUES is deliberately NOT set by this script.
 
@@ -51,11 +52,11 @@ def main():
             descs.append(gsum_amd.describe_kernel(Matern(0.2, nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed"), 1))
             descs.append(gsum_amd.describe_kernel(RBF(30.0), 1))                  # numerically singular: info > 0
             nug = 1e-10
-            ctx.set_option("batch_mode", 0)
+            ctx.set_option("wave_min", 1000)              # the reference: one evaluation after the other, single-factorisation schedule
             G0, s0, i0 = ctx.lml_resident(descs, nug)
+            ctx.set_option("wave_min", 3)
             res = {"n": n, "evals": len(descs), "info": i0.tolist()}
             for (g, b) in ((2, 10), (3, 2), (1, 4), (4, 1)):
-                ctx.set_option("batch_mode", 1)
                 ctx.set_option("wave_groups", g)
                 ctx.set_option("wave_size", b)
                 G1, s1, i1 = ctx.lml_resident(descs, nug)
@@ -85,13 +86,6 @@ def main():
         return K / float(np.median(ts)), K / min(ts)
 
     K = args.evals
-    ctx.set_option("batch_mode", 0)
-    med, best = rate(K, args.reps)
-    rec = {"mode": "slots", "slots": ctx.get_option("batch_slots"), "K": K, "evals_per_s_median": med, "best": best}
-    print(json.dumps(rec), flush=True)
-    out["timing"].append(rec)
-    ctx.set_option("release_scratch", 1)
-    ctx.set_option("batch_mode", 1)
     layouts = [(2, 10, 1), (2, 10, 0), (3, 7, 1), (4, 5, 1), (1, 20, 1), (2, 12, 1)] if not args.quick else [(2, 10, 1), (3, 7, 1)]
     for g, b, near in layouts:
         ctx.set_option("wave_groups", g)
@@ -101,6 +95,24 @@ def main():
         rec = {"mode": "wave", "groups": g, "size": b, "near_on_chain": near, "K": K, "evals_per_s_median": med, "best": best}
         print(json.dumps(rec), flush=True)
         out["timing"].append(rec)
+    # deeper grouping of the trailing updates (K = 256 x depth for the far region)
+    ctx.set_option("wave_groups", 2)
+    ctx.set_option("wave_size", 10)
+    ctx.set_option("wave_near_on_chain", 1)
+    ells = np.linspace(0.19, 0.21, K)
+    dd = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in ells])
+    ref = ctx.lml_resident(dd, 1e-10)
+    for depth, rows in ((2, 3072), (3, 3072), (4, 3072), (4, 1024), (4, 5120), (6, 4096), (8, 4096), (1, 0), (2, 3072)):
+        ctx.set_option("wave_depth", depth)
+        ctx.set_option("wave_deep_rows", rows)
+        got = ctx.lml_resident(dd, 1e-10)
+        same = all(np.array_equal(a, b) for a, b in zip(ref, got))
+        med, best = rate(K, args.reps)
+        rec = {"mode": "wave", "depth": depth, "deep_rows": rows, "K": K, "bit_identical": same, "evals_per_s_median": med, "best": best}
+        print(json.dumps(rec), flush=True)
+        out["timing"].append(rec)
+    ctx.set_option("wave_depth", 2)
+    ctx.set_option("wave_deep_rows", 3072)
     # per-class HIP-event times of one profiled call in the default layout
     ctx.set_option("wave_groups", 2)
     ctx.set_option("wave_size", 10)
