@@ -188,15 +188,28 @@ struct gsum_ctx {
     std::set<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this context's device
     // grouped batch schedule (gs_lml_wave): the evaluations of a call advance in groups, one launch per kernel class and outer step
     gs_wave wave;
-    int wave_groups = 2;             // groups = chain streams; their bulk launches alternate on ONE bulk stream
-    int wave_size = 10;              // evaluations per group at most
+    int wave_groups = 3;             // groups = chain streams; their bulk launches alternate on ONE bulk stream (4 streams: the HIP runtime's
+                                     // default number of hardware queues)
+    int wave_size = 7;               // evaluations per group at most
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
     int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
     int wave_last_streams = 0;
+    int wave_serial = 0;             // 1: a group's panels and ALL its trailing updates on the one bulk stream, only its diagonal blocks on the
+                                     // chain stream.  Panels and near updates are chip-filling MFMA work themselves (7 + 5.5 ms of a 20-evaluation
+                                     // call at n = 8192, against 48 ms of far updates): run beside the far updates of another group they
+                                     // slow those down by as much as they take (far updates 65.8 TF/s alone, 56.5 beside them), so nothing
+                                     // is gained by the overlap and no per-launch time means anything.  One after the other every kernel
+                                     // runs at its exclusive rate and the sum of the bulk stream's launches IS the step time; what still
+                                     // overlaps is what is latency-bound: the diagonal blocks (10 workgroups) and the kernel builds.
+                                     // 0 (default): panels and near updates on the chain streams.  Measured (tools/gpu_wave_profile.py,
+                                     // 2 x 10): serial 300 evals/s with the bulk stream's launches at 63.5 TF/s, overlapped 316 with
+                                     // the far updates at 56.5 -- the overlap does hide ~4 ms of a 64-ms call (launch gaps, the
+                                     // panels' latency-bound share), so it stays the default
     int wave_near_on_chain = 1;      // the small "near" trailing updates (K = 256, the next panel's columns only) on the group's chain stream
-    int wave_depth = 3;              // panels per macro-step of the batch schedule: the far trailing region is updated once per `wave_depth`
+    int wave_depth = 4;              // panels per macro-step of the batch schedule: the far trailing region is updated once per `wave_depth`
                                      // panels with K = 256 x wave_depth (2: the pairing of rounds 2-3).  n = 8192, 20 evaluations per call
-                                     // (tools/gpu_wave_check.py): 313.0 / 316.4 / 315.9 / 314.7 / 312.0 evals/s at depth 2 / 3 / 4 / 6 / 8
+                                     // (tools/gpu_wave_check.py, 2 groups of 10): 313.0 / 316.4 / 315.9 / 314.7 / 312.0 evals/s at depth 2 / 3 / 4 / 6 / 8;
+                                     // 3 groups of 7 (tools/gpu_wave_profile.py): 315.3 / 320.4 / 321.3 at depth 2 / 3 / 4, 84 per call 316.3 / 321.4 / 322.2
     int wave_deep_rows = 3072;       // ... deeper than 2 only while the trailing matrix has at least this many rows
 };
 
@@ -1364,6 +1377,7 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "wave_depth")) return ctx->wave_depth;
     if (!strcmp(name, "wave_deep_rows")) return ctx->wave_deep_rows;
     if (!strcmp(name, "wave_near_on_chain")) return ctx->wave_near_on_chain;
+    if (!strcmp(name, "wave_serial")) return ctx->wave_serial;
     if (!strcmp(name, "wave_groups")) return ctx->wave_groups;
     if (!strcmp(name, "wave_size")) return ctx->wave_size;
     if (!strcmp(name, "wave_shift")) return ctx->wave_shift;
@@ -1463,6 +1477,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
+    else if (!strcmp(name, "wave_serial")) ctx->wave_serial = value != 0;
     else if (!strcmp(name, "wave_depth")) ctx->wave_depth = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "wave_deep_rows")) ctx->wave_deep_rows = (int)std::max<int64_t>(0, value);
     else GS_FAIL(std::string("unknown option: ") + name);
@@ -2257,17 +2272,23 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     gs_prof_end(ctx, g->sc, rec);
                 }
                 const int64_t c0 = 2 * GS_NB * (int64_t)g->step, r2 = c0 + 2 * GS_NB, mrest = naug - r2;
+                const bool serial = ctx->wave_serial != 0;
+                if (serial) {                  // only the diagonal blocks run beside the bulk stream's kernels (see wave_serial)
+                    GS_CHECK(hipEventRecord(g->evChain, g->sc));
+                    GS_CHECK(hipStreamWaitEvent(wv->sb, g->evChain, 0));
+                }
                 {
+                    hipStream_t spn = serial ? wv->sb : g->sc;
                     const int groups = gs_wave_fill_chain(g, &ca, true);
-                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
-                    hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, g->sc, ca);
-                    gs_prof_end(ctx, g->sc, rec);
+                    const int rec = gs_prof_begin(ctx, spn, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
+                    hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, spn, ca);
+                    gs_prof_end(ctx, spn, rec);
                 }
                 GS_CHECK(hipGetLastError());
                 const gs_wave_step st = plan[(size_t)g->step];
-                const bool near = st.near && ctx->wave_near_on_chain;
+                const bool near = st.near && ctx->wave_near_on_chain && !serial;
                 hipStream_t su = near ? g->sc : wv->sb;
-                if (!near) {
+                if (!near && !serial) {
                     GS_CHECK(hipEventRecord(g->evChain, g->sc));
                     GS_CHECK(hipStreamWaitEvent(wv->sb, g->evChain, 0));
                 }
@@ -2296,8 +2317,10 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     run += tiles;
                     ga.end[e] = run;
                 }
-                const int rec = gs_prof_begin(ctx, su, near ? GS_PROF_PANEL : GS_PROF_BULK, fl * g->cnt);
-                hipLaunchKernelGGL(k_gemm_ld3g, dim3((unsigned)run), dim3(512), 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double), su, ga);
+                const int rec = gs_prof_begin(ctx, su, near ? GS_PROF_PANEL : GS_PROF_BULK, fl * g->cnt);     // (near updates on the bulk stream: the same kernel, the same class)
+                const size_t shm = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+                if (near) hipLaunchKernelGGL(k_gemm_ld3n, dim3((unsigned)run), dim3(512), shm, su, ga);
+                else hipLaunchKernelGGL(k_gemm_ld3g, dim3((unsigned)run), dim3(512), shm, su, ga);
                 gs_prof_end(ctx, su, rec);
                 GS_CHECK(hipGetLastError());
                 ++g->step;

@@ -3360,7 +3360,7 @@ struct gs_wv_gemm_args {
     int end[GS_WV_MAX];            // running tile counts: entry e owns block ids [end[e - 1], end[e])
     gs_wv_gemm_entry e[GS_WV_MAX];
 };
-__global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) {
+__device__ __forceinline__ void gs_gemm_ld3g_body(const gs_wv_gemm_args& a) {
     const int bid = (int)blockIdx.x;
     int e = 0;
     while (e + 1 < a.n && bid >= a.end[e]) ++e;
@@ -3370,6 +3370,11 @@ __global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) {
     gs_gemm_ld3_body<2>(W + en.offC, a.ld, W + en.offA, a.ld, W + en.offB, a.ld, en.M, en.N, en.K, en.tri, 1, -1.0,
                         (unsigned long long*)nullptr, 0, (unsigned*)nullptr, bid - first);
 }
+// k_gemm_ld3g: the big ("far") trailing updates, one after the other on the batch schedule's bulk stream.  k_gemm_ld3n: the same
+// code under a name of its own for the small "near" updates that run on the groups' chain streams BESIDE them -- so that a
+// per-kernel profile (rocprofv3 --stats) keeps the two roles apart and the far updates' launch times add up to the step time.
+__global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
+__global__ __launch_bounds__(512, 7) void k_gemm_ld3n(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
 
 // Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
 // res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
