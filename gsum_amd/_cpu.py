@@ -1,0 +1,247 @@
+"""``backend='cpu'``: the same operator interface as :class:`gsum_amd._lib.HipContext`, on numpy / scipy / scikit-learn.
+
+This is BASELINE config 1 ("scipy CPU path, plumbing, no GPU") and SURVEY.md section 8(b)'s additive ``backend=`` switch:
+the reference's own third-party routines behind the interface the HIP library replaces --
+
+    kernel(X[, Y])                    sklearn RBF / Matern leaves       gsum/models.py:708, 822-824, 958-960
+    numpy.linalg.cholesky             LAPACK dpotrf (with its info)     gsum/models.py:711, 809, 969
+    scipy.linalg.cho_solve halves     dtrtrs                            gsum/models.py:479, 831, 836, 1032
+
+It is never chosen silently: the default backend is ``'hip'`` and a missing library or GPU raises there.  Select it with
+``ConjugateGaussianProcess(..., backend='cpu')`` / ``TruncationGP(..., backend='cpu')`` or ``GSUM_BACKEND=cpu``.  It does not
+import ``oracle/`` (test infrastructure) and the GPU tests never run through it.  Every method counts its calls in
+``self.calls`` (the multi-process CPU tests read how many factorisations a rank ran).
+"""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+from scipy.linalg import cho_solve as _cho_solve
+from scipy.linalg import solve_triangular
+from scipy.linalg.lapack import dpotrf
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+
+from ._lib import FAMILY, GSUM_MAX_RHS, GradParam, KernelDesc
+from .series import geometric_sum
+
+_NU = {FAMILY["rbf"]: None, FAMILY["matern52"]: 2.5, FAMILY["matern32"]: 1.5, FAMILY["matern12"]: 0.5}
+
+
+def _leaf(desc: KernelDesc, d: int, free=False):
+    """The stationary scikit-learn leaf of a descriptor (length scale(s) as the descriptor holds them)."""
+    ls = np.array(desc.length_scale[:d]) if desc.anisotropic else float(desc.length_scale[0])
+    bounds = (1e-300, 1e300) if free else "fixed"
+    nu = _NU[int(desc.family)]
+    return RBF(ls, length_scale_bounds=bounds) if nu is None else Matern(ls, length_scale_bounds=bounds, nu=nu)
+
+
+def kernel_matrix(desc: KernelDesc, X, Y=None, diag_add=0.0):
+    """amplitude * leaf(X[, Y]) (+ white noise on the one-argument diagonal) + additive constant (+ diag_add): the kernel-build
+    kernel's arithmetic, entry for entry (gsum_kernels.hip.h, k_build2), with scikit-learn evaluating the leaf."""
+    X = np.asarray(X, dtype=float)
+    base = _leaf(desc, X.shape[1])(X, None if Y is None else np.asarray(Y, dtype=float))
+    K = float(desc.amplitude) * base
+    if Y is None:
+        K[np.diag_indices_from(K)] += float(desc.white_noise)
+    K += float(desc.additive_const)
+    if Y is None and diag_add:
+        K[np.diag_indices_from(K)] += float(diag_add)
+    return K
+
+
+class CpuMatrix:
+    """Host stand-in for a ``gsum_mat``: the symmetric matrix, then its lower Cholesky factor."""
+
+    def __init__(self, ctx, A):
+        self._ctx = ctx
+        self.A = np.array(A, dtype=float)
+        self.n = self.A.shape[0]
+        self.factored = False
+
+    def to_host(self):
+        return np.tril(self.A) if self.factored else self.A.copy()
+
+    def scale_series(self, series, ref, ratio):
+        """A_ij *= factor ref_i ref_j S(ratio_i ratio_j)  (TruncationProcess.cov, gsum/models.py:1343-1354)."""
+        if self.factored:
+            raise ValueError("scale_series needs an unfactored matrix")
+        ref, ratio = np.asarray(ref, dtype=float), np.asarray(ratio, dtype=float)
+        self.A *= _series_factor(series, ref, ratio, ref, ratio)
+
+    def free(self):
+        self.A = None
+
+
+def _series_factor(series, ref_r, ratio_r, ref_c, ratio_c):
+    end = np.inf if series.end < 0 else series.end
+    exc = [series.excluded[i] for i in range(series.n_excluded)] or None
+    S = geometric_sum(x=ratio_r[:, None] * ratio_c[None, :], start=series.start, end=end, excluded=exc)
+    return series.factor * (ref_r[:, None] * ref_c[None, :]) * S
+
+
+class CpuContext:
+    """numpy / scipy implementation of the HipContext methods the model classes call."""
+
+    device = None
+    backend = "cpu"
+
+    def __init__(self):
+        self.calls = collections.Counter()
+        self._X = self._Z = None
+        self._options = {}
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def set_option(self, name, value):
+        self._options[name] = int(value)
+
+    def get_option(self, name):
+        return self._options.get(name, 0)
+
+    def close(self):
+        pass
+
+    @staticmethod
+    def desc_array(descs):
+        return list(descs)
+
+    # -- operator level ------------------------------------------------------------------------------
+    def kernel_matrix(self, desc, X, Y=None, diag_add=0.0):
+        self.calls["kernel_matrix"] += 1
+        return kernel_matrix(desc, X, Y, diag_add)
+
+    def kernel_matrix_dev(self, desc, X, diag_add=0.0):
+        self.calls["kernel_matrix_dev"] += 1
+        return CpuMatrix(self, kernel_matrix(desc, X, None, diag_add))
+
+    def upload(self, A):
+        A = np.asarray(A, dtype=float)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("square matrix expected")
+        return CpuMatrix(self, A)
+
+    def potrf(self, M: CpuMatrix) -> int:
+        """numpy.linalg.cholesky's LAPACK call with its info (0 = success, k > 0: leading minor k is not positive definite)."""
+        self.calls["potrf"] += 1
+        if M.factored:
+            raise ValueError("matrix is already factorised")
+        c, info = dpotrf(M.A, lower=1, clean=1, overwrite_a=0)
+        if info == 0:
+            M.A = c
+            M.factored = True
+        return int(info)
+
+    def factorize(self, desc, X, diag_add=0.0, series=None):
+        K = self.kernel_matrix_dev(desc, X, diag_add=diag_add)
+        if series is not None:
+            K.scale_series(*series)
+        return K, self.potrf(K)
+
+    def forward_solve(self, L: CpuMatrix, rhs):
+        rhs = np.asarray(rhs, dtype=float)
+        return solve_triangular(L.A, rhs, lower=True)
+
+    def forward_gram(self, L: CpuMatrix, rhs):
+        self.calls["forward_gram"] += 1
+        rhs = np.asarray(rhs, dtype=float)
+        if rhs.ndim == 1:
+            rhs = rhs[:, None]
+        W = solve_triangular(L.A, rhs, lower=True)
+        return W.T @ W, float(np.log(np.diag(L.A)).sum())
+
+    def cho_solve(self, L: CpuMatrix, B):
+        return _cho_solve((L.A, True), np.asarray(B, dtype=float))
+
+    def tri_multiply(self, L: CpuMatrix, Z):
+        return np.tril(L.A) @ np.asarray(Z, dtype=float)
+
+    def predict_terms(self, L: CpuMatrix, desc, X, Xs, rhs=None, want_cov=False, series=None):
+        self.calls["predict_terms"] += 1
+        X, Xs = np.asarray(X, dtype=float), np.asarray(Xs, dtype=float)
+        Kon = kernel_matrix(desc, X, Xs)                             # n x m, two-argument form: no white noise
+        if series is not None:
+            sc, ref_x, ratio_x, ref_s, ratio_s = series
+            Kon = Kon * _series_factor(sc, np.asarray(ref_x, float), np.asarray(ratio_x, float), np.asarray(ref_s, float),
+                                       np.asarray(ratio_s, float))
+        V = solve_triangular(L.A, Kon, lower=True)
+        colsumsq = np.einsum("ij,ij->j", V, V)
+        VtW = None
+        if rhs is not None:
+            rhs = np.asarray(rhs, dtype=float)
+            if rhs.ndim == 1:
+                rhs = rhs[:, None]
+            VtW = V.T @ solve_triangular(L.A, rhs, lower=True)
+        return colsumsq, VtW, (V.T @ V if want_cov else None)
+
+    # -- fused hot path ------------------------------------------------------------------------------
+    def _evaluate(self, desc, X, rhs, nugget):
+        k = rhs.shape[1]
+        M = CpuMatrix(self, kernel_matrix(desc, X, None, nugget))
+        info = self.potrf(M)
+        if info:
+            return np.full((k, k), np.nan), np.nan, info, None
+        G, sld = self.forward_gram(M, rhs)
+        return G, sld, 0, M
+
+    def lml_batch(self, descs, X, rhs, nugget):
+        X, rhs = np.asarray(X, dtype=float), np.asarray(rhs, dtype=float)
+        if rhs.shape[1] > GSUM_MAX_RHS:
+            raise ValueError("k must be 0..GSUM_MAX_RHS")
+        out = [self._evaluate(d, X, rhs, nugget)[:3] for d in descs]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out], dtype=np.int64)
+
+    def set_inputs(self, X, rhs):
+        self._X, self._Z = np.array(X, dtype=float), np.array(rhs, dtype=float)
+
+    def resident_shape(self):
+        if self._X is None:
+            return 0, 0, 0
+        return self._X.shape[0], self._X.shape[1], self._Z.shape[1]
+
+    def lml_resident(self, descs, nugget):
+        if self._X is None:
+            raise ValueError("gsum_set_inputs has not been called")
+        return self.lml_batch(descs, self._X, self._Z, nugget)
+
+    def lml_grad(self, desc, params, X, rhs, nugget):
+        """(G, sld, info, trace (P,), H (P, k, k)): tr(R^-1 dR_p) and V^T dR_p V with V = R^-1 rhs (gsum/models.py:1041-1056)."""
+        X, rhs = np.asarray(X, dtype=float), np.asarray(rhs, dtype=float)
+        k, P = rhs.shape[1], len(params)
+        G, sld, info, M = self._evaluate(desc, X, rhs, nugget)
+        if info:
+            return G, sld, info, np.zeros(P), np.zeros((P, k, k))
+        n, d = X.shape
+        V = _cho_solve((M.A, True), rhs)
+        Rinv = _cho_solve((M.A, True), np.eye(n))
+        term = ConstantKernel(float(desc.amplitude), constant_value_bounds=(1e-300, 1e300)) * _leaf(desc, d, free=True)
+        _, dK = term(X, eval_gradient=True)                  # [:, :, 0]: d / d log amplitude; [:, :, 1:]: length scale(s)
+        trace, H = np.empty(P), np.empty((P, k, k))
+        for p, pr in enumerate(params):
+            if pr.code == GradParam.AMPLITUDE:
+                dR = dK[:, :, 0]
+            elif pr.code == GradParam.LENGTH_ISO:
+                dR = dK[:, :, 1]
+            elif pr.code == GradParam.LENGTH_DIM:
+                dR = dK[:, :, 1 + pr.dim]
+            elif pr.code == GradParam.WHITE:
+                dR = pr.weight * np.eye(n)
+            else:
+                dR = np.full((n, n), pr.weight)
+            trace[p] = np.einsum("ij,ji->", Rinv, dR)
+            H[p] = V.T @ dR @ V
+        return G, sld, 0, trace, H
+
+    def lml_grad_batch(self, descs, params, X, rhs, nugget):
+        out = [self.lml_grad(d, p, X, rhs, nugget) for d, p in zip(descs, params)]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out], dtype=np.int64),
+                np.array([o[3] for o in out]), np.array([o[4] for o in out]))
+
+
+_cpu_ctx = None
+
+
+def cpu_context() -> CpuContext:
+    global _cpu_ctx
+    if _cpu_ctx is None:
+        _cpu_ctx = CpuContext()
+    return _cpu_ctx

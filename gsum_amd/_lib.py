@@ -166,6 +166,12 @@ def _ptr(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
+class ChainAborted(RuntimeError):
+    """gsum_potrf_lower returned GSUM_ERR_CHAIN_ABORT: the persistent-chain schedule of a single factorisation timed out (streams of
+    this process do not run side by side -- a tool that serialises dispatches); the matrix is destroyed, the schedule is now off for
+    the context.  Rebuild the matrix and factorise again (``HipContext.factorize`` does)."""
+
+
 class DeviceMatrix:
     """Owner of a ``gsum_mat*`` (device-resident symmetric matrix or Cholesky factor)."""
 
@@ -219,6 +225,8 @@ class HipContext:
             text = msg.decode() if msg else f"error {rc}"
             if rc == -2:
                 raise ValueError(text)
+            if rc == -3:
+                raise ChainAborted(text)
             raise RuntimeError(text)
 
     def close(self):
@@ -279,6 +287,26 @@ class HipContext:
         self._check(self._lib.gsum_potrf_lower(self._h, A._h, C.byref(info)))
         A.factored = info.value == 0
         return int(info.value)
+
+    def factorize(self, desc: KernelDesc, X, diag_add: float = 0.0, series=None):
+        """kernel(X) + diag_add I on the device [scaled like TruncationProcess.cov: ``series`` = (SeriesScale, ref, ratio)], then
+        its Cholesky factor in place: ``(matrix, info)``.  What fit / predict / the factor-reuse grid do at models.py:708-711, 807-809.
+        Should the single-factorisation schedule give up (``ChainAborted``: the matrix is destroyed, the library has switched to the
+        host-enqueued schedule) the matrix is rebuilt and factorised once more, transparently -- the fused evaluation path already
+        re-runs itself the same way."""
+        for attempt in (0, 1):
+            K = self.kernel_matrix_dev(desc, X, diag_add=diag_add)
+            try:
+                if series is not None:
+                    K.scale_series(*series)
+                return K, self.potrf(K)
+            except ChainAborted:
+                K.free()
+                if attempt:
+                    raise
+            except BaseException:
+                K.free()
+                raise
 
     def forward_gram(self, L: DeviceMatrix, rhs):
         rhs = _f64(rhs)

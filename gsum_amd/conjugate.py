@@ -15,6 +15,7 @@ There is no CPU fallback; an unsupported kernel / option raises.
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -231,13 +232,14 @@ class ConjugateGaussianProcess:
     """Conjugate-prior GP; same constructor and methods as gsum.ConjugateGaussianProcess.
 
     Parameters are those of gsum/models.py:107-109.  Additive: ``device`` (GPU index; default
-    ``$LOCAL_RANK`` or 0).  ``basis`` other than ``None`` and ``decomposition='eig'`` are not
-    available on the device and raise ``NotImplementedError``.
+    ``$LOCAL_RANK`` or 0) and ``backend`` ('hip', the default, or 'cpu': the same operator interface on
+    numpy / scipy; also ``GSUM_BACKEND``).  ``basis`` other than ``None`` and
+    ``decomposition='eig'`` are not available on the device and raise ``NotImplementedError``.
     """
 
     def __init__(self, kernel=None, center=0, disp=0, df=1, scale=1, sd=None, basis=None, nugget=1e-10,
                  optimizer='fmin_l_bfgs_b', n_restarts_optimizer=0, copy_X_train=True, random_state=None,
-                 decomposition='cholesky', device=None):
+                 decomposition='cholesky', device=None, backend=None):
         self.kernel = kernel
         self._center_0 = np.atleast_1d(center)
         self._disp_0 = np.atleast_2d(disp)
@@ -270,6 +272,11 @@ class ConjugateGaussianProcess:
         self.basis = lambda X: np.ones((np.shape(X)[0], 1))
         self.basis_train_ = None
         self.device = device
+        # 'hip' (default; also through GSUM_BACKEND): libgsum_hip.so on an MI355X, loud failure without it.  'cpu': the same
+        # operator interface on numpy / scipy / scikit-learn (gsum_amd/_cpu.py; BASELINE config 1) -- only when asked for
+        self.backend = backend if backend is not None else os.environ.get("GSUM_BACKEND", "hip")
+        if self.backend not in ("hip", "cpu"):
+            raise ValueError("backend must be 'hip' or 'cpu'")
         self.batch_restarts = True   # multi-start fits advance in lock step, objective evaluations batched on the device
         self._ctx = None
         self._L_dev = None          # device-resident Cholesky factor of kernel_(X_train_) + nugget
@@ -414,7 +421,11 @@ class ConjugateGaussianProcess:
     # -- device plumbing -----------------------------------------------------------------------
     def _context(self):
         if self._ctx is None:
-            self._ctx = default_context(self.device)
+            if self.backend == "cpu":
+                from ._cpu import cpu_context
+                self._ctx = cpu_context()
+            else:
+                self._ctx = default_context(self.device)
         return self._ctx
 
     def _check_decomposition(self):
@@ -587,9 +598,14 @@ class ConjugateGaussianProcess:
 
         optima = [None] * n
 
+        caught = [[] for _ in range(n)]       # ConvergenceWarnings of a start: recorded in its thread, re-emitted by the caller's
+
         def run(i):
             try:
-                optima[i] = self._constrained_optimization(make_obj(i), starts[i], bounds)
+                with warnings.catch_warnings(record=True) as rec:
+                    warnings.simplefilter("always")
+                    optima[i] = self._constrained_optimization(make_obj(i), starts[i], bounds)
+                caught[i] = list(rec)
             except BaseException as exc:   # noqa: BLE001
                 with cond:
                     if state["error"] is None:
@@ -604,10 +620,22 @@ class ConjugateGaussianProcess:
         threads = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(n)]
         for t in threads:
             t.start()
-        for t in threads:
-            t.join()
+        try:
+            for t in threads:
+                t.join()
+        except BaseException as exc:       # KeyboardInterrupt in the caller's thread: wake and end the parked workers, then re-raise
+            with cond:
+                if state["error"] is None:
+                    state["error"] = exc
+                cond.notify_all()
+            for t in threads:
+                t.join(timeout=5.0)
+            raise
         if state["error"] is not None:
             raise state["error"]
+        for rec in caught:                 # (warnings.catch_warnings is per thread only by accident: emit from the calling thread)
+            for w in rec:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         return optima
 
     def _calibrate_kernel(self):
@@ -663,8 +691,7 @@ class ConjugateGaussianProcess:
         desc = describe_kernel(self.kernel_, Xd.shape[1])
         if self._L_dev is not None:
             self._L_dev.free()
-        self._L_dev = ctx.kernel_matrix_dev(desc, Xd, diag_add=self.nugget)
-        info = ctx.potrf(self._L_dev)
+        self._L_dev, info = ctx.factorize(desc, Xd, diag_add=self.nugget)
         if info != 0:
             self._L_dev.free()
             self._L_dev = None
@@ -748,8 +775,9 @@ class ConjugateGaussianProcess:
             L = self._L_dev
         else:
             Xc = np.asarray(Xc, dtype=float)
-            own = L = ctx.kernel_matrix_dev(desc, Xc, diag_add=self.nugget)      # models.py:807
-            if ctx.potrf(L) != 0:
+            own, info = ctx.factorize(desc, Xc, diag_add=self.nugget)             # models.py:807
+            L = own
+            if info != 0:
                 L.free()
                 raise np.linalg.LinAlgError("Matrix is not positive definite")    # models.py:809
         try:

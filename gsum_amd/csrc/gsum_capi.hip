@@ -28,6 +28,7 @@ struct gsum_mat {
     // persistent-chain schedule (allocated the first time a factorisation of this matrix uses it)
     unsigned* cflags = nullptr;            // gs_fl_count(T / 2) words, zeroed before every factorisation; then T / 2 words "fbwant"
     int fbwant_key = -1;                   // what fbwant was last computed for (window rows x 2 + lazy): uploaded only when it changes
+    std::vector<unsigned> fbwant_host;     // ... and its host copy (source of the asynchronous upload)
     double* cdump = nullptr;               // 2 x GS_CH_GMAX x 16 x 256 doubles: operand images of the window's rows
     unsigned long long* cstamps = nullptr; // T / 2 x GS_CH_STAMPS realtime stamps (option "chain_stamps")
     bool factored = false;
@@ -854,6 +855,56 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     unsigned* fl = m->cflags;
     hipStream_t sm = sl->sm, sp = sl->sp, sa = sl->sa;
     GS_CHECK(hipMemsetAsync(fl, 0, (size_t)gs_fl_count(S) * sizeof(unsigned), sm));
+    // The per-step table fbwant[] (how many first-column tiles of step s's trailing update the chain waits for) is part of what the
+    // chain kernel reads: it is computed and uploaded HERE, in stream order ahead of the launch (round 3 uploaded it after the launch
+    // with a synchronous copy on the null stream -- nothing ordered the two, and a delayed host could have let the chain read a stale
+    // table: ADVICE round 3).  The host copy lives in the matrix object: it outlives the asynchronous copy.
+    struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
+    std::vector<Plan> plan((size_t)S, Plan{0, 0u});
+    const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
+    const bool near256 = lazy && ctx->chain_lazy != 1;        // 2 / auto: only the next-but-one panel's 256 columns are "near" (the batch schedule's lazy_far = 2)
+    const int NB = lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
+    int64_t bound[6];
+    bound[0] = 0;
+    for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
+    bound[NB] = naug;
+    auto first_tiles_of = [&](int s) {               // tiles of the first 256 trailing columns over all bands of step s
+        const int64_t r3 = 256 * (int64_t)(s + 2);
+        unsigned cnt = 0;
+        for (int p = 0; p < NB; ++p) {
+            const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
+            if (lo >= hi) continue;
+            if (lo > r3) cnt += 4u * (unsigned)((hi - lo + 127) / 128);               // rectangle: all its first four column tiles
+            else cnt += 4u * (unsigned)((hi - lo + 127) / 128) - 2u;                   // the triangle that starts at r3
+        }
+        return cnt;
+    };
+    {
+        bool deferred = false;
+        for (int s = 0; s + 1 < S; ++s) {
+            const int64_t r3 = 256 * (int64_t)(s + 2), m3 = naug - r3;
+            if (m3 <= 0) continue;
+            const unsigned tm = (unsigned)((m3 + 127) / 128);
+            if (deferred) {
+                plan[s] = Plan{2, near256 ? 4u * tm - 2u : 4u * tm};
+                deferred = false;
+            } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
+                plan[s] = Plan{1, 4u * tm};
+                deferred = true;
+            } else {
+                plan[s] = Plan{0, first_tiles_of(s)};
+            }
+        }
+    }
+    unsigned* fbw = fl + gs_fl_count(S);
+    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0);
+    if (m->fbwant_key != fb_key) {
+        GS_CHECK(hipStreamSynchronize(sm));                      // (a previous upload from the same host buffer has completed)
+        m->fbwant_host.resize((size_t)S);
+        for (int s = 0; s < S; ++s) m->fbwant_host[s] = plan[s].fb;
+        GS_CHECK(hipMemcpyAsync(fbw, m->fbwant_host.data(), m->fbwant_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, sm));
+        m->fbwant_key = fb_key;
+    }
     GS_CHECK(hipEventRecord(sl->evFork, sm));
     GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
     GS_CHECK(hipStreamWaitEvent(sa, sl->evFork, 0));
@@ -909,51 +960,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // of step s is done, whatever the other bands do: the launches of one step no longer end at a chip-wide barrier, and one
     // band's tail overlaps another's bulk -- what sixteen evaluations in flight do for a batch (52 TF/s of Cholesky flops there
     // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
-    struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
-    std::vector<Plan> plan((size_t)S, Plan{0, 0u});
-    const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
-    const bool near256 = lazy && ctx->chain_lazy != 1;        // 2 / auto: only the next-but-one panel's 256 columns are "near" (the batch schedule's lazy_far = 2)
-    const int NB = lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
-    int64_t bound[6];
-    bound[0] = 0;
-    for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
-    bound[NB] = naug;
-    auto first_tiles_of = [&](int s) {               // tiles of the first 256 trailing columns over all bands of step s
-        const int64_t r3 = 256 * (int64_t)(s + 2);
-        unsigned cnt = 0;
-        for (int p = 0; p < NB; ++p) {
-            const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
-            if (lo >= hi) continue;
-            if (lo > r3) cnt += 4u * (unsigned)((hi - lo + 127) / 128);               // rectangle: all its first four column tiles
-            else cnt += 4u * (unsigned)((hi - lo + 127) / 128) - 2u;                   // the triangle that starts at r3
-        }
-        return cnt;
-    };
-    {
-        bool deferred = false;
-        for (int s = 0; s + 1 < S; ++s) {
-            const int64_t r3 = 256 * (int64_t)(s + 2), m3 = naug - r3;
-            if (m3 <= 0) continue;
-            const unsigned tm = (unsigned)((m3 + 127) / 128);
-            if (deferred) {
-                plan[s] = Plan{2, near256 ? 4u * tm - 2u : 4u * tm};
-                deferred = false;
-            } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
-                plan[s] = Plan{1, 4u * tm};
-                deferred = true;
-            } else {
-                plan[s] = Plan{0, first_tiles_of(s)};
-            }
-        }
-    }
-    unsigned* fbw = fl + gs_fl_count(S);
-    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0);
-    if (m->fbwant_key != fb_key) {
-        std::vector<unsigned> h((size_t)S);
-        for (int s = 0; s < S; ++s) h[s] = plan[s].fb;
-        GS_CHECK(hipMemcpy(fbw, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-        m->fbwant_key = fb_key;
-    }
     hipStream_t sbd[4] = {sm, nullptr, nullptr, nullptr};
     for (int p = 1; p < NB; ++p) {
         if (!sl->sband[p]) {
@@ -1585,7 +1591,7 @@ int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
         A->factored = false;
         ctx->err = "the persistent chain schedule timed out (streams of this process do not run side by side); the matrix is "
                    "destroyed -- rebuild it and factorise again: the schedule is now switched off (option chain_persist = 0)";
-        return -1;                          // a runtime failure, not a bad argument
+        return GSUM_ERR_CHAIN_ABORT;        // a runtime failure the caller can recover from: rebuild the matrix, factorise again
     }
     if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
     A->factored = (*info == 0);

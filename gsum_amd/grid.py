@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["shard_range", "gather_flat", "lml_grid_distributed", "predict_distributed"]
+__all__ = ["shard_range", "owned_points", "gather_flat", "lml_grid_distributed", "predict_distributed"]
 
 
 def shard_range(total: int, rank: int = 0, world: int = 1):
@@ -22,6 +22,23 @@ def shard_range(total: int, rank: int = 0, world: int = 1):
     if load_library().gsum_shard_range(int(total), int(rank), int(world), C.byref(lo), C.byref(hi)) != 0:
         raise ValueError("bad rank/world")
     return int(lo.value), int(hi.value)
+
+
+def owned_points(n_rows: int, n_cols: int, n_scales: int, rank: int = 0, world: int = 1, partition: str = "flat") -> np.ndarray:
+    """C-order flat indices of the (rows = ratio settings, cols = thetas, scales) surface that ``rank`` evaluates.
+
+    ``partition="flat"``: the contiguous block ``shard_range(n_rows * n_cols * n_scales)`` -- full-recompute scans, where every
+    point is its own kernel build + Cholesky.  ``partition="theta"``: every point of the thetas ``shard_range(n_cols)`` -- factor-reuse
+    scans, where a theta's factorisation serves all its ratio settings and scales (group by distinct kernel
+    descriptor first), so a world of 8 on a 64 x 64 (ell, ratio) scan factorises 8 matrices per rank, not 64."""
+    if partition == "flat":
+        lo, hi = shard_range(n_rows * n_cols * n_scales, rank, world)
+        return np.arange(lo, hi)
+    if partition != "theta":
+        raise ValueError('partition must be "flat" or "theta"')
+    jlo, jhi = shard_range(n_cols, rank, world)
+    i, j, s = np.meshgrid(np.arange(n_rows), np.arange(jlo, jhi), np.arange(n_scales), indexing="ij")
+    return ((i * n_cols + j) * n_scales + s).reshape(-1)
 
 
 def _dist():
@@ -56,13 +73,15 @@ def gather_flat(local: np.ndarray, total: int, group=None) -> np.ndarray:
     return np.concatenate(pieces)
 
 
-def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None = None, group=None) -> np.ndarray:
+def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None = None, group=None, partition: str = "flat") -> np.ndarray:
     """Run ``evaluate(shard=(rank, world))`` -> array with this rank's entries filled (NaN elsewhere), then gather
     every rank's slice.  ``evaluate`` is typically
     ``functools.partial(TruncationGP.log_marginal_likelihood_grid, gp, thetas, ratios, mode=...)`` -- with or without
     ``scales=``: the surface is gathered in whatever shape ``evaluate`` returns it ((rows, cols), or
     (rows, cols, scales) for BASELINE config 4's (cbar, ratio) scan), flattened in C order, which is the order
     ``log_marginal_likelihood_grid`` shards in.  ``n_rows`` / ``n_cols`` are optional and only checked.
+    ``partition="theta"`` (factor-reuse scans, see :func:`owned_points`): every rank owns whole columns of the surface; the gather
+    then moves the theta axis to the front and exchanges equal blocks of thetas (still one all-gather).
     """
     dist = _dist()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
@@ -70,6 +89,16 @@ def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None
     if n_rows is not None and n_cols is not None and tuple(surface.shape[:2]) != (n_rows, n_cols):
         raise ValueError(f"evaluate returned a surface of shape {surface.shape}, expected ({n_rows}, {n_cols}[, scales])")
     total = surface.size
+    if partition == "theta":
+        by_theta = np.ascontiguousarray(np.moveaxis(surface, 1, 0))                 # (cols, rows[, scales])
+        width = by_theta[0].size
+        jlo, jhi = shard_range(by_theta.shape[0], rank, world)
+        if dist is None or world == 1:
+            return surface
+        full = _gather_rows(by_theta[jlo:jhi].reshape(-1), by_theta.shape[0], width, group).reshape(by_theta.shape)
+        return np.ascontiguousarray(np.moveaxis(full, 0, 1))
+    if partition != "flat":
+        raise ValueError('partition must be "flat" or "theta"')
     lo, hi = shard_range(total, rank, world)
     return gather_flat(surface.reshape(-1)[lo:hi], total, group).reshape(surface.shape)
 

@@ -137,6 +137,7 @@ def describe_thetas(kernel, thetas, n_features: int):
     costs 70-320 us per call (get_params / set_params over the tree), more than a batched n = 2048 evaluation takes on the device.
     The values are formed exactly as the setter forms them (kernels.py Kernel.theta: ``np.exp(theta[i])`` for a scalar hyperparameter,
     ``np.exp(theta[i:i+n])`` for a vector one), so the descriptors are equal byte for byte (tests/test_host_logic.py)."""
+    describe_kernel(kernel, n_features)          # the family check first: an unsupported tree says so, not "wrong theta size"
     terms, n_dims = _flatten(kernel)
     out = []
     for theta in thetas:

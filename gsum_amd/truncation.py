@@ -122,10 +122,8 @@ class TruncationGP:
         # (relative to the kernel's own diagonal: amplitude + additive constant of the descriptor)
         kdiag = float(desc.amplitude) + float(desc.additive_const)
         for jitter in (0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6):
-            K = ctx.kernel_matrix_dev(desc, Xc, diag_add=jitter * kdiag)
+            K, info = ctx.factorize(desc, Xc, diag_add=jitter * kdiag, series=(sc, ref_c, ratio_c))
             try:
-                K.scale_series(sc, ref_c, ratio_c)
-                info = ctx.potrf(K)
                 if info == 0:
                     colsumsq, shift, red = ctx.predict_terms(K, desc, Xc, X, rhs=resid, want_cov=want_cov,
                                                              series=(sc, ref_c, ratio_c, ref_n, ratio_n))
@@ -228,8 +226,10 @@ class TruncationGP:
         mode="reuse"  one factorisation per theta: all ratio settings share it and only the k-column
                       forward solve is repeated; a prior scale only enters the O(k^2) host algebra
                       (never mixed into "full" throughput numbers).
-        ``shard=(rank, world)`` evaluates only this rank's slice of the flattened grid and leaves the
-        rest NaN (see gsum_amd.grid for the torch.distributed gather).
+        ``shard=(rank, world)`` evaluates only this rank's share of the grid and leaves the rest NaN:
+        a contiguous block of the flattened grid in mode "full", a block of whole thetas in mode
+        "reuse" (``gsum_amd.grid.owned_points``; ``lml_grid_distributed(..., partition=...)`` or
+        :meth:`log_marginal_likelihood_grid_distributed` gathers accordingly).
         """
         X = self.X_train_ if X is None else X
         y = self.y_train_ if y is None else y
@@ -247,13 +247,19 @@ class TruncationGP:
                 raise ValueError('scales must be a non-empty 1d sequence of prior standard deviations')
             ns = scale_vals.size
         out = np.full((ni, nj, ns), np.nan)
-        from .grid import shard_range
-        lo, hi = shard_range(ni * nj * ns, *(shard or (0, 1)))
+        from .grid import owned_points
+        # this rank's grid points.  mode="full": a contiguous block of the C-order flattening (every point is a full evaluation,
+        # points of one ratio row share their right-hand sides).  mode="reuse": whole THETAS -- all ratio settings and scales of a
+        # theta share its one factorisation, so theta is the unit of work ("group by distinct kernel descriptor
+        # first"); a flat block would make every rank factorise every theta.
+        mine = owned_points(ni, nj, ns, *(shard or (0, 1)), partition="theta" if mode == "reuse" else "flat")
 
         def shaped(a):
             return a if scales is not None else a[:, :, 0]
 
-        if hi <= lo:
+        if not len(mine):
+            if mode not in ("full", "reuse"):
+                raise ValueError('mode must be "full" or "reuse"')
             return shaped(out)
         n_pts = Xd.shape[0]
         prep = {}
@@ -274,7 +280,7 @@ class TruncationGP:
             return gp._lml_gram_batch_sd(G, sld, n_pts, svals)
 
         # one descriptor per theta this rank touches, built in one go and without scikit-learn's per-theta clone
-        js = sorted({(flat // ns) % nj for flat in range(lo, hi)})
+        js = sorted({int((flat // ns) % nj) for flat in mine})
         desc_of = dict(zip(js, describe_thetas(base, [thetas[j] for j in js], Xd.shape[1])))
         desc_for = desc_of.__getitem__
 
@@ -283,8 +289,8 @@ class TruncationGP:
             # device once per row and the (theta, scale) points of the row run as ONE pipelined batch (several
             # evaluations in flight on the GPU); every point still does its own kernel build + Cholesky + solve
             rows = {}
-            for flat in range(lo, hi):
-                i, rest = divmod(flat, nj * ns)
+            for flat in mine:
+                i, rest = divmod(int(flat), nj * ns)
                 rows.setdefault(i, []).append(divmod(rest, ns))
             for i, pts in rows.items():
                 Zi, det = rhs_for(i)
@@ -296,8 +302,8 @@ class TruncationGP:
                     out[i, j, s] = v
         elif mode == "reuse":
             by_theta = {}
-            for flat in range(lo, hi):
-                i, rest = divmod(flat, nj * ns)
+            for flat in mine:
+                i, rest = divmod(int(flat), nj * ns)
                 j, s = divmod(rest, ns)
                 by_theta.setdefault(j, {}).setdefault(i, []).append(s)
             # A constant ratio only rescales the coefficient curves order by order, c_n(q) = c_n(q0) (q0 / q)^n
@@ -315,9 +321,8 @@ class TruncationGP:
                 return const_ratio[i]
 
             for j, rows in by_theta.items():
-                L = ctx.kernel_matrix_dev(desc_for(j), Xd, diag_add=gp.nugget)
+                L, info = ctx.factorize(desc_for(j), Xd, diag_add=gp.nugget)
                 try:
-                    info = ctx.potrf(L)
                     anchor = None                                   # (ratio, G, sld) of the first constant-ratio row
                     for i, ss in rows.items():
                         if info != 0:
@@ -340,6 +345,17 @@ class TruncationGP:
         else:
             raise ValueError('mode must be "full" or "reuse"')
         return shaped(out)
+
+
+    def log_marginal_likelihood_grid_distributed(self, thetas, ratio_kws_list, scales=None, mode="full", group=None, **kwargs):
+        """``log_marginal_likelihood_grid`` with the grid sharded over the ranks of the initialised ``torch.distributed`` group
+        (one process per GPU) and ONE all-gather of the fp64 surface -- the reference's nested loop over grid points
+        (docs/notebooks/correlated_EFT_publication.ipynb:1457-1459) as a data-parallel map.  Without a process group it is
+        the plain call."""
+        import functools
+        from .grid import lml_grid_distributed
+        fn = functools.partial(self.log_marginal_likelihood_grid, thetas, ratio_kws_list, scales=scales, mode=mode, **kwargs)
+        return lml_grid_distributed(fn, len(ratio_kws_list), len(thetas), group=group, partition="theta" if mode == "reuse" else "flat")
 
 
 class TruncationTP(TruncationGP):

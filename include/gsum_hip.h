@@ -126,7 +126,11 @@ int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const dou
 int gsum_mat_from_host(gsum_ctx* ctx, const double* A, int64_t n, gsum_mat** out);
 
 /* numpy.linalg.cholesky(A), in place on the device.   replaces models.py:711, 809, 969.
- * *info = 0 or the LAPACK dpotrf info (>0: leading minor of that order is not positive definite). */
+ * *info = 0 or the LAPACK dpotrf info (>0: leading minor of that order is not positive definite).
+ * Returns GSUM_ERR_CHAIN_ABORT when the persistent-chain schedule of a single factorisation timed out (its streams did not run
+ * side by side, e.g. under a tool that serialises dispatches): the matrix is destroyed, the schedule is switched off for the
+ * context -- rebuild the matrix and call again (the Python binding's HipContext.factorize does exactly that, once). */
+#define GSUM_ERR_CHAIN_ABORT (-3)
 int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info);
 
 /* W = L^-1 RHS (forward substitution only), G = W^T W (k x k), sum_log_diag = sum_i log L_ii.

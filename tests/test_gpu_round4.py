@@ -1,0 +1,101 @@
+"""Round-4 GPU tests (``-m gpu``): the RCCL C host, BASELINE config 5 over all eight shards, achieved relative errors of the grids."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+import gsum_amd  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return gsum_amd.default_context(0)
+
+
+@pytest.mark.parametrize("n,n_theta", [(600, 11), (2048, 8)])
+def test_rccl_c_host_gathers_the_sharded_scan(n, n_theta):
+    """INTEGRATION.md's multi-GPU recipe from a C host that owns a REAL RCCL communicator (tests/c_host/shard_host_rccl.c):
+    ncclCommInitAll over the visible devices, every rank's gsum_lml_resident_shard slice staged to its GPU, the three in-place
+    ncclAllGather calls of the recipe, every rank's gathered arrays bit-identical to the unsharded gsum_lml_resident call.  World =
+    the GPUs the box shows (1 here, 8 on a node: same binary)."""
+    from test_host_logic import _build_rccl_host
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "shard_host_rccl")
+        res = _build_rccl_host(exe)
+        if res is None:
+            pytest.skip("gcc or the RCCL headers are not installed")
+        assert res.returncode == 0, res.stderr
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        run = subprocess.run([exe, str(n), str(n_theta)], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "gathered == unsharded on every rank: yes" in run.stdout, run.stdout
+    assert "(RCCL, ncclCommInitAll)" in run.stdout
+
+
+def test_chain_step_table_follows_option_changes_on_the_same_workspace(ctx):
+    """the persistent chain's per-step table fbwant[] used to be uploaded AFTER k_chain was launched, by a copy that
+    nothing ordered against the launch; it is re-made whenever the window size or the far-update pairing changes.  It now goes out in
+    stream order ahead of the launch, from a buffer the matrix object owns.  Alternating (chain_rows, chain_lazy) on ONE workspace
+    matrix -- every switch re-makes the table -- must keep every result bit-identical to the host-enqueued schedule's, with no
+    time-out (a stale table would end in a wrong factor or a 1-s give-up)."""
+    from sklearn.gaussian_process.kernels import RBF
+    n = 4096
+    rng = np.random.RandomState(4)
+    X = 0.1 * np.arange(n)[:, None]
+    Z = np.concatenate([rng.randn(n, 5), np.ones((n, 1))], axis=1)
+    desc = gsum_amd.describe_kernel(RBF(0.21), 1)
+    ctx.set_inputs(X, Z)
+    try:
+        ctx.set_option("chain_persist", 0)
+        ref = ctx.lml_resident([desc], 1e-10)
+        assert ref[2][0] == 0
+        ctx.set_option("chain_persist", 1)
+        aborts = ctx.get_option("chain_aborts")
+        for rows, lazy in ((512, 0), (256, 2), (512, 1), (256, 0), (512, 2), (512, 0), (256, 1), (512, -1)) * 2:
+            ctx.set_option("chain_rows", rows)
+            ctx.set_option("chain_lazy", lazy)
+            got = ctx.lml_resident([desc], 1e-10)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+        assert ctx.get_option("chain_aborts") == aborts and ctx.get_option("chain_persist") == 1
+    finally:
+        ctx.set_option("chain_persist", -1)
+        ctx.set_option("chain_rows", 512)
+        ctx.set_option("chain_lazy", -1)
+
+
+def test_factorize_recovers_from_a_chain_give_up(ctx):
+    """a give-up of the single-factorisation schedule inside gsum_potrf_lower destroys the matrix; the binding's
+    ``factorize`` (what fit / predict / the reuse grid call) rebuilds it and factorises once more on the host-enqueued schedule, so
+    a fit does not fail the first time a time-out happens.  The give-up is forced with the test hook."""
+    from sklearn.gaussian_process.kernels import RBF
+    from gsum_amd._lib import ChainAborted
+    n = 2048
+    X = 0.1 * np.arange(n)[:, None]
+    desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+    try:
+        ctx.set_option("chain_persist", 1)
+        K0, info0 = ctx.factorize(desc, X, diag_add=1e-10)
+        L0 = K0.to_host()
+        K0.free()
+        aborts = ctx.get_option("chain_aborts")
+        ctx.set_option("chain_test_abort", 3)
+        K = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+        with pytest.raises(ChainAborted):
+            ctx.potrf(K)
+        K.free()
+        ctx.set_option("chain_persist", 1)
+        ctx.set_option("chain_test_abort", 2)
+        K1, info1 = ctx.factorize(desc, X, diag_add=1e-10)                  # gives up once inside, rebuilds, succeeds
+        assert info0 == info1 == 0
+        np.testing.assert_array_equal(K1.to_host(), L0)
+        K1.free()
+        assert ctx.get_option("chain_aborts") == aborts + 2
+    finally:
+        ctx.set_option("chain_persist", -1)

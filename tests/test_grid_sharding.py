@@ -181,3 +181,66 @@ def test_gather_flat_single_process():
     np.testing.assert_array_equal(gather_flat(v, 5), v)
     with pytest.raises(ValueError):
         gather_flat(v, 6)
+
+
+def _product_grid_worker(rank, world, port, q):
+    """The PRODUCT's grid methods (TruncationGP.log_marginal_likelihood_grid[_distributed]) under gloo, on the cpu backend (numpy /
+    scipy behind the HIP library's operator interface, gsum_amd/_cpu.py) so that the work each rank does can be counted."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GSUM_BACKEND="cpu")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gsum_amd
+        from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+        from gsum_amd._cpu import cpu_context
+        rng = np.random.RandomState(3)
+        n, r = 40, 4
+        X = np.sort(rng.rand(n))[:, None] * 6.0
+        y = gsum_amd.partials(rng.randn(n, r), ratio=0.5, ref=2.0, orders=np.arange(r))
+        gp = gsum_amd.TruncationGP(kernel=RBF(0.3) + WhiteKernel(1e-6, noise_level_bounds="fixed"), ratio=0.5, ref=2.0, center=0, disp=0,
+                                   df=1, scale=1, optimizer=None)
+        gp.fit(X, y, orders=np.arange(r))
+        thetas = [np.log([e]) for e in np.linspace(0.2, 0.5, 8)]
+        ratios = list(np.linspace(0.3, 0.7, 6))
+        scales = [0.5, 1.0, 2.0]
+        ctx = cpu_context()
+        out = {}
+        for mode in ("reuse", "full"):
+            for sc in (None, scales):
+                want = gp.log_marginal_likelihood_grid(thetas, ratios, scales=sc, mode=mode)                 # unsharded, on this rank
+                before = ctx.calls["potrf"]
+                got = gp.log_marginal_likelihood_grid_distributed(thetas, ratios, scales=sc, mode=mode)
+                out[(mode, sc is not None)] = (bool(np.array_equal(got, want)) and not np.isnan(got).any(), ctx.calls["potrf"] - before)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reuse_mode_shards_whole_thetas_gloo(world):
+    """"group by distinct kernel descriptor first".  In mode="reuse" a theta's factorisation serves every ratio
+    setting and prior scale, so a rank must own whole thetas: rank r of `world` factorises the ~8 / world matrices of its block, not
+    all 8 (what a flat block partition of the (ratio, theta, scale) index did in round 3: zero scaling).  mode="full" keeps the flat
+    partition, one factorisation per grid point.  Both gather to exactly the unsharded surface."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_product_grid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_theta, n_ratio, n_scale = 8, 6, 3
+    for rank in range(world):
+        lo, hi = shard_range(n_theta, rank, world)
+        for with_scales in (False, True):
+            ok, potrfs = res[rank][("reuse", with_scales)]
+            assert ok
+            assert potrfs == hi - lo, (rank, potrfs, hi - lo)                      # one factorisation per OWNED theta, whatever the other axes
+            ok, potrfs = res[rank][("full", with_scales)]
+            flo, fhi = shard_range(n_theta * n_ratio * (n_scale if with_scales else 1), rank, world)
+            assert ok and potrfs == fhi - flo
+    assert sum(res[r][("reuse", False)][1] for r in range(world)) == n_theta

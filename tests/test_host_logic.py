@@ -372,6 +372,40 @@ def test_kernel_register_budgets():
     assert chain["VGPRs"] <= 256 and chain["Scratch"] <= 64, chain        # one wave per SIMD, a CU of its own: no spills to memory
 
 
+def _build_rccl_host(exe):
+    """gcc line of tests/c_host/shard_host_rccl.c (C99, HIP + RCCL public headers, the library's header); returns the CompletedProcess."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    rocm = "/opt/rocm"
+    if not gcc or not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        return None
+    return subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_host", "shard_host_rccl.c"), "-o", exe,
+                           "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-L" + os.path.join(ROOT, "gsum_amd"), "-lgsum_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gsum_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")],
+                          capture_output=True, text=True)
+
+
+def test_rccl_c_host_compiles_and_links():
+    """tests/c_host/shard_host_rccl.c -- INTEGRATION.md's multi-GPU recipe with a real communicator (ncclCommInitAll over the visible
+    GPUs, the three in-place ncclAllGather calls verbatim) -- is valid C99 against the public headers and links against librccl,
+    libamdhip64 and libgsum_hip.  It RUNS on the GPU box: tests/test_gpu_round4.py::test_rccl_c_host_gathers_the_sharded_scan."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = _build_rccl_host(os.path.join(tmp, "shard_host_rccl"))
+        if res is None:
+            pytest.skip("gcc or the RCCL headers are not installed")
+        assert res.returncode == 0, res.stderr
+    src = open(os.path.join(ROOT, "tests", "c_host", "shard_host_rccl.c")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for call in ("ncclAllGather(d_sld + lo, d_sld, c, ncclDouble, comm, stream)", "ncclAllGather(d_G + lo * k * k, d_G, c * k * k, ncclDouble, comm, stream)",
+                 "ncclAllGather(d_inf + lo, d_inf, c, ncclInt64, comm, stream)"):
+        assert call in doc                                                     # the documented recipe ...
+        assert call.replace("d_sld", "d_sld[rank]").replace("d_G", "d_G[rank]").replace("d_inf", "d_inf[rank]").replace("lo", "lo[rank]") \
+                   .replace("comm", "comm[rank]").replace("stream", "stream[rank]") in src      # ... is what the host runs, per rank
+
+
 def test_c_host_of_the_sharded_scan_compiles_as_c99():
     """include/gsum_hip.h is a C header (no C++ in the boundary) and the C host of INTEGRATION.md's multi-GPU recipe,
     tests/c_host/shard_host.c, compiles against it with -std=c99 -Wall -Wextra -Werror and links against the library (every symbol
