@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 LIB_PATH = os.environ.get("GSUM_HIP_LIBRARY") or os.path.join(_HERE, "libgsum_hip.so")
+LAB_LIB_PATH = os.path.join(_HERE, "libgsum_hip_lab.so")     # the same sources with -DGSUM_LAB: + include/gsum_hip_debug.h
 
 GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
@@ -82,7 +83,8 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
 _kp = C.POINTER(KernelDesc)
 
-# name -> (restype, argtypes); must list every symbol include/gsum_hip.h declares
+# name -> (restype, argtypes); must list every symbol include/gsum_hip.h declares (PROTOTYPES) / include/gsum_hip_debug.h adds
+# in the lab build (LAB_PROTOTYPES)
 PROTOTYPES = {
     "gsum_init": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "gsum_destroy": (None, [_p]),
@@ -117,41 +119,45 @@ PROTOTYPES = {
     "gsum_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _ip, _ip]),
     "gsum_lml_resident_shard": (C.c_int, [_p, _kp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _ip, _ip, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
+    "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
+}
+LAB_PROTOTYPES = {
     "gsum_debug_diag_stamps": (C.c_int, [_p, _ip]),
     "gsum_debug_chain_stamps": (C.c_int, [_p, _dp, C.c_int32, C.POINTER(C.c_int32)]),
-    "gsum_gemm_profile": (C.c_int, [_p, _dp, _dp, _ip]),
-    "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "gsum_probe_hbm_write": (C.c_int, [_p, C.c_int64, _dp]),
-    "gsum_probe_cu_mask": (C.c_int, [_p, C.POINTER(C.c_uint32), C.c_int32, C.c_int32, _ip]),
     "gsum_bench_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp]),
-    "gsum_debug_gemm_phases": (C.c_int, [_p, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "gsum_debug_gemm_nt": (C.c_int, [_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int32, C.c_double]),
 }
 
 _lib = None
+_lab_lib = None
 _lib_lock = threading.Lock()
 
 
-def load_library(path: str | None = None):
-    """dlopen libgsum_hip.so and attach prototypes.  Raises if it is absent."""
-    global _lib
+def load_library(path: str | None = None, lab: bool = False):
+    """dlopen libgsum_hip.so (``lab=True``: libgsum_hip_lab.so, the lab build) and attach prototypes.  Raises if it is absent."""
+    global _lib, _lab_lib
     with _lib_lock:
-        if _lib is not None and path is None:
-            return _lib
-        p = path or LIB_PATH
+        if path is None and (_lab_lib if lab else _lib) is not None:
+            return _lab_lib if lab else _lib
+        p = path or (LAB_LIB_PATH if lab else LIB_PATH)
         if not os.path.exists(p):
             raise RuntimeError(
-                f"{p} not found: the HIP extension is not built. Run `python -m gsum_amd.build` "
-                "(hipcc --offload-arch=gfx950). gsum_amd has no CPU fallback.")
+                f"{p} not found: the HIP extension is not built. Run `python -m gsum_amd.build" + (" --lab" if lab else "") + "` "
+                "(hipcc --offload-arch=gfx950). The 'hip' backend has no CPU fallback.")
         lib = C.CDLL(p)
-        for name, (res, args) in PROTOTYPES.items():
+        protos = dict(PROTOTYPES, **LAB_PROTOTYPES) if lab else PROTOTYPES
+        for name, (res, args) in protos.items():
             fn = getattr(lib, name)        # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
         if path is None:
-            _lib = lib
+            if lab:
+                _lab_lib = lib
+            else:
+                _lib = lib
         return lib
 
 
@@ -208,8 +214,9 @@ class DeviceMatrix:
 class HipContext:
     """One GPU, one ``gsum_ctx``.  Not thread-safe (one context per thread)."""
 
-    def __init__(self, device: int = 0):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, lab: bool = False):
+        self._lib = load_library(lab=lab)
+        self.lab = bool(lab)
         h = _p()
         rc = self._lib.gsum_init(int(device), C.byref(h))
         if rc != 0:
@@ -245,7 +252,7 @@ class HipContext:
 
     def get_option(self, name: str) -> int:
         v = int(self._lib.gsum_get_option(self._h, name.encode()))
-        if v < 0 and name not in ("reserve_cus", "chain_persist", "chain_probe"):
+        if v < 0 and name not in ("chain_persist", "chain_probe", "medium_min_batch", "wave_shift"):
             raise ValueError(f"unknown option: {name}")
         return v
 
@@ -533,12 +540,6 @@ class HipContext:
         out = out[: steps.value]
         return np.where(out < 0, np.nan, out * 0.01)
 
-    def gemm_profile(self):
-        """(total ms, total algorithmic flops, launches) of the profiled big-tile GEMM launches; resets."""
-        ms, fl, cnt = C.c_double(0), C.c_double(0), C.c_int64(0)
-        self._check(self._lib.gsum_gemm_profile(self._h, C.byref(ms), C.byref(fl), C.byref(cnt)))
-        return float(ms.value), float(fl.value), int(cnt.value)
-
     PROFILE_CLASSES = ("kernel_build", "diag_block", "panel_gemm", "bulk_update", "other")
 
     def kernel_profile(self):
@@ -560,24 +561,11 @@ class HipContext:
         self._check(self._lib.gsum_probe_hbm_write(self._h, nbytes, C.byref(v)))
         return float(v.value)
 
-    def probe_cu_mask(self, mask_words=None, nblocks=4096):
-        """Placement of nblocks workgroups under a stream CU mask: array (nblocks, 2) of (XCC id, HW_ID)."""
-        out = np.zeros((nblocks, 2), dtype=np.int64)
-        words = np.asarray(mask_words if mask_words is not None else [], dtype=np.uint32)
-        mp = words.ctypes.data_as(C.POINTER(C.c_uint32)) if words.size else None
-        self._check(self._lib.gsum_probe_cu_mask(self._h, mp, int(words.size), nblocks, out.ctypes.data_as(_ip)))
-        return out
-
     def bench_gemm_nt(self, cfg, M, N, K, tri=False, lda=None, reps=5):
         """(TFLOP/s, us per launch) of the MFMA tile kernel on device-resident random operands."""
         v = np.zeros(2)
         self._check(self._lib.gsum_bench_gemm_nt(self._h, cfg, int(tri), M, N, K, lda or K, reps, _ptr(v)))
         return float(v[0]), float(v[1])
-
-    def debug_gemm_phases(self, M, K, lda=None):
-        v = np.zeros(5)
-        self._check(self._lib.gsum_debug_gemm_phases(self._h, M, K, lda or K, _ptr(v)))
-        return dict(zip(("prologue", "load_issue", "mfma", "wait_store", "barrier"), v.tolist()))
 
     def debug_gemm_nt(self, cfg, Cm, A, B, tri=False, beta=1, sign=-1.0):
         Cm, A, B = _f64(Cm).copy(), _f64(A), _f64(B)
@@ -589,18 +577,20 @@ class HipContext:
 
 
 _default_ctx = {}
+_lab_ctx = {}
 
 
 def _close_default_contexts():
     # Streams with a CU mask must be gone before the C++ finalisers of the HIP runtime / a profiler run (rocprofv3
     # segfaults in __cxa_finalize on a process that exits with one alive): destroy the contexts first.  DeviceMatrix
     # objects still alive only lose their handle (their frees become no-ops).
-    for ctx in list(_default_ctx.values()):
+    for ctx in list(_default_ctx.values()) + list(_lab_ctx.values()):
         try:
             ctx.close()
         except Exception:
             pass
     _default_ctx.clear()
+    _lab_ctx.clear()
 
 
 import atexit  # noqa: E402
@@ -616,4 +606,16 @@ def default_context(device: int | None = None) -> HipContext:
     if ctx is None or ctx._h is None:
         ctx = HipContext(device)
         _default_ctx[device] = ctx
+    return ctx
+
+
+def lab_context(device: int | None = None) -> HipContext:
+    """Process-wide context on the LAB build of the library (libgsum_hip_lab.so: include/gsum_hip_debug.h's diagnostics, probes and
+    schedule switches on top of the product ABI).  A context of its own -- streams, workspaces -- beside ``default_context``'s."""
+    if device is None:
+        device = int(os.environ.get("GSUM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _lab_ctx.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = HipContext(device, lab=True)
+        _lab_ctx[device] = ctx
     return ctx

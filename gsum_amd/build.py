@@ -1,4 +1,12 @@
-"""Build libgsum_hip.so in-tree with hipcc for gfx950.   python -m gsum_amd.build"""
+"""Build the HIP library in-tree with hipcc for gfx950.
+
+    python -m gsum_amd.build [--force] [--lab]
+
+``libgsum_hip.so``      the product: the C ABI of include/gsum_hip.h, nothing else exported
+``libgsum_hip_lab.so``  the same sources with -DGSUM_LAB: plus include/gsum_hip_debug.h (diagnostics, probes, microbenchmarks,
+                        schedule switches); what tools/ and the schedule-equivalence tests load.  Built by ``--lab`` / ``build(lab=True)``
+                        and by ``__graft_entry__.build()``.
+"""
 from __future__ import annotations
 
 import os
@@ -9,8 +17,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "gsum_capi.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "gsum_kernels.hip.h"), os.path.join(ROOT, "include", "gsum_hip.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "gsum_kernels.hip.h"), os.path.join(ROOT, "include", "gsum_hip.h"),
+        os.path.join(ROOT, "include", "gsum_hip_debug.h")]
 OUT = os.path.join(HERE, "libgsum_hip.so")
+OUT_LAB = os.path.join(HERE, "libgsum_hip_lab.so")
 
 
 def hipcc_path():
@@ -20,20 +30,23 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+def up_to_date(out=OUT):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and up_to_date():
-        return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), "-o", OUT, SRC]
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
+    out = OUT_LAB if lab else OUT
+    if not force and up_to_date(out):
+        return out
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")] + (["-DGSUM_LAB"] if lab else []) + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--lab" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, lab=True))

@@ -1,5 +1,12 @@
 // libgsum_hip.so — host side of the C ABI declared in include/gsum_hip.h.
 // One context = one GPU = two HIP streams (main + high-priority panel stream for look-ahead).
+// the library is built with -fvisibility=hidden: what include/gsum_hip.h declares (and, in the lab build, gsum_hip_debug.h) is all it exports
+#pragma GCC visibility push(default)
+#include "gsum_hip.h"
+#ifdef GSUM_LAB
+#include "gsum_hip_debug.h"
+#endif
+#pragma GCC visibility pop
 #include "gsum_kernels.hip.h"
 
 #include <algorithm>
@@ -16,9 +23,9 @@ struct gsum_mat {
     int64_t n = 0, np = 0, ld = 0;
     int T = 0;                 // np / 128
     double* A = nullptr;       // (np + 16) x ld augmented matrix
-    double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L (diag_algo 1: by the factorisation;
-                               // diag_algo 2: lazily, from the tables, for the consumers that multiply by L_bb^-1)
-    double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks (diag_algo 2)
+    double* Linv = nullptr;    // T x 128 x 128 inverses of the diagonal blocks of L: built lazily from the tables, for the one consumer
+                               // that multiplies by L_bb^-1 (gsum_cho_solve's back-substitution)
+    double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks
     double* Lsib = nullptr;    // (T / 2 + 1) x GS_LSIB: L(j+1, j) of every outer step in operand layout (k_potrf_diag256 -> k_panel256)
     bool have_ltab = false, have_linv = false;
     std::vector<double> solved_rhs;     // host copy of the right-hand sides whose forward solve W^T = (L^-1 RHS)^T the border rows
@@ -41,18 +48,10 @@ struct gs_slot {
     hipStream_t sm = nullptr, sp = nullptr;   // main (bulk) / high-priority panel chain
     hipStream_t su = nullptr;        // gradient path: the U = L^-T sweep, trailing the factorisation panel by panel
     hipEvent_t evU = nullptr;
-    hipStream_t sb = nullptr;        // bulk stream restricted by a CU mask (look-ahead schedules, reserve_cus > 0)
-    int sb_reserve = 0;              // reserve_cus value sb was created for
-    hipStream_t sc = nullptr, srm = nullptr;   // windowed schedule with reserve_cus > 0: the chain on the reserved CUs ONLY,
-                                               // the rest stream on the bulk stream's CUs
-    hipStream_t sr = nullptr;        // windowed look-ahead schedule: the rows below the window (panel rest, far look-ahead columns)
-    hipStream_t sband[4] = {nullptr, nullptr, nullptr, nullptr};   // persistent-chain schedule: row bands 1.. of the trailing update (band 0: sm)
-    hipEvent_t evBand[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t sa = nullptr;        // persistent-chain schedule: the panel of the rows below the window and the near updates A, B
     hipEvent_t evC = nullptr, evS = nullptr;     // ... its joins (chain kernel / stream sa -> main stream)
     std::vector<hipEvent_t> evP, evM, evA;
-    std::vector<hipEvent_t> evW;     // windowed schedule: five events per outer step (GS_EVW_*)
-    hipEvent_t evFork = nullptr, evR = nullptr;
+    hipEvent_t evFork = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
     double* dres = nullptr; int* dinfo = nullptr;
     double* hres = nullptr;          // pinned
@@ -102,31 +101,18 @@ struct gsum_ctx {
     std::string err;
     int lookahead = 1;
     double next_algo_flops = -1.0;   // profile only: algorithmic flops of the next cfg-5 launch when not M(M+1)K / 2MNK
-    int bulk_cfg = 7;                // bulk trailing-update kernel: 7 = k_gemm_ld3 (LDS-direct, 128x64 tile, 3 workgroups per CU),
-                                     // 6 = k_gemm_ld (LDS-direct, 128x128), 5 = k_gemm_nt<4,2,2,4> (register staging)
-    int bulk_stages = 2;             // LDS stages of the bulk tile: 2 (48 KB, three workgroups per CU) or 3 (74 KB, two per CU, operands two chunks ahead)
     int predict_lazy = 1;            // the predictive sweep V^T = K* L^-T with the same pairing of trailing updates (K = 512 every other step)
     int lazy_min_np = 4352;          // smallest padded order the lazy far updates are used at (profiles/r03_lazy_threshold.log, 20 in flight: +3 % at 4352,
                                      // +3.7 / +4.8 / +5.3 / +6 / +6 % at 5120 / 6144 / 7168 / 8192 / 12288; neutral at 4096, -0.5 ... -3 % at 1536 ... 3072)
     int lazy_far = 2;                // batch mode: K = 512 updates of the far trailing region every other panel (1: the next TWO panels' columns are "near",
                                      // updated with K = 256 at every step; 2: only the next panel's, the one after it takes both updates in the K = 512 launch)
     int bench_fill = 0;              // gsum_bench_gemm_nt operands: 0 random, 1 zeros (timing is value-independent, board power is not)
-    int reserve_cus = 0;             // CUs per XCD kept free of bulk workgroups while a look-ahead schedule runs (CU-masked
-                                     // bulk stream).  Off by default: worth 2-3 % at n >= 8192, but a masked stream
-                                     // created after ~20 other streams exist made the same schedule 1.7x slower
-                                     // (measured: 14.3 vs 8.5 ms); -1 = 2 from order 6144 up
     int build_lower_only = 1;
-    int bulk_pad_below = 0;          // > 0: apply bulk_lds_pad only to bulk launches with fewer rows than this (the outer steps
-                                     // where the chain, not the bulk update, sets the pace)
     int bulk_lds_pad = 80 * 1024;    // bytes of dynamic LDS the bulk kernel asks for in the look-ahead schedule of a factorisation
                                      // (0 = what it needs, 53 KB): at 80 KB two bulk workgroups share a CU instead of three and a
                                      // retiring one leaves room for a chain workgroup at once -- one factorisation 6.85 -> 6.70 ms
     bool bulk_pad_now = false;       // set around the bulk launches of gs_potrf's look-ahead branch only
-    int build_algo = 2;              // kernel-matrix build: 2 = k_build2 (templated, 32 x 128 tiles), 1 = the round-1 kernel
     int chain_prefetch = 1;          // 32 x 128 tile (sibling / look-ahead updates): four operand chunks in flight instead of one
-    int la_split = 0;                // look-ahead schedule: while the trailing matrix has at least this many rows, only the next
-                                     // diagonal block's piece of the look-ahead update runs on the chain's stream (0 = never split,
-                                     // the default: measured 1 % slower at 1024 ... 4096 -- two more events on the chain's stream)
     int la_depth2 = 1;               // look-ahead schedule: the bulk update in two launches, the chain waits for the first only
                                      // (-1 % with the 80-KB bulk launches: 6.69 -> 6.62 ms; nothing without them)
     int chain_fused = -1;            // two diagonal blocks per launch (k_potrf_diag256) and both panels of the rows below in one
@@ -135,20 +121,12 @@ struct gsum_ctx {
                                      // 31 + 12 + 11 + 31 + 12) but two launches instead of five and less CU time: with 16 evaluations
                                      // in flight latency is hidden and the batch runs 1.8 % faster (279 vs 274 evals/s), one
                                      // factorisation alone is 10-30 % slower with them
-    int chain_window = 0;            // look-ahead schedule: 1 = windowed (only the rows the next panels need are on the chain's
-                                     // stream, the rest of each panel trails on a stream of its own), 0 = whole panels on the chain
     int chain_persist = -1;          // ONE factorisation alone: the dependent chain as a persistent kernel on CUs of its own (k_chain),
                                      // the M-proportional work host-enqueued and gated on its flags.  -1 (default) = when the order
                                      // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
     int chain_min_np = 2048;
     int chain_lazy = -1;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
                                      // -1 (default): on from padded order 10240 up, where it pays -- 13.6 -> 13.3 ms at n = 12288, 29.15 -> 28.13 ms at 16384, 5.28 -> 5.31 at 8192
-    int chain_bands = 1;             // persistent-chain schedule: the trailing update in this many row bands (fixed absolute boundaries, equal
-                                     // areas), each on a stream of its own: a band's tiles depend on their own previous version and the panel
-                                     // only, so band p of step s + 1 starts when band p of step s is done -- no chip-wide barrier per step.
-                                     // Measured (profiles/r03_chain_check.log): 2 / 3 / 4 bands 5.84 / 5.87 / 6.79 ms against 5.45 with one at
-                                     // n = 8192, 2.45-2.84 against 2.00 at 4096 -- B's tiles of a step then queue behind the other bands'
-                                     // previous launches instead of starting on an empty chip, and the chain waits for ALL of them.  Off.
     int chain_rows = 512;            // the chain's window: rows under the panel it solves and updates itself (256 or 512)
     int chain_stamps = 0;            // record the chain kernel's per-step realtime stamps (gsum_debug_chain_stamps)
     int chain_probe = 0;             // two-stream concurrency probe: 0 not run, 1 streams run side by side, -1 they do not (a
@@ -160,8 +138,6 @@ struct gsum_ctx {
     unsigned long long* panel_stats = nullptr;   // diagnostics (option panel_stats): {sum of wave lifetimes in 10-ns ticks, waves} of every k_panel256 launch
     int first_tiles = 0;                  // the NEXT bulk (cfg 7) launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
     unsigned* first_done = nullptr;
-    int diag_algo = 2;               // diagonal-block kernel: 2 = micro-blocks in accumulator registers, single-wave pivot
-                                     // recurrence (round 2); 1 = the round-1 kernel (mailbox per two columns), kept for A/B
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
     // point (operator level, gsum_lml_batch, gsum_lml_grad) uploads into `op`.  `in` is the set the fused path reads.
     gs_inputs op, res;
@@ -184,7 +160,6 @@ struct gsum_ctx {
     int medium_path = 1;             // 128 < n <= 2048 and >= medium_min_batch evaluations per call: one workgroup per
     int medium_min_batch = -1;       // evaluation on its own HBM-resident matrix (k_lml_medium); -1 = auto: max(4, n^1.45 / 985),
                                      // the measured break-even against the pipelined multi-kernel path
-    int stagger = -1;                // de-phasing of co-resident workgroups: -1 = auto (K/16 x 2048 cycles), 0 = off
     double host_enqueue_ms = 0.0;    // host wall time spent enqueuing the last evaluation
     std::set<const void*> lds_attr_done;   // kernels whose dynamic-LDS limit has been raised on this context's device
     // grouped batch schedule (gs_lml_wave): the evaluations of a call advance in groups, one launch per kernel class and outer step
@@ -291,32 +266,28 @@ static int gs_launch_gemm(gsum_ctx* ctx, hipStream_t s, double* C, int64_t ldc, 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), shmem, s, C, ldc, A, lda, B, ldb, (int)M,
                        (int)N, K, tri, beta, sign, (unsigned long long*)nullptr,
-                       (BM == 128 && BN == 128) ? (ctx->stagger < 0 ? std::min(K / 16, 32) : ctx->stagger) : 0);
+                       (BM == 128 && BN == 128) ? std::min(K / 16, 32) : 0);
     GS_CHECK(hipGetLastError());
     return 0;
 }
 
-// cfg 0: 128x128 tile (2x2 waves of 64x64)   — trailing SYRK / big updates
-// cfg 1:  32x128 tile (1x4 waves of 32x32)   — panel TRSM against the explicit block inverse
-// cfg 2:  16x256 tile (1x4 waves of 16x64)   — border rows (RHS^T) only
-// cfg 5: 128x128 tile (2x4 waves of 64x32, 512 threads, 4 waves per SIMD) — bulk trailing update: +3-9 % over
-//        cfg 0 in interleaved A/B runs (more independent waves per SIMD to fill issue gaps)
+// cfg 1:  32x128 tile (1x4 waves of 32x32)   -- chain GEMMs: sibling-column / look-ahead updates, gradient and predict sweeps
+// cfg 2:  16x256 tile (1x4 waves of 16x64)   -- border rows (RHS^T) only
+// cfg 5: 128x128 tile (2x4 waves of 64x32, register staging) -- stand-in for the bulk tile when operands are not 16-B aligned
+// cfg 7: 128x64 tile, LDS-direct operand staging, three workgroups per CU -- the bulk trailing update (k_gemm_ld3)
 static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                        const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
     // the LDS-direct loads fetch 16 B per lane: operands must be 16-B aligned with even leading dimensions (true for
     // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
-    if (cfg == 6 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (cfg == 7 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (ctx->first_tiles && cfg != 7) GS_FAIL("internal: only the cfg-7 bulk tile counts first-column tiles");
     if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
-        const int nst = ctx->bulk_stages == 3 ? 3 : 2;
-        size_t shmem = nst * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
-        // experiment knob: pad the request so that fewer bulk workgroups share a CU and chain kernels find LDS at once
-        if (ctx->bulk_pad_now && ctx->bulk_lds_pad > 0 && (ctx->bulk_pad_below <= 0 || M < ctx->bulk_pad_below))
-            shmem = std::max(shmem, (size_t)ctx->bulk_lds_pad);
-        const void* kfn = nst == 3 ? (const void*)k_gemm_ld3<3> : (const void*)k_gemm_ld3<2>;
+        size_t shmem = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+        // pad the request so that fewer bulk workgroups share a CU and chain kernels find LDS at once (look-ahead schedules)
+        if (ctx->bulk_pad_now && ctx->bulk_lds_pad > 0) shmem = std::max(shmem, (size_t)ctx->bulk_lds_pad);
+        const void* kfn = (const void*)k_gemm_ld3<2>;
         if (!ctx->lds_attr_done.count(kfn)) {
             GS_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             ctx->lds_attr_done.insert(kfn);
@@ -329,43 +300,15 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         } else {
             blocks = ((M + 127) / 128) * ((N + 63) / 64);
         }
-        if (nst == 3)
-            hipLaunchKernelGGL(k_gemm_ld3<3>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                               beta, sign, ctx->kst_ptr,
-                               tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
-        else
-            hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                               beta, sign, ctx->kst_ptr,
-                               tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
+        hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
+                           beta, sign, ctx->kst_ptr, tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
         ctx->kst_ptr = nullptr;
         ctx->first_tiles = 0;
         ctx->first_done = nullptr;
         GS_CHECK(hipGetLastError());
         return 0;
     }
-    if (cfg == 6) {                                   // LDS-direct staging variant of cfg 5
-        if (M <= 0 || N <= 0) return 0;
-        if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
-        const size_t shmem = 2 * 2 * (size_t)(128 * GS_KC + 2) * sizeof(double);
-        if (!ctx->lds_attr_done.count((const void*)k_gemm_ld)) {
-            GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            ctx->lds_attr_done.insert((const void*)k_gemm_ld);
-        }
-        int64_t blocks;
-        if (tri) {
-            if (M != N) GS_FAIL("gemm: tri mode needs a square C");
-            const int64_t Tt = (M + 127) / 128;
-            blocks = Tt * (Tt + 1) / 2;
-        } else {
-            blocks = ((M + 127) / 128) * ((N + 127) / 128);
-        }
-        hipLaunchKernelGGL(k_gemm_ld, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                           beta, sign, ctx->stagger < 0 ? std::min(K / 16, 32) : ctx->stagger);
-        GS_CHECK(hipGetLastError());
-        return 0;
-    }
     switch (cfg) {
-        case 0: return gs_launch_gemm<4, 4, 2, 2>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
         case 1:
             if (ctx->chain_prefetch && K % 64 == 0) return gs_launch_gemm<2, 2, 1, 4, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
             return gs_launch_gemm<2, 2, 1, 4>(ctx, s, C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign);
@@ -375,16 +318,14 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     GS_FAIL("gemm: unknown tile configuration");
 }
 
-// cfg GS_BULK stands for the bulk trailing-update kernel the context is configured with (option "bulk_cfg": 7 = the
-// LDS-direct 128x64 tile, 6 = the LDS-direct 128x128 tile, 5 = that tile with register staging); those launches are
-// the ones the profile records.
+// cfg GS_BULK stands for the bulk trailing-update kernel (cfg 7); those launches are the ones the profile records as "bulk".
 #define GS_BULK (-5)
 static int gs_gemm(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t ldc, const double* A, int64_t lda,
                    const double* B, int64_t ldb, int64_t M, int64_t N, int K, int tri, int beta, double sign) {
     const double algo_override = ctx->next_algo_flops;      // consumed by this call whether or not it is profiled
     ctx->next_algo_flops = -1.0;
     const bool bulk = cfg == GS_BULK;
-    if (bulk) cfg = ctx->bulk_cfg;
+    if (bulk) cfg = 7;
     if (M <= 0 || N <= 0) return 0;
     // algorithmic flops of the update: lower-triangular SYRK M(M+1)K, rectangular 2MNK
     double fl = tri ? (double)M * (double)(M + 1) * K : 2.0 * (double)M * (double)N * K;
@@ -412,7 +353,7 @@ static int gs_bulk_la(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t 
 // factorisation that is 15 % faster).
 static int64_t gs_padded_order(const gsum_ctx* ctx, int64_t n) {
     const int64_t p128 = (n + GS_NB - 1) / GS_NB * GS_NB, p256 = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB);
-    if (ctx->chain_persist != 0 && ctx->diag_algo == 2 && p256 >= ctx->chain_min_np) return p256;
+    if (ctx->chain_persist != 0 && p256 >= ctx->chain_min_np) return p256;
     return p128;
 }
 
@@ -466,19 +407,11 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
     return 0;
 }
 
-// Kernel-matrix build launcher: picks the template instance (family, one-dimensional fast path) of k_build2, or the
-// round-1 kernel with option "build_algo" = 1.  tri != 0: lower 128-column tiles of a square padded matrix only.
+// Kernel-matrix build launcher: picks the template instance (family, one-dimensional fast path) of k_build2.
+// tri != 0: lower 128-column tiles of a square padded matrix only.
 template <bool CROSS>
 static int gs_launch_build(gsum_ctx* ctx, hipStream_t s, double* out, int64_t ldo, const double* X, const double* Y, int64_t n,
                            int64_t m, int64_t prow, int64_t pcol, int d, const gsum_kernel_desc* desc, double diag_add, int tri) {
-    if (ctx->build_algo == 1) {
-        const int64_t tr = (prow + 127) / 128, tc = (pcol + 127) / 128;
-        const int64_t blocks = tri ? tr * (tr + 1) / 2 : tr * tc;
-        hipLaunchKernelGGL(k_build<CROSS>, dim3((unsigned)blocks), dim3(256), 0, s, out, ldo, X, Y, (int)n, (int)m, (int)prow,
-                           (int)pcol, d, *desc, diag_add, tri);
-        GS_CHECK(hipGetLastError());
-        return 0;
-    }
     const int64_t tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS, tc = (pcol + 127) / 128, t128 = (prow + 127) / 128;
     const int64_t blocks = tri ? 4 * (t128 * (t128 + 1) / 2) : tr * tc;
 #define GS_B2_LAUNCH(FAM, D1)                                                                                              \
@@ -544,65 +477,9 @@ static int gs_potrf_events(gsum_ctx* ctx, gs_slot* sl, int T) {
     return 0;
 }
 
-// Bulk stream of a look-ahead schedule.  With reserve_cus = R > 0 it carries a CU mask that leaves R CUs of every
-// XCD to the chain kernels: a bulk workgroup holds its CU for ~80 us, and without free CUs every small chain
-// launch first waits for one to retire.  Mask bit i is CU i / 8 of XCD i % 8 (measured with gsum_probe_cu_mask),
-// so clearing the top 8 R bits takes R CUs from each XCD.
-// The high-priority panel stream exists only on slots that run a look-ahead schedule: a batch keeps ~10 slots busy
-// on their main streams, and every extra stream competes for the runtime's hardware queues.
+// The high-priority panel stream exists only on slots that run a look-ahead schedule.
 static int gs_panel_stream(gsum_ctx* ctx, gs_slot* sl) {
     if (!sl->sp) GS_CHECK(hipStreamCreateWithPriority(&sl->sp, hipStreamNonBlocking, ctx->prio_hi));
-    return 0;
-}
-
-enum { GS_EVW_D0 = 0, GS_EVW_T0 = 1, GS_EVW_D1 = 2, GS_EVW_T1 = 3, GS_EVW_NEW = 4, GS_EVW_FAR = 5, GS_EVW_N = 6 };
-
-static int gs_window_streams(gsum_ctx* ctx, gs_slot* sl, int T) {
-    if (!sl->sr) {
-        GS_CHECK(hipStreamCreateWithPriority(&sl->sr, hipStreamNonBlocking, ctx->prio_hi));
-        GS_CHECK(hipEventCreateWithFlags(&sl->evR, hipEventDisableTiming));
-    }
-    const size_t want = (size_t)GS_EVW_N * (T + 1);
-    for (size_t i = sl->evW.size(); i < want; ++i) {
-        hipEvent_t ev;
-        GS_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        sl->evW.push_back(ev);
-    }
-    return 0;
-}
-
-static int gs_bulk_stream(gsum_ctx* ctx, gs_slot* sl, int64_t np, hipStream_t* out) {
-    const int R = ctx->reserve_cus >= 0 ? ctx->reserve_cus : (np >= 6144 ? 2 : 0);
-    // CU-masked streams are destroyed as soon as the option no longer asks for them: idle ones are not harmless (with three
-    // of them alive a schedule that uses a second chain stream ran 1.5-2x slower -- tools/gpu_single_sweep.py found it)
-    if (sl->sb && sl->sb_reserve != R) {
-        for (hipStream_t* q : {&sl->sb, &sl->sc, &sl->srm}) {
-            if (!*q) continue;
-            GS_CHECK(hipStreamSynchronize(*q));
-            GS_CHECK(hipStreamDestroy(*q));
-            *q = nullptr;
-        }
-        sl->sb_reserve = 0;
-    }
-    if (R <= 0) {
-        *out = sl->sm;
-        return 0;
-    }
-    if (!sl->sb) {
-        hipDeviceProp_t prop;
-        GS_CHECK(hipGetDeviceProperties(&prop, ctx->device));
-        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-        if (ncu % 8 != 0 || 8 * R >= ncu) GS_FAIL("reserve_cus: does not fit this device's CU count");
-        std::vector<uint32_t> mask(words, 0u), rmask(words, 0u);
-        for (int i = 0; i < ncu; ++i) (i < ncu - 8 * R ? mask : rmask)[i >> 5] |= 1u << (i & 31);
-        GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sb, (uint32_t)words, mask.data()));
-        if (ctx->chain_window) {        // the windowed schedule's chain / rest streams: only when that schedule is selected
-            GS_CHECK(hipExtStreamCreateWithCUMask(&sl->srm, (uint32_t)words, mask.data()));
-            GS_CHECK(hipExtStreamCreateWithCUMask(&sl->sc, (uint32_t)words, rmask.data()));
-        }
-        sl->sb_reserve = R;
-    }
-    *out = sl->sb;
     return 0;
 }
 
@@ -611,24 +488,17 @@ static int gs_diag(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
     const int64_t c = (int64_t)b * GS_NB;
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, (double)GS_NB * GS_NB * GS_NB / 3.0);
-    if (m->have_linv)          // this factorisation runs the round-1 kernel (see gs_potrf)
-        hipLaunchKernelGGL(k_potrf_diag<1>, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Linv + (size_t)b * GS_NB * GS_NB,
-                           (double*)nullptr, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
-    else
-        hipLaunchKernelGGL(k_potrf_diag<2>, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, (double*)nullptr,
-                           m->Ltab + (size_t)b * GS_LTAB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB, m->logdet + b,
+                       sl->dinfo, (int)c, m->diag0 + c, stamps);
     gs_prof_end(ctx, s, rec);
     GS_CHECK(hipGetLastError());
     return 0;
 }
 
 // P (M rows x 128 columns, leading dimension ldp)  <-  P L_bb^-T for diagonal block b of the factor m: blocked
-// substitution against the block's tables (k_panel), or -- for a factor made by the round-1 kernel -- the product with
-// the explicit inverse on the 32 x 128 MFMA tile.
+// substitution against the block's tables (k_panel).
 static int gs_trsm_rows(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
     if (M <= 0) return 0;
-    if (!m->have_ltab)
-        return gs_gemm(ctx, s, 1, P, ldp, P, ldp, m->Linv + (size_t)b * GS_NB * GS_NB, GS_NB, M, GS_NB, GS_NB, 0, 0, 1.0);
     const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, (double)M * GS_NB * GS_NB);
     hipLaunchKernelGGL(k_panel, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB);
     gs_prof_end(ctx, s, rec);
@@ -663,133 +533,11 @@ static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, d
 // the explicit 128 x 128 inverses of the diagonal blocks, for the consumers that want them (cho_solve's back-substitution)
 static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
     if (m->have_linv) return 0;
-    if (!m->have_ltab) GS_FAIL("internal: factor has neither tables nor inverses");
     hipLaunchKernelGGL(k_trtri_blocks, dim3((unsigned)m->T), dim3(256), 0, s, m->Ltab, m->Linv);
     GS_CHECK(hipGetLastError());
     m->have_linv = true;
     return 0;
 }
-
-// Windowed look-ahead schedule (one factorisation alone).  rocprofv3's timeline of the whole-panel schedule below showed
-// what bounds it: the chain D -> panel -> sibling update -> D -> panel -> look-ahead update runs every kernel over ALL
-// rows under the panel, so beside the bulk update each of them queues for CU slots (panel 44 us, sibling 55 us, look-ahead
-// 100 us at n = 8192 against 17 / 15 / 43 us alone) and the chain, not the bulk update, sets the pace from the fifth outer
-// step on.  But the NEXT diagonal blocks only need the rows just below the panel.  So the chain's stream (sp) now works on
-// a window of rows [c0, r2 + 512) only -- the current panel's rows that the next two panels' diagonal blocks and top rows
-// come from -- with kernels of at most 640 rows, and everything below the window trails on a second stream (sr):
-//   sp : D(j)  Ptop(j)  U1top  D(j+1)  Ptop(j+1)  LAtop      rows [c1, Wend),  LAtop: rows [r2, Wend) x cols [r2, r2+256)
-//   sr : Prest(j)  U1rest  Prest(j+1)  LAnew  LAfar            rows [Wend, naug); LAnew = the 256 rows that enter the next
-//                                                              step's window, LAfar = the rest of the look-ahead columns
-//   sb : bulk(s)                                               rows, cols >= r2 + 256 (lower tiles, K = 256)
-// Step s + 1's window rows [r2 + 128, r2 + 768) come from LAtop (sp order) and LAnew (event); the rest rows of step s + 1
-// follow LAfar in sr's order.  Every element still receives the same products in the same ascending order: the regions
-// are a partition of the whole-panel schedule's launches, results are bit-identical to it.
-static int gs_potrf_window(gsum_ctx* ctx, gsum_mat* m, hipStream_t sb) {
-    gs_slot* sl = ctx->cur;
-    const int T = m->T;
-    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
-    double* A = m->A;
-    // with reserved CUs the chain runs on them ALONE and the rest stream keeps off them: a small chain kernel whose
-    // workgroups land beside bulk waves shares their matrix pipe and takes 3-6x its time (rocprofv3: 20-workgroup sibling
-    // update 47 us, diagonal block 60-95 us)
-    const bool masked = sb != sl->sm && sl->sc && sl->srm;
-    hipStream_t sm = sl->sm, sp = masked ? sl->sc : sl->sp, sr = masked ? sl->srm : sl->sr;
-    const int ccfg = 1;
-    const bool fused = ctx->chain_fused > 0;            // a look-ahead schedule: only when asked for
-    auto EV = [&](int k, int which) { return sl->evW[(size_t)GS_EVW_N * k + which]; };
-    int prev = -1, pending_new = -1, pending_far = -1;
-    bool rest_used = false;
-    for (int k = 0; k < T; k += 2) {
-        const bool two = k + 1 < T;
-        const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
-        const int64_t r2 = two ? c1 + GS_NB : c1;
-        const int Kp = two ? 2 * GS_NB : GS_NB;
-        const int64_t Wend = std::min<int64_t>(r2 + 4 * GS_NB, naug), mr = naug - Wend;
-        double* Pa = A + c1 * ld + c0;
-        // ---- the chain, window rows only
-        if (two && fused) {
-            if (gs_diag256(ctx, sp, m, k)) return -1;
-            GS_CHECK(hipEventRecord(EV(k, GS_EVW_D1), sp));
-            if (pending_new >= 0) GS_CHECK(hipStreamWaitEvent(sp, EV(pending_new, GS_EVW_NEW), 0));
-            if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, Wend - r2)) return -1;
-        } else {
-            if (gs_diag(ctx, sp, m, k)) return -1;
-            GS_CHECK(hipEventRecord(EV(k, GS_EVW_D0), sp));
-            if (pending_new >= 0) GS_CHECK(hipStreamWaitEvent(sp, EV(pending_new, GS_EVW_NEW), 0));
-            if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, Wend - c1)) return -1;
-            GS_CHECK(hipEventRecord(EV(k, GS_EVW_T0), sp));
-            if (two) {
-                if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, Wend - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-                if (gs_diag(ctx, sp, m, k + 1)) return -1;
-                GS_CHECK(hipEventRecord(EV(k, GS_EVW_D1), sp));
-                if (gs_trsm_rows(ctx, sp, m, k + 1, A + r2 * ld + c1, ld, Wend - r2)) return -1;
-            }
-        }
-        GS_CHECK(hipEventRecord(EV(k, GS_EVW_T1), sp));
-        // ---- the rows below the window
-        if (mr > 0) {
-            rest_used = true;
-            double* Ra = A + Wend * ld + c0;
-            if (pending_far >= 0) GS_CHECK(hipStreamWaitEvent(sr, EV(pending_far, GS_EVW_FAR), 0));
-            if (two && fused) {
-                GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D1), 0));
-                if (gs_panel256(ctx, sr, m, k, Ra, ld, mr)) return -1;
-            } else {
-                GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D0), 0));
-                if (gs_trsm_rows(ctx, sr, m, k, Ra, ld, mr)) return -1;
-                if (two) {
-                    GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_T0), 0));
-                    if (gs_gemm(ctx, sr, ccfg, A + Wend * ld + c1, ld, Ra, ld, Pa, ld, mr, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-                    GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_D1), 0));
-                    if (gs_trsm_rows(ctx, sr, m, k + 1, A + Wend * ld + c1, ld, mr)) return -1;
-                }
-            }
-            GS_CHECK(hipStreamWaitEvent(sr, EV(k, GS_EVW_T1), 0));
-            GS_CHECK(hipEventRecord(sl->evP[k], sr));               // the whole panel of this outer step is final
-        } else {
-            GS_CHECK(hipEventRecord(sl->evP[k], sp));
-        }
-        pending_new = pending_far = -1;
-        double* P = A + r2 * ld + c0;                               // panel rows r2.., both block columns
-        if (r2 < m->np) {
-            const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2), r3 = r2 + wn, m3 = naug - r3;
-            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evM[prev], 0));
-            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, Wend - r2, wn, Kp, 0, 1, -1.0)) return -1;
-            GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
-            if (mr > 0) {
-                // the 256 rows that enter the next step's window: small, ahead of everything else on the rest stream
-                if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sr, sl->evM[prev], 0));
-                const int64_t mnew = std::min<int64_t>(2 * GS_NB, mr);
-                if (gs_gemm(ctx, sr, ccfg, A + Wend * ld + r2, ld, A + Wend * ld + c0, ld, P, ld, mnew, wn, Kp, 0, 1, -1.0)) return -1;
-                GS_CHECK(hipEventRecord(EV(k, GS_EVW_NEW), sr));
-                pending_new = k;
-                if (mr > mnew) {
-                    // the rest of the look-ahead columns: at the head of the bulk stream, where the chip has just come free
-                    const int64_t rf = Wend + mnew;
-                    if (gs_gemm(ctx, sb, ccfg, A + rf * ld + r2, ld, A + rf * ld + c0, ld, P, ld, naug - rf, wn, Kp, 0, 1, -1.0)) return -1;
-                    GS_CHECK(hipEventRecord(EV(k, GS_EVW_FAR), sb));
-                    pending_far = k;
-                }
-            }
-            double* P3 = A + r3 * ld + c0;
-            if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
-            GS_CHECK(hipEventRecord(sl->evM[k], sb));
-            prev = k;
-        } else {
-            // last panel: only the 16x16 corner (the Gram matrix) is left
-            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
-            if (sb != sm && prev >= 0) GS_CHECK(hipStreamWaitEvent(sm, sl->evM[prev], 0));
-            if (rest_used) {
-                GS_CHECK(hipEventRecord(sl->evR, sr));
-                GS_CHECK(hipStreamWaitEvent(sm, sl->evR, 0));
-            }
-            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, naug - r2, naug - r2, Kp, 1, 1, -1.0)) return -1;
-        }
-    }
-    m->factored = true;
-    return 0;
-}
-
 
 // ---- persistent-chain schedule (see k_chain) ------------------------------------------------------------------------
 // Do kernels of two streams of this process run side by side?  The chain kernel waits for flags that host-enqueued kernels
@@ -835,7 +583,7 @@ static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
 }
 
 static bool gs_chain_wanted(const gsum_ctx* ctx, const gsum_mat* m) {
-    if (ctx->chain_persist == 0 || ctx->chain_events_needed || !m->have_ltab || ctx->bulk_cfg != 7) return false;
+    if (ctx->chain_persist == 0 || ctx->chain_events_needed) return false;
     if (m->T < 4 || (m->T & 1)) return false;
     return ctx->chain_persist > 0 || m->np >= ctx->chain_min_np;
 }
@@ -863,7 +611,8 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     std::vector<Plan> plan((size_t)S, Plan{0, 0u});
     const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
     const bool near256 = lazy && ctx->chain_lazy != 1;        // 2 / auto: only the next-but-one panel's 256 columns are "near" (the batch schedule's lazy_far = 2)
-    const int NB = lazy ? 1 : std::max(1, std::min(4, ctx->chain_bands));
+    const int NB = 1;                 // (row bands of the trailing update on streams of their own were measured in round 3 and removed in round 4:
+                                      //  2 / 3 / 4 bands 5.84 / 5.87 / 6.79 ms against 5.45 with one at n = 8192)
     int64_t bound[6];
     bound[0] = 0;
     for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
@@ -960,15 +709,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // of step s is done, whatever the other bands do: the launches of one step no longer end at a chip-wide barrier, and one
     // band's tail overlaps another's bulk -- what sixteen evaluations in flight do for a batch (52 TF/s of Cholesky flops there
     // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
-    hipStream_t sbd[4] = {sm, nullptr, nullptr, nullptr};
-    for (int p = 1; p < NB; ++p) {
-        if (!sl->sband[p]) {
-            GS_CHECK(hipStreamCreateWithPriority(&sl->sband[p], hipStreamNonBlocking, ctx->prio_lo));
-            GS_CHECK(hipEventCreateWithFlags(&sl->evBand[p], hipEventDisableTiming));
-        }
-        sbd[p] = sl->sband[p];
-        GS_CHECK(hipStreamWaitEvent(sbd[p], sl->evFork, 0));
-    }
+    hipStream_t sbd[1] = {sm};
     for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
         const int k = 2 * s;
         const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
@@ -1045,10 +786,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             }
         }
     }
-    for (int p = 1; p < NB; ++p) {
-        GS_CHECK(hipEventRecord(sl->evBand[p], sbd[p]));
-        GS_CHECK(hipStreamWaitEvent(sm, sl->evBand[p], 0));
-    }
     GS_CHECK(hipEventRecord(sl->evC, sp));
     GS_CHECK(hipEventRecord(sl->evS, sa));
     GS_CHECK(hipStreamWaitEvent(sm, sl->evC, 0));
@@ -1064,8 +801,8 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     const int T = m->T;
     gs_slot* sl = ctx->cur;
     if (gs_potrf_events(ctx, sl, T)) return -1;
-    m->have_linv = ctx->diag_algo == 1;        // round-1 kernel: explicit inverses, TRSM as a product with them
-    m->have_ltab = !m->have_linv;              // round-2 kernel: substitution tables, TRSM by blocked substitution
+    m->have_linv = false;                      // (explicit block inverses: built on demand, gs_need_linv)
+    m->have_ltab = true;
     m->solved_k = -1;
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;
     double* A = m->A;
@@ -1078,10 +815,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     GS_CHECK(hipGetLastError());
     // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
     // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
-    // Only slot 0 ever runs a look-ahead schedule.  Those schedules create streams of their own (panel chain, near updates, row bands), and the HIP
-    // runtime stops running a process's streams side by side somewhere between 22 and 24 of them (tools/gpu_slots_sweep.py: 20 fine, 24 collapses):
-    // a call of exactly TWO evaluations used to give slot 1 its own set -- 24 streams with the 20 slot streams -- after which every later batch of the
-    // process ran 5-6 times slower (94 instead of 15 ms for 64 evaluations at n = 2048), and two persistent chains side by side were slow themselves.
+    // Only slot 0 ever runs a look-ahead schedule (the gradient batch's other slots run everything on their one stream).
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3 && sl == &ctx->slots[0];
     ctx->bulk_pad_now = false;
     if (la && gs_panel_stream(ctx, sl)) return -1;
@@ -1093,23 +827,8 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm, sb = sl->sm;
     if (la) {
-        if (gs_bulk_stream(ctx, sl, m->np, &sb)) return -1;
         GS_CHECK(hipEventRecord(sl->evFork, sm));
         GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
-        if (sb != sm) GS_CHECK(hipStreamWaitEvent(sb, sl->evFork, 0));
-        if (ctx->la_split > 0 || (ctx->chain_window && m->have_ltab)) {
-            if (gs_window_streams(ctx, sl, T)) return -1;
-            GS_CHECK(hipStreamWaitEvent(sl->sr, sl->evFork, 0));
-        }
-        if (ctx->chain_window && m->have_ltab) {
-            if (gs_window_streams(ctx, sl, T)) return -1;
-            GS_CHECK(hipStreamWaitEvent(sl->sr, sl->evFork, 0));
-            if (sl->sc && sb != sm) {
-                GS_CHECK(hipStreamWaitEvent(sl->sc, sl->evFork, 0));
-                GS_CHECK(hipStreamWaitEvent(sl->srm, sl->evFork, 0));
-            }
-            return gs_potrf_window(ctx, m, sb);
-        }
     }
     // panel GEMMs (TRSM against the block inverse, sibling column) stay on the low-latency 32x128 tile in every mode.
     // (In a batch the LDS-direct 128x128 tile is 1 % cheaper overall, but then one kernel symbol would serve two
@@ -1118,23 +837,19 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
     bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
-    int pending_lr = -1;                             // outer step whose split look-ahead update (rest part) is in flight
     for (int k = 0; k < T; k += 2) {
         const bool two = k + 1 < T;
         const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
         const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
         const int Kp = two ? 2 * GS_NB : GS_NB;
         double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
-        if (two && m->have_ltab && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && ctx->batch_active >= 3))) {
+        if (two && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && ctx->batch_active >= 3))) {
             // both diagonal blocks in one launch, then both panels of the rows below in one
             if (gs_diag256(ctx, sp, m, k)) return -1;
-            if (pending_lr >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evW[(size_t)GS_EVW_N * pending_lr + GS_EVW_FAR], 0));
             if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
         } else {
             // ---- sub-step a
             if (gs_diag(ctx, sp, m, k)) return -1;
-            // (split look-ahead update, below: the diagonal block only needed its own 128 x 128 piece)
-            if (pending_lr >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evW[(size_t)GS_EVW_N * pending_lr + GS_EVW_FAR], 0));
             if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
             if (two) {
                 // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
@@ -1189,24 +904,11 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
             continue;
         }
         GS_CHECK(hipEventRecord(sl->evP[k], sp));
-        pending_lr = -1;
         if (r2 < m->np) {
             const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
             // look-ahead columns: need the previous bulk update to have finished with THEM (evA: see below)
             if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evA[prev], 0));
-            if (ctx->la_split > 0 && mrest >= ctx->la_split && wn == 2 * GS_NB && sl->sr) {
-                // Split: the next diagonal block needs only ITS 128 x 128 piece of this update -- on the chain's stream,
-                // four workgroups -- and the rest (all rows below, both block columns; the piece above the diagonal is never
-                // read) goes to a second stream beside the diagonal block; the next panel solve waits for it.  While the
-                // trailing matrix is large this update is 0.3-1 GF and took 60-90 us on the chain beside the bulk update.
-                if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, GS_NB, GS_NB, Kp, 0, 1, -1.0)) return -1;
-                hipStream_t sq = sl->sr;
-                GS_CHECK(hipStreamWaitEvent(sq, sl->evP[k], 0));
-                if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sq, sl->evA[prev], 0));
-                if (gs_gemm(ctx, sq, ccfg, A + (r2 + GS_NB) * ld + r2, ld, P + GS_NB * ld, ld, P, ld, mrest - GS_NB, wn, Kp, 0, 1, -1.0)) return -1;
-                GS_CHECK(hipEventRecord(sl->evW[(size_t)GS_EVW_N * k + GS_EVW_FAR], sq));
-                pending_lr = k;
-            } else if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
             const int64_t r3 = r2 + wn, m3 = naug - r3;
             double* P3 = A + r3 * ld + c0;
             GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
@@ -1231,7 +933,6 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
         } else {
             // last panel: only the 16x16 corner (the Gram matrix) is left
             GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
-            if (sb != sm && prev >= 0) GS_CHECK(hipStreamWaitEvent(sm, sl->evM[prev], 0));
             if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
         }
     }
@@ -1305,12 +1006,6 @@ int gsum_init(int device, gsum_ctx** out) {
     (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
-    const char* cf = getenv("GSUM_CHAIN_FUSED");
-    if (cf) ctx->chain_fused = atoi(cf) < 0 ? -1 : (atoi(cf) != 0);
-    const char* cw = getenv("GSUM_CHAIN_WINDOW");
-    if (cw) ctx->chain_window = atoi(cw) != 0;
-    const char* bp = getenv("GSUM_BULK_LDS_PAD");
-    if (bp) ctx->bulk_lds_pad = std::max(0, std::min(80 * 1024, atoi(bp)));
     const char* pg = getenv("GSUM_PIVOT_GUARD_ULPS");
     if (pg) {
         const double g = (double)std::max(0, std::min(1024, atoi(pg))) * 2.220446049250313e-16;
@@ -1318,8 +1013,6 @@ int gsum_init(int device, gsum_ctx** out) {
     }
     const char* cp = getenv("GSUM_CHAIN_PERSIST");
     if (cp) ctx->chain_persist = atoi(cp) < 0 ? -1 : (atoi(cp) != 0);
-    const char* rc = getenv("GSUM_RESERVE_CUS");
-    if (rc) ctx->reserve_cus = std::max(-1, std::min(8, atoi(rc)));
     *out = ctx;
     return 0;
 }
@@ -1342,18 +1035,8 @@ void gsum_destroy(gsum_ctx* ctx) {
             if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
         if (sl->sm) (void)hipStreamDestroy(sl->sm);
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
-        if (sl->sr) (void)hipStreamDestroy(sl->sr);
-        for (auto ev : sl->evW) (void)hipEventDestroy(ev);
-        if (sl->evR) (void)hipEventDestroy(sl->evR);
-        if (sl->sb) (void)hipStreamDestroy(sl->sb);
-        if (sl->sc) (void)hipStreamDestroy(sl->sc);
-        if (sl->srm) (void)hipStreamDestroy(sl->srm);
         if (sl->su) (void)hipStreamDestroy(sl->su);
         if (sl->evU) (void)hipEventDestroy(sl->evU);
-        for (int q = 0; q < 4; ++q) {
-            if (sl->sband[q]) (void)hipStreamDestroy(sl->sband[q]);
-            if (sl->evBand[q]) (void)hipEventDestroy(sl->evBand[q]);
-        }
         if (sl->gws) (void)hipFree(sl->gws);
         if (sl->hgrad) (void)hipHostFree(sl->hgrad);
         if (sl->sa) (void)hipStreamDestroy(sl->sa);
@@ -1378,22 +1061,29 @@ const char* gsum_last_error(gsum_ctx* ctx) { return ctx ? ctx->err.c_str() : g_i
 
 int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!ctx || !name) return -1;
-    if (!strcmp(name, "batch_slots")) return ctx->batch_slots;
+    // ---- the contract (include/gsum_hip.h)
     if (!strcmp(name, "wave_streams")) return ctx->wave_last_streams;     // streams the last batch call used (groups + 1; 0: none yet)
+    if (!strcmp(name, "wave_groups")) return ctx->wave_groups;
+    if (!strcmp(name, "wave_size")) return ctx->wave_size;
+    if (!strcmp(name, "lookahead")) return ctx->lookahead;
+    if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
+    if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
+    if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
+    if (!strcmp(name, "profile_gemm")) return ctx->profile_gemm;
+    if (!strcmp(name, "small_path")) return ctx->small_path;
+    if (!strcmp(name, "medium_path")) return ctx->medium_path;
+    if (!strcmp(name, "medium_min_batch")) return ctx->medium_min_batch;
+#ifdef GSUM_LAB
+    // ---- the lab (include/gsum_hip_debug.h)
+    if (!strcmp(name, "batch_slots")) return ctx->batch_slots;
     if (!strcmp(name, "wave_depth")) return ctx->wave_depth;
     if (!strcmp(name, "wave_deep_rows")) return ctx->wave_deep_rows;
     if (!strcmp(name, "wave_near_on_chain")) return ctx->wave_near_on_chain;
     if (!strcmp(name, "wave_serial")) return ctx->wave_serial;
-    if (!strcmp(name, "wave_groups")) return ctx->wave_groups;
-    if (!strcmp(name, "wave_size")) return ctx->wave_size;
     if (!strcmp(name, "wave_shift")) return ctx->wave_shift;
     if (!strcmp(name, "wave_min")) return ctx->wave_min;
-    if (!strcmp(name, "lookahead")) return ctx->lookahead;
-    if (!strcmp(name, "bulk_cfg")) return ctx->bulk_cfg;
-    if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
-    if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
-    if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
     if (!strcmp(name, "chain_rows")) return ctx->chain_rows;
+    if (!strcmp(name, "lazy_far")) return ctx->lazy_far;
     if (!strcmp(name, "panel_wave_ticks") || !strcmp(name, "panel_waves")) {         // read-back of option panel_stats (synchronises)
         if (!ctx->panel_stats) return -1;
         unsigned long long h[2] = {0, 0};
@@ -1401,37 +1091,15 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
             hipMemcpy(h, ctx->panel_stats, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return (int64_t)h[!strcmp(name, "panel_wave_ticks") ? 0 : 1];
     }
+#endif
     return -1;
 }
 
-int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
-    if (!ctx || !name) return -2;
-    if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
-    else if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
-    else if (!strcmp(name, "profile_gemm")) {
-        ctx->profile_gemm = (int)std::max<int64_t>(0, value);
-        ctx->prof_eval_count = 0;
-        ctx->prof_this_eval = true;
-    }
+#ifdef GSUM_LAB
+// the lab's switches (include/gsum_hip_debug.h): schedule variants and diagnostics, all bit-identical in results
+static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
+    if (!strcmp(name, "build_lower_only")) ctx->build_lower_only = (int)value;
     else if (!strcmp(name, "diag_stamps")) ctx->diag_stamps = (int)value;
-    else if (!strcmp(name, "stagger")) ctx->stagger = (int)value;
-    else if (!strcmp(name, "release_scratch")) {
-        // hand the grown work buffers back (the medium path keeps up to 40 GB, the gradient path 2 n^2 doubles)
-        GS_CHECK(hipSetDevice(ctx->device));
-        GS_CHECK(hipDeviceSynchronize());
-        if (ctx->scratch) GS_CHECK(hipFree(ctx->scratch));
-        if (ctx->gws) GS_CHECK(hipFree(ctx->gws));
-        ctx->scratch = ctx->gws = nullptr;
-        ctx->scratch_cap = ctx->gws_cap = 0;
-        gs_wave_release(ctx, false);                           // the groups' workspaces (their streams stay)
-        for (int i = 0; i < ctx->n_slots_ready; ++i) {         // and the per-slot workspace matrices of the fused path
-            gs_mat_release(ctx->slots[i].ws);
-            ctx->slots[i].ws = nullptr;
-            if (ctx->slots[i].gws) GS_CHECK(hipFree(ctx->slots[i].gws));      // ... and gradient buffers (3 n^2 doubles each)
-            ctx->slots[i].gws = nullptr;
-            ctx->slots[i].gws_cap = 0;
-        }
-    }
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "predict_lazy")) ctx->predict_lazy = value != 0;
     else if (!strcmp(name, "medium_lazy")) {            // (process-wide: a __device__ variable of the code object)
@@ -1449,37 +1117,16 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         if (value) GS_CHECK(hipMemset(ctx->panel_stats, 0, 2 * sizeof(unsigned long long)));
         if (!value && ctx->panel_stats) { (void)hipFree(ctx->panel_stats); ctx->panel_stats = nullptr; }
     }
-    else if (!strcmp(name, "bulk_stages")) ctx->bulk_stages = value == 3 ? 3 : 2;
-    else if (!strcmp(name, "diag_algo")) ctx->diag_algo = value == 1 ? 1 : 2;
-    else if (!strcmp(name, "build_algo")) ctx->build_algo = value == 1 ? 1 : 2;
     else if (!strcmp(name, "bulk_lds_pad")) ctx->bulk_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(80 * 1024, value));
-    else if (!strcmp(name, "bulk_cfg")) ctx->bulk_cfg = (value == 5 || value == 6) ? (int)value : 7;
-    else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
-    else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
-    else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
-    else if (!strcmp(name, "bulk_pad_below")) ctx->bulk_pad_below = (int)std::max<int64_t>(0, value);
-    else if (!strcmp(name, "chain_window")) ctx->chain_window = value != 0;
     else if (!strcmp(name, "chain_fused")) ctx->chain_fused = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "la_depth2")) ctx->la_depth2 = value != 0;
-    else if (!strcmp(name, "la_split")) ctx->la_split = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_prefetch")) ctx->chain_prefetch = value != 0;
-    else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
     else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value < 0 ? -1 : (int)std::min<int64_t>(2, value);
     else if (!strcmp(name, "chain_test_abort")) ctx->chain_test_abort = (int)std::max<int64_t>(0, value);
-    else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
-        const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
-        GS_CHECK(hipSetDevice(ctx->device));
-        GS_CHECK(hipDeviceSynchronize());
-        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_pivot_guard), &g, sizeof g));
-    }
-    else if (!strcmp(name, "chain_bands")) ctx->chain_bands = (int)std::max<int64_t>(1, std::min<int64_t>(4, value));
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
-    else if (!strcmp(name, "reserve_cus")) ctx->reserve_cus = (int)std::max<int64_t>(-1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
-    else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_GROUPS, value));
-    else if (!strcmp(name, "wave_size")) ctx->wave_size = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WVC_MAX, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
@@ -1487,6 +1134,54 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "wave_depth")) ctx->wave_depth = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "wave_deep_rows")) ctx->wave_deep_rows = (int)std::max<int64_t>(0, value);
     else GS_FAIL(std::string("unknown option: ") + name);
+    return 0;
+}
+#endif
+
+int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return -2;
+    if (!strcmp(name, "lookahead")) ctx->lookahead = (int)value;
+    else if (!strcmp(name, "profile_gemm")) {
+        ctx->profile_gemm = (int)std::max<int64_t>(0, value);
+        ctx->prof_eval_count = 0;
+        ctx->prof_this_eval = true;
+    }
+    else if (!strcmp(name, "release_scratch")) {
+        // hand the grown work buffers back (the medium path keeps up to 40 GB, the gradient path 2 n^2 doubles)
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        if (ctx->scratch) GS_CHECK(hipFree(ctx->scratch));
+        if (ctx->gws) GS_CHECK(hipFree(ctx->gws));
+        ctx->scratch = ctx->gws = nullptr;
+        ctx->scratch_cap = ctx->gws_cap = 0;
+        gs_wave_release(ctx, false);                           // the groups' workspaces (their streams stay)
+        for (int i = 0; i < ctx->n_slots_ready; ++i) {         // and the per-slot workspace matrices of the fused path
+            gs_mat_release(ctx->slots[i].ws);
+            ctx->slots[i].ws = nullptr;
+            if (ctx->slots[i].gws) GS_CHECK(hipFree(ctx->slots[i].gws));      // ... and gradient buffers (3 n^2 doubles each)
+            ctx->slots[i].gws = nullptr;
+            ctx->slots[i].gws_cap = 0;
+        }
+    }
+    else if (!strcmp(name, "small_path")) ctx->small_path = (int)value;
+    else if (!strcmp(name, "medium_path")) ctx->medium_path = (int)value;
+    else if (!strcmp(name, "medium_min_batch")) ctx->medium_min_batch = value > 0 ? (int)value : -1;
+    else if (!strcmp(name, "chain_persist")) ctx->chain_persist = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(name, "pivot_guard_ulps")) {        // (process-wide: a __device__ variable of the code object)
+        const double g = (double)std::max<int64_t>(0, std::min<int64_t>(1024, value)) * 2.220446049250313e-16;
+        GS_CHECK(hipSetDevice(ctx->device));
+        GS_CHECK(hipDeviceSynchronize());
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_pivot_guard), &g, sizeof g));
+    }
+    else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_GROUPS, value));
+    else if (!strcmp(name, "wave_size")) ctx->wave_size = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WVC_MAX, value));
+    else {
+#ifdef GSUM_LAB
+        return gs_set_option_lab(ctx, name, value);
+#else
+        GS_FAIL(std::string("unknown option: ") + name + " (schedule experiments and diagnostics live in libgsum_hip_lab.so)");
+#endif
+    }
     return 0;
 }
 
@@ -2379,11 +2074,11 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    if (n_kernels >= ctx->wave_min && ctx->diag_algo == 2 && ctx->bulk_cfg == 7 && ctx->build_algo == 2) {
+    if (n_kernels >= ctx->wave_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_wave(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    // one or two evaluations (or a non-default kernel generation under test): one after the other, each with the schedule of a
+    // one or two evaluations: one after the other, each with the schedule of a
     // single factorisation (look-ahead / persistent chain) on the context's own streams
     gs_slot* sl = &ctx->slots[0];
     ctx->cur = sl;
@@ -2635,6 +2330,7 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
     return 0;
 }
 
+#ifdef GSUM_LAB
 // Realtime stamps (100 MHz ticks, relative to the first) of the last persistent-chain factorisation on slot 0's workspace
 // (option "chain_stamps" = 1): GS_CH_STAMPS = 16 per outer step -- D role 0 step begins, 1 its diagonal block is up to date,
 // 2 T0 set, 3 block row k + 1 up to date, 4 TL set, 5 sibling update done, 6 T1 set; P wave 0: 8 rows ready, 9 T0 seen,
@@ -2673,6 +2369,8 @@ int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64) {
     return 0;
 }
 
+#endif  // GSUM_LAB
+
 int gsum_kernel_profile(gsum_ctx* ctx, double* ms5, double* flops5, int64_t* launches5) {
     if (!ctx || !ms5 || !flops5 || !launches5) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
@@ -2693,18 +2391,7 @@ int gsum_kernel_profile(gsum_ctx* ctx, double* ms5, double* flops5, int64_t* lau
     return 0;
 }
 
-int gsum_gemm_profile(gsum_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
-    if (!ctx || !total_ms || !total_flops || !launches) return -2;
-    double ms5[GS_PROF_CLASSES], fl5[GS_PROF_CLASSES];
-    int64_t n5[GS_PROF_CLASSES];
-    const int rc = gsum_kernel_profile(ctx, ms5, fl5, n5);
-    if (rc) return rc;
-    *total_ms = ms5[GS_PROF_BULK];
-    *total_flops = fl5[GS_PROF_BULK];
-    *launches = n5[GS_PROF_BULK];
-    return 0;
-}
-
+#ifdef GSUM_LAB
 int gsum_probe_mfma_f64(gsum_ctx* ctx, int32_t iters, int32_t waves_per_simd, int32_t n_acc, double* out3) {
     if (!ctx || !out3 || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
@@ -2760,55 +2447,6 @@ int gsum_probe_hbm_write(gsum_ctx* ctx, int64_t bytes, double* gbps) {
     float ms = 0.f;
     GS_CHECK(hipEventElapsedTime(&ms, ctx->cur->tev[0], ctx->cur->tev[1]));
     *gbps = (double)(nvec * 16) / (ms * 1e-3) / 1e9;
-    return 0;
-}
-
-// diagnostic: placement of nblocks workgroups launched on a stream restricted by a CU mask (nwords = 0: no mask)
-int gsum_probe_cu_mask(gsum_ctx* ctx, const uint32_t* mask, int32_t nwords, int32_t nblocks, int64_t* out) {
-    if (!ctx || !out || nblocks <= 0 || nwords < 0 || (nwords > 0 && !mask)) return -2;
-    GS_CHECK(hipSetDevice(ctx->device));
-    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)nblocks * 16)) return -1;
-    hipStream_t s = nullptr;
-    if (nwords > 0) GS_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask));
-    else GS_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    hipLaunchKernelGGL(k_probe_where, dim3((unsigned)nblocks), dim3(256), 0, s, (long long*)ctx->scratch, 20000);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = hipMemcpy(out, ctx->scratch, (size_t)nblocks * 16, hipMemcpyDeviceToHost);
-    (void)hipStreamDestroy(s);
-    GS_CHECK(e);
-    return 0;
-}
-
-// diagnostic: phase stamps of the 128x128-tile kernel on a square SYRK launch; out5 = mean shader cycles per
-// wave spent in {prologue, load issue, MFMA+fragment reads, vmcnt wait + LDS stores, barrier}
-int gsum_debug_gemm_phases(gsum_ctx* ctx, int64_t M, int64_t K, int64_t lda, double* out5) {
-    if (!ctx || !out5 || M <= 0 || K <= 0 || lda < K) return -2;
-    GS_CHECK(hipSetDevice(ctx->device));
-    const int64_t T = (M + 127) / 128, blocks = T * (T + 1) / 2;
-    const size_t cb = (size_t)M * M * 8, ab = (size_t)M * lda * 8, sb = (size_t)blocks * 4 * 5 * 8;
-    const size_t oa = (cb + 255) / 256 * 256, os = oa + (ab + 255) / 256 * 256;
-    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, os + sb)) return -1;
-    char* base = (char*)ctx->scratch;
-    double *dC = (double*)base, *dA = (double*)(base + oa);
-    unsigned long long* dS = (unsigned long long*)(base + os);
-    hipStream_t s = ctx->cur->sm;
-    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dC, (int64_t)(cb / 8), 1u);
-    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, dA, (int64_t)(ab / 8), 2u);
-    auto kern = k_gemm_nt<4, 4, 2, 2, true>;
-    const size_t shmem = 2 * (size_t)256 * GS_LSTR * sizeof(double);
-    GS_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    for (int rep = 0; rep < 2; ++rep)
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, s, dC, M, dA, lda, dA, lda, (int)M, (int)M, (int)K, 1, 1,
-                           -1.0, dS, 0);
-    GS_CHECK(hipGetLastError());
-    std::vector<unsigned long long> h((size_t)blocks * 20);
-    GS_CHECK(hipMemcpyAsync(h.data(), dS, sb, hipMemcpyDeviceToHost, s));
-    GS_CHECK(hipStreamSynchronize(s));
-    for (int i = 0; i < 5; ++i) out5[i] = 0.0;
-    for (size_t wv = 0; wv < (size_t)blocks * 4; ++wv)
-        for (int i = 0; i < 5; ++i) out5[i] += (double)h[wv * 5 + i];
-    for (int i = 0; i < 5; ++i) out5[i] /= (double)(blocks * 4);
     return 0;
 }
 
@@ -2884,5 +2522,7 @@ int gsum_debug_gemm_nt(gsum_ctx* ctx, int32_t cfg, int32_t tri, double* C, const
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
 }
+
+#endif  // GSUM_LAB
 
 }  // extern "C"

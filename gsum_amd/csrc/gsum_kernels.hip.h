@@ -1,10 +1,10 @@
 // Device kernels of libgsum_hip.so — written for gfx950 (MI355X, CDNA4) only.
 //
-//   k_build        pairwise-distance + RBF/Matern kernel matrix   (HBM-store bound)
+//   k_build2       pairwise-distance + RBF/Matern kernel matrix   (HBM-store bound)
 //   k_set_border   RHS^T -> border rows of the augmented matrix
-//   k_potrf_diag   128x128 diagonal block: Cholesky + inverse, in registers
+//   k_potrf_diag[256]  128x128 diagonal block(s): Cholesky + substitution tables, micro-blocks in MFMA accumulator registers
 //   k_gemm_ld3     C (+)= s * A * B^T on v_mfma_f64_16x16x4_f64, 128x64 tiles, operands staged global -> LDS directly,
-//                  three workgroups per CU: the bulk trailing update   (fp64 MFMA bound; k_gemm_ld: 128x128 variant)
+//                  three workgroups per CU: the bulk trailing update   (fp64 MFMA bound); k_gemm_ld3g: one launch for a group of evaluations
 //   k_gemm_nt      the same product with register staging: panel TRSM / sibling / border tiles (32x128, 16x256) and the
 //                  earlier bulk tiles
 //   k_lml_small, k_lml_medium   whole evaluations in one workgroup (n <= 128; 128 < n <= 4096 on HBM-resident matrices)
@@ -114,86 +114,6 @@ __device__ __forceinline__ double gs_base_value(int family, double s) {
     return gs_exp_np(-dist);
 }
 
-// One 128x128 tile per 256-thread workgroup.  Each lane owns two adjacent columns (one 16-B store per
-// row), each wave strides over the tile's rows: every store instruction writes 1 KiB of one row.
-// CROSS=false: symmetric one-argument form into the (identity-padded) square matrix; tri!=0 builds
-// only tiles on or below the diagonal.  CROSS=true: rectangular k(X, Y), no diagonal terms.
-template <bool CROSS>
-__global__ __launch_bounds__(256) void k_build(double* out, int64_t ldo, const double* X, const double* Y,
-                                                int n, int m, int prow, int pcol, int d,
-                                                gsum_kernel_desc desc, double diag_add, int tri) {
-#pragma clang fp contract(off)
-    __shared__ double ui[128 * GSUM_MAX_D];
-    __shared__ double uj[128 * GSUM_MAX_D];
-    const int t = threadIdx.x;
-    int bi, bj;
-    if (tri) {
-        int bid = blockIdx.x;
-        bi = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bi + 1) * (bi + 2) / 2 <= bid) ++bi;
-        while ((int64_t)bi * (bi + 1) / 2 > bid) --bi;
-        bj = bid - (int)((int64_t)bi * (bi + 1) / 2);
-    } else {
-        int tr = (prow + 127) / 128;
-        bi = blockIdx.x % tr;
-        bj = blockIdx.x / tr;
-    }
-    const double* Yp = CROSS ? Y : X;
-    const int ny = CROSS ? m : n;
-    for (int idx = t; idx < 128 * d; idx += 256) {
-        int r = idx / d, dd = idx - r * d;
-        double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
-        int gi = bi * 128 + r, gj = bj * 128 + r;
-        ui[idx] = gi < n ? X[(int64_t)gi * d + dd] / ls : 0.0;
-        uj[idx] = gj < ny ? Yp[(int64_t)gj * d + dd] / ls : 0.0;
-    }
-    __syncthreads();
-    const int lane = t & 63, w = t >> 6;
-    const int gj0 = bj * 128 + 2 * lane;
-    double vj0[GSUM_MAX_D], vj1[GSUM_MAX_D];
-#pragma unroll
-    for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-        vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
-        vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
-    }
-    if (gj0 >= pcol) return;
-    for (int rr = w; rr < 128; rr += 4) {
-        const int gi = bi * 128 + rr;
-        if (gi >= prow) break;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-            if (dd < d) {
-                double xi = ui[rr * d + dd];
-                double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
-                s0 = s0 + e0 * e0;
-                s1 = s1 + e1 * e1;
-            }
-        }
-        double v[2];
-        const double s[2] = {s0, s1};
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int gj = gj0 + c;
-            double val;
-            if (CROSS) {
-                val = (gi < n && gj < m) ? desc.amplitude * gs_base_value(desc.family, s[c]) + desc.additive_const : 0.0;
-            } else if (gi >= n || gj >= n) {
-                val = (gi == gj) ? 1.0 : 0.0;                 // identity padding up to a multiple of 128
-            } else {
-                const bool dg = gi == gj;
-                double b = dg ? 1.0 : gs_base_value(desc.family, s[c]);   // np.fill_diagonal(K, 1)
-                val = desc.amplitude * b;
-                if (dg) val = val + desc.white_noise;
-                val = val + desc.additive_const;
-                if (dg) val = val + diag_add;
-            }
-            v[c] = val;
-        }
-        gs_d2 o = {v[0], v[1]};
-        *reinterpret_cast<gs_d2*>(out + (int64_t)gi * ldo + gj0) = o;
-    }
-}
 
 // ---- second version of the kernel build (round 2) ---------------------------------------------------------------
 // The first version was bound by instruction issue, not by HBM: a runtime switch over the kernel family and a runtime
@@ -596,28 +516,9 @@ __global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2a: diagonal block (128x128), one workgroup, two phases.
-//
-// Phase 1 — unblocked right-looking Cholesky with the block held ENTIRELY IN REGISTERS: 2-D cyclic
-// 16x16 thread grid, thread (tr, tc) owns element (tr, tc) of each of the 36 lower 16x16 sub-blocks.
-// One barrier per TWO columns: the unscaled columns go through a double-buffered LDS mailbox whose layout
-// is permuted (row i at (i & 15) * 10 + (i >> 4)) so that every thread fetches its 8 row values and its 8
-// column values with four conflict-free ds_read_b128 each.  1/sqrt(pivot) comes from v_rsq_f64 + two Newton steps (a
-// 90-cycle dependent chain instead of ~250 for sqrt + divide); masks are needed only inside the active
-// sub-block.  The inverses of the eight 16x16 DIAGONAL sub-blocks are built alongside by forward
-// elimination on an identity (one extra fma per thread per column).
-// LAPACK dpotf2 semantics: pivot <= 0 or NaN -> info.  One addition: a pivot that has lost every
-// significant bit (p <= 8 eps * original A_jj) also counts as not positive.  On an exactly singular
-// matrix (duplicated points, nugget 0) the sign of such a pivot is rounding noise that depends on the
-// summation order; LAPACK's order happens to give <= 0 on the reference's case (tests/golden nonpd), a
-// right-looking order gives +1e-17.  The threshold makes the outcome the mathematically right one.
-//
-// Phase 2 — L^-1 on the matrix cores.  Block column j of the inverse depends only on L and the diagonal
-// inverses:  X_jj = D_j^-1,  X_ij = -D_i^-1 * sum_{p=j}^{i-1} L_ip X_pj.  Wave w owns block columns w and
-// 7-w (140..92 MFMAs each way) and keeps them in registers: the accumulator layout of
-// v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 reg) IS its B-operand layout for k-step
-// reg, so X_pj feeds the next product with no data movement; L_ip is read as the A operand from an LDS copy
-// of the factor that phase 1 leaves behind.  No barrier inside phase 2.
+// K2a: diagonal block (128x128), one workgroup.  (The round-1 routine -- the block in the registers of a 16 x 16 thread grid, an
+// LDS mailbox round trip per two columns, the explicit 128 x 128 inverse -- was removed in round 4; gs_diag_block below is what runs.)
+// LAPACK dpotf2 semantics: pivot <= 0 or NaN -> info, plus the guard of gs_pivot_guard (top of this file).
 // ------------------------------------------------------------------------------------------------
 #define GS_DV_STR 17     // padded row stride of the 16x16 diagonal inverses in LDS
 
@@ -632,262 +533,7 @@ __device__ __forceinline__ double gs_rsqrt_nr(double p) {
     return r;
 }
 
-#define GS_MB_STR 10     // mailbox: row i of a column lives at (i & 15) * 10 + (i >> 4): 16-B aligned groups of 8,
-                         // 80-B group stride -> the four ds_read_b128 of a thread are bank-conflict free
-#define GS_MB_SIZE (16 * GS_MB_STR)
-
-// Columns j0 = 16 JB + jr and j0 + 1 per barrier.  Every thread receives both (unscaled) columns, scales
-// column j0, applies it to column j0 + 1 itself (8 + 8 extra fmas), scales that, and performs the rank-2
-// update of its 36 sub-block entries.  One LDS round trip and one barrier per TWO columns.
-template <int JB>
-__device__ __forceinline__ bool gs_diag_steps(double (&a)[8][8], double (&vd)[8], double* mail, double* rmail,
-                                              double* dbuf, const double* thr, int tr, int tc, int* fail_col) {
-    for (int jr = 0; jr < 16; jr += 2) {
-        const int j0 = JB * 16 + jr, j1 = j0 + 1;
-        const int buf = (jr >> 1) & 1;
-        double* cA = mail + buf * 2 * GS_MB_SIZE;
-        double* cB = cA + GS_MB_SIZE;
-        double* rA = rmail + buf * 32;
-        double* rB = rA + 16;
-        if (tc == jr) {
-#pragma unroll
-            for (int ii = JB; ii < 8; ++ii) cA[tr * GS_MB_STR + ii] = a[ii][JB];
-        }
-        if (tc == jr + 1) {
-#pragma unroll
-            for (int ii = JB; ii < 8; ++ii) cB[tr * GS_MB_STR + ii] = a[ii][JB];
-        }
-        if (tr == jr) rA[tc] = vd[JB];
-        if (tr == jr + 1) rB[tc] = vd[JB];
-        __syncthreads();
-        // every LDS read of the step is issued before the dependent rsqrt chains start
-        const double p0 = cA[jr * GS_MB_STR + JB];               // A[j0][j0]
-        const double a10 = cA[(jr + 1) * GS_MB_STR + JB];        // A[j1][j0]
-        const double p1raw = cB[(jr + 1) * GS_MB_STR + JB];      // A[j1][j1], before column j0 is applied
-        const double t0 = thr[j0], t1 = thr[j1];
-        const double rAv = rA[tc], rBv = rB[tc];
-        double ar[8], ac[8], br[8], bc[8];
-        {
-            const gs_d2* q0 = reinterpret_cast<const gs_d2*>(cA + tr * GS_MB_STR);
-            const gs_d2* q1 = reinterpret_cast<const gs_d2*>(cA + tc * GS_MB_STR);
-            const gs_d2* q2 = reinterpret_cast<const gs_d2*>(cB + tr * GS_MB_STR);
-            const gs_d2* q3 = reinterpret_cast<const gs_d2*>(cB + tc * GS_MB_STR);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const gs_d2 x0 = q0[q], x1 = q1[q], x2 = q2[q], x3 = q3[q];
-                ar[2 * q] = x0[0]; ar[2 * q + 1] = x0[1];
-                ac[2 * q] = x1[0]; ac[2 * q + 1] = x1[1];
-                br[2 * q] = x2[0]; br[2 * q + 1] = x2[1];
-                bc[2 * q] = x3[0]; bc[2 * q + 1] = x3[1];
-            }
-        }
-        if (!(p0 > t0)) {                       // same value in every thread: uniform exit (catches NaN)
-            *fail_col = j0;
-            return false;
-        }
-        // The two pivots' reciprocal square roots are independent chains: with q = p1raw p0 - a10^2 (formed
-        // from mailbox values only), p1 = q / p0 and 1/sqrt(p1) = sqrt(p0) rsqrt(q), so rsqrt(q) runs beside
-        // rsqrt(p0) instead of after it.
-        const double qq = __builtin_fma(p1raw, p0, -(a10 * a10));
-        if (!(qq > t1 * p0)) {                  // <=> p1 = q / p0 <= threshold (or NaN)
-            *fail_col = j1;
-            return false;
-        }
-        const double r0 = gs_rsqrt_nr(p0);
-        const double rq = gs_rsqrt_nr(qq);
-        double d0 = p0 * r0;                                            // sqrt(p0) ...
-        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);   // ... corrected to ~0.5 ulp
-        const double l10 = a10 * r0;                                    // L[j1][j0]
-        const double r1 = d0 * rq;                                      // 1 / sqrt(p1)
-        double sq = qq * rq;                                            // sqrt(q), corrected like d0
-        sq = __builtin_fma(__builtin_fma(-sq, sq, qq), 0.5 * rq, sq);
-        const double d1 = sq * r0;                                      // sqrt(p1): the same q as r1, so that
-                                                                        // L_j1j1 r1 = 1 to a few ulp
-        if (threadIdx.x == 0) {
-            dbuf[j0] = d0;
-            dbuf[j1] = d1;
-        }
-        double l0r[8], l0c[8], l1r[8], l1c[8];
-#pragma unroll
-        for (int ii = JB; ii < 8; ++ii) {
-            l0r[ii] = ar[ii] * r0;
-            l1r[ii] = __builtin_fma(-l0r[ii], l10, br[ii]) * r1;       // column j1 after column j0, scaled
-        }
-#pragma unroll
-        for (int kk = JB; kk < 8; ++kk) {
-            l0c[kk] = ac[kk] * r0;
-            l1c[kk] = __builtin_fma(-l0c[kk], l10, bc[kk]) * r1;
-        }
-        // inside the active sub-block only rows / columns beyond the pivots take part
-        l0r[JB] = (tr > jr) ? l0r[JB] : 0.0;
-        l1r[JB] = (tr > jr + 1) ? l1r[JB] : 0.0;
-        l0c[JB] = (tc > jr) ? l0c[JB] : 0.0;
-        l1c[JB] = (tc > jr + 1) ? l1c[JB] : 0.0;
-        // scaled pivot rows of the diagonal-block inverse
-        const double vk0 = (tc <= jr) ? rAv * r0 : 0.0;
-        const double vk1 = (tc <= jr + 1) ? __builtin_fma(-l10, vk0, rBv) * r1 : 0.0;
-        // rank-2 trailing update:  A_ik -= l0_i l0_k + l1_i l1_k
-#pragma unroll
-        for (int ii = JB; ii < 8; ++ii)
-#pragma unroll
-            for (int kk = JB; kk <= ii; ++kk)
-                a[ii][kk] = __builtin_fma(-l1r[ii], l1c[kk], __builtin_fma(-l0r[ii], l0c[kk], a[ii][kk]));
-        // columns j0 and j1 are final
-        if (tc == jr) {
-#pragma unroll
-            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = l0r[ii];
-            a[JB][JB] = (tr > jr) ? l0r[JB] : ((tr == jr) ? d0 : a[JB][JB]);
-        }
-        if (tc == jr + 1) {
-#pragma unroll
-            for (int ii = JB + 1; ii < 8; ++ii) a[ii][JB] = l1r[ii];
-            a[JB][JB] = (tr > jr + 1) ? l1r[JB] : ((tr == jr + 1) ? d1 : a[JB][JB]);
-        }
-        // diagonal-block inverse: eliminate against both scaled pivot rows
-        vd[JB] = (tr == jr) ? vk0
-               : (tr == jr + 1) ? vk1
-                                : __builtin_fma(-l1r[JB], vk1, __builtin_fma(-l0r[JB], vk0, vd[JB]));
-    }
-    return true;
-}
-
-#define GS_LS_BLK (16 * 17)   // LDS copy of L for phase 2: the 28 strictly lower 16x16 blocks, block (i, p) at
-                              // index i (i - 1) / 2 + p, rows padded to 17 doubles (61 KB)
-
-// One block column J of L^-1 on the matrix cores (see the header comment above).  Ls: LDS copy of the factored
-// block's strictly lower 16x16 blocks; Dv: the eight 16x16 diagonal inverses in LDS.
-template <int J>
-__device__ __forceinline__ void gs_trtri_col(const double* Ls, const double* Dv, double* Linv, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    gs_d4 X[8];
-    // X_JJ = D_J^-1, fetched in accumulator layout: reg x holds row fq + 4x, column fr
-#pragma unroll
-    for (int x = 0; x < 4; ++x) X[J][x] = Dv[(J * 16 + fq + 4 * x) * GS_DV_STR + fr];
-#pragma unroll
-    for (int i = J + 1; i < 8; ++i) {
-        gs_d4 T = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int p = J; p < i; ++p) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const double av = Ls[(i * (i - 1) / 2 + p) * GS_LS_BLK + fr * 17 + 4 * s4 + fq];   // A operand: L_ip
-                T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[p][s4], T, 0, 0, 0);
-            }
-        }
-        gs_d4 R = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const double av = Dv[(i * 16 + fr) * GS_DV_STR + 4 * s4 + fq];                     // A operand: D_i^-1
-            R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], R, 0, 0, 0);
-        }
-        X[i] = -R;
-    }
-    // write block column J of the 128x128 inverse: zeros above the diagonal block
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            Linv[(16 * i + fq + 4 * x) * 128 + 16 * J + fr] = (i < J) ? 0.0 : X[i][x];
-}
-
-// The whole diagonal-block routine as a device function, so the fused small-n kernel can share it.
-// A: the 128x128 block (leading dimension ld), factored in place (lower part).  Linv: 128x128 row-major
-// output (zeros above the diagonal).  diag0: the block's 128 original diagonal entries.
-// Returns 0 or the 1-based local column of the first bad pivot (uniform over the workgroup); *logdet_out
-// (written by thread 0 only) = sum_j log L_jj.  Ends with a workgroup barrier after the Linv stores.
-// wsp: the caller's LDS workspace of GS_DIAG_WS doubles (16-B aligned).  Phase 2 keeps the LDS copy of L (Ls, 61 KB)
-// and the diagonal inverses (Dv) there; phase 1's mailboxes and thresholds alias its beginning (they are dead when
-// Ls / Dv are written, one barrier separates the two uses).  Passing the workspace in lets a fused kernel lend the
-// same bytes to its other phases (k_lml_medium: the tile routine's staging buffers) instead of stacking them.
-#define GS_DIAG_WS (28 * GS_LS_BLK + 128 * GS_DV_STR)      // 9792 doubles = 76.5 KB
-__device__ __forceinline__ int gs_diag_block_v1(double* A, int64_t ld, double* Linv, double* logdet_out,
-                                                const double* diag0, unsigned long long* stamps, double* wsp) {
-    __shared__ double dbuf[128];
-    double* Ls = wsp;
-    double* Dv = wsp + 28 * GS_LS_BLK;
-    double* mail = wsp;                              // 4 * GS_MB_SIZE doubles, phase 1 only
-    double* rmail = wsp + 4 * GS_MB_SIZE;            // 64
-    double* thr = rmail + 64;                        // 128
-    const int t = threadIdx.x;
-    // optional phase stamps (diagnostics only: own buffer, never feeds a result)
-    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
-    if (stamps) {
-        st0 = __builtin_amdgcn_s_memtime();
-        sr0 = __builtin_amdgcn_s_memrealtime();
-    }
-    if (t < 128) {
-        const double d0 = diag0[t];
-        thr[t] = d0 > 0.0 ? d0 * gs_pivot_guard : 0.0;
-    }
-    const int tr = t >> 4, tc = t & 15;
-    double a[8][8], vd[8];
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-#pragma unroll
-        for (int kk = 0; kk <= ii; ++kk) a[ii][kk] = A[(int64_t)(tr + 16 * ii) * ld + tc + 16 * kk];
-        vd[ii] = (tr == tc) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    if (stamps) st1 = __builtin_amdgcn_s_memtime();
-    int fail_col = -1;
-    bool ok = gs_diag_steps<0>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<1>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<2>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<3>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<4>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<5>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<6>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (ok) ok = gs_diag_steps<7>(a, vd, mail, rmail, dbuf, thr, tr, tc, &fail_col);
-    if (!ok) return fail_col + 1;
-    __syncthreads();                                 // every thread is done with the mailboxes: Ls / Dv may overwrite them
-    // L back to the matrix (lower part), strictly lower blocks and diagonal inverses to LDS
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-#pragma unroll
-        for (int kk = 0; kk <= ii; ++kk) {
-            const int row = tr + 16 * ii, col = tc + 16 * kk;
-            if (col <= row) A[(int64_t)row * ld + col] = a[ii][kk];
-            if (kk < ii) Ls[(ii * (ii - 1) / 2 + kk) * GS_LS_BLK + tr * 17 + tc] = a[ii][kk];   // for phase 2
-        }
-        Dv[(ii * 16 + tr) * GS_DV_STR + tc] = (tc <= tr) ? vd[ii] : 0.0;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (stamps) st2 = __builtin_amdgcn_s_memtime();
-    if (t < 128) dbuf[t] = log(dbuf[t]);
-    // phase 2: wave w builds block columns w and 7-w of L^-1
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (w == 0) {
-        gs_trtri_col<0>(Ls, Dv, Linv, lane);
-        gs_trtri_col<7>(Ls, Dv, Linv, lane);
-    } else if (w == 1) {
-        gs_trtri_col<1>(Ls, Dv, Linv, lane);
-        gs_trtri_col<6>(Ls, Dv, Linv, lane);
-    } else if (w == 2) {
-        gs_trtri_col<2>(Ls, Dv, Linv, lane);
-        gs_trtri_col<5>(Ls, Dv, Linv, lane);
-    } else {
-        gs_trtri_col<3>(Ls, Dv, Linv, lane);
-        gs_trtri_col<4>(Ls, Dv, Linv, lane);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (t == 0) {
-        double sl = 0.0;
-        for (int j = 0; j < 128; ++j) sl += dbuf[j];
-        *logdet_out = sl;
-        if (stamps) {
-            const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
-            stamps[0] = st1 - st0;      // prologue (loads)
-            stamps[1] = st2 - st1;      // phase 1 (column loop + store)
-            stamps[2] = st3 - st2;      // phase 2 (block inverse)
-            stamps[3] = st3 - st0;      // total shader cycles
-            stamps[4] = sr3 - sr0;      // total 100 MHz ticks
-        }
-    }
-    return 0;
-}
+#define GS_DIAG_WS 9792      // LDS doubles the fused small / medium kernels reserve for the diagonal routine (76.5 KB >= its 9472)
 
 // ------------------------------------------------------------------------------------------------
 // K2a, second version (round 2): the 128x128 diagonal block as an 8 x 8 grid of 16x16 micro-blocks that live in the
@@ -1271,7 +917,11 @@ __device__ __forceinline__ void gs_trtri_block(const double* Ls, const double* D
     }
 }
 
-// Contract as gs_diag_block_v1 (see there), except for what it leaves behind:
+// The diagonal-block routine as a device function (k_potrf_diag, k_potrf_diag256, k_chain and the fused small / medium kernels
+// share it).  A: the 128 x 128 block (leading dimension ld), factored in place (lower part).  diag0: the block's 128 original
+// diagonal entries (pivot guard).  Returns 0 or the 1-based local column of the first bad pivot (uniform over the workgroup);
+// *logdet_out (thread 0) = sum_j log L_jj.  wsp: the caller's LDS workspace (16-B aligned); passing it in lets a fused kernel lend
+// the same bytes to its other phases.  What it leaves behind:
 //   - the substitution tables of the block stay in the caller's LDS workspace, wsp[0 .. GS_LTAB): the 28 panel dumps
 //     (-L_kj in A-operand layout) and the 8 micro-block inverses D_j.  gs_panel16 solves rows against them;
 //   - Ltab != NULL: the same GS_LTAB doubles are copied to global memory for kernels that come later;
@@ -1733,20 +1383,16 @@ __global__ __launch_bounds__(256) void k_trtri_blocks(const double* Ltab, double
     gs_trtri_block(tab + GS_D2_LS, tab + GS_D2_DV, Linv + (size_t)blockIdx.x * 128 * 128, w, lane);
 }
 
-// info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).
-// ALGO 1: the round-1 routine (explicit inverse to Linv).  ALGO 2: micro-block routine, substitution tables to Ltab.
-template <int ALGO>
-__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet,
-                                                     int* info, int col0, const double* diag0,
-                                                     unsigned long long* stamps) {
-    // ALGO 2: 34 KB (one panel column at a time in LDS, dumps exported as they are made) -- with its 124 VGPRs the
-    // workgroup fits where ONE bulk workgroup (53 KB, 8 waves) has just retired; at 77 KB it waited for two on the same CU
-    // while lower-priority bulk workgroups kept taking the single slots (rocprofv3: 90-250 us per call beside the bulk update)
-    __shared__ __attribute__((aligned(16))) double wsd[ALGO == 1 ? GS_DIAG_WS : GS_D2C_WS];
+// info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).  Micro-block routine, substitution tables to Ltab.
+__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Ltab, double* logdet, int* info, int col0,
+                                                     const double* diag0, unsigned long long* stamps) {
+    // 34 KB of LDS (one panel column at a time, dumps exported as they are made): with its 124 VGPRs the workgroup fits where ONE
+    // bulk workgroup (53 KB, 8 waves) has just retired; at 77 KB it waited for two on the same CU while lower-priority bulk
+    // workgroups kept taking the single slots (rocprofv3: 90-250 us per call beside the bulk update)
+    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
     if (*info != 0) return;                    // an earlier block already failed (uniform)
-    if (ALGO == 2) __builtin_amdgcn_s_setprio(3);      // the chain's one workgroup: ahead of the bulk waves on its SIMDs
-    const int bad = ALGO == 1 ? gs_diag_block_v1(A, ld, Linv, logdet, diag0, stamps, wsd)
-                              : gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
+    __builtin_amdgcn_s_setprio(3);             // the chain's one workgroup: ahead of the bulk waves on its SIMDs
+    const int bad = gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
 }
 
@@ -2603,7 +2249,7 @@ __device__ int gs_medium_lazy = 64;                 // option "medium_lazy": dep
                                                     // written once, when its panel is next, with all the panels before it in one pass: the default, this sweep is HBM-bound)
 
 // C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
-// 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld's layout: XOR-swizzled
+// 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld3's layout: XOR-swizzled
 // k-pairs, even / odd rows in regions one double apart (no bank conflicts), the sign carried by negated accumulators.
 // LDS: 2 stages x 2 operands x (128 x 16 + 2) doubles.  Ends with a workgroup barrier after the stores (fenced).
 #define GS_TILE_LD_DOUBLES (2 * 2 * (128 * GS_KC + 2))
@@ -2892,149 +2538,6 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K2b': the 8-wave 128x128 tile with LDS-DIRECT operand staging (gfx950 global_load_lds_dwordx4): the A / B chunks go
-// from global memory straight into LDS -- no staging VGPRs, no ds_write, no vmcnt-wait-then-store phase.
-//   - An LDS-direct load writes the wave's 64 x 16 B contiguously, so tile rows are unpadded (16 doubles = 128 B); bank
-//     conflicts are avoided by an XOR swizzle chosen on the GLOBAL side: LDS granule g of row r holds k-pair
-//     g ^ ((r >> 1) & 7).  A fragment read (16 rows x 4 k-groups per instruction) then touches 64 distinct 8-B slots.
-//   - The sign cannot ride on the staged operand any more: for sign = -1 the accumulators start as -C, accumulate
-//     +A B^T and are negated on store.  Round-to-nearest is sign-symmetric, so results equal k_gemm_nt's bit for bit.
-// Same tile mapping, tri modes and stagger as k_gemm_nt<4, 2, 2, 4>.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void k_gemm_ld(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                                     int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                     int stagger) {
-    constexpr int WM = 4, WN = 2, WAVES_M = 2, BM = 128, BN = 128;
-    // Per operand tile: even rows in one 8-KB region, odd rows in a second one that starts ONE DOUBLE later, so a row and
-    // its neighbour never share a bank pair (128-B rows alone would put rows 2m and 2m + 1 on the same banks).
-    constexpr int OPER = BM * GS_KC + 2;                // doubles per operand tile (+1 shift, +1 to keep 16-B alignment)
-    constexpr int STAGE = 2 * OPER;                     // doubles per stage
-    extern __shared__ double lds[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = w % WAVES_M, wn = w / WAVES_M;
-    int bm, bn;
-    if (tri) {
-        const int bid = blockIdx.x;
-        bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
-        while ((int64_t)bm * (bm + 1) / 2 > bid) --bm;
-        bn = bid - (int)((int64_t)bm * (bm + 1) / 2);
-    } else {
-        const int tm = (M + BM - 1) / BM;
-        bm = blockIdx.x % tm;
-        bn = blockIdx.x / tm;
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    if (tri == 2) {
-        A += m0;
-        B += m0;
-        K -= m0;
-    }
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-    const int fr = lane & 15, fq = lane >> 4;
-    const bool neg = sign < 0.0;
-    gs_d4 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
-                acc[i][j][x] = neg ? -c : c;
-            }
-        }
-    // this wave's four operand slices per chunk: A rows [16 w, 16 w + 16), B rows [16 w, 16 w + 16), 8 rows per load
-    const int lrow = lane >> 3, lg = lane & 7;
-    const double* srcA[2];
-    const double* srcB[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 16 * w + 2 * lrow + h;                       // tile row this lane fetches: load h takes parity h
-        const int kp = lg ^ ((r >> 1) & 7);                        // swizzled k-pair
-        int ra = m0 + r, rb = n0 + r;
-        ra = ra < M ? ra : M - 1;
-        rb = rb < N ? rb : N - 1;
-        srcA[h] = A + (int64_t)ra * lda + 2 * kp;
-        srcB[h] = B + (int64_t)rb * ldb + 2 * kp;
-    }
-    auto stage_load = [&](int kc, int stage) {
-        double* base = lds + stage * STAGE;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // region h (row parity) starts at h * (BM / 2 * GS_KC + 1); this wave's 8 rows of that parity are contiguous
-            double* dstA = base + h * (BM / 2 * GS_KC + 1) + 8 * w * GS_KC;
-            double* dstB = base + OPER + h * (BN / 2 * GS_KC + 1) + 8 * w * GS_KC;
-            __builtin_amdgcn_global_load_lds(srcA[h] + kc * GS_KC, dstA, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(srcB[h] + kc * GS_KC, dstB, 16, 0, 0);
-        }
-    };
-    // fragment addresses inside a parity region: (row >> 1) * 16 + ((2 ks + (fq >> 1)) ^ swz) * 2 + (fq & 1), with
-    // swz = (fr >> 1) & 7 for every 16-row block; odd rows live one double further (region offset)
-    const int swz = (fr >> 1) & 7;
-    const int rsel = (fr & 1) * (BM / 2 * GS_KC + 1) + (fr >> 1) * GS_KC;      // BM == BN
-    int goff[GS_KC / 4];
-#pragma unroll
-    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
-    const int nk = K / GS_KC;
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < nk; ++c) {
-        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
-        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rsel;
-        const double* sB = lds + (c & 1) * STAGE + OPER + wn * WN * 8 * GS_KC + rsel;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 4; ++ks) {
-            double af[WM], bf[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
-            }
-        }
-}
-
-// K2b'': the LDS-direct tile as 128 x 64 per workgroup, 8 waves of 32 x 32 (4 x 2) -- the shipped bulk kernel (cfg 7).
-// 32 accumulator VGPRs per wave (65 in all) and 48 KB of LDS per workgroup put THREE workgroups = 6 waves per SIMD on a
-// CU instead of two = 4: while one workgroup moves its C tile two others feed the matrix pipe, and twice as many,
-// half-sized tiles quantise better against the resident slots (M = 4096: 1056 tiles on 768 slots instead of 528 on
-// 512).  Costs 50 % more operand loads per flop (served by L2).  Same staging layout and sign handling as k_gemm_ld;
-// results identical bit for bit.  Measured against k_gemm_ld in the same process: equal at M = 7936, +18 % at M = 4096
-// exclusive; -4 % time per pipelined evaluation, -6 % for one factorisation alone (n = 8192).
-// Persistent-chain schedule: the launch is held back by a k_wait_flag in front of it on its stream until the chain has published the
-// panel rows it reads (per-workgroup polling was measured: 24 us per outer step).
-// nfirst > 0 (tri launches of that schedule): the tiles of the first 256 COLUMNS take the first nfirst block ids -- they
-// are dispatched first, stored write-through and counted in *first_done, because the chain's next-but-one outer step and the
-// next step's A update wait for exactly them ("B"), not for the rest of the trailing update ("Far") behind them in the same
-// launch.  One launch instead of two: B starts on an empty chip the moment the previous trailing update ends.
-// What the fp64 matrix pipes sustain with NOTHING else going on: every wave issues `iters` rounds of NACC independent
-// v_mfma_f64_16x16x4_f64 on register operands (no LDS, no memory, no barrier).  gsum_bench_gemm_nt(cfg = 99): the ceiling a K loop can be
-// measured against on this part at the clock it holds.
 template <int NACC>
 __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
     gs_d4 acc[NACC];
@@ -3844,14 +3347,3 @@ __global__ __launch_bounds__(64) void k_probe_spin(unsigned long long ticks) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
-// diagnostic: where does each workgroup run?  out[2b] = XCC id, out[2b+1] = HW_ID register (CU / SH / SE fields)
-__global__ __launch_bounds__(256) void k_probe_where(long long* out, int spin_cycles) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spin_cycles) __builtin_amdgcn_s_sleep(8);
-    if (threadIdx.x == 0) {
-        out[2 * blockIdx.x] = (long long)xcc;
-        out[2 * blockIdx.x + 1] = (long long)hw;
-    }
-}

@@ -24,6 +24,7 @@ def pytest_sessionstart(session):
     try:
         from gsum_amd import build as _build
         _build.build()
+        _build.build(lab=True)
     except Exception as exc:          # leave the failure to the tests that need the library, with their own message
         print(f"[conftest] could not build libgsum_hip.so: {exc}")
 

@@ -628,7 +628,19 @@ def gen_s5_predict():
     mean, std = gp.predict(Xs[:16], return_std=True)
     print("s5 predict", time.time() - t0, flush=True)
     mean_n, std_n = gp.predict(Xs[:16], return_std=True, pred_noise=True)
-    return dict(n=n, r=r, m=m, probes=16, side=L(side), length_scale=[0.7, 1.3], white=1e-6, nugget=1e-10,
+    # round 4: the configuration's full set of new points is 16384 = 8 shards of 2048 (one per GPU); RandomState(1).rand(16384, 2)
+    # continues the stream whose first 2048 rows are Xs above.  32 probes in EVERY shard (every 64th point of the shard).
+    m_all, shards, per = 16384, 8, 32
+    Xs_all = np.random.RandomState(1).rand(m_all, 2) * side
+    assert np.array_equal(Xs_all[:m], Xs)
+    probe_idx = np.concatenate([g * (m_all // shards) + (m_all // shards // per) * np.arange(per) for g in range(shards)])
+    mean_s, std_s = gp.predict(Xs_all[probe_idx], return_std=True)
+    _, std_sn = gp.predict(Xs_all[probe_idx], return_std=True, pred_noise=True)
+    print("s5 shard probes", time.time() - t0, flush=True)
+    shard_probes = dict(m_all=m_all, shards=shards, per_shard=per, index=[int(i) for i in probe_idx], mean=L(mean_s), std=L(std_s),
+                        std_pred_noise=L(std_sn),
+                        recipe="Xs_all = RandomState(1).rand(16384, 2) * side; shard g = rows [2048 g, 2048 (g + 1)); probes = every 64th row of a shard")
+    return dict(n=n, r=r, m=m, probes=16, shard_probes=shard_probes, side=L(side), length_scale=[0.7, 1.3], white=1e-6, nugget=1e-10,
                 recipe="X = RandomState(0).rand(n,2)*side; Xs = RandomState(1).rand(m,2)*side; y = RandomState(2).randn(n,r); "
                        "side = [0.35, 0.65]*sqrt(n); ConjugateGaussianProcess(Matern([0.7,1.3],2.5)+White(1e-6,fixed), "
                        "center=0, disp=0, df=1, scale=1, optimizer=None)",

@@ -27,6 +27,13 @@ def ctx():
     return gsum_amd.default_context(0)
 
 
+@pytest.fixture(scope="module")
+def lab():
+    """A context on the LAB build of the library (libgsum_hip_lab.so, include/gsum_hip_debug.h): the tile-level entry point and the
+    schedule switches whose bit-equivalence these tests assert are not part of the product ABI."""
+    return gsum_amd.lab_context(0)
+
+
 def lml_tol(R):
     return max(1e-10, 1e-16 * np.linalg.cond(R))
 
@@ -35,36 +42,34 @@ def lml_tol(R):
 # building blocks
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("cfg,M,N,K", [(0, 128, 128, 128), (0, 300, 300, 128), (0, 144, 128, 256), (0, 130, 70, 64),
-                                       (1, 32, 128, 128), (1, 700, 128, 128), (1, 50, 16, 384),
+@pytest.mark.parametrize("cfg,M,N,K", [(1, 32, 128, 128), (1, 700, 128, 128), (1, 50, 16, 384),
                                        (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32),
                                        (5, 128, 128, 128), (5, 300, 300, 256), (5, 130, 70, 64),
-                                       (6, 128, 128, 128), (6, 300, 300, 256), (6, 130, 70, 64), (6, 1000, 257, 512),
                                        (7, 128, 128, 128), (7, 300, 300, 256), (7, 130, 70, 64), (7, 1000, 257, 512),
                                        (7, 128, 128, 16), (7, 200, 100, 32), (7, 128, 64, 48), (7, 257, 129, 16)])     # one, two, three chunks: the pipelined K loop's edges
-def test_mfma_gemm_tiles(ctx, cfg, M, N, K):
+def test_mfma_gemm_tiles(lab, cfg, M, N, K):
     """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
     swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
     rng = np.random.RandomState(cfg * 1000 + M + N)
     A, B, C = rng.randn(M, K), rng.randn(N, K), rng.randn(M, N)
-    got = ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=1, sign=-1.0)
+    got = lab.debug_gemm_nt(cfg, C, A, B, tri=False, beta=1, sign=-1.0)
     np.testing.assert_allclose(got, C - A @ B.T, rtol=1e-12, atol=1e-12 * K)
-    got = ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=0, sign=1.0)
+    got = lab.debug_gemm_nt(cfg, C, A, B, tri=False, beta=0, sign=1.0)
     np.testing.assert_allclose(got, A @ B.T, rtol=1e-12, atol=1e-12 * K)
-    if cfg in (6, 7):   # LDS-direct staging: bit-identical to the register-staged 8-wave tile
+    if cfg == 7:   # LDS-direct staging: bit-identical to the register-staged 8-wave tile
         for beta, sign in ((1, -1.0), (0, 1.0), (1, 1.0)):
-            np.testing.assert_array_equal(ctx.debug_gemm_nt(cfg, C, A, B, tri=False, beta=beta, sign=sign),
-                                          ctx.debug_gemm_nt(5, C, A, B, tri=False, beta=beta, sign=sign))
+            np.testing.assert_array_equal(lab.debug_gemm_nt(cfg, C, A, B, tri=False, beta=beta, sign=sign),
+                                          lab.debug_gemm_nt(5, C, A, B, tri=False, beta=beta, sign=sign))
 
 
 @pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552])
-@pytest.mark.parametrize("cfg,BM", [(0, 128), (5, 128), (6, 128), (7, 128)])
-def test_mfma_gemm_lower_tiles(ctx, M, cfg, BM):
+@pytest.mark.parametrize("cfg,BM", [(5, 128), (7, 128)])
+def test_mfma_gemm_lower_tiles(lab, M, cfg, BM):
     """SYRK mode: every element of the lower triangle is updated exactly once (also through the XCD-aware
     tile map, M >= 1024), and tiles that lie wholly above the diagonal are never touched."""
     rng = np.random.RandomState(M)
     A, C = rng.randn(M, 128), rng.randn(M, M)
-    got = ctx.debug_gemm_nt(cfg, C, A, A, tri=True, beta=1, sign=-1.0)
+    got = lab.debug_gemm_nt(cfg, C, A, A, tri=True, beta=1, sign=-1.0)
     want = C - A @ A.T
     low = np.tril(np.ones((M, M), dtype=bool))
     np.testing.assert_allclose(got[low], want[low], rtol=1e-12, atol=1e-10)
@@ -100,7 +105,7 @@ def ulp_close(a, b, ulps=4):
 
 @pytest.mark.parametrize("spec", KERNEL_SPECS)
 @pytest.mark.parametrize("n", [7, 128, 333])
-def test_kernel_matrix_matches_sklearn(ctx, spec, n):
+def test_kernel_matrix_matches_sklearn(ctx, lab, spec, n):
     kern = make_kernel(spec)
     d = 1 if np.ndim(spec["length_scale"]) == 0 else len(spec["length_scale"])
     rng = np.random.RandomState(n)
@@ -122,12 +127,15 @@ def test_kernel_matrix_matches_sklearn(ctx, spec, n):
     if SVML_HOST:
         np.testing.assert_array_equal(Kc, kern(X, Y))
     # device-resident build (lower tiles only + mirror on export) gives the same matrix
+    M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+    np.testing.assert_array_equal(M.to_host(), Kd)
+    M.free()
     for lower in (1, 0):
-        ctx.set_option("build_lower_only", lower)
-        M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
+        lab.set_option("build_lower_only", lower)
+        M = lab.kernel_matrix_dev(desc, X, diag_add=1e-10)
         np.testing.assert_array_equal(M.to_host(), Kd)
         M.free()
-    ctx.set_option("build_lower_only", 1)
+    lab.set_option("build_lower_only", 1)
 
 
 def spd(n, seed, cond=1e4):
@@ -138,11 +146,11 @@ def spd(n, seed, cond=1e4):
 
 
 @pytest.mark.parametrize("n", [1, 5, 128, 129, 200, 384, 1000])
-@pytest.mark.parametrize("lookahead", [1, 0, 2, 3])
-def test_potrf_matches_lapack(ctx, n, lookahead):
-    # 2 / 3: the fused chain kernels (k_potrf_diag256 + k_panel256), whole-panel and windowed look-ahead
+@pytest.mark.parametrize("lookahead", [1, 0, 2])
+def test_potrf_matches_lapack(lab, n, lookahead):
+    # 2: the fused chain kernels (k_potrf_diag256 + k_panel256) in the look-ahead schedule
+    ctx = lab
     ctx.set_option("chain_fused", 1 if lookahead >= 2 else 0)
-    ctx.set_option("chain_window", 1 if lookahead == 3 else 0)
     ctx.set_option("lookahead", min(lookahead, 1))
     A = spd(n, n)
     M = ctx.upload(A)
@@ -162,13 +170,13 @@ def test_potrf_matches_lapack(ctx, n, lookahead):
     M.free()
     ctx.set_option("lookahead", 1)
     ctx.set_option("chain_fused", -1)
-    ctx.set_option("chain_window", 0)
 
 
 @pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("n,bad", [(6, 3), (200, 0), (200, 130), (300, 299), (384, 255), (600, 300)])
-def test_potrf_info_matches_lapack(ctx, n, bad, fused):
+def test_potrf_info_matches_lapack(lab, n, bad, fused):
     """Not positive definite -> LAPACK-style info (index exact), as numpy.linalg.cholesky's LinAlgError."""
+    ctx = lab
     ctx.set_option("chain_fused", fused)
     A = spd(n, 7, cond=10.0)
     A[bad, bad] = -1.0
@@ -553,7 +561,7 @@ def test_full_size_properties_n8192():
     from sklearn.gaussian_process.kernels import RBF
     n, r = 8192, 6
     X, y = s_inputs(n, r)
-    ctx = gsum_amd.default_context(0)
+    ctx = gsum_amd.lab_context(0)            # the schedule switches live in the lab build; the product context is compared below
     desc = gsum_amd.describe_kernel(RBF(0.2), 1)
     c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
     Z = np.concatenate([c, np.ones((n, 1))], axis=1)
@@ -565,51 +573,53 @@ def test_full_size_properties_n8192():
             out[(la, lower)] = ctx.lml_batch([desc], X, Z, 1e-10)
     ctx.set_option("lookahead", 1)
     ctx.set_option("build_lower_only", 1)
-    for reserve in (0, 4):                   # bulk stream with / without a CU mask: scheduling only
-        ctx.set_option("reserve_cus", reserve)
-        out[("reserve", reserve)] = ctx.lml_batch([desc], X, Z, 1e-10)
-    ctx.set_option("reserve_cus", 0)
-    # the alternative chain schedules ("Chain experiments"): two diagonal blocks per launch + both panels of the
-    # rows below in one, and the windowed look-ahead with and without reserved CUs -- all partitions / fusions of the same
-    # products in the same order
-    for fused, window, reserve, la in ((1, 0, 0, 1), (1, 1, 0, 1), (0, 1, 0, 1), (1, 1, 2, 1), (1, 0, 0, 0)):
+    out[("product context",)] = gsum_amd.default_context(0).lml_batch([desc], X, Z, 1e-10)
+    # the alternative chain schedules ("Chain experiments"): two diagonal blocks per launch + both panels of the rows
+    # below in one, with and without look-ahead, persistent chain on / off -- fusions / partitions of the same products in the same order
+    for fused, la, persist in ((1, 1, 0), (1, 0, 0), (0, 1, 0), (0, 1, 1)):
         ctx.set_option("chain_fused", fused)
-        ctx.set_option("chain_window", window)
-        ctx.set_option("reserve_cus", reserve)
         ctx.set_option("lookahead", la)
-        out[("chain", fused, window, reserve, la)] = ctx.lml_batch([desc], X, Z, 1e-10)
-    for name, v in (("chain_fused", -1), ("chain_window", 0), ("reserve_cus", 0), ("lookahead", 1)):
+        ctx.set_option("chain_persist", persist)
+        out[("chain", fused, la, persist)] = ctx.lml_batch([desc], X, Z, 1e-10)
+    for name, v in (("chain_fused", -1), ("chain_persist", -1), ("lookahead", 1)):
         ctx.set_option(name, v)
+    ctx.set_option("chain_persist", 0)                          # (the look-ahead schedule these two switches belong to)
     for depth2, pad in ((0, 0), (1, 0), (0, 80 * 1024)):        # bulk update in one / two launches, 3 / 2 workgroups per CU
         ctx.set_option("la_depth2", depth2)
         ctx.set_option("bulk_lds_pad", pad)
         out[("bulk", depth2, pad)] = ctx.lml_batch([desc], X, Z, 1e-10)
     ctx.set_option("la_depth2", 1)
     ctx.set_option("bulk_lds_pad", 80 * 1024)
-    for split in (1024, 4096):                                 # look-ahead update split (default: whole on the chain's stream)
-        ctx.set_option("la_split", split)
-        out[("la_split", split)] = ctx.lml_batch([desc], X, Z, 1e-10)
-    ctx.set_option("la_split", 0)
+    ctx.set_option("chain_persist", -1)
     G0, s0, i0 = out[(1, 1)]
     assert i0[0] == 0
     # a batch (grouped launches, gs_lml_wave): the group layout is scheduling only; so is the batch schedule's pairing of trailing
     # updates (K = 512 every other step) and the stream its small "near" updates go out on
     many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for groups, size, lazy, near in ((2, 10, 2, 1), (1, 20, 2, 1), (3, 7, 0, 1), (2, 5, 2, 0), (4, 5, 2, 1)):
+    for groups, size, lazy, near, depth, serial in ((3, 7, 2, 1, 4, 0), (2, 10, 2, 1, 2, 0), (1, 20, 2, 1, 3, 0), (3, 7, 0, 1, 4, 0), (2, 5, 2, 0, 4, 0),
+                                                    (4, 5, 2, 1, 8, 0), (2, 10, 2, 1, 4, 1)):
         ctx.set_option("wave_groups", groups)
         ctx.set_option("wave_size", size)
         ctx.set_option("lazy_far", lazy)
         ctx.set_option("wave_near_on_chain", near)
+        ctx.set_option("wave_depth", depth)
+        ctx.set_option("wave_serial", serial)
         Gs, ss, infos = ctx.lml_resident(many, 1e-10)
         assert np.all(infos == 0)
         for b in range(len(many)):
             np.testing.assert_array_equal(Gs[b], G0[0])
             assert ss[b] == s0[0]
     ctx.set_option("lazy_far", 2)                              # the library's defaults
-    ctx.set_option("wave_groups", 2)
-    ctx.set_option("wave_size", 10)
+    ctx.set_option("wave_groups", 3)
+    ctx.set_option("wave_size", 7)
     ctx.set_option("wave_near_on_chain", 1)
+    ctx.set_option("wave_depth", 4)
+    ctx.set_option("wave_serial", 0)
+    Gp, sp_, ip = gsum_amd.default_context(0).lml_batch([desc] * 4, X, Z, 1e-10)      # the product library's batch: the same bits
+    for b in range(4):
+        np.testing.assert_array_equal(Gp[b], G0[0])
+        assert sp_[b] == s0[0] and ip[b] == 0
     for key, (G, s, i) in out.items():
         np.testing.assert_array_equal(G, G0)
         np.testing.assert_array_equal(s, s0)
@@ -1082,10 +1092,11 @@ def test_sample_y_default_path_reproduces_the_reference_draws():
 
 
 @pytest.mark.parametrize("n", [4400, 5000, 7000])
-def test_batch_lazy_far_updates_are_scheduling_only_below_8192(ctx, n):
+def test_batch_lazy_far_updates_are_scheduling_only_below_8192(lab, n):
     """The batch schedule's K = 512 far updates (lazy_far = 2) are used from padded order 4352 up: a batch evaluated with them, without them
     and one evaluation at a time (the look-ahead / persistent-chain schedule) gives the same bits."""
     from sklearn.gaussian_process.kernels import RBF
+    ctx = lab
     rng = np.random.RandomState(n)
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([rng.randn(n, 4), np.ones((n, 1))], axis=1)

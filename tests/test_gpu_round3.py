@@ -18,6 +18,12 @@ def ctx():
     return gsum_amd.default_context(0)
 
 
+@pytest.fixture(scope="module")
+def lab():
+    """A context on the LAB build of the library (include/gsum_hip_debug.h: schedule switches, test hooks)."""
+    return gsum_amd.lab_context(0)
+
+
 def test_config5_s5_as_specified_against_reference():
     """BASELINE configs[4] / SURVEY.md 8(d) S5, nothing varied: n = 16384 points X = RandomState(0).rand(n, 2) * side, side =
     [0.35, 0.65] sqrt(n), Matern-5/2(ell = [0.7, 1.3]) + White(1e-6) fixed, 8 curves, nugget 1e-10.  The reference's own
@@ -78,14 +84,13 @@ def _inputs(n, r, d, seed):
 
 @pytest.mark.parametrize("n,kern,d", [(1024, RBF(0.2), 1), (2048, RBF(0.2), 1), (2100, RBF(0.2), 1),
                                       (2304, Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2), (4096, RBF(0.2), 1)])
-def test_persistent_chain_schedule_is_bit_identical(ctx, n, kern, d):
+def test_persistent_chain_schedule_is_bit_identical(lab, n, kern, d):
     """One factorisation alone: the persistent chain kernel + gated host-enqueued updates (k_chain) against
     the host-enqueued look-ahead schedule -- G, sum log L_ii and info array_equal, both window sizes, several runs each (a
     hand-off race would show as a mismatch on some run), no time-outs, and the schedule really ran (chain_probe = 1)."""
+    ctx = lab
     X, Z = _inputs(n, 4, d, n)
     desc = gsum_amd.describe_kernel(kern, d)
-    old_slots = ctx.get_option("batch_slots")
-    ctx.set_option("batch_slots", 1)
     ctx.set_inputs(X, Z)
     try:
         ctx.set_option("chain_persist", 0)
@@ -110,12 +115,12 @@ def test_persistent_chain_schedule_is_bit_identical(ctx, n, kern, d):
     finally:
         ctx.set_option("chain_persist", -1)
         ctx.set_option("chain_rows", 512)
-        ctx.set_option("batch_slots", old_slots)
 
 
-def test_persistent_chain_factor_and_info_codes(ctx):
+def test_persistent_chain_factor_and_info_codes(lab):
     """The factor itself through the operator-level entry (gsum_potrf_lower -> L, array_equal between the schedules), and a
     matrix that is not positive definite: the same LAPACK info (1-based first failing column) from both, -inf upstream."""
+    ctx = lab
     n = 2048
     X = 0.1 * np.arange(n)[:, None]
     desc = gsum_amd.describe_kernel(RBF(0.2), 1)
@@ -141,9 +146,10 @@ def test_persistent_chain_factor_and_info_codes(ctx):
         ctx.set_option("chain_persist", -1)
 
 
-def test_persistent_chain_full_size_n8192(ctx):
+def test_persistent_chain_full_size_n8192(lab):
     """BASELINE config 3's factorisation on the new schedule: bit-identical to the host-enqueued schedule at n = 8192 and the
     known answer of SURVEY.md 8(c) (reference value, tests/golden/large_lml.json) at 1e-10."""
+    ctx = lab
     g = [c for c in load_golden("large_lml.json") if c["n"] == 8192][0]
     n, r = g["n"], g["r"]
     X = g["dx"] * np.arange(n)[:, None]
@@ -271,16 +277,15 @@ def test_c_host_sharded_scan_equals_unsharded(n, n_theta, world):
     assert "gathered == unsharded: yes" in res.stdout
 
 
-def test_chain_give_up_path_falls_back_to_the_host_enqueued_schedule(ctx):
+def test_chain_give_up_path_falls_back_to_the_host_enqueued_schedule(lab):
     """Every spin of the persistent-chain schedule is bounded; when one expires every party leaves at its next wait, the info word says
     so and the evaluation is re-run on the host-enqueued schedule, which is then kept (chain_persist = 0).  The test hook
     chain_test_abort makes the D role give up at outer step 2 exactly as a time-out would: the result must equal the normal one bit
     for bit, chain_aborts counts it, and an in-place factorisation (gsum_potrf_lower: the matrix is destroyed) reports an error."""
+    ctx = lab
     n = 2048
     X, Z = _inputs(n, 4, 1, 7)
     desc = gsum_amd.describe_kernel(RBF(0.2), 1)
-    old_slots = ctx.get_option("batch_slots")
-    ctx.set_option("batch_slots", 1)
     ctx.set_inputs(X, Z)
     try:
         ctx.set_option("chain_persist", 1)
@@ -306,7 +311,6 @@ def test_chain_give_up_path_falls_back_to_the_host_enqueued_schedule(ctx):
         assert ctx.get_option("chain_aborts") == aborts + 2
     finally:
         ctx.set_option("chain_persist", -1)
-        ctx.set_option("batch_slots", old_slots)
 
 
 @pytest.mark.parametrize("n,d,kern", [(256, 1, C(1.0) * RBF(0.2)), (300, 2, C(2.0) * Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6)),

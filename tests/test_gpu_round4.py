@@ -18,6 +18,12 @@ def ctx():
     return gsum_amd.default_context(0)
 
 
+@pytest.fixture(scope="module")
+def lab():
+    """A context on the LAB build of the library (include/gsum_hip_debug.h: schedule switches, test hooks)."""
+    return gsum_amd.lab_context(0)
+
+
 @pytest.mark.parametrize("n,n_theta", [(600, 11), (2048, 8)])
 def test_rccl_c_host_gathers_the_sharded_scan(n, n_theta):
     """INTEGRATION.md's multi-GPU recipe from a C host that owns a REAL RCCL communicator (tests/c_host/shard_host_rccl.c):
@@ -38,12 +44,13 @@ def test_rccl_c_host_gathers_the_sharded_scan(n, n_theta):
     assert "(RCCL, ncclCommInitAll)" in run.stdout
 
 
-def test_chain_step_table_follows_option_changes_on_the_same_workspace(ctx):
+def test_chain_step_table_follows_option_changes_on_the_same_workspace(lab):
     """the persistent chain's per-step table fbwant[] used to be uploaded AFTER k_chain was launched, by a copy that
     nothing ordered against the launch; it is re-made whenever the window size or the far-update pairing changes.  It now goes out in
     stream order ahead of the launch, from a buffer the matrix object owns.  Alternating (chain_rows, chain_lazy) on ONE workspace
     matrix -- every switch re-makes the table -- must keep every result bit-identical to the host-enqueued schedule's, with no
     time-out (a stale table would end in a wrong factor or a 1-s give-up)."""
+    ctx = lab
     from sklearn.gaussian_process.kernels import RBF
     n = 4096
     rng = np.random.RandomState(4)
@@ -70,10 +77,11 @@ def test_chain_step_table_follows_option_changes_on_the_same_workspace(ctx):
         ctx.set_option("chain_lazy", -1)
 
 
-def test_factorize_recovers_from_a_chain_give_up(ctx):
+def test_factorize_recovers_from_a_chain_give_up(lab):
     """a give-up of the single-factorisation schedule inside gsum_potrf_lower destroys the matrix; the binding's
     ``factorize`` (what fit / predict / the reuse grid call) rebuilds it and factorises once more on the host-enqueued schedule, so
     a fit does not fail the first time a time-out happens.  The give-up is forced with the test hook."""
+    ctx = lab
     from sklearn.gaussian_process.kernels import RBF
     from gsum_amd._lib import ChainAborted
     n = 2048

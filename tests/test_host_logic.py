@@ -129,6 +129,20 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     import ctypes
     assert ctypes.sizeof(_lib.KernelDesc) == 8 + 8 * _lib.GSUM_MAX_D + 24
+    # ... and NOTHING else: the product library is the contract (<= 30 entry points, a header a maintainer can read in one sitting);
+    # diagnostics, probes and schedule switches are the lab build's (include/gsum_hip_debug.h, libgsum_hip_lab.so)
+    import subprocess
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("gsum_")}
+    assert exported(_lib.LIB_PATH) == declared and len(declared) <= 30
+    assert len(header.splitlines()) <= 200
+    debug = open(os.path.join(ROOT, "include", "gsum_hip_debug.h")).read()
+    lab_declared = set(re.findall(r"\b(gsum_[a-z0-9_]+)\s*\(", debug)) - declared
+    assert lab_declared == set(_lib.LAB_PROTOTYPES), lab_declared ^ set(_lib.LAB_PROTOTYPES)
+    assert exported(_lib.LAB_LIB_PATH) == declared | lab_declared
+    for name in ("gsum_debug", "gsum_probe", "gsum_bench"):
+        assert name not in header
 
 
 def test_no_gpu_means_loud_failure():
@@ -365,9 +379,14 @@ def test_kernel_register_budgets():
 
     bulk = find("k_gemm_ld3ILi2E")
     assert bulk["VGPRs"] <= 72 and bulk["Scratch"] == 0, bulk
+    for grouped in ("11k_gemm_ld3g", "11k_gemm_ld3n"):                       # the batch schedule's launches: the same tile, the same budget
+        g = find(grouped)
+        assert g["VGPRs"] <= 72 and g["Scratch"] == 0, (grouped, g)
     assert find("10k_panel256")["VGPRs"] <= 224 and find("10k_panel256")["Scratch"] == 0
+    assert find("11k_panel256g")["VGPRs"] <= 224 and find("11k_panel256g")["Scratch"] == 0
     assert find("7k_panelP")["VGPRs"] <= 224
-    assert find("12k_potrf_diagILi2E")["VGPRs"] <= 224
+    assert find("12k_potrf_diagP")["VGPRs"] <= 224
+    assert find("16k_potrf_diag256g")["VGPRs"] <= 256
     chain = find("7k_chain")
     assert chain["VGPRs"] <= 256 and chain["Scratch"] <= 64, chain        # one wave per SIMD, a CU of its own: no spills to memory
 

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 tag = os.environ.get("AB_TAG", "?")
 ctx.bench_gemm_nt(7, 7936, 7936, 256, True, 8208)           # warm-up (first measurement in a process reads low)
 res = {}

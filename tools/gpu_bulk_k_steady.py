@@ -8,10 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 M = 7936
 for rnd in range(2):
     for K in (256, 512, 1024, 2048):

@@ -11,12 +11,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_option("batch_slots", 1)
 out = {"cases": []}
 bad = 0

@@ -15,7 +15,7 @@ sys.path.insert(0, %r)
 import numpy as np
 import gsum_amd
 from sklearn.gaussian_process.kernels import RBF
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_option("batch_slots", 1)
 out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
 for n in (2048, 8192):

@@ -14,13 +14,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from gsum_amd._lib import HipContext  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_option("batch_slots", 1)
 noise = HipContext(0)
 stop = threading.Event()

@@ -9,14 +9,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 r = 6
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_option("batch_slots", 1)
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)

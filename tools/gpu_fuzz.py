@@ -19,7 +19,7 @@ from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantK
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 SPECIAL = [1, 2, 5, 16, 17, 127, 128, 129, 130, 255, 256, 257, 383, 384, 385, 511, 512, 513, 1000, 1024, 1025]
 fails = 0
 for it in range(cases):

@@ -8,12 +8,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from gsum_amd.kernels import describe_kernel, describe_gradient  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 for n in (1024, 2048, 4096, 8192):
     r = 6
     X = 0.1 * np.arange(n)[:, None]

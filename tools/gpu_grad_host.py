@@ -9,7 +9,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from gsum_amd.kernels import describe_gradient, describe_kernel  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, ConstantKernel as C, Matern, WhiteKernel  # noqa: E402

@@ -8,11 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, Matern  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_option("medium_path", 0)
 guard = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ctx.set_option("pivot_guard_ulps", guard)

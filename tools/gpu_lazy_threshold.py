@@ -10,11 +10,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
 for n in [int(a) for a in sys.argv[1:]] or (4352, 5120, 6144, 7168, 8192, 12288):
     X = 0.1 * np.arange(n)[:, None]

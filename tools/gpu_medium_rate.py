@@ -9,11 +9,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 LAZY = [int(a) for a in sys.argv[1:]] or [64]              # e.g. `gpu_medium_rate.py 1 2 1 2`: option medium_lazy (grouping depth) alternated (same-process A/B)
 for n, count in [(n, c) for n, c in ((512, 2048), (1024, 2048), (1536, 1024), (2048, 1024), (3072, 512), (4096, 512)) for _ in LAZY]:
     X = 0.1 * np.arange(n)[:, None]

@@ -8,12 +8,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from gsum_amd.kernels import describe_gradient, describe_kernel  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 for n, cnt in ((100, 8192), (256, 1024), (512, 1024), (1024, 1024), (2048, 1024), (4096, 512)):
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([np.random.RandomState(0).randn(n, 4), np.ones((n, 1))], axis=1)

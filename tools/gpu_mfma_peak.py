@@ -7,10 +7,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 for rnd in range(2):
     for nacc in (4, 8):
         for threads, wgs_per_cu in ((256, 1), (512, 1), (512, 2), (512, 3), (512, 4)):

@@ -13,7 +13,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
@@ -56,7 +55,7 @@ if not sensors:
     print("no readable hwmon sensors: nothing measured")
     sys.exit(0)
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 n = 8192
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, 6), np.ones((n, 1))], axis=1)

@@ -10,11 +10,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 for n, d, m in ((16384, 2, 2048), (8192, 1, 2048), (8192, 1, 4096)):
     rng = np.random.RandomState(n + m)
     if d == 2:

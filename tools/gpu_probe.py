@@ -13,7 +13,7 @@ import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 out = {}
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 out["mfma_f64"] = {f"wps{w}_acc{a}": ctx.probe_mfma_f64(4000, w, a)
                    for w, a in ((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 8), (2, 16), (4, 4), (4, 8), (8, 4), (1, 16))}
 for k, v in out["mfma_f64"].items():

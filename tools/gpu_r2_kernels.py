@@ -11,12 +11,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C  # noqa: E402
 
 out = {}
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 
 # ---- kernel build: equality of the two kernels, then timing
 for name, kern, d in (("rbf1d", RBF(0.2), 1), ("m52_2d", C(1.3) * Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-3), 2),

@@ -13,7 +13,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", sys.argv[1] if len(sys.argv) > 1 else
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 n = 8192
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, 6), np.ones((n, 1))], axis=1)

@@ -37,7 +37,7 @@ def main():
     args = ap.parse_args()
     import gsum_amd
     from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel
-    ctx = gsum_amd.default_context(0)
+    ctx = gsum_amd.lab_context(0)
     print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
     out = {"identity": [], "timing": []}
 

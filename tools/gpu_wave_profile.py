@@ -19,7 +19,7 @@ n, r = 8192, 6
 X = 0.1 * np.arange(n)[:, None]
 c = np.random.RandomState(0).randn(n, r)
 Z = np.concatenate([c, np.ones((n, 1))], axis=1)
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_inputs(X, Z)
 descs = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.19, 0.21, K)])
 for groups, size, depth, serial in ((3, 7, 3, 0), (2, 10, 3, 0), (3, 7, 3, 0), (2, 10, 3, 0), (3, 7, 2, 0), (3, 7, 4, 0), (3, 8, 3, 0), (3, 7, 3, 0), (2, 10, 3, 0)):

@@ -12,7 +12,7 @@ import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 n, ne, slots = (int(a) for a in (sys.argv[1:] + ["8192", "8", "4"])[:3])
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, 6), np.ones((n, 1))], axis=1)

@@ -11,7 +11,7 @@ import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 n, reps = (int(a) for a in (sys.argv[1:] + ["8192", "3"])[:2])
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 X = 0.1 * np.arange(n)[:, None]
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
 for _ in range(reps):

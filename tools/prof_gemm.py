@@ -8,5 +8,5 @@ sys.path.insert(0, ROOT)
 import gsum_amd  # noqa: E402
 
 cfg, M, K, tri, reps = (int(a) for a in (sys.argv[1:] + ["5", "8192", "256", "1", "3"])[:5])
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 print(cfg, M, K, tri, ctx.bench_gemm_nt(cfg, M, M, K, bool(tri), 8208, reps), flush=True)

@@ -14,7 +14,7 @@ from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 kern = C(1.0) * RBF(0.2) + WhiteKernel(1e-10, noise_level_bounds="fixed")
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, 6), np.ones((n, 1))], axis=1)

@@ -15,7 +15,7 @@ K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 n, r = 8192, 6
 X = 0.1 * np.arange(n)[:, None]
 Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis=1)
-ctx = gsum_amd.default_context(0)
+ctx = gsum_amd.lab_context(0)
 ctx.set_inputs(X, Z)
 ctx.set_option("wave_groups", G)
 ctx.set_option("wave_size", B)
