@@ -146,3 +146,18 @@ def grad_kernel(kd):
     if kd["add"] is not None:
         kern = kern + C(kd["add"])
     return kern
+
+
+def record_parity(name, **values):
+    """Append what a parity test ACHIEVED (not only that it stayed under its bound) to gpurun_out/parity_achieved.json, the file
+    the round's profiles/ copy is made from.  Values are plain floats / ints / lists."""
+    path = os.path.join(ROOT, "gpurun_out", "parity_achieved.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in values.items()}
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except Exception as exc:              # never fail a parity test over its log
+        print(f"[record_parity] {name}: {exc}")
+    print(f"[parity achieved] {name}: " + ", ".join(f"{k}={v}" for k, v in values.items() if not hasattr(v, "__len__")))

@@ -477,8 +477,19 @@ def test_notebook_grid_known_answer(notebook_grid):
         assert list(np.unravel_index(np.argmax(grid), grid.shape)) == [36, 39]
         assert not np.isneginf(grid).any() and not np.isnan(grid).any()
         # 5 training points 0.24 apart: columns with ell >~ 0.3 are ill-conditioned by construction
-        np.testing.assert_allclose(grid, want, rtol=1e-6)
-        np.testing.assert_allclose(grid[:, :45], want[:, :45], rtol=1e-9)
+        # (rounds 1-3 asserted 1e-6 / 1e-9 here on a conditioning argument; measured in round 4: 1.1e-14 over all 8000 entries --
+        # nugget + white noise keep cond(R) of the 5-point matrix below 4200 -- so the bound is the north star's, with room)
+        np.testing.assert_allclose(grid, want, rtol=1e-12)
+        # what is achieved, column class by column class: the 5 training points sit 0.24 apart, so
+        # cond(R) -- and with it the distance between any two valid fp64 factorisations -- grows with ell
+        from conftest import record_parity
+        rel = np.abs(grid - want) / np.abs(want)
+        conds = [float(np.linalg.cond(RBF(e)(X) + 2.0 * g["nugget"] * np.eye(len(X)))) for e in g["ls_vals"]]
+        well = np.array(conds) <= 1e5
+        assert well.any() and np.all(rel[:, well] <= 1e-10), rel[:, well].max()         # the conditioned columns: plain 1e-10
+        record_parity(f"notebook_grid_80x100_{mode}", max_plain_rel_all=float(rel.max()), max_plain_rel_cond_le_1e5=float(rel[:, well].max()),
+                      columns_cond_le_1e5=int(well.sum()), max_plain_rel_first_45_columns=float(rel[:, :45].max()),
+                      max_cond=float(max(conds)), argmax=[36, 39])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -627,7 +638,10 @@ def test_full_size_properties_n8192():
     c2 = gsum_amd.coefficients(y, rho, 1.0, np.arange(r))
     G2, _, _ = ctx.lml_batch([desc], X, np.concatenate([c2, np.ones((n, 1))], axis=1), 1e-10)
     D = np.append((0.5 / rho) ** np.arange(r), 1.0)
-    np.testing.assert_allclose(G2[0], D[:, None] * G0[0] * D[None, :], rtol=1e-7)
+    np.testing.assert_allclose(G2[0], D[:, None] * G0[0] * D[None, :], rtol=1e-10)      # (1e-7 until round 4; achieved 1.5e-11)
+    from conftest import record_parity
+    record_parity("n8192_ratio_rescaling_identity", max_plain_rel=float(np.max(np.abs(G2[0] - D[:, None] * G0[0] * D[None, :]) / np.abs(G2[0]))),
+                  note="G(rho) = D G(rho0) D between two separately factorised evaluations of the white-noise S3 input (lambda_min 2.7e-8)")
     M = ctx.kernel_matrix_dev(desc, X, diag_add=1e-10)
     assert ctx.potrf(M) == 0
     L = M.to_host()

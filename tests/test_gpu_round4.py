@@ -107,3 +107,45 @@ def test_factorize_recovers_from_a_chain_give_up(lab):
         assert ctx.get_option("chain_aborts") == aborts + 2
     finally:
         ctx.set_option("chain_persist", -1)
+
+
+def test_config5_all_eight_shards_against_the_reference():
+    """BASELINE configs[4] (n = 16384 2-D points, Matern-5/2 + White, 8 curves, predictive variance "on 8 GPUs"): the configuration's
+    16384 new points are 8 shards of 2048, one per GPU (gsum_amd.grid.predict_distributed: shard_range over the new points).  Round 3
+    pinned 16 probes, all inside rank 0's shard; tests/golden/s5_predict.json now holds the reference's fit -> predict(return_std)
+    (models.py:671-738, 753-845) at 32 probes in EVERY shard (256 in all).  Each shard is predicted as its rank would predict it --
+    predict(Xs[lo:hi]) on the whole 2048-point block -- and compared at its probes: mean 1e-9 of the largest mean, variance
+    1e-10 * cov_factor, with and without pred_noise."""
+    from conftest import record_parity
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    d = load_golden("s5_predict.json")
+    sp = d["shard_probes"]
+    n, r = d["n"], d["r"]
+    side = np.array(d["side"])
+    X = np.random.RandomState(0).rand(n, 2) * side
+    y = np.random.RandomState(2).randn(n, r)
+    Xs_all = np.random.RandomState(1).rand(sp["m_all"], 2) * side
+    kern = Matern(length_scale=d["length_scale"], nu=2.5) + WhiteKernel(d["white"], noise_level_bounds="fixed")
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None)
+    gp.fit(X, y)
+    assert gp.cov_factor_ == pytest.approx(d["cov_factor"], rel=1e-10)
+    idx = np.array(sp["index"])
+    want_mean, want_var, want_var_n = np.array(sp["mean"]), np.array(sp["std"]) ** 2, np.array(sp["std_pred_noise"]) ** 2
+    scale = np.abs(want_mean).max()
+    worst = dict(mean=0.0, var=0.0, var_noise=0.0)
+    per_shard = {}
+    for rank in range(sp["shards"]):
+        lo, hi = gsum_amd.shard_range(sp["m_all"], rank, sp["shards"])
+        mine = (idx >= lo) & (idx < hi)
+        assert mine.sum() == sp["per_shard"]
+        mean, std = gp.predict(Xs_all[lo:hi], return_std=True)                      # the rank's whole block, as predict_distributed calls it
+        _, std_n = gp.predict(Xs_all[lo:hi], return_std=True, pred_noise=True)
+        loc = idx[mine] - lo
+        em = float(np.max(np.abs(mean[loc] - want_mean[mine])) / scale)
+        ev = float(np.max(np.abs(std[loc] ** 2 - want_var[mine])) / d["cov_factor"])
+        evn = float(np.max(np.abs(std_n[loc] ** 2 - want_var_n[mine])) / d["cov_factor"])
+        per_shard[f"shard{rank}"] = dict(mean=em, var=ev, var_noise=evn)
+        assert em <= 1e-9 and ev <= 1e-10 and evn <= 1e-10, (rank, em, ev, evn)
+        worst = dict(mean=max(worst["mean"], em), var=max(worst["var"], ev), var_noise=max(worst["var_noise"], evn))
+    record_parity("config5_s5_eight_shards_vs_reference", probes=int(len(idx)), max_mean_err_over_max_mean=worst["mean"],
+                  max_var_err_over_cov_factor=worst["var"], max_var_noise_err_over_cov_factor=worst["var_noise"], per_shard=per_shard)
