@@ -106,9 +106,14 @@ class CpuContext:
         return list(descs)
 
     # -- operator level ------------------------------------------------------------------------------
-    def kernel_matrix(self, desc, X, Y=None, diag_add=0.0):
+    def kernel_matrix(self, desc, X, Y=None, diag_add=0.0, series=None):
         self.calls["kernel_matrix"] += 1
-        return kernel_matrix(desc, X, Y, diag_add)
+        K = kernel_matrix(desc, X, Y, diag_add)
+        if series is not None:
+            sc, ref_x, ratio_x = series[0], np.asarray(series[1], float), np.asarray(series[2], float)
+            ref_y, ratio_y = (ref_x, ratio_x) if Y is None else (np.asarray(series[3], float), np.asarray(series[4], float))
+            K = _series_factor(sc, ref_x, ratio_x, ref_y, ratio_y) * K
+        return K
 
     def kernel_matrix_dev(self, desc, X, diag_add=0.0):
         self.calls["kernel_matrix_dev"] += 1

@@ -92,6 +92,8 @@ PROTOTYPES = {
     "gsum_set_option": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "gsum_get_option": (C.c_int64, [_p, C.c_char_p]),
     "gsum_kernel_build": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, C.c_double, _dp]),
+    "gsum_kernel_build_series": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, C.c_double, C.POINTER(SeriesScale),
+                                          _dp, _dp, _dp, _dp, _dp]),
     "gsum_kernel_build_dev": (C.c_int, [_p, _kp, _dp, C.c_int64, C.c_int32, C.c_double, C.POINTER(_p)]),
     "gsum_mat_from_host": (C.c_int, [_p, _dp, C.c_int64, C.POINTER(_p)]),
     "gsum_potrf_lower": (C.c_int, [_p, _p, _ip]),
@@ -257,9 +259,29 @@ class HipContext:
         return v
 
     # -- operator level ------------------------------------------------------
-    def kernel_matrix(self, desc: KernelDesc, X, Y=None, diag_add: float = 0.0) -> np.ndarray:
+    def kernel_matrix(self, desc: KernelDesc, X, Y=None, diag_add: float = 0.0, series=None) -> np.ndarray:
+        """kernel(X[, Y]) as a host array.  ``series`` = (SeriesScale, ref_x, ratio_x[, ref_y, ratio_y]) scales it on the device
+        like TruncationProcess.cov before it is copied out (gsum_kernel_build_series)."""
         X = _f64(X)
         n, d = X.shape
+        if series is not None:
+            sc, ref_x, ratio_x = series[0], _f64(series[1]), _f64(series[2])
+            if ref_x.shape != (n,) or ratio_x.shape != (n,):
+                raise ValueError("series scaling needs one ref / ratio value per point")
+            if Y is None:
+                out, Yp, m, ref_y, ratio_y = np.empty((n, n)), None, 0, None, None
+            else:
+                Y = _f64(Y)
+                if Y.shape[1] != d:
+                    raise ValueError("X and Y must have the same number of features")
+                m = Y.shape[0]
+                ref_y, ratio_y = _f64(series[3]), _f64(series[4])
+                if ref_y.shape != (m,) or ratio_y.shape != (m,):
+                    raise ValueError("series scaling needs one ref / ratio value per point")
+                out, Yp = np.empty((n, m)), _ptr(Y)
+            self._check(self._lib.gsum_kernel_build_series(self._h, C.byref(desc), _ptr(X), n, d, Yp, m, float(diag_add), C.byref(sc),
+                                                           _ptr(ref_x), _ptr(ratio_x), _ptr(ref_y), _ptr(ratio_y), _ptr(out)))
+            return out
         if Y is None:
             out = np.empty((n, n))
             self._check(self._lib.gsum_kernel_build(self._h, C.byref(desc), _ptr(X), n, d, None, 0,

@@ -733,17 +733,19 @@ class ConjugateGaussianProcess:
         center = self.center_ if self._fit else self.center0
         return self.basis(X) @ center
 
-    def cov(self, X, Xp=None):
+    def _cov_parts(self, d):
+        """(factor, descriptor): the process covariance is ``factor * kernel_desc(X[, Xp])`` -- prior quantities before ``fit``
+        (models.py:579-589), ``cov_factor_`` and the fitted kernel after (:590-599).  One-argument form: the descriptor's own white
+        noise stays in."""
         if not self._fit:
             if self.df0 <= 2:
                 raise ValueError('df must be greater than 2 for the covariance to exist')
-            factor = cov_factor(self.scale0 ** 2, self.df0)
-            kernel = self._default_kernel if self.kernel is None else self.kernel
-        else:
-            factor = self.cov_factor_
-            kernel = self.kernel_
+            return cov_factor(self.scale0 ** 2, self.df0), describe_kernel(self._default_kernel if self.kernel is None else self.kernel, d)
+        return self.cov_factor_, describe_kernel(self.kernel_, d)
+
+    def cov(self, X, Xp=None):
         X = np.asarray(X, dtype=float)
-        desc = describe_kernel(kernel, X.shape[1])
+        factor, desc = self._cov_parts(X.shape[1])
         return factor * self._context().kernel_matrix(desc, X, None if Xp is None else np.asarray(Xp, dtype=float))
 
     def underlying_properties(self, X, return_std=False, return_cov=False):
@@ -882,7 +884,7 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
         desc.additive_const += float(self.disp_[0, 0])
         return cov_factor(self.scale_ ** 2, self.df_), desc
 
-    def cov(self, X, Xp=None):                                           # models.py:1099-1125
+    def _cov_parts(self, d):                                             # models.py:1099-1125
         import copy
         if not self._fit:
             df, scale, disp = self.df0, self.scale0, self.disp0
@@ -892,11 +894,9 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
             kernel = self.kernel_
         if df <= 2:
             raise ValueError('df must be greater than 2 for the covariance to exist')
-        X = np.asarray(X, dtype=float)
-        desc = copy.copy(describe_kernel(kernel, X.shape[1]))
-        desc.additive_const += float(np.atleast_2d(disp)[0, 0])
-        corr = self._context().kernel_matrix(desc, X, None if Xp is None else np.asarray(Xp, dtype=float))
-        return cov_factor(scale ** 2, df) * corr
+        desc = copy.copy(describe_kernel(kernel, d))
+        desc.additive_const += float(np.atleast_2d(disp)[0, 0])         # corr + basis disp basis^T with the constant basis
+        return cov_factor(scale ** 2, df), desc
 
     def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):   # models.py:1127-1184
         pred, basis = self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, True)

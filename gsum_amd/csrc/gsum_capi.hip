@@ -1203,8 +1203,12 @@ static int gs_upload_Z(gsum_ctx* ctx, gs_inputs* I, const double* Z, int64_t n, 
     return 0;
 }
 
-int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
-                      const double* Y, int64_t m, double diag_add, double* out) {
+static int gs_check_series(gsum_ctx* ctx, const gsum_series_scale* sc);
+
+// kernel(X[, Y]) -> host, optionally scaled like TruncationProcess.cov on the device before it leaves (sc != NULL)
+static int gs_kernel_build_host(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
+                                double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x, const double* ref_y,
+                                const double* ratio_y, double* out) {
     if (!ctx) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
     if (gs_check_desc(ctx, desc, d)) return -2;
@@ -1212,24 +1216,52 @@ int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double*
     const bool cross = Y != nullptr;
     const int64_t cols = cross ? m : n;
     if (cols <= 0) GS_FAIL("bad argument");
+    if (sc && (gs_check_series(ctx, sc) || !ref_x || !ratio_x || (cross && (!ref_y || !ratio_y)))) {
+        if (ctx->err.empty()) ctx->err = "series scaling needs ref / ratio for both point sets";
+        return -2;
+    }
     const int64_t ldo = (cols + 1) / 2 * 2;
     const size_t xb = (size_t)n * d * sizeof(double), yb = cross ? (size_t)m * d * sizeof(double) : 0;
-    const size_t ob = (size_t)n * ldo * sizeof(double);
-    const size_t off_y = (xb + 255) / 256 * 256, off_o = off_y + (yb + 255) / 256 * 256;
-    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, off_o + ob)) return -1;
+    const size_t ob = (size_t)n * ldo * sizeof(double), vb = sc ? (size_t)2 * (n + cols) * sizeof(double) : 0;
+    const size_t off_y = (xb + 255) / 256 * 256, off_o = off_y + (yb + 255) / 256 * 256, off_v = off_o + (ob + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, off_v + vb)) return -1;
     char* base = (char*)ctx->scratch;
     double* dXl = (double*)base;
     double* dYl = (double*)(base + off_y);
     double* dO = (double*)(base + off_o);
-    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, ctx->cur->sm));
-    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, ctx->cur->sm));
-    if (cross ? gs_launch_build<true>(ctx, ctx->cur->sm, dO, ldo, dXl, dYl, n, m, n, ldo, d, desc, 0.0, 0)
-              : gs_launch_build<false>(ctx, ctx->cur->sm, dO, ldo, dXl, nullptr, n, n, n, ldo, d, desc, diag_add, 0))
+    hipStream_t s = ctx->cur->sm;
+    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, s));
+    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, s));
+    if (cross ? gs_launch_build<true>(ctx, s, dO, ldo, dXl, dYl, n, m, n, ldo, d, desc, 0.0, 0)
+              : gs_launch_build<false>(ctx, s, dO, ldo, dXl, nullptr, n, n, n, ldo, d, desc, diag_add, 0))
         return -1;
+    if (sc) {
+        double* v = (double*)(base + off_v);
+        double *d_ref_r = v, *d_rat_r = v + n, *d_ref_c = v + 2 * n, *d_rat_c = v + 2 * n + cols;
+        GS_CHECK(hipMemcpyAsync(d_ref_r, ref_x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_rat_r, ratio_x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_ref_c, cross ? ref_y : ref_x, (size_t)cols * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_rat_c, cross ? ratio_y : ratio_x, (size_t)cols * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((cols + 255) / 256), (unsigned)n), dim3(256), 0, s, dO, ldo, (int)n, (int)cols,
+                           d_ref_r, d_rat_r, d_ref_c, d_rat_c, *sc);
+        GS_CHECK(hipGetLastError());
+    }
     GS_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dO, (size_t)ldo * sizeof(double),
-                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->cur->sm));
-    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
     return 0;
+}
+
+int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                      const double* Y, int64_t m, double diag_add, double* out) {
+    return gs_kernel_build_host(ctx, desc, X, n, d, Y, m, diag_add, nullptr, nullptr, nullptr, nullptr, nullptr, out);
+}
+
+int gsum_kernel_build_series(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
+                             double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                             const double* ref_y, const double* ratio_y, double* out) {
+    if (!ctx || !sc) return -2;
+    return gs_kernel_build_host(ctx, desc, X, n, d, Y, m, diag_add, sc, ref_x, ratio_x, ref_y, ratio_y, out);
 }
 
 int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,

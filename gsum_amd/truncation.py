@@ -24,74 +24,81 @@ class TruncationGP:
     _coeffs_process_class = ConjugateGaussianProcess
 
     def __init__(self, kernel=None, ratio=0.5, ref=1, excluded=None, ratio_kws=None, **kwargs):
-        if not callable(ref):
-            self.ref = lambda X, ref=ref: ref * np.ones(X.shape[0])          # models.py:1309-1312
-        else:
-            self.ref = ref
-        if not callable(ratio):
-            self.ratio = lambda X, ratio=ratio: ratio * np.ones(X.shape[0])  # models.py:1314-1317
-        else:
-            self.ratio = ratio
+        # ref / ratio: a number (broadcast over the points) or a callable of X (models.py:1309-1317); kept under the reference's
+        # attribute names because user code calls gp.ratio(X, **kws) / gp.ref(X)
+        self.ref = self._per_point("ref", ref)
+        self.ratio = self._per_point("ratio", ratio)
+        self.kernel, self.excluded = kernel, excluded
+        self.ratio_kws = dict(ratio_kws or {})
         self.coeffs_process = self._coeffs_process_class(kernel=kernel, **kwargs)
-        self.kernel = kernel
-        self._log_like = None
-        self.excluded = excluded
-        self.ratio_kws = {} if ratio_kws is None else ratio_kws
-        self._fit = False
-        self.X_train_ = None
-        self.y_train_ = None
-        self.orders_ = None
-        self.dX_ = None
-        self.dy_ = None
-        self.coeffs_ = None
+        self.X_train_ = self.y_train_ = self.orders_ = self.dX_ = self.dy_ = self.coeffs_ = None
+        self._fit, self._log_like = False, None
         # predict() conditions on cov(Xc, Xc), which carries no nugget (reference quirk Q7).  When that matrix is singular
         # to working precision the device Cholesky fails; by default the conditioning is then retried with the smallest
         # relative diagonal jitter that makes it factorise, with a RuntimeWarning.  True: raise LinAlgError instead.
         self.strict_conditioning = False
 
-    # -- scaled mean / cov / basis (models.py:1337-1365) -----------------------------------------
-    def mean(self, X, start=0, end=np.inf):
-        coeff_mean = self.coeffs_process.mean(X=X)
-        ratio_sum = geometric_sum(x=self.ratio(X, **self.ratio_kws), start=start, end=end, excluded=self.excluded)
-        return self.ref(X) * ratio_sum * coeff_mean
+    @staticmethod
+    def _per_point(name, value):
+        """A number becomes a function of X that broadcasts it over the points and can be overridden per call through the keyword
+        of the same name -- ``gp.log_marginal_likelihood(theta, ratio=0.45)`` relies on that (models.py:1310, 1315, 1493)."""
+        if callable(value):
+            return value
 
-    def cov(self, X, Xp=None, start=0, end=np.inf):
-        coeff_cov = self.coeffs_process.cov(X=X, Xp=Xp)
-        Xp = X if Xp is None else Xp        # must be reassigned *after* calling cov (WhiteKernel), :1344
-        ratio_mat = self.ratio(X, **self.ratio_kws)[:, None] * self.ratio(Xp, **self.ratio_kws)
-        ratio_sum = geometric_sum(x=ratio_mat, start=start, end=end, excluded=self.excluded)
-        ref_mat = self.ref(X)[:, None] * self.ref(Xp)
-        return ref_mat * ratio_sum * coeff_cov
+        def constant(X, **override):
+            extra = set(override) - {name}
+            if extra:
+                raise TypeError(f"{name}() got an unexpected keyword argument {sorted(extra)[0]!r}")
+            return override.get(name, value) * np.ones(np.shape(X)[0])
+        return constant
+
+    def _series(self, X, start, end, factor=1.0):
+        """(SeriesScale, ref(X), ratio(X)) of the points X for orders start..end: what the device needs to turn a coefficient
+        quantity into a partial-sum quantity -- ref_i ref_j S(ratio_i ratio_j), S the geometric sum with the excluded orders left
+        out (helpers.py:149-182)."""
+        from ._lib import SeriesScale
+        return SeriesScale.make(start, end, self.excluded, factor), self.ref(X), self.ratio(X, **self.ratio_kws)
+
+    # -- scaled mean / cov / basis (models.py:1337-1365) -----------------------------------------
+    def _order_sum(self, X, start, end):
+        """ref(x) * sum over the orders start..end of ratio(x)^n, one value per point."""
+        return self.ref(X) * geometric_sum(x=self.ratio(X, **self.ratio_kws), start=start, end=end, excluded=self.excluded)
+
+    def mean(self, X, start=0, end=np.inf):
+        return self._order_sum(X, start, end) * self.coeffs_process.mean(X=X)
 
     def basis(self, X, start=0, end=np.inf):
-        cn_basis = self.coeffs_process.basis(X)
-        ratio = self.ratio(X, **self.ratio_kws)[:, None]
-        ratio_sum = geometric_sum(x=ratio, start=start, end=end, excluded=self.excluded)
-        return self.ref(X)[:, None] * ratio_sum * cn_basis
+        return self._order_sum(X, start, end)[:, None] * self.coeffs_process.basis(X)
+
+    def cov(self, X, Xp=None, start=0, end=np.inf):
+        """cov_ij = ref_i ref_j S(ratio_i ratio_j) x [coefficient covariance]_ij.  The coefficient covariance is built AND scaled on
+        the device (gsum_kernel_build_series) and crosses PCIe once: no n x m host temporaries (the reference forms four,
+        models.py:1343-1348; 8 GiB of host traffic per call at n = 16384).  Xp=None is the one-argument kernel call -- WhiteKernel
+        noise on the diagonal -- exactly as in the reference, where Xp is replaced by X only after that call (:1344)."""
+        gp = self.coeffs_process
+        X = np.asarray(X, dtype=float)
+        factor, desc = gp._cov_parts(X.shape[1])
+        sc, ref_x, ratio_x = self._series(X, start, end, factor)
+        if Xp is None:
+            return gp._context().kernel_matrix(desc, X, series=(sc, ref_x, ratio_x))
+        Xp = np.asarray(Xp, dtype=float)
+        return gp._context().kernel_matrix(desc, X, Xp, series=(sc, ref_x, ratio_x, self.ref(Xp), self.ratio(Xp, **self.ratio_kws)))
 
     def underlying_properties(self, X, order, return_std=False, return_cov=False):
+        """Truncation error beyond ``order``: prior mean [and covariance / its diagonal] of the orders order + 1 .. inf."""
         y_mean = self.mean(X, start=order + 1)
-        if return_cov:
-            return y_mean, self.cov(X, start=order + 1)
-        if return_std:
-            return y_mean, np.sqrt(np.diag(self.cov(X, start=order + 1)))
-        return y_mean
+        if not (return_cov or return_std):
+            return y_mean
+        y_cov = self.cov(X, start=order + 1)
+        return y_mean, (y_cov if return_cov else np.sqrt(np.diag(y_cov)))
 
     # -- fit (models.py:1367-1387) -------------------------------------------------------------------
     def fit(self, X, y, orders, dX=None, dy=None):
-        self.X_train_ = X
-        self.y_train_ = y
-        self.orders_ = orders
-        orders_mask = ~np.isin(orders, self.excluded)
-        self.dX_ = dX
-        self.dy_ = dy
-        ratio = self.ratio(X, **self.ratio_kws)
-        ref = self.ref(X)
-        if np.atleast_1d(ratio).ndim > 1:
-            raise ValueError('ratio must return a 1d array or a scalar')
-        if np.atleast_1d(ref).ndim > 1:
-            raise ValueError('ref must return a 1d array or a scalar')
-        self.coeffs_ = coefficients(y=y, ratio=ratio, ref=ref, orders=orders)[:, orders_mask]
+        for name, fn in (("ratio", lambda: self.ratio(X, **self.ratio_kws)), ("ref", lambda: self.ref(X))):
+            if np.atleast_1d(fn()).ndim > 1:
+                raise ValueError(f'{name} must return a 1d array or a scalar')            # models.py:1379-1382
+        self.X_train_, self.y_train_, self.orders_, self.dX_, self.dy_ = X, y, orders, dX, dy
+        self.coeffs_, _ = self._coeffs_and_jacobian(X, y, orders, self.ratio_kws)
         self.coeffs_process.fit(X=X, y=self.coeffs_)
         self._fit = True
         return self

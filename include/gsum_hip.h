@@ -92,6 +92,12 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name);
  * one-argument form (n x n, unit diagonal forced, WhiteKernel noise and diag_add on the diagonal); else n x m, no diagonal terms. */
 int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
                       const double* Y, int64_t m, double diag_add, double* out);
+/* ... scaled on the device before it leaves: out_ij = sc.factor * ref_i ref_j S(ratio_i ratio_j) * kernel_ij, i.e. TruncationProcess.cov
+ * (models.py:1343-1348: ref_mat * geometric_sum(ratio_mat) * coeff_cov) without its four n x m host temporaries.  Y == NULL: ref_y,
+ * ratio_y are ignored (the row values serve both sides). */
+int gsum_kernel_build_series(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
+                             double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                             const double* ref_y, const double* ratio_y, double* out);
 /* kernel(X) + diag_add * I kept on the device, ready to factorise.  Replaces models.py:958-963, 708 + 711. */
 int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
                           double diag_add, gsum_mat** out);

@@ -149,3 +149,48 @@ def test_config5_all_eight_shards_against_the_reference():
         worst = dict(mean=max(worst["mean"], em), var=max(worst["var"], ev), var_noise=max(worst["var_noise"], evn))
     record_parity("config5_s5_eight_shards_vs_reference", probes=int(len(idx)), max_mean_err_over_max_mean=worst["mean"],
                   max_var_err_over_cov_factor=worst["var"], max_var_noise_err_over_cov_factor=worst["var_noise"], per_shard=per_shard)
+
+
+def test_truncation_cov_is_built_and_scaled_on_the_device(ctx):
+    """TruncationProcess.cov (models.py:1343-1348) = ref_i ref_j S(ratio_i ratio_j) cov_factor kernel_ij with position-dependent
+    ratio and ref and excluded orders: one device build + one device scaling (gsum_kernel_build_series), against the reference's
+    array expression evaluated with numpy on sampled rows -- one- and two-argument forms, fitted and unfitted process."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    rng = np.random.RandomState(8)
+    n, m, r = 4096, 700, 5
+    X = np.sort(rng.rand(n))[:, None] * 40.0
+    Xp = rng.rand(m, 1) * 40.0
+    kern = C(1.7) * RBF(0.9) + WhiteKernel(1e-5, noise_level_bounds="fixed")
+    ratio = lambda Z, q=0.4: q + 0.2 * np.sin(Z[:, 0] / 7.0) ** 2          # noqa: E731
+    ref = lambda Z: 3.0 + 0.1 * Z[:, 0]                                       # noqa: E731
+    gp = gsum_amd.TruncationGP(kernel=kern, ratio=ratio, ref=ref, excluded=[2], center=0, disp=0, df=3, scale=1.3, optimizer=None)
+    rows = np.array([0, 1, 17, 2048, 4095])
+
+    def want(Xa, Xb, start, end, one_arg):
+        cp = gp.coeffs_process
+        factor = cp.cov_factor_ if cp._fit else gsum_amd.cov_factor(cp.scale0 ** 2, cp.df0)
+        k = cp.kernel_ if cp._fit else kern
+        K = k(Xa[rows], Xb)
+        if one_arg:
+            K[np.arange(len(rows)), rows] += 1e-5                             # the one-argument call's WhiteKernel diagonal
+        rm = ratio(Xa[rows])[:, None] * ratio(Xb)
+        return (ref(Xa[rows])[:, None] * ref(Xb)) * gsum_amd.geometric_sum(x=rm, start=start, end=end, excluded=[2]) * (factor * K)
+
+    for fitted in (False, True):
+        if fitted:
+            y = gsum_amd.partials(rng.randn(n, r), ratio=ratio(X), ref=ref(X), orders=np.arange(r))
+            gp.fit(X, y, orders=np.arange(r))
+        for start, end in ((0, np.inf), (3, np.inf), (1, 4)):
+            got = gp.cov(X, start=start, end=end)
+            assert got.shape == (n, n)
+            np.testing.assert_allclose(got[rows], want(X, X, start, end, True), rtol=1e-12)
+            got = gp.cov(X, Xp, start=start, end=end)
+            assert got.shape == (n, m)
+            np.testing.assert_allclose(got[rows], want(X, Xp, start, end, False), rtol=1e-12)
+    m0, s0 = gp.underlying_properties(X[:50], order=2, return_std=True)
+    np.testing.assert_allclose(s0 ** 2, np.diag(gp.cov(X[:50], start=3)), rtol=1e-13)
+    with pytest.raises(ValueError):
+        gp.cov(X[:5], start=3, end=2)
+    with pytest.raises(TypeError):
+        gsum_amd.TruncationGP(ratio=0.5).ratio(X[:3], scale=2.0)            # a constant ratio takes `ratio=` only, like the reference's lambda
+    assert np.all(gsum_amd.TruncationGP(ratio=0.5).ratio(X[:3], ratio=0.25) == 0.25)
