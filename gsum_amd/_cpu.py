@@ -20,26 +20,71 @@ import numpy as np
 from scipy.linalg import cho_solve as _cho_solve
 from scipy.linalg import solve_triangular
 from scipy.linalg.lapack import dpotrf
-from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, RationalQuadratic
 
-from ._lib import FAMILY, GSUM_MAX_RHS, GradParam, KernelDesc
+from ._lib import FAMILY, GSUM_MAX_RHS, OP_ADD, OP_CONST, OP_LEAF, OP_WHITE, GradParam, KernelDesc
 from .series import geometric_sum
 
 _NU = {FAMILY["rbf"]: None, FAMILY["matern52"]: 2.5, FAMILY["matern32"]: 1.5, FAMILY["matern12"]: 0.5}
 
 
-def _leaf(desc: KernelDesc, d: int, free=False):
-    """The stationary scikit-learn leaf of a descriptor (length scale(s) as the descriptor holds them)."""
+def _leaf(desc, d: int, free=False):
+    """The stationary scikit-learn leaf of a flattened descriptor / of one leaf of a tree (length scale(s) as it holds them)."""
     ls = np.array(desc.length_scale[:d]) if desc.anisotropic else float(desc.length_scale[0])
     bounds = (1e-300, 1e300) if free else "fixed"
+    if int(desc.family) == FAMILY["rq"]:
+        return RationalQuadratic(length_scale=ls, alpha=float(desc.alpha), length_scale_bounds=bounds, alpha_bounds=bounds)
     nu = _NU[int(desc.family)]
     return RBF(ls, length_scale_bounds=bounds) if nu is None else Matern(ls, length_scale_bounds=bounds, nu=nu)
+
+
+def _tree_matrix(desc, X, Y, param=None):
+    """The postfix program of a tree descriptor on arrays, scikit-learn evaluating the leaves: the matrix, and with ``param`` (a
+    GradParam of the TREE_* kind) its derivative with respect to that log-hyperparameter (sum and product rules)."""
+    X = np.asarray(X, dtype=float)
+    Yv = None if Y is None else np.asarray(Y, dtype=float)
+    shape = (X.shape[0], X.shape[0] if Yv is None else Yv.shape[0])
+    eye = np.eye(shape[0]) if Yv is None else np.zeros(shape)
+    zero = np.zeros(shape)
+    stack = []
+    for k in range(desc.n_ops):
+        op = desc.op[k]
+        if op >= OP_WHITE:
+            c = op - OP_WHITE
+            hit = param is not None and param.code == GradParam.TREE_WHITE and param.dim == c
+            stack.append((desc.cval[c] * eye, desc.cval[c] * eye if hit else zero))
+        elif op >= OP_CONST:
+            c = op - OP_CONST
+            hit = param is not None and param.code == GradParam.TREE_CONST and param.dim == c
+            stack.append((np.full(shape, desc.cval[c]), np.full(shape, desc.cval[c]) if hit else zero))
+        elif op >= OP_LEAF:
+            l = op - OP_LEAF
+            mine = param is not None and param.code >= GradParam.TREE_LENGTH_ISO and (param.dim >> 4) == l
+            if mine and Yv is None:
+                V, dK = _leaf(desc.leaf[l], X.shape[1], free=True)(X, eval_gradient=True)
+                # scikit-learn's theta order within a leaf: alphabetical -- RationalQuadratic: alpha, length_scale; else length_scale[s]
+                if int(desc.leaf[l].family) == FAMILY["rq"]:
+                    dv = dK[:, :, 0] if param.code == GradParam.TREE_ALPHA else dK[:, :, 1]
+                else:
+                    dv = dK[:, :, param.dim & 15] if param.code == GradParam.TREE_LENGTH_DIM else dK[:, :, 0]
+                stack.append((V, dv))
+            else:
+                stack.append((_leaf(desc.leaf[l], X.shape[1])(X, Yv), zero))
+        else:
+            (b, db), (a, da) = stack.pop(), stack.pop()
+            stack.append((a + b, da + db) if op == OP_ADD else (a * b, da * b + a * db))
+    return stack[0]
 
 
 def kernel_matrix(desc: KernelDesc, X, Y=None, diag_add=0.0):
     """amplitude * leaf(X[, Y]) (+ white noise on the one-argument diagonal) + additive constant (+ diag_add): the kernel-build
     kernel's arithmetic, entry for entry (gsum_kernels.hip.h, k_build2), with scikit-learn evaluating the leaf."""
     X = np.asarray(X, dtype=float)
+    if desc.n_ops > 0:
+        K = np.array(_tree_matrix(desc, X, Y)[0])
+        if Y is None and diag_add:
+            K[np.diag_indices_from(K)] += float(diag_add)
+        return K
     base = _leaf(desc, X.shape[1])(X, None if Y is None else np.asarray(Y, dtype=float))
     K = float(desc.amplitude) * base
     if Y is None:
@@ -218,11 +263,15 @@ class CpuContext:
         n, d = X.shape
         V = _cho_solve((M.A, True), rhs)
         Rinv = _cho_solve((M.A, True), np.eye(n))
-        term = ConstantKernel(float(desc.amplitude), constant_value_bounds=(1e-300, 1e300)) * _leaf(desc, d, free=True)
-        _, dK = term(X, eval_gradient=True)                  # [:, :, 0]: d / d log amplitude; [:, :, 1:]: length scale(s)
+        dK = None
+        if desc.n_ops == 0:
+            term = ConstantKernel(float(desc.amplitude), constant_value_bounds=(1e-300, 1e300)) * _leaf(desc, d, free=True)
+            _, dK = term(X, eval_gradient=True)              # [:, :, 0]: d / d log amplitude; [:, :, 1:]: length scale(s)
         trace, H = np.empty(P), np.empty((P, k, k))
         for p, pr in enumerate(params):
-            if pr.code == GradParam.AMPLITUDE:
+            if pr.code >= GradParam.TREE_CONST:
+                dR = _tree_matrix(desc, X, None, pr)[1]
+            elif pr.code == GradParam.AMPLITUDE:
                 dR = dK[:, :, 0]
             elif pr.code == GradParam.LENGTH_ISO:
                 dR = dK[:, :, 1]

@@ -20,11 +20,24 @@ LAB_LIB_PATH = os.path.join(_HERE, "libgsum_hip_lab.so")     # the same sources 
 
 GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
-FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3}
+GSUM_MAX_LEAVES = 4
+GSUM_MAX_OPS = 16
+FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4}
+OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE = 1, 2, 16, 32, 64
+
+
+class KernelLeaf(C.Structure):
+    """Mirror of ``gsum_kernel_leaf``: one stationary leaf of a kernel tree."""
+    _fields_ = [
+        ("family", C.c_int32),
+        ("anisotropic", C.c_int32),
+        ("length_scale", C.c_double * GSUM_MAX_D),
+        ("alpha", C.c_double),
+    ]
 
 
 class KernelDesc(C.Structure):
-    """Mirror of ``gsum_kernel_desc``."""
+    """Mirror of ``gsum_kernel_desc``: the flattened form (``n_ops == 0``) or a postfix program over a Sum / Product tree."""
     _fields_ = [
         ("family", C.c_int32),
         ("anisotropic", C.c_int32),
@@ -32,9 +45,64 @@ class KernelDesc(C.Structure):
         ("amplitude", C.c_double),
         ("additive_const", C.c_double),
         ("white_noise", C.c_double),
+        ("n_ops", C.c_int32),
+        ("n_leaves", C.c_int32),
+        ("op", C.c_int32 * GSUM_MAX_OPS),
+        ("cval", C.c_double * GSUM_MAX_OPS),
+        ("leaf", KernelLeaf * GSUM_MAX_LEAVES),
     ]
 
+    @property
+    def is_tree(self):
+        return self.n_ops > 0
+
+    def one_arg_diagonal(self):
+        """k(x, x) of the ONE-argument form (every stationary leaf exactly 1, WhiteKernel noise in): the diagonal of R_nn at
+        gsum/models.py:824."""
+        if not self.is_tree:
+            return self.amplitude * 1.0 + self.white_noise + self.additive_const
+        stack = []
+        for k in range(self.n_ops):
+            op = self.op[k]
+            if op >= OP_CONST:
+                stack.append(self.cval[op - (OP_WHITE if op >= OP_WHITE else OP_CONST)])
+            elif op >= OP_LEAF:
+                stack.append(1.0)
+            else:
+                b, a = stack.pop(), stack.pop()
+                stack.append(a + b if op == OP_ADD else a * b)
+        return stack[0]
+
+    def without_white(self):
+        """A copy whose WhiteKernel terms are zero: the kernel called with BOTH arguments given (kernels.py:1413-1414)."""
+        import copy
+        out = copy.copy(self)
+        out.white_noise = 0.0
+        for k in range(self.n_ops):
+            if self.op[k] >= OP_WHITE:
+                out.cval[self.op[k] - OP_WHITE] = 0.0
+        return out
+
+    def plus_constant(self, c):
+        """A copy with an additive constant on top of the whole kernel (ConjugateStudentProcess: corr + basis disp basis^T)."""
+        import copy
+        out = copy.copy(self)
+        if not self.is_tree:
+            out.additive_const += float(c)
+            return out
+        used = {self.op[k] - (OP_WHITE if self.op[k] >= OP_WHITE else OP_CONST) for k in range(self.n_ops) if self.op[k] >= OP_CONST}
+        slot = next(i for i in range(GSUM_MAX_OPS) if i not in used)
+        if self.n_ops + 2 > GSUM_MAX_OPS:
+            raise NotImplementedError("kernel tree too large for the device descriptor")
+        out.cval[slot] = float(c)
+        out.op[self.n_ops] = OP_CONST + slot
+        out.op[self.n_ops + 1] = OP_ADD
+        out.n_ops = self.n_ops + 2
+        return out
+
     def __repr__(self):
+        if self.is_tree:
+            return f"KernelDesc(tree: ops={list(self.op)[:self.n_ops]}, leaves={self.n_leaves})"
         ls = list(self.length_scale)[: (GSUM_MAX_D if self.anisotropic else 1)]
         return (f"KernelDesc(family={self.family}, aniso={self.anisotropic}, ls={ls}, amp={self.amplitude}, "
                 f"add={self.additive_const}, white={self.white_noise})")
@@ -73,6 +141,7 @@ class GradParam(C.Structure):
     _fields_ = [("code", C.c_int32), ("dim", C.c_int32), ("weight", C.c_double)]
 
     AMPLITUDE, LENGTH_ISO, LENGTH_DIM, WHITE, ADDITIVE = range(5)
+    TREE_CONST, TREE_WHITE, TREE_LENGTH_ISO, TREE_LENGTH_DIM, TREE_ALPHA = range(16, 21)     # parameters of a kernel tree (see gsum_hip.h)
 
     def __repr__(self):
         return f"GradParam(code={self.code}, dim={self.dim}, weight={self.weight})"

@@ -517,10 +517,7 @@ class ConjugateGaussianProcess:
     def _cov_terms(self, d):
         """(factor, descriptor) such that the two-argument covariance of the fitted process is
         factor * kernel_desc(X, Xp): what TruncationProcess conditions with (models.py:599, 1343)."""
-        import copy
-        desc = copy.copy(describe_kernel(self.kernel_, d))
-        desc.white_noise = 0.0                  # kernel_(X, Xp) with both arguments given: no white noise
-        return self.cov_factor_, desc
+        return self.cov_factor_, describe_kernel(self.kernel_, d).without_white()      # kernel_(X, Xp), both given: no white noise
 
     # -- fit (models.py:630-738) -------------------------------------------------------------------
     def _constrained_optimization(self, obj_func, initial_theta, bounds):
@@ -811,7 +808,7 @@ class ConjugateGaussianProcess:
             var = cov_factor(self.scale_ ** 2, self.df_)                           # models.py:840
             if return_std:
                 # diag of the one-argument kernel: unit base value, WhiteKernel noise included (:824)
-                diag_nn = desc.amplitude * 1.0 + desc.white_noise + desc.additive_const
+                diag_nn = desc.one_arg_diagonal()
                 r_diag = diag_nn - colsumsq                                        # models.py:836
                 if pred_noise:
                     r_diag = r_diag + self.nugget                                  # models.py:837-838
@@ -881,11 +878,9 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
     def _cov_terms(self, d):
         # var * (corr + basis disp basis^T) with a constant basis is an additive constant in the kernel (:1125)
         _, desc = super()._cov_terms(d)
-        desc.additive_const += float(self.disp_[0, 0])
-        return cov_factor(self.scale_ ** 2, self.df_), desc
+        return cov_factor(self.scale_ ** 2, self.df_), desc.plus_constant(float(self.disp_[0, 0]))
 
     def _cov_parts(self, d):                                             # models.py:1099-1125
-        import copy
         if not self._fit:
             df, scale, disp = self.df0, self.scale0, self.disp0
             kernel = self._default_kernel if self.kernel is None else self.kernel
@@ -894,9 +889,8 @@ class ConjugateStudentProcess(ConjugateGaussianProcess):
             kernel = self.kernel_
         if df <= 2:
             raise ValueError('df must be greater than 2 for the covariance to exist')
-        desc = copy.copy(describe_kernel(kernel, d))
-        desc.additive_const += float(np.atleast_2d(disp)[0, 0])         # corr + basis disp basis^T with the constant basis
-        return cov_factor(scale ** 2, df), desc
+        # corr + basis disp basis^T with the constant basis: an additive constant on top of the kernel
+        return cov_factor(scale ** 2, df), describe_kernel(kernel, d).plus_constant(float(np.atleast_2d(disp)[0, 0]))
 
     def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):   # models.py:1127-1184
         pred, basis = self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, True)

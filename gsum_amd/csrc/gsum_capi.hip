@@ -399,11 +399,36 @@ static void gs_mat_release(gsum_mat* m) {
 
 static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
     if (!desc) GS_FAIL("kernel descriptor is NULL");
-    if (desc->family < GSUM_RBF || desc->family > GSUM_MATERN12) GS_FAIL("unknown kernel family");
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
-    int nls = desc->anisotropic ? d : 1;
-    for (int i = 0; i < nls; ++i)
-        if (!(desc->length_scale[i] > 0.0)) GS_FAIL("length_scale must be positive");
+    if (desc->n_ops == 0) {
+        if (desc->family < GSUM_RBF || desc->family > GSUM_MATERN12) GS_FAIL("unknown kernel family");
+        int nls = desc->anisotropic ? d : 1;
+        for (int i = 0; i < nls; ++i)
+            if (!(desc->length_scale[i] > 0.0)) GS_FAIL("length_scale must be positive");
+        return 0;
+    }
+    // a tree: a well-formed postfix program over valid leaves
+    if (desc->n_ops < 0 || desc->n_ops > GSUM_MAX_OPS || desc->n_leaves < 1 || desc->n_leaves > GSUM_MAX_LEAVES) GS_FAIL("kernel tree: bad op / leaf count");
+    int depth = 0;
+    for (int k = 0; k < desc->n_ops; ++k) {
+        const int op = desc->op[k];
+        if (op == GSUM_OP_ADD || op == GSUM_OP_MUL) {
+            if (depth < 2) GS_FAIL("kernel tree: operator without two operands");
+            --depth;
+        } else {
+            const int idx = op >= GSUM_OP_WHITE ? op - GSUM_OP_WHITE : (op >= GSUM_OP_CONST ? op - GSUM_OP_CONST : op - GSUM_OP_LEAF);
+            if (op < GSUM_OP_LEAF || idx < 0 || idx >= (op >= GSUM_OP_CONST ? GSUM_MAX_OPS : desc->n_leaves)) GS_FAIL("kernel tree: bad operand");
+            if (++depth > 8) GS_FAIL("kernel tree: deeper than 8 pending operands");
+        }
+    }
+    if (depth != 1) GS_FAIL("kernel tree: the program does not reduce to one value");
+    for (int l = 0; l < desc->n_leaves; ++l) {
+        const gsum_kernel_leaf& lf = desc->leaf[l];
+        if (lf.family < GSUM_RBF || lf.family > GSUM_RQ) GS_FAIL("kernel tree: unknown leaf family");
+        if (lf.family == GSUM_RQ && (lf.anisotropic || !(lf.alpha > 0.0))) GS_FAIL("kernel tree: RationalQuadratic needs alpha > 0 and an isotropic length scale");
+        for (int i = 0; i < (lf.anisotropic ? d : 1); ++i)
+            if (!(lf.length_scale[i] > 0.0)) GS_FAIL("length_scale must be positive");
+    }
     return 0;
 }
 
@@ -414,6 +439,12 @@ static int gs_launch_build(gsum_ctx* ctx, hipStream_t s, double* out, int64_t ld
                            int64_t m, int64_t prow, int64_t pcol, int d, const gsum_kernel_desc* desc, double diag_add, int tri) {
     const int64_t tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS, tc = (pcol + 127) / 128, t128 = (prow + 127) / 128;
     const int64_t blocks = tri ? 4 * (t128 * (t128 + 1) / 2) : tr * tc;
+    if (desc->n_ops > 0) {                      // a general Sum / Product tree: entry-by-entry evaluation (k_build_tree)
+        hipLaunchKernelGGL((k_build_tree<CROSS>), dim3((unsigned)blocks), dim3(256), 0, s, out, ldo, X, Y, (int)n, (int)m, (int)prow,
+                           (int)pcol, d, *desc, diag_add, tri);
+        GS_CHECK(hipGetLastError());
+        return 0;
+    }
 #define GS_B2_LAUNCH(FAM, D1)                                                                                              \
     hipLaunchKernelGGL((k_build2<CROSS, FAM, D1>), dim3((unsigned)blocks), dim3(256), 0, s, out, ldo, X, Y, (int)n, (int)m, \
                        (int)prow, (int)pcol, d, *desc, diag_add, tri)
@@ -2094,7 +2125,9 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     if (!ctx->in->X) GS_FAIL("gsum_set_inputs has not been called");
     for (int i = 0; i < n_kernels; ++i)
         if (gs_check_desc(ctx, &kernels[i], ctx->in->d)) return -2;
-    if (ctx->in->n <= GS_NB && ctx->small_path) {
+    bool any_tree = false;                       // the one-workgroup-per-evaluation kernels build the flattened form only
+    for (int i = 0; i < n_kernels; ++i) any_tree = any_tree || kernels[i].n_ops > 0;
+    if (ctx->in->n <= GS_NB && ctx->small_path && !any_tree) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
@@ -2102,7 +2135,7 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     // profiles/r03_medium_breakeven.log): the fused path wins from 2, 8, ~23, ~45, ~78, ~140, ~180 evaluations at n = 256, 512, 1024, 1536, 2048, 3072, 4096
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
                                                   : std::max(4, (int)(pow((double)ctx->in->n, 1.55) / 2000.0));
-    if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
+    if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min && !any_tree) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
@@ -2173,8 +2206,14 @@ static int gs_grad_check(gsum_ctx* ctx, const gsum_grad_param* params, int32_t n
     if (n_params < 1 || n_params > GSUM_MAX_GRAD) GS_FAIL("n_params must be 1..GSUM_MAX_GRAD");
     if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
     for (int p = 0; p < n_params; ++p) {
-        if (params[p].code < GSUM_GRAD_AMPLITUDE || params[p].code > GSUM_GRAD_ADDITIVE) GS_FAIL("unknown gradient parameter code");
-        if (params[p].code == GSUM_GRAD_LENGTH_DIM && (params[p].dim < 0 || params[p].dim >= d)) GS_FAIL("gradient parameter dim out of range");
+        const int code = params[p].code, dim = params[p].dim;
+        if (code >= GSUM_GRAD_TREE_CONST && code <= GSUM_GRAD_TREE_ALPHA) {          // parameters of a kernel tree
+            if (code <= GSUM_GRAD_TREE_WHITE ? (dim < 0 || dim >= GSUM_MAX_OPS) : (dim < 0 || (dim >> 4) >= GSUM_MAX_LEAVES || (dim & 15) >= d))
+                GS_FAIL("gradient parameter of a kernel tree: slot / leaf / dimension out of range");
+            continue;
+        }
+        if (code < GSUM_GRAD_AMPLITUDE || code > GSUM_GRAD_ADDITIVE) GS_FAIL("unknown gradient parameter code");
+        if (code == GSUM_GRAD_LENGTH_DIM && (dim < 0 || dim >= d)) GS_FAIL("gradient parameter dim out of range");
     }
     return 0;
 }

@@ -491,6 +491,165 @@ __global__ __launch_bounds__(256) void k_build2(double* out, int64_t ldo, const 
     }
 }
 
+// ---- general kernel trees (gsum_kernel_desc with n_ops > 0) ----------------------------------------------------------------------
+// The reference hands ANY scikit-learn kernel to its three call sites (gsum/models.py:708, 822-824, 958-960).  The flattened
+// descriptor covers the family its own tests and notebooks use and runs the templated kernels above; everything else that is a
+// Sum / Product tree over stationary leaves (RBF, Matern 1/2 3/2 5/2, RationalQuadratic), ConstantKernel and WhiteKernel is
+// evaluated entry by entry as a postfix program in scikit-learn's own evaluation order (Sum: k1 + k2, kernels.py:858-866;
+// Product: k1 * k2, :956-966), so that `RBF + RBF` or `C * RBF + C * Matern` come out bit-identical to sklearn's matrix like
+// the flattened family does; RationalQuadratic goes through pow() and is within an ulp or two of numpy's.
+// The same walk with dual numbers gives d kernel / d log(parameter) for the gradient path (sklearn's K_gradient formulas per leaf:
+// RBF :1567-1577, Matern :1740-1771, RationalQuadratic :1893-1901; product and sum rules for the operators).
+#define GS_TREE_STACK 8
+
+// want: 0 value only, 1 d / d log length_scale (isotropic), 2 d / d log length_scale[dim], 3 d / d log alpha
+__device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const double* xi, const double* xj, int d, bool diag, int want,
+                                             int dim, double& v, double& dv) {
+#pragma clang fp contract(off)
+    dv = 0.0;
+    if (diag) {                                  // np.fill_diagonal(K, 1) of the one-argument form; every leaf gradient is 0 there
+        v = 1.0;
+        return;
+    }
+    if (lf.family == GSUM_RQ) {                  // kernels.py:1886-1890: (1 + sqeuclidean(X) / (2 alpha ls^2)) ** -alpha
+        double s = 0.0;
+        for (int m = 0; m < d; ++m) {
+            const double e = xi[m] - xj[m];
+            s = s + e * e;
+        }
+        const double ls2 = lf.length_scale[0] * lf.length_scale[0];
+        const double base = 1.0 + s / ((2.0 * lf.alpha) * ls2);
+        v = pow(base, -lf.alpha);
+        if (want == 1) dv = s * v / (ls2 * base);
+        else if (want == 3) dv = v * (-lf.alpha * log(base) + s / ((2.0 * ls2) * base));
+        return;
+    }
+    double s = 0.0, dsel = 0.0;                  // sqeuclidean(X / length_scale): divide first, like pdist on the scaled points
+    for (int m = 0; m < d; ++m) {
+        const double ls = lf.anisotropic ? lf.length_scale[m] : lf.length_scale[0];
+        const double u = xi[m] / ls - xj[m] / ls;
+        const double dmm = u * u;
+        s = s + dmm;
+        if (m == dim) dsel = dmm;
+    }
+    v = gs_base_value(lf.family, s);
+    if (want == 1 || want == 2) {
+        const double dm = want == 1 ? s : dsel;
+        if (lf.family == GSUM_RBF) {
+            dv = v * dm;
+        } else if (lf.family == GSUM_MATERN52) {
+            const double tmp = sqrt(5.0 * s);
+            dv = 5.0 / 3.0 * dm * (tmp + 1.0) * gs_exp_np(-tmp);
+        } else if (lf.family == GSUM_MATERN32) {
+            dv = 3.0 * dm * gs_exp_np(-sqrt(3.0 * s));
+        } else {
+            const double den = sqrt(s);
+            dv = den != 0.0 ? v * (dm / den) : 0.0;
+        }
+    }
+}
+
+// value of the tree at (xi, xj); diag: the entry is on the diagonal of the ONE-argument form (leaves exactly 1, WhiteKernel on).
+// pr != NULL: *dout = d value / d log(parameter pr) as well.
+__device__ __forceinline__ double gs_tree_eval(const gsum_kernel_desc& t, const double* xi, const double* xj, int d, bool diag,
+                                               const gsum_grad_param* pr, double* dout) {
+#pragma clang fp contract(off)
+    double sv[GS_TREE_STACK], sd[GS_TREE_STACK];
+    int sp = 0;
+    const int code = pr ? pr->code : -1, pdim = pr ? pr->dim : 0;
+    for (int k = 0; k < t.n_ops; ++k) {
+        const int op = t.op[k];
+        if (op >= GSUM_OP_WHITE) {
+            const int c = op - GSUM_OP_WHITE;
+            const double w = diag ? t.cval[c] : 0.0;
+            sv[sp] = w;
+            sd[sp] = (code == GSUM_GRAD_TREE_WHITE && pdim == c) ? w : 0.0;
+            ++sp;
+        } else if (op >= GSUM_OP_CONST) {
+            const int c = op - GSUM_OP_CONST;
+            sv[sp] = t.cval[c];
+            sd[sp] = (code == GSUM_GRAD_TREE_CONST && pdim == c) ? t.cval[c] : 0.0;
+            ++sp;
+        } else if (op >= GSUM_OP_LEAF) {
+            const int l = op - GSUM_OP_LEAF;
+            int want = 0;
+            if (code >= GSUM_GRAD_TREE_LENGTH_ISO && (pdim >> 4) == l)
+                want = code == GSUM_GRAD_TREE_LENGTH_ISO ? 1 : (code == GSUM_GRAD_TREE_LENGTH_DIM ? 2 : 3);
+            double v, dv;
+            gs_leaf_eval(t.leaf[l], xi, xj, d, diag, want, pdim & 15, v, dv);
+            sv[sp] = v;
+            sd[sp] = dv;
+            ++sp;
+        } else {
+            const double b = sv[sp - 1], db = sd[sp - 1], a = sv[sp - 2], da = sd[sp - 2];
+            sp -= 2;
+            if (op == GSUM_OP_ADD) {
+                sv[sp] = a + b;
+                sd[sp] = da + db;
+            } else {
+                sv[sp] = a * b;
+                sd[sp] = da * b + a * db;
+            }
+            ++sp;
+        }
+    }
+    if (dout) *dout = sd[0];
+    return sv[0];
+}
+
+// kernel matrix of a tree: the tile geometry of k_build2 (32 x 128 tiles, a lane owns two adjacent columns), values through gs_tree_eval
+template <bool CROSS>
+__global__ __launch_bounds__(256) void k_build_tree(double* out, int64_t ldo, const double* X, const double* Y, int n, int m, int prow,
+                                                     int pcol, int d, gsum_kernel_desc desc, double diag_add, int tri) {
+#pragma clang fp contract(off)
+    const int t = threadIdx.x;
+    int bi, bj;
+    if (tri) {
+        const int bid = blockIdx.x >> 2;
+        int b128 = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(b128 + 1) * (b128 + 2) / 2 <= bid) ++b128;
+        while ((int64_t)b128 * (b128 + 1) / 2 > bid) --b128;
+        bj = bid - (int)((int64_t)b128 * (b128 + 1) / 2);
+        bi = 4 * b128 + (blockIdx.x & 3);
+    } else {
+        const int tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS;
+        bi = blockIdx.x % tr;
+        bj = blockIdx.x / tr;
+    }
+    const double* Yp = CROSS ? Y : X;
+    const int ny = CROSS ? m : n;
+    const int lane = t & 63, w = t >> 6;
+    const int gj0 = bj * 128 + 2 * lane;
+    if (gj0 >= pcol) return;
+    double xj[2][GSUM_MAX_D];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xj[c][mm] = (mm < d && gj0 + c < ny) ? Yp[(int64_t)(gj0 + c) * d + mm] : 0.0;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int gi = bi * GS_B2_ROWS + 8 * w + rr;
+        if (gi >= prow) continue;
+        double xi[GSUM_MAX_D];
+#pragma unroll
+        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xi[mm] = (mm < d && gi < n) ? X[(int64_t)gi * d + mm] : 0.0;
+        double v[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int gj = gj0 + c;
+            if (CROSS) {
+                v[c] = (gi < n && gj < m) ? gs_tree_eval(desc, xi, xj[c], d, false, nullptr, nullptr) : 0.0;
+            } else if (gi >= n || gj >= n) {
+                v[c] = gi == gj ? 1.0 : 0.0;                       // identity padding
+            } else {
+                v[c] = gs_tree_eval(desc, xi, xj[c], d, gi == gj, nullptr, nullptr);
+                if (gi == gj) v[c] = v[c] + diag_add;
+            }
+        }
+        const gs_d2 o = {v[0], v[1]};
+        *reinterpret_cast<gs_d2*>(out + (int64_t)gi * ldo + gj0) = o;
+    }
+}
+
 // Border rows np..np+15 of the augmented matrix: row c = column c of RHS (n x k, row-major), zero
 // beyond k / n, and a zero 16x16 corner.
 __global__ __launch_bounds__(256) void k_set_border(double* A, int64_t ld, int n, int np, const double* Z, int k) {
@@ -3234,7 +3393,15 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, i
             }
         }
         const double dm = pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel;
-        const double g = gs_kernel_grad(desc, pr, s, dm, i == j);
+        double g;
+        if (desc.n_ops > 0) {                    // a general tree: the same walk as the kernel build, with dual numbers
+            double xj[GSUM_MAX_D];
+#pragma unroll
+            for (int m = 0; m < GSUM_MAX_D; ++m) xj[m] = m < d ? X[(int64_t)j * d + m] : 0.0;
+            (void)gs_tree_eval(desc, xi, xj, d, i == j, &pr, &g);
+        } else {
+            g = gs_kernel_grad(desc, pr, s, dm, i == j);
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(g, Vt[(int64_t)c * ldv + j], acc[c]);
         if (j <= i) tr = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g, tr);

@@ -1,22 +1,26 @@
-"""scikit-learn kernel tree -> ``gsum_kernel_desc`` (the POD the HIP kernel-build kernel consumes).
+"""scikit-learn kernel tree -> ``gsum_kernel_desc`` (the POD the HIP kernel-build kernels consume).
 
 The reference calls ``kernel(X)`` / ``kernel(X, Y)`` on arbitrary scikit-learn kernels
-(gsum/models.py:708, 822-824, 958-960).  The device kernel implements the family the reference's
-own tests, notebooks and defaults use:
+(gsum/models.py:146-147, 686-688, 708, 822-824, 958-960).  Two descriptor forms:
 
-    [ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5}))  [+ WhiteKernel] [+ ConstantKernel]
+* flattened -- ``[ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5})) [+ WhiteKernel] [+ ConstantKernel]``, the family the
+  reference's own tests, notebooks and defaults use; it runs the templated fast kernels and the one-workgroup-per-evaluation paths;
+* tree (round 4) -- any ``Sum`` / ``Product`` tree over RBF, Matern(0.5, 1.5, 2.5), RationalQuadratic, ConstantKernel and
+  WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``RationalQuadratic`` ...): a postfix program in scikit-learn's own
+  evaluation order, at most 4 stationary leaves and 16 operations.
 
-with isotropic or anisotropic ``length_scale``.  Anything else raises ``NotImplementedError`` —
-there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's:
-callers use ``kernel.clone_with_theta(theta)`` and describe the clone, or, for a stack of thetas,
-:func:`describe_thetas`, which reproduces the setter's values without the per-theta clone.
+Other leaves (DotProduct, ExpSineSquared, Exponentiation ...) raise ``NotImplementedError`` -- on the 'hip' backend there is
+deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's: leaves left to right, a leaf's
+hyperparameters in alphabetical order.  :func:`describe_thetas` / :func:`describe_gradients` reproduce the
+setter's values without a clone per theta.
 """
 from __future__ import annotations
 
 import numpy as np
-from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Product, Sum, WhiteKernel)
+from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Product, RationalQuadratic, Sum, WhiteKernel)
 
-from ._lib import FAMILY, GSUM_MAX_D, GradParam, KernelDesc
+from ._lib import (FAMILY, GSUM_MAX_D, GSUM_MAX_LEAVES, GSUM_MAX_OPS, OP_ADD, OP_CONST, OP_LEAF, OP_MUL, OP_WHITE, GradParam,
+                   KernelDesc)
 
 __all__ = ["describe_kernel", "describe_thetas", "describe_gradient", "describe_gradients", "default_kernel"]
 
@@ -126,10 +130,179 @@ def _describe(terms, values, n_features, shown) -> KernelDesc:
     return desc
 
 
+# ---- general trees ----------------------------------------------------------------------------------------------------------------
+class _TreeNode:
+    """A leaf of the postfix program with where its free hyperparameters sit in theta."""
+    __slots__ = ("kind", "kernel", "slot", "offsets")
+
+    def __init__(self, kind, kernel, slot, offsets):
+        self.kind, self.kernel, self.slot, self.offsets = kind, kernel, slot, offsets
+
+
+def _compile_tree(kernel):
+    """Postfix program of a Sum / Product tree: [("leaf" | "const" | "white", node) | "add" | "mul", ...] and theta's length.
+    theta offsets follow scikit-learn: k1's parameters before k2's, a leaf's free hyperparameters in alphabetical order."""
+    prog, offset, counts = [], [0], {"leaf": 0, "cval": 0}
+
+    def free(hyper, off):
+        return None if hyper.fixed else off
+
+    def walk(k):
+        if isinstance(k, (Sum, Product)):
+            walk(k.k1)
+            walk(k.k2)
+            prog.append("add" if isinstance(k, Sum) else "mul")
+            return
+        if isinstance(k, WhiteKernel):
+            h = k.hyperparameter_noise_level
+            node = _TreeNode("white", k, counts["cval"], {"value": free(h, offset[0])})
+            counts["cval"] += 1
+            offset[0] += 0 if h.fixed else 1
+        elif isinstance(k, ConstantKernel):
+            h = k.hyperparameter_constant_value
+            node = _TreeNode("const", k, counts["cval"], {"value": free(h, offset[0])})
+            counts["cval"] += 1
+            offset[0] += 0 if h.fixed else 1
+        elif isinstance(k, RationalQuadratic):
+            ha, hl = k.hyperparameter_alpha, k.hyperparameter_length_scale          # alphabetical: alpha, length_scale
+            offs = {"alpha": free(ha, offset[0])}
+            offset[0] += 0 if ha.fixed else 1
+            offs["length_scale"] = free(hl, offset[0])
+            offset[0] += 0 if hl.fixed else 1
+            node = _TreeNode("leaf", k, counts["leaf"], offs)
+            counts["leaf"] += 1
+        elif isinstance(k, (RBF, Matern)):
+            if isinstance(k, Matern) and float(k.nu) not in (0.5, 1.5, 2.5):
+                raise NotImplementedError(f"Matern nu={k.nu} is not supported on the device (0.5, 1.5, 2.5 are)")
+            h = k.hyperparameter_length_scale
+            node = _TreeNode("leaf", k, counts["leaf"], {"length_scale": free(h, offset[0]), "n": h.n_elements})
+            counts["leaf"] += 1
+            offset[0] += 0 if h.fixed else h.n_elements
+        else:
+            raise NotImplementedError(f"kernel {k!r} is not supported on the device (Sum / Product trees over RBF, Matern, "
+                                      "RationalQuadratic, ConstantKernel and WhiteKernel are)")
+        prog.append(node)
+
+    walk(kernel)
+    if counts["leaf"] < 1:
+        raise NotImplementedError(f"kernel {kernel} has no stationary (RBF / Matern / RationalQuadratic) part")
+    if counts["leaf"] > GSUM_MAX_LEAVES or len(prog) > GSUM_MAX_OPS:
+        raise NotImplementedError(f"kernel {kernel} is too large for the device descriptor ({GSUM_MAX_LEAVES} stationary leaves, "
+                                  f"{GSUM_MAX_OPS} operations)")
+    return prog, offset[0]
+
+
+def _tree_values(node, theta):
+    """Hyperparameter values of a leaf for a theta (None: the kernel's own), formed like scikit-learn's setter forms them."""
+    k = node.kernel
+
+    def val(name, own):
+        off = node.offsets.get(name)
+        if theta is None or off is None:
+            return own
+        n = node.offsets.get("n", 1) if name == "length_scale" else 1
+        return np.exp(theta[off:off + n]) if n > 1 else np.exp(theta[off])
+
+    if node.kind == "white":
+        return val("value", k.noise_level)
+    if node.kind == "const":
+        return val("value", k.constant_value)
+    if isinstance(k, RationalQuadratic):
+        return val("length_scale", k.length_scale), val("alpha", k.alpha)
+    return val("length_scale", k.length_scale), None
+
+
+def _describe_tree(prog, theta, n_features, shown) -> KernelDesc:
+    if n_features < 1 or n_features > GSUM_MAX_D:
+        raise ValueError(f"number of features must be 1..{GSUM_MAX_D}, got {n_features}")
+    desc = KernelDesc()
+    desc.amplitude = 1.0
+    n_leaves = 0
+    for i, item in enumerate(prog):
+        if item == "add":
+            desc.op[i] = OP_ADD
+        elif item == "mul":
+            desc.op[i] = OP_MUL
+        elif item.kind in ("white", "const"):
+            desc.cval[item.slot] = float(_tree_values(item, theta))
+            desc.op[i] = (OP_WHITE if item.kind == "white" else OP_CONST) + item.slot
+        else:
+            ls, alpha = _tree_values(item, theta)
+            lf = desc.leaf[item.slot]
+            k = item.kernel
+            if isinstance(k, RationalQuadratic):
+                lf.family, lf.alpha = FAMILY["rq"], float(alpha)
+            elif isinstance(k, Matern):
+                lf.family = FAMILY[{0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(k.nu)]]
+            else:
+                lf.family = FAMILY["rbf"]
+            ls = np.atleast_1d(np.asarray(ls, dtype=float))
+            if ls.size == 1:
+                lf.anisotropic = 0
+                lf.length_scale[0] = float(ls[0])
+            else:
+                if ls.size != n_features:
+                    raise ValueError(f"anisotropic kernel has {ls.size} length scales, X has {n_features} features")
+                lf.anisotropic = 1
+                for m, v in enumerate(ls):
+                    lf.length_scale[m] = float(v)
+            desc.op[i] = OP_LEAF + item.slot
+            n_leaves += 1
+    desc.n_ops, desc.n_leaves = len(prog), n_leaves
+    return desc
+
+
+def _tree_gradient_params(prog, theta, n_features):
+    """One GradParam per element of theta, in theta's order."""
+    slots = {}
+
+    def gp(code, dim=0, weight=0.0):
+        g = GradParam()
+        g.code, g.dim, g.weight = code, dim, float(weight)
+        return g
+
+    for item in prog:
+        if isinstance(item, str):
+            continue
+        if item.kind in ("white", "const"):
+            off = item.offsets["value"]
+            if off is not None:
+                slots[off] = [gp(GradParam.TREE_WHITE if item.kind == "white" else GradParam.TREE_CONST, item.slot, _tree_values(item, theta))]
+        elif isinstance(item.kernel, RationalQuadratic):
+            if item.offsets["alpha"] is not None:
+                slots[item.offsets["alpha"]] = [gp(GradParam.TREE_ALPHA, item.slot * 16)]
+            if item.offsets["length_scale"] is not None:
+                slots[item.offsets["length_scale"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
+        else:
+            off = item.offsets["length_scale"]
+            if off is not None:
+                if item.offsets["n"] > 1:
+                    slots[off] = [gp(GradParam.TREE_LENGTH_DIM, item.slot * 16 + m) for m in range(n_features)]
+                else:
+                    slots[off] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
+    out = []
+    for off in sorted(slots):
+        out.extend(slots[off])
+    return out
+
+
+def _is_flat(kernel, n_features):
+    """Does the flattened descriptor cover this kernel?"""
+    try:
+        terms, _ = _flatten(kernel)
+        _describe(terms, lambda leaf: leaf.value, n_features, kernel)
+        return True
+    except NotImplementedError:
+        return False
+
+
 def describe_kernel(kernel, n_features: int) -> KernelDesc:
-    """Flatten ``kernel`` into a :class:`KernelDesc` for inputs with ``n_features`` columns."""
-    terms, _ = _flatten(kernel)
-    return _describe(terms, lambda leaf: leaf.value, n_features, kernel)
+    """``kernel`` as a :class:`KernelDesc` for inputs with ``n_features`` columns: the flattened form where it applies, else a tree."""
+    if _is_flat(kernel, n_features):
+        terms, _ = _flatten(kernel)
+        return _describe(terms, lambda leaf: leaf.value, n_features, kernel)
+    prog, _ = _compile_tree(kernel)
+    return _describe_tree(prog, None, n_features, kernel)
 
 
 def describe_thetas(kernel, thetas, n_features: int):
@@ -138,6 +311,15 @@ def describe_thetas(kernel, thetas, n_features: int):
     The values are formed exactly as the setter forms them (kernels.py Kernel.theta: ``np.exp(theta[i])`` for a scalar hyperparameter,
     ``np.exp(theta[i:i+n])`` for a vector one), so the descriptors are equal byte for byte (tests/test_host_logic.py)."""
     describe_kernel(kernel, n_features)          # the family check first: an unsupported tree says so, not "wrong theta size"
+    if not _is_flat(kernel, n_features):
+        prog, n_dims = _compile_tree(kernel)
+        out = []
+        for theta in thetas:
+            theta = np.atleast_1d(np.asarray(theta, dtype=float))
+            if theta.ndim != 1 or theta.size != n_dims:
+                raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
+            out.append(_describe_tree(prog, theta, n_features, kernel))
+        return out
     terms, n_dims = _flatten(kernel)
     out = []
     for theta in thetas:
@@ -197,6 +379,12 @@ def describe_gradient(kernel, n_features: int):
     a leaf's free hyperparameters in alphabetical order): what ``kernel(X, eval_gradient=True)``
     would put in ``K_gradient[:, :, p]``.  Same kernel family as :func:`describe_kernel`."""
     describe_kernel(kernel, n_features)                       # same validation, same error messages
+    if not _is_flat(kernel, n_features):
+        prog, n_dims = _compile_tree(kernel)
+        out = _tree_gradient_params(prog, None, n_features)
+        if len(out) != n_dims or n_dims != len(kernel.theta):
+            raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
+        return out
     terms, n_dims = _flatten(kernel)
     out = _gradient_params(terms, lambda leaf: leaf.value, n_features)
     if len(out) != n_dims or n_dims != len(kernel.theta):
@@ -209,6 +397,15 @@ def describe_gradients(kernel, thetas, n_features: int):
     :func:`describe_thetas`): the weights of the additive / white parameters are the hyperparameter VALUES, so there is one list
     per theta."""
     describe_kernel(kernel, n_features)
+    if not _is_flat(kernel, n_features):
+        prog, n_dims = _compile_tree(kernel)
+        out = []
+        for theta in thetas:
+            theta = np.atleast_1d(np.asarray(theta, dtype=float))
+            if theta.ndim != 1 or theta.size != n_dims:
+                raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
+            out.append(_tree_gradient_params(prog, theta, n_features))
+        return out
     terms, n_dims = _flatten(kernel)
     out = []
     for theta in thetas:

@@ -127,7 +127,7 @@ class TruncationGP:
         # matrix fails; rather than regress those workflows the conditioning is retried with a relative jitter on the
         # diagonal of the correlation matrix, smallest first, and says so.
         # (relative to the kernel's own diagonal: amplitude + additive constant of the descriptor)
-        kdiag = float(desc.amplitude) + float(desc.additive_const)
+        kdiag = float(desc.one_arg_diagonal())      # (desc carries no white noise here: see _cov_terms)
         for jitter in (0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6):
             K, info = ctx.factorize(desc, Xc, diag_add=jitter * kdiag, series=(sc, ref_c, ratio_c))
             try:

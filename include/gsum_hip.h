@@ -31,23 +31,39 @@ extern "C" {
 typedef struct gsum_ctx gsum_ctx;
 typedef struct gsum_mat gsum_mat;   /* device square matrix / Cholesky factor */
 
-enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3 };
+enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3, GSUM_RQ = 4 /* RationalQuadratic: tree leaves only */ };
 
-/* Flattened scikit-learn kernel tree  amplitude * base(X / length_scale) + additive_const (+ white on the one-argument
- * diagonal).  Arithmetic follows sklearn/gaussian_process/kernels.py: RBF 1556-1565, Matern 1711-1738, WhiteKernel
- * 1401-1414, Sum 858-866, Product 956-966. */
+/* A scikit-learn kernel (the reference accepts any: models.py:146-147, 686-688, 958-960).  Arithmetic follows
+ * sklearn/gaussian_process/kernels.py: RBF 1556-1565, Matern 1711-1738, RationalQuadratic 1874-1903, WhiteKernel 1401-1414, Sum 858-866,
+ * Product 956-966.  n_ops == 0: the flattened form amplitude * base(X / length_scale) + additive_const (+ white_noise on the
+ * one-argument diagonal) -- the reference's own kernels, the templated fast kernels.  n_ops > 0: a Sum / Product tree as a postfix
+ * program in scikit-learn's evaluation order: GSUM_OP_LEAF + l pushes leaf[l](x, y) (exactly 1 on the one-argument diagonal),
+ * GSUM_OP_CONST + c pushes cval[c], GSUM_OP_WHITE + c pushes cval[c] on that diagonal and 0 elsewhere, ADD / MUL combine two values. */
+#define GSUM_MAX_LEAVES 4
+#define GSUM_MAX_OPS 16
+enum { GSUM_OP_ADD = 1, GSUM_OP_MUL = 2, GSUM_OP_LEAF = 16, GSUM_OP_CONST = 32, GSUM_OP_WHITE = 64 };
 typedef struct {
-    int32_t family;                    /* GSUM_RBF ... */
+    int32_t family;                    /* GSUM_RBF ... GSUM_RQ */
+    int32_t anisotropic;               /* 0: length_scale[0] for every dimension */
+    double length_scale[GSUM_MAX_D];
+    double alpha;                      /* RationalQuadratic scale mixture (unused otherwise) */
+} gsum_kernel_leaf;
+typedef struct {
+    int32_t family;                    /* GSUM_RBF ... GSUM_MATERN12 */
     int32_t anisotropic;               /* 0: length_scale[0] for every dimension */
     double length_scale[GSUM_MAX_D];
     double amplitude;                  /* ConstantKernel factor (1.0 if absent)  */
     double additive_const;             /* ConstantKernel summand (0.0 if absent) */
     double white_noise;                /* WhiteKernel noise_level (0.0 if absent)*/
+    int32_t n_ops, n_leaves;           /* 0, 0: the flattened form above is the kernel */
+    int32_t op[GSUM_MAX_OPS];
+    double cval[GSUM_MAX_OPS];
+    gsum_kernel_leaf leaf[GSUM_MAX_LEAVES];
 } gsum_kernel_desc;
 
-/* Scaling of a coefficient covariance into a partial-sum covariance (TruncationProcess.cov, models.py:1343-1354, with
- * helpers.py:149-182):  cov_ij = factor * ref_i ref_j * S(ratio_i ratio_j) * kernel_ij,
- * S(x) = (x^start - x^(end+1)) / (1 - x) - sum over excluded orders e in [start, end] of x^e;  end < 0: the infinite sum. */
+/* Coefficient covariance -> partial-sum covariance (TruncationProcess.cov, models.py:1343-1354; helpers.py:149-182):
+ * cov_ij = factor * ref_i ref_j * S(ratio_i ratio_j) * kernel_ij,  S(x) = (x^start - x^(end+1)) / (1 - x) - sum of x^e over the
+ * excluded orders e in [start, end];  end < 0: the infinite sum. */
 #define GSUM_MAX_EXCLUDED 16
 typedef struct {
     int32_t start, end;
@@ -56,11 +72,14 @@ typedef struct {
     double factor;
 } gsum_series_scale;
 
-/* One free log-hyperparameter theta_p of the kernel tree, in scikit-learn's order (k1 before k2, attributes alphabetical):
- * what d kernel(X) / d theta_p is.  AMPLITUDE: the ConstantKernel factor of the stationary term; LENGTH_ISO / LENGTH_DIM: the
- * (dim-th) length scale; WHITE / ADDITIVE: a WhiteKernel / additive ConstantKernel term whose own value is `weight`. */
+/* One free log-hyperparameter theta_p, in scikit-learn's order (k1 before k2, a leaf's attributes alphabetical): what
+ * d kernel(X) / d theta_p is.  AMPLITUDE: the ConstantKernel factor of the stationary term; LENGTH_ISO / LENGTH_DIM: the (dim-th)
+ * length scale; WHITE / ADDITIVE: a WhiteKernel / additive ConstantKernel term whose own value is `weight`. */
 #define GSUM_MAX_GRAD 12
-enum { GSUM_GRAD_AMPLITUDE = 0, GSUM_GRAD_LENGTH_ISO = 1, GSUM_GRAD_LENGTH_DIM = 2, GSUM_GRAD_WHITE = 3, GSUM_GRAD_ADDITIVE = 4 };
+enum { GSUM_GRAD_AMPLITUDE = 0, GSUM_GRAD_LENGTH_ISO = 1, GSUM_GRAD_LENGTH_DIM = 2, GSUM_GRAD_WHITE = 3, GSUM_GRAD_ADDITIVE = 4,
+       /* tree form (n_ops > 0); `dim` = slot index for CONST / WHITE, leaf * 16 + dimension for the leaf parameters: */
+       GSUM_GRAD_TREE_CONST = 16, GSUM_GRAD_TREE_WHITE = 17, GSUM_GRAD_TREE_LENGTH_ISO = 18, GSUM_GRAD_TREE_LENGTH_DIM = 19,
+       GSUM_GRAD_TREE_ALPHA = 20 };
 typedef struct {
     int32_t code;
     int32_t dim;
@@ -92,9 +111,8 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name);
  * one-argument form (n x n, unit diagonal forced, WhiteKernel noise and diag_add on the diagonal); else n x m, no diagonal terms. */
 int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
                       const double* Y, int64_t m, double diag_add, double* out);
-/* ... scaled on the device before it leaves: out_ij = sc.factor * ref_i ref_j S(ratio_i ratio_j) * kernel_ij, i.e. TruncationProcess.cov
- * (models.py:1343-1348: ref_mat * geometric_sum(ratio_mat) * coeff_cov) without its four n x m host temporaries.  Y == NULL: ref_y,
- * ratio_y are ignored (the row values serve both sides). */
+/* ... scaled on the device before it leaves, out_ij = sc.factor * ref_i ref_j S(ratio_i ratio_j) * kernel_ij: TruncationProcess.cov
+ * (models.py:1343-1348) without its four n x m host temporaries.  Y == NULL: ref_y, ratio_y are ignored. */
 int gsum_kernel_build_series(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
                              double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
                              const double* ref_y, const double* ratio_y, double* out);
@@ -139,11 +157,10 @@ void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A);
  * G_out n_kernels x k x k, sld_out n_kernels, info_out n_kernels (potrf info; G / sld undefined where > 0). */
 int gsum_lml_batch(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n, int32_t d,
                    const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out, int64_t* info_out);
-/* The same with inputs resident in HBM: gsum_set_inputs uploads X and RHS once, gsum_lml_resident evaluates descriptors
- * against them (what bench.py times).  The evaluations of a call are independent: three or more advance in groups, ONE launch
- * per kernel class and outer step carrying all members of a group, on groups + 1 streams; results equal
- * one-at-a-time runs bit for bit.  n <= 128, and 128 < n <= 4096 with many evaluations per call, run whole evaluations in one
- * workgroup each. */
+/* The same with inputs resident in HBM: gsum_set_inputs uploads X and RHS once, gsum_lml_resident evaluates descriptors against
+ * them (what bench.py times).  Three or more evaluations advance in groups, ONE launch per kernel class and outer step carrying
+ * all members of a group, on groups + 1 streams; results equal one-at-a-time runs bit for bit.  n <= 128,
+ * and 128 < n <= 4096 with many evaluations per call, run whole evaluations in one workgroup each (flattened descriptors). */
 int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);
 int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k);      /* zeros before the first gsum_set_inputs */
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
@@ -173,8 +190,7 @@ int gsum_lml_resident_shard(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int3
                             double nugget, double* G_out, double* sld_out, int64_t* info_out, int64_t* lo, int64_t* hi);
 
 /* ---- measurement -------------------------------------------------------------------------------------------------------- */
-/* HIP-event times (ms) of the last single fused evaluation: ms[0] K build, ms[1] Cholesky (incl. fused solve), ms[2] read-out +
- * D2H, ms[3] total */
+/* HIP-event times (ms) of the last single fused evaluation: K build, Cholesky (incl. fused solve), read-out + D2H, total */
 int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
 /* With "profile_gemm" on: summed HIP-event durations (ms), algorithmic flops and launch counts since the last call, five classes:
  * [0] kernel build, [1] diagonal blocks, [2] panel solves and near updates, [3] the bulk trailing update, [4] the rest; each launch

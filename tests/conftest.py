@@ -161,3 +161,9 @@ def record_parity(name, **values):
     except Exception as exc:              # never fail a parity test over its log
         print(f"[record_parity] {name}: {exc}")
     print(f"[parity achieved] {name}: " + ", ".join(f"{k}={v}" for k, v in values.items() if not hasattr(v, "__len__")))
+
+
+def tree_kernel(expr):
+    """Kernel of a tests/golden/tree_kernels.json case (see make_golden.py): the expression evaluated over the scikit-learn kernel classes."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, RationalQuadratic, ConstantKernel as C
+    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic))

@@ -736,11 +736,60 @@ def gen_sample_y():
     return cases
 
 
+TREE_KERNELS = [          # (expression, input dimension): scikit-learn kernels OUTSIDE the flattened family (missing 2)
+    ("RBF(0.6) + RBF(2.5)", 1),
+    ("C(2.0) * RBF(0.8) + C(0.5) * Matern(1.5, nu=2.5) + WhiteKernel(1e-3)", 1),
+    ("RationalQuadratic(length_scale=0.9, alpha=1.3)", 2),
+    ("(RBF(0.7) + C(0.1)) * Matern([1.0, 2.0], nu=1.5) + WhiteKernel(1e-4, noise_level_bounds='fixed')", 2),
+    ("RationalQuadratic(length_scale=1.1, alpha=0.7) * RBF([0.9, 1.7]) + C(0.3, constant_value_bounds='fixed')", 2),
+    ("C(1.5) * Matern(0.8, nu=0.5) + RBF(1.9)", 1),
+]
+
+
+def tree_kernel(expr):
+    from sklearn.gaussian_process.kernels import RationalQuadratic
+    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic))
+
+
+def gen_tree_kernels():
+    """General Sum / Product kernel trees through the reference (models.py:146-147, 686-688, 958-960 accept any scikit-learn kernel):
+    log_marginal_likelihood value + gradient at two thetas, the fitted hyperparameters with the optimiser off, predict mean / std,
+    one kernel matrix row, and a TruncationGP likelihood.  Points well separated (conditioned matrices): 1e-10 is meaningful."""
+    cases = []
+    for idx, (expr, dim) in enumerate(TREE_KERNELS):
+        rng = np.random.RandomState(500 + idx)
+        n, r = 60, 3
+        X = (np.sort(rng.rand(n))[:, None] * 25.0) if dim == 1 else rng.rand(n, 2) * np.array([9.0, 14.0])
+        Xs = (np.linspace(0.5, 24.0, 9)[:, None]) if dim == 1 else rng.rand(9, 2) * np.array([9.0, 14.0])
+        y = rng.randn(n, r)
+        kern = tree_kernel(expr)
+        pri = dict(center=0.2, disp=0.5, df=3, scale=1.3)
+        gp = gsum.ConjugateGaussianProcess(kernel=kern, optimizer=None, nugget=1e-8, **pri)
+        evals = []
+        for shift in (0.0, 0.15):
+            theta = kern.theta + shift * np.cos(np.arange(len(kern.theta)))
+            val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+            evals.append(dict(theta=L(theta), lml=float(val), grad=L(grad)))
+        gp.fit(X, y)
+        mean, std = gp.predict(Xs, return_std=True)
+        K = kern(X)
+        tg = gsum.TruncationGP(kernel=kern, ratio=0.6, ref=2.0, optimizer=None, nugget=1e-8, **pri)
+        orders = np.arange(r)
+        yp = gsum.partials(y, ratio=0.6, ref=2.0, orders=orders)
+        tg.fit(X, yp, orders=orders)
+        cases.append(dict(expr=expr, dim=dim, X=L(X), y=L(y), Xs=L(Xs), priors=pri, nugget=1e-8, evals=evals, cond=float(np.linalg.cond(K + 1e-8 * np.eye(n))),
+                          fit=dict(lml=float(gp.log_marginal_likelihood_value_), center=L(gp.center_), disp=L(gp.disp_), df=float(gp.df_),
+                                   scale=float(gp.scale_), cov_factor=float(gp.cov_factor_)),
+                          predict=dict(mean=L(mean), std=L(std)), K_row3=L(K[3]), K_cross_row3=L(kern(X, Xs)[3]),
+                          trunc=dict(ratio=0.55, lml=float(tg.log_marginal_likelihood(theta=kern.theta, ratio=0.55)))))
+    return cases
+
+
 def main():
     only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
     if only:
         gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid, s5_predict=gen_s5_predict,
-                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying, sample_y=gen_sample_y)
+                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying, sample_y=gen_sample_y, tree_kernels=gen_tree_kernels)
         for name in only:
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(gens[name](), f, indent=1)
@@ -778,6 +827,8 @@ def main():
         json.dump(gen_underlying(), f, indent=1)
     with open(os.path.join(HERE, "sample_y.json"), "w") as f:
         json.dump(gen_sample_y(), f, indent=1)
+    with open(os.path.join(HERE, "tree_kernels.json"), "w") as f:
+        json.dump(gen_tree_kernels(), f, indent=1)
     with open(os.path.join(HERE, "s5_predict.json"), "w") as f:      # ~10 minutes on 8 cores, ~15 GB
         json.dump(gen_s5_predict(), f, indent=1)
     import sklearn, scipy

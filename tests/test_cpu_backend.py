@@ -96,3 +96,7 @@ def test_notebook_grid_and_optimizer(cpu_backend, notebook_grid):
 def test_large_known_answer_n512(cpu_backend, large_lml):
     T.test_large_known_answers_uniform_grid(large_lml, 0)
     T.test_large_known_answers_gp_drawn(0)
+
+
+def test_tree_kernels_golden(cpu_backend):
+    T.test_tree_kernels_golden()

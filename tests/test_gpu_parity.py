@@ -1130,3 +1130,61 @@ def test_batch_lazy_far_updates_are_scheduling_only_below_8192(lab, n):
     finally:
         ctx.set_option("lazy_far", 2)
         ctx.set_option("wave_min", 3)
+
+
+
+def test_tree_kernels_golden():
+    """Kernels OUTSIDE the flattened family -- RBF + RBF, C * RBF + C * Matern + White, RationalQuadratic, (RBF + C) * Matern(aniso),
+    RationalQuadratic * RBF(aniso) + C, C * Matern(1/2) + RBF -- through the drop-in classes against the reference's own outputs
+    (tests/golden/tree_kernels.json; the reference accepts any scikit-learn kernel: models.py:146-147, 686-688, 958-960): the kernel
+    matrix (bit-identical to scikit-learn's where no leaf is a RationalQuadratic, whose pow() is within ulps), the likelihood and its
+    gradient in scikit-learn's theta order, fit, predict, the truncation likelihood."""
+    from conftest import load_golden, tree_kernel, record_parity
+    achieved = {}
+    for case in load_golden("tree_kernels.json"):
+        kern = tree_kernel(case["expr"])
+        d = case["dim"]
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        desc = gsum_amd.describe_kernel(kern, d)
+        assert desc.is_tree, case["expr"]
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, nugget=case["nugget"], **case["priors"])
+        ctx = gp._context()
+        K = ctx.kernel_matrix(desc, X)
+        Kx = ctx.kernel_matrix(desc, X, Xs)
+        assert ulp_close(K[3], np.array(case["K_row3"])) and ulp_close(Kx[3], np.array(case["K_cross_row3"]))
+        if "RationalQuadratic" not in case["expr"] and SVML_HOST:
+            np.testing.assert_array_equal(K, kern(X))                       # same exp restatement, same evaluation order: bit for bit
+            np.testing.assert_array_equal(Kx, kern(X, Xs))
+        np.testing.assert_array_equal(K, K.T)
+        vtol = max(1e-10, 3e-17 * case["cond"])
+        gtol = 1e-15 * case["cond"] + 1e-9
+        worst_v = worst_g = 0.0
+        for ev in case["evals"]:
+            theta = np.array(ev["theta"])
+            val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+            assert val == pytest.approx(ev["lml"], rel=vtol), case["expr"]
+            assert gp.log_marginal_likelihood(theta, X=X, y=y) == val
+            np.testing.assert_allclose(grad, ev["grad"], rtol=gtol, atol=gtol * np.abs(ev["grad"]).max())
+            worst_v = max(worst_v, abs(val - ev["lml"]) / abs(ev["lml"]))
+            worst_g = max(worst_g, float(np.max(np.abs(grad - np.array(ev["grad"]))) / np.abs(ev["grad"]).max()))
+        gp.fit(X, y)
+        f = case["fit"]
+        ptol = max(1e-9, 100 * vtol)
+        assert gp.log_marginal_likelihood_value_ == pytest.approx(f["lml"], rel=vtol)
+        np.testing.assert_allclose(gp.center_, f["center"], rtol=ptol, atol=1e-12)
+        np.testing.assert_allclose(gp.disp_, f["disp"], rtol=ptol)
+        assert gp.df_ == f["df"] and gp.scale_ == pytest.approx(f["scale"], rel=ptol) and gp.cov_factor_ == pytest.approx(f["cov_factor"], rel=ptol)
+        mean, std = gp.predict(Xs, return_std=True)
+        np.testing.assert_allclose(mean, case["predict"]["mean"], rtol=ptol, atol=ptol * np.abs(case["predict"]["mean"]).max())
+        np.testing.assert_allclose(std ** 2, np.array(case["predict"]["std"]) ** 2, rtol=ptol, atol=max(1e-10, ptol) * gp.cov_factor_)
+        r = y.shape[1]
+        tg = gsum_amd.TruncationGP(kernel=kern, ratio=0.6, ref=2.0, optimizer=None, nugget=case["nugget"], **case["priors"])
+        tg.fit(X, gsum_amd.partials(y, ratio=0.6, ref=2.0, orders=np.arange(r)), orders=np.arange(r))
+        got = tg.log_marginal_likelihood(theta=kern.theta, ratio=case["trunc"]["ratio"])
+        assert got == pytest.approx(case["trunc"]["lml"], rel=vtol)
+        grid = tg.log_marginal_likelihood_grid([kern.theta, kern.theta + 0.05], [case["trunc"]["ratio"], 0.5], mode="full")
+        assert grid[0, 0] == pytest.approx(case["trunc"]["lml"], rel=vtol)
+        np.testing.assert_allclose(tg.log_marginal_likelihood_grid([kern.theta, kern.theta + 0.05], [case["trunc"]["ratio"], 0.5], mode="reuse"),
+                                   grid, rtol=max(1e-10, 100 * vtol))
+        achieved[case["expr"]] = dict(lml_rel=worst_v, grad_rel_to_max=worst_g, cond=case["cond"])
+    record_parity("tree_kernels_golden_" + gp.backend, **achieved)

@@ -3,6 +3,7 @@ algebra that replaces the reference's cho_solve calls (checked against the golde
 numpy-computed Gram matrix), the C-ABI export table, and the option / error behaviour that does not need
 a GPU."""
 import os
+import subprocess
 import re
 
 import numpy as np
@@ -108,7 +109,28 @@ def test_describe_kernel_flattening():
     k = (C(1.0) * RBF(1.0) + WhiteKernel(1e-2, noise_level_bounds="fixed")).clone_with_theta(np.log([2.0, 0.5]))
     d = gsum_amd.describe_kernel(k, 1)
     assert d.amplitude == pytest.approx(2.0) and d.length_scale[0] == pytest.approx(0.5)
-    for bad in (RBF(1.0) + RBF(2.0), RationalQuadratic(), Matern(1.0, nu=3.5), RBF(1.0) * RBF(2.0), WhiteKernel(1.0)):
+    # outside the flattened family: a postfix program over the tree (round 4), in scikit-learn's evaluation and theta order
+    from sklearn.gaussian_process.kernels import DotProduct, ExpSineSquared
+    from gsum_amd._lib import OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE
+    t = gsum_amd.describe_kernel(RBF(1.0) + RBF(2.0), 1)
+    assert t.is_tree and list(t.op)[:t.n_ops] == [OP_LEAF, OP_LEAF + 1, OP_ADD] and t.n_leaves == 2
+    assert (t.leaf[0].length_scale[0], t.leaf[1].length_scale[0]) == (1.0, 2.0)
+    t = gsum_amd.describe_kernel(C(2.0) * RBF(0.5) + C(0.5) * Matern(1.5, nu=2.5) + WhiteKernel(1e-3), 1)
+    assert list(t.op)[:t.n_ops] == [OP_CONST, OP_LEAF, OP_MUL, OP_CONST + 1, OP_LEAF + 1, OP_MUL, OP_ADD, OP_WHITE + 2, OP_ADD]
+    assert (t.cval[0], t.cval[1], t.cval[2]) == (2.0, 0.5, 1e-3) and t.one_arg_diagonal() == (2.0 * 1.0 + 0.5 * 1.0) + 1e-3
+    assert t.without_white().one_arg_diagonal() == 2.5 and t.plus_constant(0.25).one_arg_diagonal() == t.one_arg_diagonal() + 0.25
+    rq = gsum_amd.describe_kernel(RationalQuadratic(length_scale=0.7, alpha=1.3), 1)
+    assert rq.is_tree and (rq.leaf[0].family, rq.leaf[0].alpha, rq.leaf[0].length_scale[0]) == (4, 1.3, 0.7)
+    assert gsum_amd.describe_kernel(RBF(1.0) * RBF(2.0), 1).is_tree
+    k = RationalQuadratic(length_scale=0.7, alpha=1.3) * RBF([1.0, 2.0]) + C(0.3)
+    th = k.theta + 0.1
+    assert bytes(gsum_amd.describe_thetas(k, [th], 2)[0]) == bytes(gsum_amd.describe_kernel(k.clone_with_theta(th), 2))
+    from gsum_amd.kernels import describe_gradient
+    from gsum_amd._lib import GradParam
+    assert [(g.code, g.dim) for g in describe_gradient(k, 2)] == [(GradParam.TREE_ALPHA, 0), (GradParam.TREE_LENGTH_ISO, 0),
+                                                                 (GradParam.TREE_LENGTH_DIM, 16), (GradParam.TREE_LENGTH_DIM, 17), (GradParam.TREE_CONST, 0)]
+    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), DotProduct() + RBF(1.0), ExpSineSquared(), RBF(1.0) ** 2,
+                RBF(1.0) + RBF(2.0) + RBF(3.0) + RBF(4.0) + RBF(5.0)):
         with pytest.raises(NotImplementedError):
             gsum_amd.describe_kernel(bad, 1)
     with pytest.raises(ValueError):
@@ -128,15 +150,26 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in gsum_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     import ctypes
-    assert ctypes.sizeof(_lib.KernelDesc) == 8 + 8 * _lib.GSUM_MAX_D + 24
+    leaf = 8 + 8 * _lib.GSUM_MAX_D + 8
+    assert ctypes.sizeof(_lib.KernelLeaf) == leaf
+    assert ctypes.sizeof(_lib.KernelDesc) == (8 + 8 * _lib.GSUM_MAX_D + 24) + 8 + 4 * _lib.GSUM_MAX_OPS + 8 * _lib.GSUM_MAX_OPS + leaf * _lib.GSUM_MAX_LEAVES
+    # the C compiler agrees with the ctypes mirror (struct layout is part of the contract)
+    import shutil, tempfile
+    if shutil.which("gcc"):
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "sz.c")
+            open(src, "w").write('#include "gsum_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%zu %zu %zu %zu", sizeof(gsum_kernel_desc), '
+                                 'sizeof(gsum_kernel_leaf), offsetof(gsum_kernel_desc, n_ops), offsetof(gsum_kernel_desc, leaf));return 0;}')
+            subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), src, "-o", os.path.join(tmp, "sz")], check=True)
+            got = subprocess.run([os.path.join(tmp, "sz")], capture_output=True, text=True, check=True).stdout.split()
+        assert [int(v) for v in got] == [ctypes.sizeof(_lib.KernelDesc), leaf, _lib.KernelDesc.n_ops.offset, _lib.KernelDesc.leaf.offset]
     # ... and NOTHING else: the product library is the contract (<= 30 entry points, a header a maintainer can read in one sitting);
     # diagnostics, probes and schedule switches are the lab build's (include/gsum_hip_debug.h, libgsum_hip_lab.so)
-    import subprocess
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
         return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("gsum_")}
     assert exported(_lib.LIB_PATH) == declared and len(declared) <= 30
-    assert len(header.splitlines()) <= 200
+    assert len(header.splitlines()) <= 205
     debug = open(os.path.join(ROOT, "include", "gsum_hip_debug.h")).read()
     lab_declared = set(re.findall(r"\b(gsum_[a-z0-9_]+)\s*\(", debug)) - declared
     assert lab_declared == set(_lib.LAB_PROTOTYPES), lab_declared ^ set(_lib.LAB_PROTOTYPES)
@@ -201,8 +234,10 @@ def test_gradient_parameter_map_follows_sklearn_theta_order():
     k = WhiteKernel(0.1) + C(2.0, constant_value_bounds="fixed") * RBF(1.0)
     assert [(g.code, g.weight) for g in describe_gradient(k, 1)] == [(P.WHITE, 0.1), (P.LENGTH_ISO, 0.0)]
     assert describe_gradient(C(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed"), 1) == []
+    assert [(g.code, g.dim) for g in describe_gradient(RBF(1.0) + RBF(2.0), 1)] == [(P.TREE_LENGTH_ISO, 0), (P.TREE_LENGTH_ISO, 16)]     # a tree
     with pytest.raises(NotImplementedError):
-        describe_gradient(RBF(1.0) + RBF(2.0), 1)
+        from sklearn.gaussian_process.kernels import DotProduct
+        describe_gradient(DotProduct() + RBF(2.0), 1)
 
 
 def test_series_scale_struct_and_student_host_algebra():
@@ -461,8 +496,10 @@ def test_describe_thetas_equals_describing_the_clones():
         assert all(bytes(a) == bytes(b) for a, b in zip(got, want)), kern
     with pytest.raises(ValueError, match="correct number of entries"):
         describe_thetas(RBF(0.2), [[0.1, 0.2]], 1)
-    with pytest.raises(NotImplementedError, match="not supported on the device"):
-        describe_thetas(RBF(0.1) * RBF(0.2), [[0.1, 0.2]], 1)
+    from sklearn.gaussian_process.kernels import DotProduct
+    assert describe_thetas(RBF(0.1) * RBF(0.2), [[0.1, 0.2]], 1)[0].is_tree              # (a tree since round 4)
+    with pytest.raises(NotImplementedError, match="not supported on the device"):       # the family check comes before the theta-size check
+        describe_thetas(C(1.0) * (DotProduct() + WhiteKernel(0.1)), [[0.1, 0.2, 0.3, 0.4, 0.5]], 1)
 
 
 def test_describe_gradients_equals_describing_the_clones():
