@@ -170,6 +170,11 @@ struct gsum_ctx {
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
     int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
     int wave_last_streams = 0;
+    int wave_panel_wg4 = 4;          // waves per workgroup of a batch's panel solves (k_panel256gw): 0 = one (k_panel256g), 4 (default), 8.
+                                     // n = 8192, 3 groups of 7 (tools/gpu_wave_profile.py): 321 / 325 / 314 evals/s with 1 / 4 / 8 waves per
+                                     // workgroup at 20 evaluations per call, 323.5 / 327.7 / 316.8 at 84.  With 8 the panel waves own whole
+                                     // CUs and the other groups' far updates run at 62-64 TF/s instead of 55 -- but the panels take 2.5 x longer
+                                     // (they wait for CUs to empty) and become the critical path
     int wave_serial = 0;             // 1: a group's panels and ALL its trailing updates on the one bulk stream, only its diagonal blocks on the
                                      // chain stream.  Panels and near updates are chip-filling MFMA work themselves (7 + 5.5 ms of a 20-evaluation
                                      // call at n = 8192, against 48 ms of far updates): run beside the far updates of another group they
@@ -1162,6 +1167,7 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
     else if (!strcmp(name, "wave_serial")) ctx->wave_serial = value != 0;
+    else if (!strcmp(name, "wave_panel_wg4")) ctx->wave_panel_wg4 = value == 8 ? 8 : (value != 0 ? 4 : 0);
     else if (!strcmp(name, "wave_depth")) ctx->wave_depth = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "wave_deep_rows")) ctx->wave_deep_rows = (int)std::max<int64_t>(0, value);
     else GS_FAIL(std::string("unknown option: ") + name);
@@ -2045,7 +2051,9 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     hipStream_t spn = serial ? wv->sb : g->sc;
                     const int groups = gs_wave_fill_chain(g, &ca, true);
                     const int rec = gs_prof_begin(ctx, spn, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
-                    hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, spn, ca);
+                    if (ctx->wave_panel_wg4 == 8) hipLaunchKernelGGL(k_panel256gw<8>, dim3((unsigned)((groups + 7) / 8)), dim3(512), 0, spn, ca);
+                    else if (ctx->wave_panel_wg4) hipLaunchKernelGGL(k_panel256gw<4>, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, spn, ca);
+                    else hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, spn, ca);
                     gs_prof_end(ctx, spn, rec);
                 }
                 GS_CHECK(hipGetLastError());

@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned l
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
 __device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
                                                  const double* Ltab1, unsigned long long* kst, unsigned long long* wstat, const int group) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int r0 = group * 16;
     if (r0 >= M) return;
     const unsigned long long w_t0 = wstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1661,6 +1661,25 @@ __global__ __launch_bounds__(64, 2) void k_panel256g(const gs_wv_chain_args a) {
     gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
                      a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
                      (unsigned long long*)nullptr, (unsigned long long*)nullptr, bid - first);
+}
+// The same with W = 4 (or 8) waves per workgroup, each on its own 16-row group.  Single-wave workgroups are spread round-robin
+// over the CUs, and one 224-register panel wave on a SIMD is enough to keep a whole bulk workgroup (2 waves on EACH of the CU's 4
+// SIMDs) off that CU: a thin spread of panel waves costs the trailing updates of the other groups up to a third of every CU it
+// touches.  Four waves per workgroup land on ONE CU and use the evicted workgroup's room on all four SIMDs.
+template <int W>
+__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_panel256gw(const gs_wv_chain_args a) {
+    const int grp = (int)blockIdx.x * W + (int)(threadIdx.x >> 6);
+    int e = 0;
+    while (e + 1 < a.n && grp >= a.end[e]) ++e;
+    if (grp >= a.end[a.n - 1]) return;
+    const int first = e ? a.end[e - 1] : 0;
+    const int64_t q = a.q[e];
+    const int b = 2 * a.step[e];
+    const int64_t c0 = (int64_t)b * GS_NB, r2 = c0 + 2 * GS_NB;
+    const int M = a.p.np + GS_BORDER - (int)r2;
+    gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
+                     a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
+                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, grp - first);
 }
 // entering evaluations: border rows <- RHS^T (k_set_border), grid ((np + 16) / 256 rounded up, entries)
 __global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k) {

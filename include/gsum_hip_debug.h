@@ -15,7 +15,7 @@ extern "C" {
 
 /* ---- options accepted by gsum_set_option only in the lab build ---------------------------------------------------------------
  * batch schedule: "wave_min" (calls with fewer evaluations run them one after the other), "wave_depth" (panels per far update,
- *   default 4), "wave_deep_rows", "wave_near_on_chain", "wave_serial", "wave_shift", "lazy_far" (0: no grouping of trailing
+ *   default 4), "wave_deep_rows", "wave_near_on_chain", "wave_serial", "wave_shift", "wave_panel_wg4" (0 | 4 | 8 waves per panel workgroup), "lazy_far" (0: no grouping of trailing
  *   updates), "lazy_min_np";  gradient batches: "batch_slots"
  * single factorisation: "chain_rows" 256 | 512, "chain_lazy", "chain_min_np", "chain_fused", "chain_prefetch", "la_depth2",
  *   "bulk_lds_pad", "chain_test_abort" (one-shot give-up of the persistent chain at that outer step), "chain_stamps"

@@ -419,6 +419,7 @@ def test_kernel_register_budgets():
         assert g["VGPRs"] <= 72 and g["Scratch"] == 0, (grouped, g)
     assert find("10k_panel256")["VGPRs"] <= 224 and find("10k_panel256")["Scratch"] == 0
     assert find("11k_panel256g")["VGPRs"] <= 224 and find("11k_panel256g")["Scratch"] == 0
+    assert find("k_panel256gwILi4E")["VGPRs"] <= 240 and find("k_panel256gwILi4E")["Scratch"] == 0       # four waves on one CU: beside two bulk workgroups
     assert find("7k_panelP")["VGPRs"] <= 224
     assert find("12k_potrf_diagP")["VGPRs"] <= 224
     assert find("16k_potrf_diag256g")["VGPRs"] <= 256

@@ -22,7 +22,8 @@ Z = np.concatenate([c, np.ones((n, 1))], axis=1)
 ctx = gsum_amd.lab_context(0)
 ctx.set_inputs(X, Z)
 descs = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.19, 0.21, K)])
-for groups, size, depth, serial in ((3, 7, 3, 0), (2, 10, 3, 0), (3, 7, 3, 0), (2, 10, 3, 0), (3, 7, 2, 0), (3, 7, 4, 0), (3, 8, 3, 0), (3, 7, 3, 0), (2, 10, 3, 0)):
+for groups, size, depth, serial, wg4 in ((3, 7, 4, 0, 4), (3, 7, 4, 0, 8), (3, 7, 4, 0, 0), (3, 7, 4, 0, 4), (3, 7, 4, 0, 8), (3, 7, 4, 0, 0)):
+    ctx.set_option("wave_panel_wg4", wg4)
     ctx.set_option("wave_serial", serial)
     ctx.set_option("wave_groups", groups)
     ctx.set_option("wave_size", size)
@@ -41,6 +42,6 @@ for groups, size, depth, serial in ((3, 7, 3, 0), (2, 10, 3, 0), (3, 7, 3, 0), (
     prof = ctx.kernel_profile()
     ctx.set_option("profile_gemm", 0)
     b = prof["bulk_update"]
-    print(json.dumps({"groups": groups, "size": size, "depth": depth, "serial": serial, "evals_per_s": K / float(np.median(ts)), "profiled_ms": wall * 1e3,
+    print(json.dumps({"groups": groups, "size": size, "depth": depth, "serial": serial, "wg4": wg4, "evals_per_s": K / float(np.median(ts)), "profiled_ms": wall * 1e3,
                       "bulk_ms": b["ms"], "bulk_launches": b["launches"], "bulk_tflops": b["flops"] / b["ms"] / 1e9,
                       "panel_ms": prof["panel_gemm"]["ms"], "diag_ms": prof["diag_block"]["ms"], "build_ms": prof["kernel_build"]["ms"]}), flush=True)
