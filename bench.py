@@ -442,6 +442,11 @@ def main():
         tm = ctx.timers()
         cur = np.array([tm["build_ms"], tm["potrf_ms"], tm["finalize_ms"], tm["total_ms"]])
         stage = cur if stage is None else np.minimum(stage, cur)
+    single_schedule = {"chain_probe": ctx.get_option("chain_probe"), "chain_aborts": ctx.get_option("chain_aborts"),
+                       "chain_persist": ctx.get_option("chain_persist"),
+                       "what": "schedule of ONE factorisation alone: chain_probe 1 = persistent chain kernel in use, -1 = this process' "
+                               "streams do not run side by side (e.g. under a serialising profiler): host-enqueued look-ahead schedule; "
+                               "chain_aborts > 0: a chain timed out and the evaluation was re-run on the host-enqueued schedule"}
     ctx.set_option("profile_gemm", 1)
     ctx.kernel_profile()
     ctx.lml_resident([descs[0]], 1e-10)
@@ -539,6 +544,7 @@ def main():
                         "evals_per_s_all": [total / e for e in all_elapsed]},
             "single_eval_stage_ms": {"kernel_build": stage[0], "cholesky_fused_solve": stage[1],
                                      "finalize_d2h": stage[2], "gpu_total": stage[3]},
+            "single_eval_schedule": single_schedule,
             "single_eval_kernel_ms": {name: {"ms": v["ms"], "launches": v["launches"]} for name, v in single_prof.items()},
             "cholesky": {"single_eval_gflops": chol_tflops * 1e3,
                          "single_eval_frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,

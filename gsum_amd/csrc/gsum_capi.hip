@@ -69,6 +69,7 @@ struct gs_slot {
 #define GS_WV_GROUPS 4
 struct gs_wave_group {
     hipStream_t sc = nullptr;            // this group's chain stream (high priority): kernel builds, diagonal blocks, panels, read-out
+    bool own_sc = false;                 // groups 0 and 1 borrow slot 0's panel and auxiliary streams (see gs_wave_prepare)
     hipEvent_t evChain = nullptr, evBulk = nullptr;
     gs_wv_pool pool;                     // `cap` workspaces at fixed strides
     int cap = 0;
@@ -79,7 +80,7 @@ struct gs_wave_group {
     gs_wave_group() { memset(&pool, 0, sizeof pool); }
 };
 struct gs_wave {
-    hipStream_t sb = nullptr;            // the bulk stream: the trailing updates of all groups, one launch after the other
+    hipStream_t sb = nullptr;            // the bulk stream: the trailing updates of all groups, one launch after the other (slot 0's main stream)
     gs_wave_group g[GS_WV_GROUPS];
 };
 
@@ -580,29 +581,42 @@ static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
 // on other streams set, and they wait for its flags: under a tool that serialises dispatches (rocprofv3's kernel trace does)
 // that would stall until the in-kernel timeout.  One spinning wave on one stream, the word it waits for written from another;
 // 20 ms at most, once per context.
+// The probe is the schedule's own triangle: a kernel that spins on the CHAIN's stream (sp) while the main stream (sm) and the
+// auxiliary stream (sa) each deliver a word to it.  (Round 3 probed sm against sa only; with more high-priority streams in the
+// process than hardware queues of that priority -- the groups' chain streams of a batch call created first -- sp and sa came to share
+// a queue, the probe passed and the first single factorisation timed out: found by bench.py's own single-evaluation leg.)
 static int gs_chain_probe(gsum_ctx* ctx, gs_slot* sl) {
     if (ctx->chain_probe != 0) return 0;
     unsigned* d = (unsigned*)ctx->dstamps + 64;                 // words 64.. of the 64 x u64 stamp buffer: unused by the stamps' 8 x u64
-    GS_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(unsigned), sl->sm));
+    GS_CHECK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned), sl->sm));
     GS_CHECK(hipEventRecord(sl->evFork, sl->sm));
+    GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
     GS_CHECK(hipStreamWaitEvent(sl->sa, sl->evFork, 0));
-    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, sl->sm, (const unsigned*)d, 2000000ull, d + 1);     // <= 20 ms
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sa, d, 1u);
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, sl->sp, (const unsigned*)d, (const unsigned*)(d + 1), 2000000ull, d + 2);     // <= 20 ms
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sm, d, 1u);
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sa, d + 1, 1u);
     GS_CHECK(hipGetLastError());
-    unsigned seen = 0;
-    GS_CHECK(hipMemcpyAsync(&seen, d + 1, sizeof(unsigned), hipMemcpyDeviceToHost, sl->sm));
-    GS_CHECK(hipStreamSynchronize(sl->sm));
+    GS_CHECK(hipStreamSynchronize(sl->sp));
     GS_CHECK(hipStreamSynchronize(sl->sa));
+    GS_CHECK(hipStreamSynchronize(sl->sm));
+    unsigned seen = 0;
+    GS_CHECK(hipMemcpy(&seen, d + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
     ctx->chain_probe = seen ? 1 : -1;
     return 0;
 }
 
-static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
+// the second high-priority stream of the persistent-chain schedule (rest of the panel, near update)
+static int gs_aux_stream(gsum_ctx* ctx, gs_slot* sl) {
     if (!sl->sa) {
         GS_CHECK(hipStreamCreateWithPriority(&sl->sa, hipStreamNonBlocking, ctx->prio_hi));
         GS_CHECK(hipEventCreateWithFlags(&sl->evC, hipEventDisableTiming));
         GS_CHECK(hipEventCreateWithFlags(&sl->evS, hipEventDisableTiming));
     }
+    return 0;
+}
+
+static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
+    if (gs_aux_stream(ctx, sl)) return -1;
     const int S = m->T / 2;
     if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)(gs_fl_count(S) + S + 4) * sizeof(unsigned)));    // flags | fbwant[S]
     if (!m->cdump) GS_CHECK(hipMalloc((void**)&m->cdump, (size_t)2 * GS_CH_GMAX * 16 * 256 * sizeof(double)));
@@ -1038,6 +1052,23 @@ int gsum_init(int device, gsum_ctx** out) {
         return -1;
     }
     ctx->cur = &ctx->slots[0];
+    // Every stream the context's schedules run side by side is created HERE, back to back, before anything else touches the device:
+    //   slot 0's main (low priority), chain and auxiliary streams (high)  -- the three parties of a single factorisation;
+    //   one more high-priority stream                                     -- with the other two, the chain streams of a batch's three groups,
+    //                                                                        whose bulk stream is slot 0's main stream.
+    // The command processor serves a process' queues from FOUR pipes, assigned in the order the queues were created (index mod 4: every
+    // order tried in round 4 fits, profiles/r04_stream_order.log): two streams that must run side by side on one pipe cost a batch
+    // 3-6 % (325 -> 314 / 305 evals/s at n = 8192 for a chain-chain / chain-bulk pair) and a single factorisation 30-70 % (5.3 -> 7.0 /
+    // 9.2 ms; with the round-3 probe, a 1-s time-out).  Four consecutive creations sit on four different pipes whatever the process
+    // (torch, RCCL) created before.  A fourth group of a batch (option wave_groups = 4) creates a fifth stream and shares a pipe.
+    if (gs_panel_stream(ctx, ctx->cur) || gs_aux_stream(ctx, ctx->cur)) {
+        g_init_error = ctx->err;
+        delete ctx;
+        return -1;
+    }
+    if ((e = hipStreamCreateWithPriority(&ctx->wave.g[2].sc, hipStreamNonBlocking, ctx->prio_hi)) != hipSuccess) return fail("hipStreamCreateWithPriority", e);
+    ctx->wave.g[2].own_sc = true;
+    ctx->wave.sb = ctx->cur->sm;
     if ((e = hipMalloc((void**)&ctx->dstamps, 64 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
     (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
     const char* la = getenv("GSUM_LOOKAHEAD");
@@ -1854,16 +1885,14 @@ static void gs_wave_release(gsum_ctx* ctx, bool streams) {
         gs_wave_group* g = &ctx->wave.g[i];
         gs_wave_free_group(g);
         if (!streams) continue;
-        if (g->sc) (void)hipStreamDestroy(g->sc);
+        if (g->sc && g->own_sc) (void)hipStreamDestroy(g->sc);
+        g->own_sc = false;
         if (g->evChain) (void)hipEventDestroy(g->evChain);
         if (g->evBulk) (void)hipEventDestroy(g->evBulk);
         g->sc = nullptr;
         g->evChain = g->evBulk = nullptr;
     }
-    if (streams && ctx->wave.sb) {
-        (void)hipStreamDestroy(ctx->wave.sb);
-        ctx->wave.sb = nullptr;
-    }
+    if (streams) ctx->wave.sb = nullptr;             // (slot 0's main stream: not the groups' to destroy)
 }
 
 static double gs_wave_ws_bytes(int64_t np) {
@@ -1874,13 +1903,20 @@ static double gs_wave_ws_bytes(int64_t np) {
 
 static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
     gs_wave* wv = &ctx->wave;
-    if (!wv->sb) GS_CHECK(hipStreamCreateWithPriority(&wv->sb, hipStreamNonBlocking, ctx->prio_lo));
+    if (!wv->sb) wv->sb = ctx->slots[0].sm;
     const int T = (int)(np / GS_NB);
     const int64_t ld = np + GS_BORDER;
     for (int i = 0; i < G; ++i) {
         gs_wave_group* g = &wv->g[i];
         if (!g->sc) {
-            GS_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, ctx->prio_hi));
+            // A batch call and a single factorisation never run at the same time: the first two groups run on slot 0's two
+            // high-priority streams, the third on the stream gsum_init created next to them (see there: four streams on four pipes)
+            gs_slot* s0 = &ctx->slots[0];
+            if (i == 0) { if (gs_panel_stream(ctx, s0)) return -1; g->sc = s0->sp; }
+            else if (i == 1) { if (gs_aux_stream(ctx, s0)) return -1; g->sc = s0->sa; }
+            else { GS_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, ctx->prio_hi)); g->own_sc = true; }
+        }
+        if (!g->evChain) {
             GS_CHECK(hipEventCreateWithFlags(&g->evChain, hipEventDisableTiming));
             GS_CHECK(hipEventCreateWithFlags(&g->evBulk, hipEventDisableTiming));
         }

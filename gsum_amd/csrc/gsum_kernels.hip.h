@@ -1488,11 +1488,11 @@ __global__ void k_chain_status(const unsigned* flags, int* info) {
 
 // two-stream probe of the chain schedule's one assumption: kernels of different streams of this process run side by side
 // (a profiler that serialises dispatches breaks it).  k_probe_wait spins until k_signal's word arrives or `ticks` pass.
-__global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, unsigned long long ticks, unsigned* out) {
+__global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, const unsigned* f2, unsigned long long ticks, unsigned* out) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned seen = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
-        if (gs_flag_ld(f)) { seen = 1; break; }
+        if (gs_flag_ld(f) && gs_flag_ld(f2)) { seen = 1; break; }
         __builtin_amdgcn_s_sleep(8);
     }
     if (threadIdx.x == 0) *out = seen;

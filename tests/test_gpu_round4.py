@@ -44,6 +44,26 @@ def test_rccl_c_host_gathers_the_sharded_scan(n, n_theta):
     assert "(RCCL, ncclCommInitAll)" in run.stdout
 
 
+@pytest.mark.parametrize("variant", ["b20", "b3"])
+def test_single_factorisation_keeps_its_chain_after_a_batch_call(variant):
+    """Found by bench.py's single-evaluation leg in round 4: in a process whose FIRST call was a batch, the groups' high-priority chain
+    streams were created before slot 0's two, the runtime's four hardware queues of that priority were oversubscribed, the chain
+    kernel's stream came to share a queue with its partner's, the two-stream probe (main vs auxiliary) passed -- and the first single
+    factorisation ran into the 1-s time-out and fell back to the host-enqueued schedule for the rest of the process (6.7 ms instead of
+    5.3 at n = 8192, plus the lost second).  Now the first two groups borrow slot 0's streams and the probe is the schedule's own
+    triangle.  A process of its own: the order of stream creation is the scenario."""
+    import json
+    import sys
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_chain_abort_repro.py"), variant], capture_output=True,
+                         text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    rows = [json.loads(line) for line in run.stdout.splitlines() if line.startswith("{")]
+    assert len(rows) == 2, run.stdout
+    for row in rows:
+        assert row["aborts"] == 0 and row["probe"] == 1 and row["persist"] == -1, row
+        assert row["wall_ms"] < 500.0, row
+
+
 def test_chain_step_table_follows_option_changes_on_the_same_workspace(lab):
     """the persistent chain's per-step table fbwant[] used to be uploaded AFTER k_chain was launched, by a copy that
     nothing ordered against the launch; it is re-made whenever the window size or the far-update pairing changes.  It now goes out in
