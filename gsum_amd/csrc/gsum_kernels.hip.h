@@ -2798,11 +2798,21 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     const int fr = lane & 15, fq = lane >> 4;
     const bool neg = sign < 0.0;
     gs_d4 acc[WM][WN];
+    // Lower-triangle launches: a wave whose 32 x 32 block lies strictly ABOVE the diagonal (5 of the 8 waves of a diagonal block's
+    // right-hand tile, 1 of 8 in its left-hand tile) neither loads, multiplies nor stores it -- nothing reads the strict upper triangle
+    // of a workspace matrix -- and leaves the matrix pipes to the CU's other workgroups: 0.75 / (tm + 1) of a launch's MFMAs (1.3 % at
+    // tm = 57 row tiles, 4.4 % at 16).  It still stages its share of the operands and keeps the barriers.
+    const bool idle = tri == 1 && __builtin_amdgcn_readfirstlane(m0 + wm * WM * 16 + WM * 16 - 1 < n0 + wn * WN * 16);
     // interior tiles (all but the last row / column of a ragged matrix): the 16 C loads -- and the 16 stores at the end -- go out back to back, without a
     // compare and a branch each (same-process A/B, profiles/r03_bulk_interior_tiles_ab.log: batch +0.8 %, K = 256 / 512 steady state at M = 7936 +2 / +1.5 %,
     // M = 4096 -1.1 %, one factorisation unchanged; bit-identical)
     const bool full = m0 + BM <= M && n0 + BN <= N;
-    if (full && beta) {
+    if (idle) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = gs_d4{0.0, 0.0, 0.0, 0.0};
+    } else if (full && beta) {
         const double* c0 = C + (int64_t)(m0 + wm * WM * 16 + fq) * ldc + n0 + wn * WN * 16 + fr;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -2894,6 +2904,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
             for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
         };
         auto mm = [&](const double (&af)[WM], const double (&bf)[WN]) {
+            if (idle) return;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -2972,7 +2983,9 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     asm volatile("" : "+v"(t2));
     const int lane2 = t2 & 63, w2 = t2 >> 6;
     const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
-    if (!first_cols && m0 + BM <= M && n0 + BN <= N) {
+    if (idle) {
+        // (nothing to store)
+    } else if (!first_cols && m0 + BM <= M && n0 + BN <= N) {
         double* c0 = C + (int64_t)(m0 + wm2 * WM * 16 + fq2) * ldc + n0 + wn2 * WN * 16 + fr2;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
