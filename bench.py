@@ -307,7 +307,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20,
                     help="evaluations per timed region = per call of the batch entry point (default: one round of the library's "
-                         "2 groups x 10 evaluations)")
+                         "3 groups, 7 + 7 + 6 evaluations)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--points", dest="n", type=int, default=8192)
     ap.add_argument("--orders", type=int, default=6)
@@ -388,6 +388,7 @@ def main():
     evaluate([descs[i % len(descs)] for i in range(max(3, K))])
     groups, gsize = ctx.get_option("wave_groups"), ctx.get_option("wave_size")
     in_flight = min(K, groups * gsize)
+    gsize = min(gsize, -(-K // groups))            # a call shorter than groups x size fills the groups equally
     if W > 0:
         evaluate([descs[i % len(descs)] for i in range(W)])
     if use_dist:
@@ -535,7 +536,7 @@ def main():
                                       " (BASELINE configs[1], S2)" if (n, r) == (2048, 4) else " (not a BASELINE size: rehearsal)"),
                        "n": n, "orders": r,
                        "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": in_flight,
-                       "batch_schedule": f"{groups} groups x {gsize} evaluations, one launch per kernel class and outer step; "
+                       "batch_schedule": f"{groups} groups x up to {gsize} evaluations, one launch per kernel class and outer step; "
                                          f"{ctx.get_option('wave_streams')} streams; GPU_MAX_HW_QUEUES "
                                          + ("unset" if "GPU_MAX_HW_QUEUES" not in os.environ else os.environ["GPU_MAX_HW_QUEUES"])},
             "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)",

@@ -167,8 +167,9 @@ struct gsum_ctx {
     gs_wave wave;
     int wave_groups = 3;             // groups = chain streams; their bulk launches alternate on ONE bulk stream (4 streams: the HIP runtime's
                                      // default number of hardware queues)
-    int wave_size = 7;               // evaluations per group at most
+    int wave_size = 8;               // evaluations per group at most
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
+    int wave_head = 124;               // first macro-step lengths of the groups in a call (decimal digits; 0: all `wave_depth`)
     int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
     int wave_last_streams = 0;
     int wave_panel_wg4 = 4;          // waves per workgroup of a batch's panel solves (k_panel256gw): 0 = one (k_panel256g), 4 (default), 8.
@@ -1196,6 +1197,7 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
+    else if (!strcmp(name, "wave_head")) ctx->wave_head = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
     else if (!strcmp(name, "wave_serial")) ctx->wave_serial = value != 0;
     else if (!strcmp(name, "wave_panel_wg4")) ctx->wave_panel_wg4 = value == 8 ? 8 : (value != 0 ? 4 : 0);
@@ -1956,7 +1958,8 @@ static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
 // price of near updates with K up to 256 (L - 1).  Per element the same products are subtracted in the same ascending order whatever
 // the grouping (an accumulator that starts as C carries across launches exactly): results do not depend on it.
 struct gs_wave_step { int near; int K; int first; };        // first: the macro-step's first outer step (the operand's first panel)
-static void gs_wave_bulk_plan(int64_t np, int depth, int64_t deep_min_rows, std::vector<gs_wave_step>& plan) {
+// first_len > 0: the FIRST macro-step has at most that many panels (the head of a call: see gs_lml_wave).
+static void gs_wave_bulk_plan(int64_t np, int depth, int64_t deep_min_rows, int first_len, std::vector<gs_wave_step>& plan) {
     const int S = (int)(np / (2 * GS_NB));
     plan.assign((size_t)S, gs_wave_step{0, 2 * GS_NB, 0});
     for (int a = 0; a < S;) {
@@ -1964,6 +1967,7 @@ static void gs_wave_bulk_plan(int64_t np, int depth, int64_t deep_min_rows, std:
         int L = 1;
         while (L < depth && r2 + 2 * GS_NB * (int64_t)(L + 1) <= np) ++L;
         if (L > 2 && np + GS_BORDER - r2 < deep_min_rows) L = 2;          // deeper than pairs only while the trailing matrix is large
+        if (a == 0 && first_len > 0) L = std::min(L, first_len);
         for (int i = 0; i < L; ++i) plan[(size_t)(a + i)] = gs_wave_step{i < L - 1 ? 1 : 0, 2 * GS_NB * (i + 1), a};
         a += L;
     }
@@ -2008,12 +2012,33 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
             B = std::max(1, fit / G);
         }
     }
+    // A call of several rounds hands out EQUAL shares: R = ceil(n / (G B)) rounds, G R group-rounds of floor or ceil(n / (G R))
+    // evaluations each (64 evaluations on 3 x 8: nine group-rounds of 7 or 8 -- not nine of 7 and a tenth with ONE evaluation
+    // running alone at the end, which is what first-come-first-served refills did to the 64-per-call scan of bench.py).
+    std::vector<int> shares;
+    {
+        const int R = (n_kernels + G * B - 1) / (G * B), parts = G * R;
+        for (int p = 0; p < parts; ++p) shares.push_back(n_kernels / parts + (p < n_kernels % parts ? 1 : 0));
+        B = std::min(B, shares[0]);
+    }
+    size_t next_share = 0;
     if (gs_wave_prepare(ctx, G, B, n, np)) return -1;
     ctx->wave_last_streams = G + 1;
     if (gs_reserve_pinned(ctx, (size_t)n_kernels * 258 * sizeof(double))) return -1;
     gs_wave* wv = &ctx->wave;
-    std::vector<gs_wave_step> plan;
-    gs_wave_bulk_plan(np, (ctx->lazy_far != 0 && np >= ctx->lazy_min_np) ? std::max(2, ctx->wave_depth) : 1, ctx->wave_deep_rows, plan);
+    // One plan per group: in a call's first round the groups' first macro-steps differ in length (option wave_head, decimal digits,
+    // one per group) -- with every group four panels deep, the bulk stream's first update starts only after four chain steps (1.6 ms
+    // of a 61-ms call at n = 8192).  Results do not depend on the grouping.
+    std::vector<gs_wave_step> plans[GS_WV_GROUPS];
+    {
+        const int depth = (ctx->lazy_far != 0 && np >= ctx->lazy_min_np) ? std::max(2, ctx->wave_depth) : 1;
+        int digits[GS_WV_GROUPS] = {0};
+        int h = ctx->wave_head, nd = 0;
+        int tmp[8];
+        while (h > 0 && nd < 8) { tmp[nd++] = h % 10; h /= 10; }
+        for (int i = 0; i < GS_WV_GROUPS; ++i) digits[i] = i < nd ? tmp[nd - 1 - i] : 0;
+        for (int i = 0; i < GS_WV_GROUPS; ++i) gs_wave_bulk_plan(np, depth, ctx->wave_deep_rows, depth > 1 ? digits[i] : 0, plans[i]);
+    }
     const bool several_rounds = n_kernels > G * B;
     // Groups out of phase in calls of several rounds (counted in sweeps of the loop below = macro-steps)?  Measured and left off:
     // the groups' big updates alternate on one stream, so all groups advance at the same macro-step rate, and a group in its
@@ -2042,7 +2067,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 if (next >= n_kernels || tick < g->start_tick) continue;
                 // ---- a new round of this group: its next evaluations enter (their workspaces are free: the read-out of the
                 // previous round is ahead of this on the chain stream)
-                g->cnt = std::min(B, n_kernels - next);
+                g->cnt = next_share < shares.size() ? shares[next_share++] : std::min(B, n_kernels - next);
                 g->first_eval = next;
                 g->step = 0;
                 g->active = true;
@@ -2093,7 +2118,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     gs_prof_end(ctx, spn, rec);
                 }
                 GS_CHECK(hipGetLastError());
-                const gs_wave_step st = plan[(size_t)g->step];
+                const gs_wave_step st = plans[i][(size_t)g->step];
                 const bool near = st.near && ctx->wave_near_on_chain && !serial;
                 hipStream_t su = near ? g->sc : wv->sb;
                 if (!near && !serial) {

@@ -96,7 +96,7 @@ const char* gsum_last_error(gsum_ctx* ctx);             /* NULL ctx: error of a 
  *                                  (gsum_kernel_profile reads them)
  *   "small_path", "medium_path" 0 | 1, "medium_min_batch"   n <= 128 / 128 < n <= 4096: whole evaluations in one workgroup when a
  *                                  call carries enough of them (<= 0: the measured break-even)
- *   "wave_groups" 1..4, "wave_size" 1..24   layout of a batch: groups x evaluations per group in flight (default 3 x 7; each
+ *   "wave_groups" 1..4, "wave_size" 1..24   layout of a batch: groups x evaluations per group in flight (default 3 x 8; each
  *                                  evaluation in flight owns a workspace matrix, 0.55 GB at n = 8192)
  *   "chain_persist"   -1 | 0 | 1   schedule of ONE factorisation: persistent chain kernel from order 2048 up / never / whenever
  *                                  the order allows;  "lookahead" 0 | 1  look-ahead in the host-enqueued schedule

@@ -608,9 +608,11 @@ def test_full_size_properties_n8192():
     # updates (K = 512 every other step) and the stream its small "near" updates go out on
     many = [desc] * 20
     ctx.set_inputs(X, Z)
-    for groups, size, lazy, near, depth, serial, wg in ((3, 7, 2, 1, 4, 0, 4), (2, 10, 2, 1, 2, 0, 0), (1, 20, 2, 1, 3, 0, 8), (3, 7, 0, 1, 4, 0, 4),
-                                                        (2, 5, 2, 0, 4, 0, 4), (4, 5, 2, 1, 8, 0, 0), (2, 10, 2, 1, 4, 1, 4)):
+    for groups, size, lazy, near, depth, serial, wg, head in ((3, 7, 2, 1, 4, 0, 4, 124), (2, 10, 2, 1, 2, 0, 0, 0), (1, 20, 2, 1, 3, 0, 8, 2),
+                                                              (3, 7, 0, 1, 4, 0, 4, 0), (2, 5, 2, 0, 4, 0, 4, 31), (4, 5, 2, 1, 8, 0, 0, 1234),
+                                                              (2, 10, 2, 1, 4, 1, 4, 124), (3, 8, 2, 1, 4, 0, 4, 0)):
         ctx.set_option("wave_panel_wg4", wg)
+        ctx.set_option("wave_head", head)
         ctx.set_option("wave_groups", groups)
         ctx.set_option("wave_size", size)
         ctx.set_option("lazy_far", lazy)
@@ -624,9 +626,10 @@ def test_full_size_properties_n8192():
             assert ss[b] == s0[0]
     ctx.set_option("lazy_far", 2)                              # the library's defaults
     ctx.set_option("wave_groups", 3)
-    ctx.set_option("wave_size", 7)
+    ctx.set_option("wave_size", 8)
     ctx.set_option("wave_near_on_chain", 1)
     ctx.set_option("wave_depth", 4)
+    ctx.set_option("wave_head", 124)
     ctx.set_option("wave_serial", 0)
     ctx.set_option("wave_panel_wg4", 4)
     Gp, sp_, ip = gsum_amd.default_context(0).lml_batch([desc] * 4, X, Z, 1e-10)      # the product library's batch: the same bits

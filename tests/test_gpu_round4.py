@@ -214,3 +214,37 @@ def test_truncation_cov_is_built_and_scaled_on_the_device(ctx):
     with pytest.raises(TypeError):
         gsum_amd.TruncationGP(ratio=0.5).ratio(X[:3], scale=2.0)            # a constant ratio takes `ratio=` only, like the reference's lambda
     assert np.all(gsum_amd.TruncationGP(ratio=0.5).ratio(X[:3], ratio=0.25) == 0.25)
+
+
+@pytest.mark.parametrize("groups,size", [(3, 2), (2, 3), (3, 8), (4, 1)])
+def test_batch_shares_cover_every_evaluation_once(lab, groups, size):
+    """A call of several rounds hands its evaluations to the groups in equal shares (gs_lml_wave: R = ceil(n / (G B)) rounds, G R
+    group-rounds of floor / ceil(n / (G R)) members).  Whatever the count -- fewer than groups, one more than a full round, a prime --
+    every evaluation comes back once, in its position, bit-identical to a single evaluation; one member that is not positive
+    definite does not disturb its neighbours."""
+    ctx = lab
+    from sklearn.gaussian_process.kernels import RBF
+    n = 700
+    rng = np.random.RandomState(11)
+    X = 0.1 * np.arange(n)[:, None]
+    Z = np.concatenate([rng.randn(n, 3), np.ones((n, 1))], axis=1)
+    ctx.set_inputs(X, Z)
+    ells = np.linspace(0.15, 0.4, 53)
+    descs = [gsum_amd.describe_kernel(RBF(float(e)), 1) for e in ells]
+    old = {k: ctx.get_option(k) for k in ("wave_groups", "wave_size", "wave_min", "medium_path")}
+    try:
+        ctx.set_option("medium_path", 0)
+        ctx.set_option("wave_min", 1000)
+        G0, s0, i0 = ctx.lml_resident(descs, 1e-10)                       # one after the other
+        assert np.all(i0 == 0) and len(set(s0.tolist())) == len(descs)
+        ctx.set_option("wave_min", 3)
+        ctx.set_option("wave_groups", groups)
+        ctx.set_option("wave_size", size)
+        for count in (3, 4, 5, 7, groups * size, groups * size + 1, 2 * groups * size - 1, 23, 53):
+            G1, s1, i1 = ctx.lml_resident(descs[:count], 1e-10)
+            np.testing.assert_array_equal(i1, i0[:count])
+            np.testing.assert_array_equal(s1, s0[:count])
+            np.testing.assert_array_equal(G1, G0[:count])
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
