@@ -462,11 +462,16 @@ def main():
     # while the clock ramps; under this kernel the package sits at its 1400 W cap with sclk ~2.34 GHz,
     # profiles/r02_clock_power.log -- the 78.6 TFLOP/s peak assumes 2.4 GHz.)
     # (the microbenchmark entry point is not part of the product ABI: it lives in the lab build of the library, include/gsum_hip_debug.h)
-    excl_tflops = None
+    excl_tflops = excl_k256 = None
     try:
         lab = gsum_amd.lab_context(dev)
         lab.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 20)
-        excl_tflops, _ = lab.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 200)
+        excl_k256, _ = lab.bench_gemm_nt(7, n - 256, n - 256, 256, True, n + 16, 200)
+        if n > 2048:                         # the shape the batch launches: four panels deep (K = 1024), the trailing matrix of outer step 3
+            lab.bench_gemm_nt(7, n - 1024, n - 1024, 1024, True, n + 16, 5)
+            excl_tflops, _ = lab.bench_gemm_nt(7, n - 1024, n - 1024, 1024, True, n + 16, 50)
+        else:
+            excl_tflops = excl_k256
         lab.set_option("release_scratch", 1)
     except Exception as exc:                 # no lab library on this box: the in-situ per-launch figure stands alone
         print(f"[bench] exclusive microbenchmark skipped: {exc}", file=sys.stderr)
@@ -505,11 +510,15 @@ def main():
         pred = predict_leg(ctx, 16384, 2048)
         ctx.set_option("release_scratch", 1)
 
-    pmc_traffic = pmc_file = None
+    pmc_traffic = pmc_file = pmc_alg = None
+    pmc_what = ""
     for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                pmc_traffic = json.load(f)["derived"]["hbm_traffic_bytes_per_launch"]
+                rec = json.load(f)
+            pmc_traffic = rec["derived"]["hbm_traffic_bytes_per_launch"]
+            pmc_alg = rec["derived"].get("algorithmic_bytes_per_launch")
+            pmc_what = rec.get("what", "HBM bytes of one M=8192, K=256 launch of this kernel's tile (FETCH_SIZE x 2 KiB + WRITE_SIZE x 1 KiB)")
             pmc_file = name
             break
         except Exception:
@@ -561,12 +570,13 @@ def main():
             # per-launch figure -- algorithmic flops of the launches / the sum of their HIP-event durations on that stream -- and
             # it is what `rocprofv3 --kernel-trace --stats` of this command reports for the kernel (profiles/).
             "roofline": {"kernel": "k_gemm_ld3g (128x64-tile, 8-wave fp64 MFMA SYRK with LDS-direct operand staging, 3 workgroups "
-                                   "per CU; one launch = the trailing update (K = 512, or 256) of every evaluation of a group)",
+                                   "per CU; one launch = the trailing update of every evaluation of a group, four panels deep: K = 1024 (512 / 256 near the end))",
                          "bound": "mfma", "achieved": launch_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": launch_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic,
-                         "traffic_source": "HBM bytes of one M=8192, K=256 launch of this kernel's tile (FETCH_SIZE x 2 + WRITE_SIZE) from "
-                                           f"the committed rocprofv3 --pmc passes, profiles/{pmc_file}; PMC cannot be "
-                                           "collected inside bench.py; algorithmic bytes of that launch: 5.61e8",
+                         "traffic_source": f"{pmc_what}; from the committed rocprofv3 --pmc passes, profiles/{pmc_file} (PMC cannot be "
+                                           "collected inside bench.py)",
+                         "algorithmic_bytes_per_launch": pmc_alg,
+                         "traffic_over_algorithmic": (pmc_traffic / pmc_alg) if pmc_traffic and pmc_alg else None,
                          "launches": gemm_launches,
                          "launches_sampled": "every launch of one extra, profiled K-step region "
                                              f"({prof_elapsed / K * 1e3:.3f} ms per step with the events in place)",
@@ -577,11 +587,13 @@ def main():
                          "region_tflops": region_tflops, "region_frac": region_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "exclusive_tflops": excl_tflops,
                          "exclusive_frac": None if excl_tflops is None else excl_tflops / FP64_MFMA_PEAK_TFLOPS,
-                         "exclusive_what": "the one-product form of the same tile alone: 200 back-to-back SYRK launches of the first outer step's shape "
-                                           "(M = n - 256, K = 256) on device-resident random operands",
-                         "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K per member (K = 512 for "
-                                             "paired updates, 256 otherwise); the small near-column updates (lower trapezoid, K = 256) "
-                                             "run on the chain streams and are counted with the panel class"},
+                         "exclusive_what": "the same tile alone on the chip (lab microbenchmark, device-resident random operands): 50 back-to-back "
+                                           "lower-triangle launches of the batch's far-update shape at outer step 3 (M = n - 1024, K = 1024)",
+                         "exclusive_tflops_K256": excl_k256,
+                         "exclusive_K256_what": "... and of the one-product shape rounds 1-3 reported (M = n - 256, K = 256: 200 launches)",
+                         "flops_per_launch": "algorithmic flops of each launch: lower-triangular SYRK M(M+1)K per member (K = 256 x the panels "
+                                             "it applies); the near updates (the next panel's 256 columns, K <= 768) run on the chain "
+                                             "streams (k_gemm_ld3n) and are counted with the panel class"},
             "kernel_time_shares": {"classes": shares,
                                    "note": "HIP-event duration of every launch inside one extra timed K-step region (not counted in "
                                            "value), per kernel class, on the launch's own stream; share = class time / that region's "

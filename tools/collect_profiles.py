@@ -93,9 +93,13 @@ if tr and not os.path.exists(os.path.join(SRC, "single_eval_chain_timeline.txt")
 json_line("bench.log", "bench_default.jsonl")
 json_line("rocprof_bench.log", "bench_under_rocprof.jsonl")
 json_line("plain_n1.log", "plain_n1.jsonl")
+json_line("torchrun_world1_nccl.log", "torchrun_world1_nccl.jsonl")
+json_line("two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_gloo.jsonl")
+for name in ("wave_trace_1x20.txt", "wave_trace_3x7.txt", "parity_achieved.json"):
+    copy(os.path.join(SRC, name), name)
 json_line("bench_predict.log", "bench_predict.jsonl")
 copy(os.path.join(SRC, "single_eval_chain_timeline.txt"), "single_eval_timeline.txt")       # round 3: the chain kernel's own stamps
-for log in ("chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages.log", "rocprof_single.log", "rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
+for log in ("wave_profile.log", "wave_sweep.log", "chain_abort_repro.log", "chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages.log", "rocprof_single.log", "rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
             "single_sweep.log", "slots_sweep.log", "clock_power.log", "medium_phases.log"):
     path = os.path.join(SRC, log)
     if os.path.exists(path):
@@ -106,26 +110,64 @@ for log in ("chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages
 copy(os.path.join(SRC, "truth_errors.json"), "truth_errors.json")
 copy(os.path.join(SRC, "r2_kernels.json"), "kernels_ab.json")
 
-# ---- PMC: bulk GEMM (exclusive launch M = 8192, K = 256) and kernel build (n = 8192)
+# ---- PMC: the dominant kernel's launches inside a batch call (k_gemm_ld3g; counter passes serialise dispatches, so each launch's
+# counters are its own), and the one-product form of the same tile (exclusive launch M = 8192, K = 256) for continuity with rounds 1-3
+def all_values(sub, prefix, counter):
+    f = newest(sub, "*counter_collection.csv")
+    if not f or stale(f):
+        return []
+    return [(float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == counter]
+
+
 g = {}
 for sub in ("pmc_gemm1", "pmc_gemm2", "pmc_gemm3", "pmc_gemm4"):
-    g.update(counters(sub, "void k_gemm_ld3"))
-    g.update(counters(sub, "k_gemm_ld3"))
+    g.update(counters(sub, "void k_gemm_ld3<"))
+    g.update(counters(sub, "k_gemm_ld3<"))
+one = None
 if g:
     fetch, write = last(g, "FETCH_SIZE"), last(g, "WRITE_SIZE")
     dur_ns = g["GRBM_GUI_ACTIVE"][-1][1] if "GRBM_GUI_ACTIVE" in g else None
     busy, gui = last(g, "SQ_VALU_MFMA_BUSY_CYCLES"), last(g, "GRBM_GUI_ACTIVE")
-    rec = {"kernel": "k_gemm_ld3", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_gemm.py 7 8192 256 1 3 (one pass per counter group; tools/gpu_r3_profiles.sh)",
+    one = {"kernel": "k_gemm_ld3<2>", "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_gemm.py 7 8192 256 1 3 (one pass per counter group)",
            "shape": {"M": 8192, "N": 8192, "K": 256, "tri": 1, "tiles": 4160},
            "counters": {k: v[-1][0] for k, v in g.items()}, "duration_us_profiled": dur_ns / 1e3 if dur_ns else None,
-           "derived": {"hbm_read_bytes": fetch * 2048 if fetch else None, "hbm_write_bytes": write * 1024 if write else None,
-                       "hbm_traffic_bytes_per_launch": (fetch * 2048 + write * 1024) if fetch and write else None,
-                       "algorithmic_bytes_per_launch": 561000000,
-                       "mfma_busy_frac_profiled": busy / (gui / 8 * 1024) if busy and gui else None,
-                       "note": "FETCH_SIZE x 2 KiB (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM), WRITE_SIZE x 1 KiB; "
-                               "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs = cycles the launch took, x 1024 SIMDs)"}}
+           "hbm_traffic_bytes_per_launch": (fetch * 2048 + write * 1024) if fetch and write else None, "algorithmic_bytes_per_launch": 561000000,
+           "mfma_busy_frac_profiled": busy / (gui / 8 * 1024) if busy and gui else None}
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from wave_plan import far_launches  # noqa: E402
+plan = far_launches(8192, [7, 7, 6])
+fetch = all_values("pmc_wave3", "k_gemm_ld3g", "FETCH_SIZE")
+write = all_values("pmc_wave4", "k_gemm_ld3g", "WRITE_SIZE")
+busy = all_values("pmc_wave1", "k_gemm_ld3g", "SQ_VALU_MFMA_BUSY_CYCLES")
+gui = all_values("pmc_wave1", "k_gemm_ld3g", "GRBM_GUI_ACTIVE")
+if fetch and write:
+    calls = len(fetch) / len(plan)
+    rd, wr = sum(v for v, _ in fetch) * 2048 / len(fetch), sum(v for v, _ in write) * 1024 / len(write)
+    alg = sum(x["bytes"] for x in plan) / len(plan)
+    rec = {"kernel": "k_gemm_ld3g",
+           "what": "HBM bytes per launch of the batch's trailing-update launches, averaged over the %d k_gemm_ld3g dispatches of %g calls of "
+                   "20 evaluations (3 groups of 7, 7, 6; n = 8192): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                   "(tools/gpu_r4_profiles.sh; FETCH_SIZE x 2 KiB -- gfx950 counts 64 B per 128-B request --, WRITE_SIZE x 1 KiB)" % (len(fetch), calls),
+           "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 tools/prof_wave.py 3 8 4",
+           "launches_per_call": len(plan), "dispatches_counted": len(fetch),
+           "derived": {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_traffic_bytes_per_launch": rd + wr,
+                       "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg,
+                       "algorithmic_flops_per_launch": sum(x["flops"] for x in plan) / len(plan),
+                       "mfma_busy_frac_profiled": (sum(v for v, _ in busy) / (sum(v for v, _ in gui) / 8 * 1024)) if busy and gui else None,
+                       "avg_launch_us_profiled": sum(d for _, d in fetch) / len(fetch) / 1e3,
+                       "note": "algorithmic bytes of a launch = for every member its C lower triangle read and written once (16 B x M (M + 1) / 2) + its "
+                               "M x K panel rows read once (tools/wave_plan.py restates the launch list); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES "
+                               "(summed over all SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), both summed over the launches (serialised by the "
+                               "counter pass: each launch alone on the chip)"},
+           "one_product_K256": one}
     json.dump(rec, open(os.path.join(OUT, f"{TAG}_gemm_pmc.json"), "w"), indent=1)
     print("wrote", f"{TAG}_gemm_pmc.json")
+elif one:
+    json.dump({"kernel": "k_gemm_ld3<2>", "derived": {"hbm_traffic_bytes_per_launch": one["hbm_traffic_bytes_per_launch"],
+                                                      "algorithmic_bytes_per_launch": 561000000}, "one_product_K256": one},
+              open(os.path.join(OUT, f"{TAG}_gemm_pmc.json"), "w"), indent=1)
+    print("wrote", f"{TAG}_gemm_pmc.json (one-product launch only)")
 b = {}
 for sub in ("pmc_build1", "pmc_build2", "pmc_build3"):
     b.update(counters(sub, "void k_build2"))

@@ -22,7 +22,7 @@ Z = np.concatenate([c, np.ones((n, 1))], axis=1)
 ctx = gsum_amd.lab_context(0)
 ctx.set_inputs(X, Z)
 descs = ctx.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in np.linspace(0.19, 0.21, K)])
-for groups, size, depth, serial, wg4 in ((3, 7, 4, 0, 4), (3, 7, 4, 0, 8), (3, 7, 4, 0, 0), (3, 7, 4, 0, 4), (3, 7, 4, 0, 8), (3, 7, 4, 0, 0)):
+for groups, size, depth, serial, wg4 in ((3, 8, 4, 0, 4), (1, 20, 4, 0, 4), (3, 8, 4, 0, 8), (3, 8, 4, 0, 0), (3, 8, 4, 1, 4), (3, 8, 4, 0, 4), (1, 20, 4, 0, 4)):
     ctx.set_option("wave_panel_wg4", wg4)
     ctx.set_option("wave_serial", serial)
     ctx.set_option("wave_groups", groups)
