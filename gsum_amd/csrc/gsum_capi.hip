@@ -169,6 +169,7 @@ struct gsum_ctx {
                                      // default number of hardware queues)
     int wave_size = 8;               // evaluations per group at most
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
+    int wave_panel_rows_lds = 1;     // ... their rows go global <-> registers as whole 128-B lines and change layout in LDS
     int wave_head = 124;               // first macro-step lengths of the groups in a call (decimal digits; 0: all `wave_depth`)
     int wave_min = 3;                // calls with at least this many evaluations take the grouped schedule
     int wave_last_streams = 0;
@@ -1198,6 +1199,7 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_head")) ctx->wave_head = (int)std::max<int64_t>(0, value);
+    else if (!strcmp(name, "wave_panel_rows_lds")) ctx->wave_panel_rows_lds = value != 0;
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;
     else if (!strcmp(name, "wave_serial")) ctx->wave_serial = value != 0;
     else if (!strcmp(name, "wave_panel_wg4")) ctx->wave_panel_wg4 = value == 8 ? 8 : (value != 0 ? 4 : 0);
@@ -2113,6 +2115,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     const int groups = gs_wave_fill_chain(g, &ca, true);
                     const int rec = gs_prof_begin(ctx, spn, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
                     if (ctx->wave_panel_wg4 == 8) hipLaunchKernelGGL(k_panel256gw<8>, dim3((unsigned)((groups + 7) / 8)), dim3(512), 0, spn, ca);
+                    else if (ctx->wave_panel_wg4 && ctx->wave_panel_rows_lds) hipLaunchKernelGGL((k_panel256gw<4, true>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, spn, ca);
                     else if (ctx->wave_panel_wg4) hipLaunchKernelGGL(k_panel256gw<4>, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, spn, ca);
                     else hipLaunchKernelGGL(k_panel256g, dim3((unsigned)groups), dim3(64), 0, spn, ca);
                     gs_prof_end(ctx, spn, rec);

@@ -1236,6 +1236,52 @@ __device__ __forceinline__ void gs_panel16_store(const gs_d4 (&P)[8], double* ro
     }
 }
 
+// The same two through a wave-private LDS tile (16 rows x 18 doubles): the register image wants lane (fr, fq) to hold columns fq + 4 x of
+// row fr, so gs_panel16_load's instruction x of micro-block k touches 16 rows x 32 B -- sixteen cache lines for 512 B, four times over
+// per micro-block, and the stores are 32-B fragments.  Here a micro-block goes global <-> registers as TWO 16-B-per-lane accesses of 8
+// whole 128-B lines each, and changes layout in LDS (a wave's LDS operations execute in order: no barrier).  Measured on the batch's
+// panel launches (probe builds, profiles/r04_panel_rows.log): the fragmented row traffic was 4 ms of a 61-ms call.  Same values.
+#define GS_PT_STR 18
+#define GS_PT_TILE (16 * GS_PT_STR)
+__device__ __forceinline__ void gs_panel16_load_t(gs_d4 (&P)[8], const double* rows, int64_t ld, int nvalid, int lane, double* tile) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r0 = lane >> 3, cp = 2 * (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)                  // raw lines into the registers the image will occupy: all 16 loads in flight together
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const gs_d2 v = (r0 + 8 * h < nvalid) ? *reinterpret_cast<const gs_d2*>(rows + (int64_t)(r0 + 8 * h) * ld + 16 * k + cp) : gs_d2{0.0, 0.0};
+            P[k][2 * h] = v[0];
+            P[k][2 * h + 1] = v[1];
+        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<gs_d2*>(tile + (r0 + 8 * h) * GS_PT_STR + cp) = gs_d2{P[k][2 * h], P[k][2 * h + 1]};
+        gs_wave_lds_sync();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) P[k][x] = -tile[fr * GS_PT_STR + fq + 4 * x];
+        gs_wave_lds_sync();
+    }
+}
+
+__device__ __forceinline__ void gs_panel16_store_t(const gs_d4 (&P)[8], double* rows, int64_t ld, int nvalid, int lane, double* tile) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r0 = lane >> 3, cp = 2 * (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) tile[fr * GS_PT_STR + fq + 4 * x] = -P[k][x];
+        gs_wave_lds_sync();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const gs_d2 v = *reinterpret_cast<const gs_d2*>(tile + (r0 + 8 * h) * GS_PT_STR + cp);
+            if (r0 + 8 * h < nvalid) *reinterpret_cast<gs_d2*>(rows + (int64_t)(r0 + 8 * h) * ld + 16 * k + cp) = v;
+        }
+        gs_wave_lds_sync();
+    }
+}
+
 __device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid, const double* tab, int lane) {
     gs_d4 P[8];
     gs_panel16_load(P, rows, ld, nvalid, lane);
@@ -1502,7 +1548,8 @@ __global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, const unsi
 //   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
 // (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
 __device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                 const double* Ltab1, unsigned long long* kst, unsigned long long* wstat, const int group) {
+                                                 const double* Ltab1, unsigned long long* kst, unsigned long long* wstat, const int group,
+                                                 double* tile = nullptr) {
     const int lane = threadIdx.x & 63;
     const int r0 = group * 16;
     if (r0 >= M) return;
@@ -1511,15 +1558,15 @@ __device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, c
     if (kst && lane == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());          // diagnostics: first start / last end of the launch
     double* rows = P + (int64_t)r0 * ld;
     gs_d4 P0[8], P1[8];
-    gs_panel16_load(P0, rows, ld, M - r0, lane);
+    if (tile) gs_panel16_load_t(P0, rows, ld, M - r0, lane, tile); else gs_panel16_load(P0, rows, ld, M - r0, lane);
     gs_panel16_solve_g(P0, Ltab0, lane);
-    gs_panel16_store(P0, rows, ld, M - r0, lane);
+    if (tile) gs_panel16_store_t(P0, rows, ld, M - r0, lane, tile); else gs_panel16_store(P0, rows, ld, M - r0, lane);
     __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now: 64 registers less at the peak
-    gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
+    if (tile) gs_panel16_load_t(P1, rows + 128, ld, M - r0, lane, tile); else gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
     gs_sib_update_lean(P1, P0, Lsib, lane);
     __builtin_amdgcn_sched_barrier(0);
     gs_panel16_solve_g(P1, Ltab1, lane);
-    gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
+    if (tile) gs_panel16_store_t(P1, rows + 128, ld, M - r0, lane, tile); else gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
     if (kst && lane == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
     if (wstat && lane == 0) {                                   // diagnostics (option panel_stats): how long the panel's waves are resident
         atomicAdd(wstat, __builtin_amdgcn_s_memrealtime() - w_t0);
@@ -1529,7 +1576,8 @@ __device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, c
 
 __global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
                                                   const double* Ltab1, unsigned long long* kst, unsigned long long* wstat) {
-    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst, wstat, (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) double tile[GS_PT_TILE];
+    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst, wstat, (int)blockIdx.x, tile);
 }
 
 // explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
@@ -1666,8 +1714,9 @@ __global__ __launch_bounds__(64, 2) void k_panel256g(const gs_wv_chain_args a) {
 // over the CUs, and one 224-register panel wave on a SIMD is enough to keep a whole bulk workgroup (2 waves on EACH of the CU's 4
 // SIMDs) off that CU: a thin spread of panel waves costs the trailing updates of the other groups up to a third of every CU it
 // touches.  Four waves per workgroup land on ONE CU and use the evicted workgroup's room on all four SIMDs.
-template <int W>
+template <int W, bool TR = false>
 __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_panel256gw(const gs_wv_chain_args a) {
+    __shared__ __attribute__((aligned(16))) double tiles[TR ? W * GS_PT_TILE : 2];
     const int grp = (int)blockIdx.x * W + (int)(threadIdx.x >> 6);
     int e = 0;
     while (e + 1 < a.n && grp >= a.end[e]) ++e;
@@ -1679,7 +1728,8 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_panel256gw(const gs_
     const int M = a.p.np + GS_BORDER - (int)r2;
     gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
                      a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
-                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, grp - first);
+                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, grp - first,
+                     TR ? tiles + (threadIdx.x >> 6) * GS_PT_TILE : (double*)nullptr);
 }
 // entering evaluations: border rows <- RHS^T (k_set_border), grid ((np + 16) / 256 rounded up, entries)
 __global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k) {

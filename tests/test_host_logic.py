@@ -417,9 +417,12 @@ def test_kernel_register_budgets():
     for grouped in ("11k_gemm_ld3g", "11k_gemm_ld3n"):                       # the batch schedule's launches: the same tile, the same budget
         g = find(grouped)
         assert g["VGPRs"] <= 72 and g["Scratch"] == 0, (grouped, g)
-    assert find("10k_panel256")["VGPRs"] <= 224 and find("10k_panel256")["Scratch"] == 0
+    # bulk waves allocate 64 registers: six leave a SIMD 128, every retiring bulk workgroup 128 more -- a panel wave of up to 256 starts
+    # where ONE bulk workgroup has left (the rows-through-LDS variants, round 4, need 4-8 more than the 224 of round 3)
+    assert find("10k_panel256P")["VGPRs"] <= 232 and find("10k_panel256P")["Scratch"] == 0
     assert find("11k_panel256g")["VGPRs"] <= 224 and find("11k_panel256g")["Scratch"] == 0
-    assert find("k_panel256gwILi4E")["VGPRs"] <= 240 and find("k_panel256gwILi4E")["Scratch"] == 0       # four waves on one CU: beside two bulk workgroups
+    for variant in ("k_panel256gwILi4ELb0E", "k_panel256gwILi4ELb1E"):                                  # four waves on one CU: beside two bulk workgroups
+        assert find(variant)["VGPRs"] <= 248 and find(variant)["Scratch"] == 0, variant
     assert find("7k_panelP")["VGPRs"] <= 224
     assert find("12k_potrf_diagP")["VGPRs"] <= 224
     assert find("16k_potrf_diag256g")["VGPRs"] <= 256

@@ -16,7 +16,7 @@ from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 from gpu_wave_check import workload  # noqa: E402
 
 DEFAULTS = {"wave_groups": 3, "wave_size": 8, "wave_depth": 4, "wave_deep_rows": 3072, "wave_shift": 0, "wave_panel_wg4": 4,
-            "wave_near_on_chain": 1, "wave_serial": 0, "wave_head": 124}
+            "wave_near_on_chain": 1, "wave_serial": 0, "wave_head": 124, "wave_panel_rows_lds": 1}
 n = int(os.environ.get("N", "8192"))
 ctx = gsum_amd.lab_context(0)
 X, Z = workload(n, 6)
