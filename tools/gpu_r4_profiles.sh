@@ -13,7 +13,7 @@ if [ "$PART" != 2 ]; then
   timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err; rc=$?; echo "bench rc=$rc"; [ $rc -eq 0 ] || stop "bench" $rc
   grep "^{" gpurun_out/bench.log | cut -c1-140
   rm -rf gpurun_out/prof_bench gpurun_out/tw1 gpurun_out/tw3
-  timeout -k 10 300 $R -d gpurun_out/prof_bench -- python3 bench.py --steps 20 --warmup 3 --cpu-evals 0 --extras 0 --repeats 5 > gpurun_out/rocprof_bench.log 2>&1; rc=$?; echo "rocprof bench rc=$rc"; [ $rc -eq 0 ] || stop "rocprof bench" $rc
+  timeout -k 10 300 $R -d gpurun_out/prof_bench -- python3 bench.py --steps 20 --warmup 20 --cpu-evals 0 --extras 0 --repeats 5 > gpurun_out/rocprof_bench.log 2>&1; rc=$?; echo "rocprof bench rc=$rc"; [ $rc -eq 0 ] || stop "rocprof bench" $rc
   grep "^{" gpurun_out/rocprof_bench.log | cut -c1-140
   timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-evals 0 --extras 0 > gpurun_out/torchrun_world1_nccl.log 2>&1; rc=$?; echo "torchrun world 1 rc=$rc"; [ $rc -eq 0 ] || stop "torchrun" $rc
   grep "^{" gpurun_out/torchrun_world1_nccl.log | cut -c1-140
