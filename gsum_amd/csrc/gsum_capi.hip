@@ -46,6 +46,8 @@ struct gsum_mat {
 // the latency-bound panel chain of one overlaps the bulk GEMMs of the others.
 struct gs_slot {
     hipStream_t sm = nullptr, sp = nullptr;   // main (bulk) / high-priority panel chain
+    bool own_su = true;
+    bool own_sm = true;              // slots 1-3 (the gradient batch's other evaluations in flight) run on slot 0's other streams
     hipStream_t su = nullptr;        // gradient path: the U = L^-T sweep, trailing the factorisation panel by panel
     hipEvent_t evU = nullptr;
     hipStream_t sa = nullptr;        // persistent-chain schedule: the panel of the rows below the window and the near updates A, B
@@ -94,9 +96,9 @@ struct gsum_ctx {
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
-    int batch_slots = 3;             // gradient evaluations kept in flight by gsum_lml_grad_batch, one stream each: 3 is the measured
-                                     // optimum on the HIP runtime's default of 4 hardware queues (value-only batches do not use
-                                     // slots: gs_lml_wave)
+    int batch_slots = 4;             // gradient evaluations kept in flight by gsum_lml_grad_batch, one stream each: the context's four
+                                     // streams on four pipes (n = 8192: 14.3 / 13.3 / 12.4 / 12.2 / 12.4 ms each with 2 / 3 / 4 / 5 / 8;
+                                     // value-only batches do not use slots: gs_lml_wave)
     int batch_active = 1;            // evaluations in flight in the current call (look-ahead is used only alone)
     int prio_lo = 0, prio_hi = 0;
     std::string err;
@@ -1008,7 +1010,15 @@ static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
 extern "C" {
 
 static int gs_slot_init(gsum_ctx* ctx, gs_slot* sl) {
-    GS_CHECK(hipStreamCreateWithPriority(&sl->sm, hipStreamNonBlocking, ctx->prio_lo));
+    // Slot 0 owns the context's streams (gsum_init: four streams on four command-processor pipes).  The gradient batch keeps up to
+    // three more evaluations in flight, each entirely on ONE stream, while slot 0 uses only its main stream: they take slot 0's chain
+    // and auxiliary streams and the third group's -- streams created later would share a pipe with one of these.
+    const int idx = (int)(sl - ctx->slots);
+    gs_slot* s0 = &ctx->slots[0];
+    if (idx == 1 && s0->sp) { sl->sm = s0->sp; sl->own_sm = false; }
+    else if (idx == 2 && s0->sa) { sl->sm = s0->sa; sl->own_sm = false; }
+    else if (idx == 3 && ctx->wave.g[2].sc) { sl->sm = ctx->wave.g[2].sc; sl->own_sm = false; }
+    else GS_CHECK(hipStreamCreateWithPriority(&sl->sm, hipStreamNonBlocking, ctx->prio_lo));
     GS_CHECK(hipEventCreateWithFlags(&sl->evFork, hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) GS_CHECK(hipEventCreate(&sl->tev[i]));
     GS_CHECK(hipMalloc((void**)&sl->dres, 258 * sizeof(double)));
@@ -1102,9 +1112,9 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->evFork) (void)hipEventDestroy(sl->evFork);
         for (int k = 0; k < 4; ++k)
             if (sl->tev[k]) (void)hipEventDestroy(sl->tev[k]);
-        if (sl->sm) (void)hipStreamDestroy(sl->sm);
+        if (sl->sm && sl->own_sm) (void)hipStreamDestroy(sl->sm);
         if (sl->sp) (void)hipStreamDestroy(sl->sp);
-        if (sl->su) (void)hipStreamDestroy(sl->su);
+        if (sl->su && sl->own_su) (void)hipStreamDestroy(sl->su);
         if (sl->evU) (void)hipEventDestroy(sl->evU);
         if (sl->gws) (void)hipFree(sl->gws);
         if (sl->hgrad) (void)hipHostFree(sl->hgrad);
@@ -2325,7 +2335,11 @@ static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* d
     hipStream_t su = s;
     if (solo) {
         if (!sl->su) {
-            GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
+            // the sweep runs beside the factorisation's main and panel streams: it takes the context's fourth stream (the third group's chain
+            // stream of a batch, idle here) -- a stream created now would share a command-processor pipe with one of those two
+            // (round 4 found the single gradient evaluation at 19.7 ms instead of 14.2 that way)
+            if (sl == &ctx->slots[0] && ctx->wave.g[2].sc) { sl->su = ctx->wave.g[2].sc; sl->own_su = false; }
+            else GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
             GS_CHECK(hipEventCreateWithFlags(&sl->evU, hipEventDisableTiming));
         }
         su = sl->su;
@@ -2369,8 +2383,13 @@ static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* d
     gs_grad_params prm;
     memset(&prm, 0, sizeof prm);
     for (int p = 0; p < P; ++p) prm.p[p] = params[p];
-    hipLaunchKernelGGL(k_grad_contract, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+    if (desc->n_ops > 0) {
+        hipLaunchKernelGGL(k_grad_contract<true>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
+    } else {
+        hipLaunchKernelGGL(k_grad_contract<false>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+                       prm, Ri, ldg, Vt, ldg, Q, trow);
+    }
     GS_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_grad_reduce1, dim3((unsigned)chunks, (unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, rows_per, part);
     GS_CHECK(hipGetLastError());
@@ -2442,7 +2461,7 @@ int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_
     const double per_slot = 3.2 * (double)(np + GS_BORDER) * (double)(np + GS_BORDER) * 8.0;
     int S = (int)std::min<double>(8.0, std::max(1.0, 0.7 * (double)free_b / per_slot));
     S = std::max(1, std::min(S, (int)n_desc));
-    if (ctx->batch_slots <= 4) S = std::min(S, 3);                  // default hardware queues: three in flight is the optimum
+    S = std::min(S, ctx->batch_slots);                              // one stream each: the context's four streams sit on four pipes
     if (gs_need_slots(ctx, S)) return -1;
     ctx->batch_active = std::max(S, 3);        // the batch schedule (no look-ahead, no intra-evaluation events) for every member
     for (int i = 0; i < n_desc && !rc; ++i) {

@@ -12,7 +12,8 @@ import gsum_amd  # noqa: E402
 from gsum_amd.kernels import describe_kernel, describe_gradient  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C  # noqa: E402
 
-ctx = gsum_amd.lab_context(0)
+ctx = gsum_amd.lab_context(0) if (len(sys.argv) < 2 or sys.argv[1] != "product") else gsum_amd.HipContext(0)
+print("library:", "product" if len(sys.argv) > 1 and sys.argv[1] == "product" else "lab", flush=True)
 for n in (1024, 2048, 4096, 8192):
     r = 6
     X = 0.1 * np.arange(n)[:, None]
