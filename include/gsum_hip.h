@@ -17,9 +17,7 @@
  */
 #ifndef GSUM_HIP_H
 #define GSUM_HIP_H
-
 #include <stdint.h>
-
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -30,9 +28,7 @@ extern "C" {
 
 typedef struct gsum_ctx gsum_ctx;
 typedef struct gsum_mat gsum_mat;   /* device square matrix / Cholesky factor */
-
 enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3, GSUM_RQ = 4 /* RationalQuadratic: tree leaves only */ };
-
 /* A scikit-learn kernel (the reference accepts any: models.py:146-147, 686-688, 958-960).  Arithmetic follows
  * sklearn/gaussian_process/kernels.py: RBF 1556-1565, Matern 1711-1738, RationalQuadratic 1874-1903, WhiteKernel 1401-1414, Sum 858-866,
  * Product 956-966.  n_ops == 0: the flattened form amplitude * base(X / length_scale) + additive_const (+ white_noise on the
@@ -196,7 +192,6 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n);
  * [0] kernel build, [1] diagonal blocks, [2] panel solves and near updates, [3] the bulk trailing update, [4] the rest; each launch
  * is timed on the stream it runs on (the bulk class of a batch runs on one stream: its sum is wall time).  Resets the record. */
 int gsum_kernel_profile(gsum_ctx* ctx, double* ms5, double* flops5, int64_t* launches5);
-
 #ifdef __cplusplus
 }
 #endif

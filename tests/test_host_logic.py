@@ -169,7 +169,7 @@ def test_library_exports_every_declared_symbol():
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
         return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("gsum_")}
     assert exported(_lib.LIB_PATH) == declared and len(declared) <= 30
-    assert len(header.splitlines()) <= 205
+    assert len(header.splitlines()) < 200
     debug = open(os.path.join(ROOT, "include", "gsum_hip_debug.h")).read()
     lab_declared = set(re.findall(r"\b(gsum_[a-z0-9_]+)\s*\(", debug)) - declared
     assert lab_declared == set(_lib.LAB_PROTOTYPES), lab_declared ^ set(_lib.LAB_PROTOTYPES)
