@@ -22,6 +22,8 @@ Z = np.concatenate([np.random.RandomState(0).randn(n, r), np.ones((n, 1))], axis
 desc = gsum_amd.describe_kernel(RBF(0.2), 1)
 ctx.set_inputs(X, Z)
 ctx.set_option("chain_rows", W)
+if len(sys.argv) > 3:
+    ctx.set_option("chain_lazy", int(sys.argv[3]))
 plain = []
 for _ in range(6):
     ctx.lml_resident([desc], 1e-10)
