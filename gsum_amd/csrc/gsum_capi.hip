@@ -2213,10 +2213,12 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
-    // break-even against the 20-slot pipelined path, re-measured at the end of round 3 (both paths had become faster; tools/gpu_medium_breakeven.py,
-    // profiles/r03_medium_breakeven.log): the fused path wins from 2, 8, ~23, ~45, ~78, ~140, ~180 evaluations at n = 256, 512, 1024, 1536, 2048, 3072, 4096
+    // break-even against the grouped schedule, re-measured in round 4 (the grouped launches made small batches much faster than round 3's
+    // 20 streams; tools/gpu_medium_breakeven.py, profiles/r04_medium_breakeven.log): the fused path wins from 2, ~24, ~56, ~104, ~130, ~190,
+    // ~215 evaluations at n = 256, 512, 1024, 1536, 2048, 3072, 4096 -- n / 16 above n = 256 (round 3's rule n^1.55 / 2000 chose the fused
+    // path up to 40 % too early: n = 2048, 96 evaluations 17.5 ms fused against 12.4 grouped)
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
-                                                  : std::max(4, (int)(pow((double)ctx->in->n, 1.55) / 2000.0));
+                                                  : (ctx->in->n <= 256 ? 2 : std::max(4, (int)(ctx->in->n / 16)));
     if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min && !any_tree) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);

@@ -13,7 +13,7 @@ import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF  # noqa: E402
 
 ctx = gsum_amd.lab_context(0)
-ctx.set_option("batch_slots", 20)
+
 for n in (256, 512, 1024, 1536, 2048, 3072, 4096):
     X = 0.1 * np.arange(n)[:, None]
     Z = np.concatenate([np.random.RandomState(0).randn(n, 4), np.ones((n, 1))], axis=1)
@@ -35,7 +35,7 @@ for n in (256, 512, 1024, 1536, 2048, 3072, 4096):
         row.append(f"{c}: {t['fused']:.2f}/{t['pipelined']:.2f}")
         if cross is None and t["fused"] < t["pipelined"]:
             cross = c
-    rule = max(4, int(n ** 1.45 / 985.0))
+    rule = max(4, int(n ** 1.55 / 2000.0))
     print(f"n={n:5d}: fused wins from c = {cross} (rule in the library: {rule});  ms fused/pipelined  " + "  ".join(row), flush=True)
 ctx.set_option("medium_path", 1)
 ctx.set_option("medium_min_batch", 0)
