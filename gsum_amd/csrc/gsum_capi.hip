@@ -2043,7 +2043,9 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
     // of a 61-ms call at n = 8192).  Results do not depend on the grouping.
     std::vector<gs_wave_step> plans[GS_WV_GROUPS];
     {
-        const int depth = (ctx->lazy_far != 0 && np >= ctx->lazy_min_np) ? std::max(2, ctx->wave_depth) : 1;
+        // (grouping from padded order 1024 up: round 3's threshold of 4352 belonged to the one-stream-per-evaluation batch; on the grouped
+        //  schedule 24 evaluations at n = 4096 take 12.5 ms with it and 13.7 without, n = 3072: 6.1 / 6.6, n = 2048: 3.1 / 3.2, n = 1024: the same)
+        const int depth = (ctx->lazy_far != 0 && np >= std::min(ctx->lazy_min_np, 1024)) ? std::max(2, ctx->wave_depth) : 1;
         int digits[GS_WV_GROUPS] = {0};
         int h = ctx->wave_head, nd = 0;
         int tmp[8];
