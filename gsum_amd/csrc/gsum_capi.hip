@@ -127,7 +127,7 @@ struct gsum_ctx {
     int chain_persist = -1;          // ONE factorisation alone: the dependent chain as a persistent kernel on CUs of its own (k_chain),
                                      // the M-proportional work host-enqueued and gated on its flags.  -1 (default) = when the order
                                      // is a multiple of 256 and at least chain_min_np, 1 = whenever the order allows, 0 = never
-    int chain_min_np = 2048;
+    int chain_min_np = 768;           // (round 4: 2048 -> 768; n = 768 ... 1536: 9-14 % shorter, bit-identical)
     int chain_lazy = -1;              // persistent-chain schedule: far region of the trailing matrix updated every other step with K = 512 (measured: no gain at n = 8192 -- the K = 512 launch reaches 47 TF/s in situ, not the 55 of the microbenchmark, and the near-only steps leave the chip half empty; +1 % at 4096)
                                      // -1 (default): on from padded order 10240 up, where it pays -- 13.6 -> 13.3 ms at n = 12288, 29.15 -> 28.13 ms at 16384, 5.28 -> 5.31 at 8192
     int chain_rows = 512;            // the chain's window: rows under the panel it solves and updates itself (256 or 512)

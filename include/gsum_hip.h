@@ -94,7 +94,7 @@ const char* gsum_last_error(gsum_ctx* ctx);             /* NULL ctx: error of a 
  *                                  call carries enough of them (<= 0: the measured break-even)
  *   "wave_groups" 1..4, "wave_size" 1..24   layout of a batch: groups x evaluations per group in flight (default 3 x 8; each
  *                                  evaluation in flight owns a workspace matrix, 0.55 GB at n = 8192)
- *   "chain_persist"   -1 | 0 | 1   schedule of ONE factorisation: persistent chain kernel from order 2048 up / never / whenever
+ *   "chain_persist"   -1 | 0 | 1   schedule of ONE factorisation: persistent chain kernel from order 768 up / never / whenever
  *                                  the order allows;  "lookahead" 0 | 1  look-ahead in the host-enqueued schedule
  *   "pivot_guard_ulps" 0..1024     a pivot p <= guard * eps * A_jj counts as not positive (default 2; process-wide)
  * gsum_get_option reads these back, plus "wave_streams" (streams the last batch call used: groups + 1), "chain_probe",
