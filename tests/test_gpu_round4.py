@@ -248,3 +248,18 @@ def test_batch_shares_cover_every_evaluation_once(lab, groups, size):
     finally:
         for k, v in old.items():
             ctx.set_option(k, v)
+
+
+def test_mixed_calls_on_one_context_stay_bit_stable():
+    """Since round 4 every schedule of a context runs on the same four streams (batch groups, the single factorisation's chain and
+    auxiliary streams, the gradient sweep, the gradient batch's other evaluations).  Ten seconds of batch calls, single evaluations,
+    gradients and operator-level factorisations in random order on ONE context (tools/gpu_mixed_soak.py; the long runs are
+    profiles/r04_mixed_soak.log): every result bit-identical to the first of its kind, no chain time-out."""
+    import json
+    import sys
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_mixed_soak.py"), "10", "2048"], capture_output=True, text=True,
+                         timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    rec = json.loads([line for line in run.stdout.splitlines() if line.startswith("{")][-1])
+    assert rec["chain_aborts"] == 0 and rec["chain_probe"] == 1
+    assert all(rec["calls"].get(k, 0) > 0 for k in ("batch", "single", "grad", "gradbatch", "factorize", "two")), rec
