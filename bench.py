@@ -68,7 +68,7 @@ def available_cpus():
 
 def host_exp_is_svml():
     """numpy's float64 exp on AVX-512 hosts is Intel SVML's __svml_exp8_ha, which is not correctly rounded (exp(-0.125) comes out one
-    ulp low); the device kernel-build restates THAT routine (gsum_kernels.hip.h, gs_exp_np) because the reference's own numbers were
+    ulp low); the device kernel-build restates THAT routine (csrc/kernels/build.hip.h, gs_exp_np) because the reference's own numbers were
     made with it.  On a host whose numpy falls back to libm the CPU leg of this bench would differ from the GPU by ~6e-10 on the
     uniform-grid workload through no fault of either: detected here (behaviour, not CPU flags) and the CPU comparison is then
     labelled instead of failing the run; the committed reference value is the pin at every N either way."""

@@ -78,7 +78,7 @@ def _tree_matrix(desc, X, Y, param=None):
 
 def kernel_matrix(desc: KernelDesc, X, Y=None, diag_add=0.0):
     """amplitude * leaf(X[, Y]) (+ white noise on the one-argument diagonal) + additive constant (+ diag_add): the kernel-build
-    kernel's arithmetic, entry for entry (gsum_kernels.hip.h, k_build2), with scikit-learn evaluating the leaf."""
+    kernel's arithmetic, entry for entry (csrc/kernels/build.hip.h, k_build2), with scikit-learn evaluating the leaf."""
     X = np.asarray(X, dtype=float)
     if desc.n_ops > 0:
         K = np.array(_tree_matrix(desc, X, Y)[0])

@@ -17,8 +17,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "gsum_capi.hip")
+KERNEL_PARTS = ("common", "build", "diag", "panel", "chain", "gemm_nt", "fused", "tile", "solve", "grad", "probes")
 DEPS = [SRC, os.path.join(HERE, "csrc", "gsum_kernels.hip.h"), os.path.join(ROOT, "include", "gsum_hip.h"),
-        os.path.join(ROOT, "include", "gsum_hip_debug.h")]
+        os.path.join(ROOT, "include", "gsum_hip_debug.h")] + [os.path.join(HERE, "csrc", "kernels", f"{p}.hip.h") for p in KERNEL_PARTS]
 OUT = os.path.join(HERE, "libgsum_hip.so")
 OUT_LAB = os.path.join(HERE, "libgsum_hip_lab.so")
 

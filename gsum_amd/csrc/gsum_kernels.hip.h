@@ -19,3584 +19,17 @@
 // A right-looking blocked Cholesky over the first np columns turns the border rows into
 // W^T = (L^-1 RHS)^T and the corner into -W^T W, so the forward solve and the Gram reduction of the
 // log-likelihood cost no extra pass over L.
+//
+// The kernels live in kernels/*.hip.h, included here in dependency order (one translation unit: gsum_capi.hip).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
-#include "gsum_hip.h"
-
-#define GS_NB 128
-// pivot test: LAPACK's dpotf2 rule (p <= 0 or NaN -> info) with a guard of 2 eps: a pivot p of column j also counts as not positive
-// when p <= gs_pivot_guard * A_jj (the original diagonal entry).  Rounds 1-2 shipped 8 eps.  Measured in round 3
-// (tools/gpu_info_sweep.py, the duplicated-point cases of the test suite): with 0 an exactly singular matrix (n = 2048 Matern-5/2,
-// one point duplicated, no nugget) factorises on the device with a pivot of +1e-17 where numpy.linalg.cholesky raises; with 4 eps
-// and more the device refuses 2-D Matern-5/2 matrices that are singular to working precision and that LAPACK still factorises;
-// 1 and 2 eps reproduce LAPACK's outcome on all of them.  Option "pivot_guard_ulps" / GSUM_PIVOT_GUARD_ULPS.
-__device__ double gs_pivot_guard = 2.0 * 2.220446049250313e-16;
-#define GS_BORDER 16
-#define GS_KC 16                  // K chunk staged through LDS (16 doubles = one 128-B line per row)
-#define GS_LSTR (GS_KC + 1)       // odd LDS row stride (17 doubles): the compiler pairs fragment reads into
-                                  // ds_read2_b64, which banks mod 32 dwords -> rows 2 dwords apart, no conflicts
-
-typedef double gs_d4 __attribute__((ext_vector_type(4)));
-typedef double gs_d2 __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------------------------------------
-// K1: kernel matrix build
-// ------------------------------------------------------------------------------------------------
-// sklearn arithmetic, restated (sklearn/gaussian_process/kernels.py):
-//   RBF     :1556-1560  exp(-0.5 * sqeuclidean(X/ls)), diagonal forced to 1
-//   Matern  :1711-1738  d = euclidean(X/ls); nu=.5: exp(-d); 1.5: t=d*sqrt3, (1+t)exp(-t);
-//                       2.5: t=d*sqrt5, (1+t+t*t/3)exp(-t)
-//   Product :956-966 (amplitude * base), Sum :858-866 (+ constant), White :1401-1414 (+ noise on diag)
-// Floating-point contraction is off so that sums of squares round like the host code does.
-//
-// exp: numpy's float64 exp on AVX512 hosts (the reference's CPU path, and the GPU box's own host) is
-// Intel SVML's __svml_exp8_ha.  It is NOT correctly rounded — e.g. exp(-0.125) comes out 1 ulp low —
-// and on a uniform grid one such value fills a whole diagonal of K: that single ulp moves the S3
-// log-likelihood by 6e-10.  gs_exp_np therefore restates the published structure of that
-// routine operation for operation (Tang-style: N = floor_{1/16}(x log2 e), two-step Cody-Waite
-// reduction, 16-entry 2^(j/16) table with tail, degree-6 polynomial, every step one IEEE fma), so
-// kernel-matrix entries come out bit-identical to sklearn's.  Checked bit-for-bit against np.exp on 13k
-// arguments by tests/test_exp_restatement.py (CPU) and on the device by tests/test_gpu_parity.py.
-// |x| >= 707.7 (results below 4.6e-308 or overflow) takes SVML's scalar "rare" path on the host; here it
-// falls through to the device library's exp: such entries are < 1e-307 against a unit diagonal.
-__device__ __constant__ double gs_exp_th[16] = {
-    0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
-    0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0,
-    0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0, 0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};
-__device__ __constant__ double gs_exp_tl[16] = {
-    0x0.0p+0, 0x1.79aa65d837b6dp-54, -0x1.01b15eaa59348p-55, 0x1.68efde3a8a894p-54,
-    0x1.34d754db0abb6p-55, 0x1.59f48a72a4c6dp-55, 0x1.690cebb7aafb0p-56, 0x1.063e1e21c5409p-54,
-    -0x1.3b3efbf5e2228p-54, -0x1.b32dcb94da51dp-56, 0x1.db72fc1f0eab4p-55, 0x1.1affc2b91ce27p-56,
-    0x1.c1a7792cb3387p-55, 0x1.36eae30af0cb3p-56, 0x1.4a385a63d07a7p-56, -0x1.ff7128fd391f0p-55};
-
-__device__ __forceinline__ double gs_exp_np(double x) {
-#pragma clang fp contract(off)
-    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
-    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
-    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
-    // M = RZ(x*L2E + SH): round-toward-zero of a positive sum = floor on the 1/16 grid.  Emulated with a
-    // round-to-nearest fma and an exact sign test of the residual.
-    const double t = __builtin_fma(x, L2E, SH);
-    const double nn = t - SH;
-    const double dd = __builtin_fma(x, L2E, -nn);
-    const double N = dd < 0.0 ? nn - 0.0625 : nn;
-    const long long k16 = (long long)(N * 16.0);
-    const int j = (int)(k16 & 15);
-    double R = __builtin_fma(-N, L2H, x);
-    R = __builtin_fma(-N, L2L, R);
-    const double R2 = R * R;
-    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
-    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
-    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
-    double pp = __builtin_fma(R2, pA, pB);
-    pp = __builtin_fma(R2, pp, pC);
-    const double q = __builtin_fma(pp, R, gs_exp_tl[j]);
-    const double th = gs_exp_th[j];
-    const double res = __builtin_fma(th, q, th);
-    return ldexp(res, (int)(k16 >> 4));
-}
-
-__device__ __forceinline__ double gs_base_value(int family, double s) {
-#pragma clang fp contract(off)
-    if (family == GSUM_RBF) return gs_exp_np(-0.5 * s);
-    double dist = sqrt(s);
-    if (family == GSUM_MATERN52) {
-        double t = dist * 2.23606797749979;      // math.sqrt(5)
-        return (1.0 + t + (t * t) / 3.0) * gs_exp_np(-t);
-    }
-    if (family == GSUM_MATERN32) {
-        double t = dist * 1.7320508075688772;    // math.sqrt(3)
-        return (1.0 + t) * gs_exp_np(-t);
-    }
-    return gs_exp_np(-dist);
-}
-
-
-// ---- second version of the kernel build (round 2) ---------------------------------------------------------------
-// The first version was bound by instruction issue, not by HBM: a runtime switch over the kernel family and a runtime
-// loop over the input dimensions inside the per-entry loop, the 2^(j/16) table read through divergent global loads from
-// constant memory, a 64-bit float -> integer conversion, and diagonal / padding tests on every entry: ~90 VALU
-// instructions per entry, 89 us for the 34 M entries of the n = 8192 lower triangle (3.1 TB/s of stores).  Here the
-// family and the one-dimensional case are template parameters, the table lives in LDS, the exponent goes through
-// v_cvt_i32_f64, tiles that touch neither the diagonal nor the padding skip every test, and a workgroup takes 32 x 128
-// entries (8320 tiles at n = 8192: 4 rounds of the 2048 resident workgroups instead of 1.02 with a one-tile tail).
-// Same arithmetic, operation for operation (array_equal to scikit-learn is asserted on the device for every family).
-__device__ __forceinline__ double gs_exp_np_t(double x, const double* th, const double* tl) {
-#pragma clang fp contract(off)
-    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
-    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
-    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
-    const double t = __builtin_fma(x, L2E, SH);
-    const double nn = t - SH;
-    const double dd = __builtin_fma(x, L2E, -nn);
-    const double N = dd < 0.0 ? nn - 0.0625 : nn;
-    const int k16 = (int)(N * 16.0);                      // |N| < 1022: exact in 32 bits
-    const int j = k16 & 15;
-    double R = __builtin_fma(-N, L2H, x);
-    R = __builtin_fma(-N, L2L, R);
-    const double R2 = R * R;
-    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
-    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
-    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
-    double pp = __builtin_fma(R2, pA, pB);
-    pp = __builtin_fma(R2, pp, pC);
-    const double q = __builtin_fma(pp, R, tl[j]);
-    const double thj = th[j];
-    const double res = __builtin_fma(thj, q, thj);
-    return ldexp(res, k16 >> 4);
-}
-
-template <int FAM>
-__device__ __forceinline__ double gs_base_value_t(double s, const double* th, const double* tl) {
-#pragma clang fp contract(off)
-    if (FAM == GSUM_RBF) return gs_exp_np_t(-0.5 * s, th, tl);
-    const double dist = sqrt(s);
-    if (FAM == GSUM_MATERN52) {
-        const double t = dist * 2.23606797749979;      // math.sqrt(5)
-        return (1.0 + t + (t * t) / 3.0) * gs_exp_np_t(-t, th, tl);
-    }
-    if (FAM == GSUM_MATERN32) {
-        const double t = dist * 1.7320508075688772;    // math.sqrt(3)
-        return (1.0 + t) * gs_exp_np_t(-t, th, tl);
-    }
-    return gs_exp_np_t(-dist, th, tl);
-}
-
-// Branch-free form for the build kernel's inner loop.  Two argument ranges need no table arithmetic at all:
-//   x < -745.2       exp(x) is exactly 0.0 in fp64 (below half the smallest denormal) -- on a grid with dx = 0.5 l that
-//                    is every entry more than 39 length scales from the diagonal, i.e. most of a large matrix;
-//   |x| < 707.7      the table algorithm (gs_exp_np_t's fast path).
-// What is left (the band -745.2 <= x <= -707.7 where the result is a denormal, overflow, NaN) is flagged and recomputed
-// by the caller with the library exp, wave-uniformly, so that the common paths carry no per-entry branch.
-__device__ __forceinline__ double gs_exp_np_nobranch(double x, const double* th, const double* tl, bool& slow) {
-#pragma clang fp contract(off)
-    const bool far = x < -745.2;
-    const bool inr = fabs(x) < 0x1.61da04cbafe44p+9;
-    slow = !(far || inr);
-    const double xs = inr ? x : 0.0;
-    const double L2E = 0x1.71547652b82fep+0, SH = 0x1.8000000003ff0p+48;
-    const double L2H = 0x1.62e42fefa39efp-1, L2L = 0x1.abc9e3b39803fp-56;
-    const double t = __builtin_fma(xs, L2E, SH);
-    const double nn = t - SH;
-    const double dd = __builtin_fma(xs, L2E, -nn);
-    const double N = dd < 0.0 ? nn - 0.0625 : nn;
-    const int k16 = (int)(N * 16.0);
-    const int j = k16 & 15;
-    double R = __builtin_fma(-N, L2H, xs);
-    R = __builtin_fma(-N, L2L, R);
-    const double R2 = R * R;
-    const double pA = __builtin_fma(0x1.7411836940c04p-10, R, 0x1.1101cbbc265c0p-7);
-    const double pB = __builtin_fma(0x1.55557242d68fep-5, R, 0x1.5555553939732p-3);
-    const double pC = __builtin_fma(0x1.000000000d008p-1, R, 0x1.fffffffffff70p-1);
-    double pp = __builtin_fma(R2, pA, pB);
-    pp = __builtin_fma(R2, pp, pC);
-    const double q = __builtin_fma(pp, R, tl[j]);
-    const double thj = th[j];
-    const double res = ldexp(__builtin_fma(thj, q, thj), k16 >> 4);
-    return far ? 0.0 : res;
-}
-
-// base value with the exp argument's class reported: far = the exponential is exactly zero
-template <int FAM>
-__device__ __forceinline__ double gs_base_value_nb(double s, const double* th, const double* tl, bool& slow) {
-#pragma clang fp contract(off)
-    if (FAM == GSUM_RBF) return gs_exp_np_nobranch(-0.5 * s, th, tl, slow);
-    const double dist = sqrt(s);
-    if (FAM == GSUM_MATERN52) {
-        const double t = dist * 2.23606797749979;
-        return (1.0 + t + (t * t) / 3.0) * gs_exp_np_nobranch(-t, th, tl, slow);
-    }
-    if (FAM == GSUM_MATERN32) {
-        const double t = dist * 1.7320508075688772;
-        return (1.0 + t) * gs_exp_np_nobranch(-t, th, tl, slow);
-    }
-    return gs_exp_np_nobranch(-dist, th, tl, slow);
-}
-
-// is the exponential of this squared scaled distance exactly zero?  (the argument of exp is -0.5 s, -sqrt(5 s), ...)
-template <int FAM>
-__device__ __forceinline__ bool gs_base_is_zero(double s) {
-    if (FAM == GSUM_RBF) return s > 1490.5;                       // -0.5 s < -745.25
-    if (FAM == GSUM_MATERN52) return s > 111100.0;                // sqrt(5 s) > 745.3
-    if (FAM == GSUM_MATERN32) return s > 185200.0;                // sqrt(3 s) > 745.4
-    return s > 555500.0;                                          // sqrt(s) > 745.3
-}
-
-// run-time family, exp tables in LDS (the fused one-workgroup kernels: the family is uniform over the workgroup, and a table
-// in LDS costs an LDS read per entry where the __constant__ one of gs_exp_np costs a vector load from memory)
-__device__ __forceinline__ double gs_base_value_f(int family, double s, const double* th, const double* tl) {
-    if (family == GSUM_RBF) return gs_base_value_t<GSUM_RBF>(s, th, tl);
-    if (family == GSUM_MATERN52) return gs_base_value_t<GSUM_MATERN52>(s, th, tl);
-    if (family == GSUM_MATERN32) return gs_base_value_t<GSUM_MATERN32>(s, th, tl);
-    return gs_base_value_t<GSUM_MATERN12>(s, th, tl);
-}
-
-// One 128 x 128 tile of the kernel matrix for the fused one-workgroup kernels (256 threads; ui / uj: the scaled coordinates
-// of the tile's rows / columns in LDS; th / tl: the exp tables in LDS): k_build2's per-entry arithmetic and its short cuts
-// -- family and the one-dimensional case as template parameters, tiles that touch neither the diagonal nor the padding
-// without per-entry tests, two rows per pass -- instead of the round-1 loop (runtime family switch and dimension loop,
-// diagonal and padding tests on every entry: ~90 VALU instructions per entry, 17-21 % of k_lml_medium at n = 512 ... 1024).
-// Wave w takes rows w, w + 4, ... ; each lane two adjacent columns.  The diagonal's values also go to diag0.
-template <int FAM, bool D1>
-__device__ __forceinline__ void gs_build_tile128(double* A, int64_t ld, const double* ui, const double* uj, const double* th,
-                                                 const double* tl, int bi, int bj, int n, int d, const gsum_kernel_desc& desc,
-                                                 double diag_add, double* diag0, int w, int lane) {
-#pragma clang fp contract(off)
-    double vj0[D1 ? 1 : GSUM_MAX_D], vj1[D1 ? 1 : GSUM_MAX_D];
-    if (D1) {
-        vj0[0] = uj[2 * lane];
-        vj1[0] = uj[2 * lane + 1];
-    } else {
-#pragma unroll
-        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-            vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
-            vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
-        }
-    }
-    const int r0 = bi * 128, c0 = bj * 128, gj0 = c0 + 2 * lane;
-    const bool plain = bi != bj && r0 + 128 <= n && c0 + 128 <= n;
-    const double amp = desc.amplitude, addc = desc.additive_const;
-#pragma unroll 1
-    for (int rp = w; rp < 128; rp += 8) {
-        double s[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rr = rp + 4 * h;
-            if (D1) {
-                const double xi = ui[rr];
-                const double e0 = xi - vj0[0], e1 = xi - vj1[0];
-                s[h][0] = e0 * e0;
-                s[h][1] = e1 * e1;
-            } else {
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-                    if (dd < d) {
-                        const double xi = ui[rr * d + dd];
-                        const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
-                        s0 = s0 + e0 * e0;
-                        s1 = s1 + e1 * e1;
-                    }
-                }
-                s[h][0] = s0;
-                s[h][1] = s1;
-            }
-        }
-        double v[2][2];
-        if (plain) {
-            const bool nz = !(gs_base_is_zero<FAM>(s[0][0]) && gs_base_is_zero<FAM>(s[0][1]) && gs_base_is_zero<FAM>(s[1][0]) &&
-                              gs_base_is_zero<FAM>(s[1][1]));
-            if (__builtin_amdgcn_ballot_w64(nz) == 0) {
-                const double z = amp * 0.0 + addc;
-                v[0][0] = v[0][1] = v[1][0] = v[1][1] = z;
-            } else {
-                bool slow[2][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) v[h][c] = amp * gs_base_value_nb<FAM>(s[h][c], th, tl, slow[h][c]) + addc;
-                if (__builtin_amdgcn_ballot_w64(slow[0][0] || slow[0][1] || slow[1][0] || slow[1][1]) != 0) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-                            if (slow[h][c]) v[h][c] = amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int gi = r0 + rp + 4 * h, gj = gj0 + c;
-                    double val;
-                    if (gi >= n || gj >= n) {
-                        val = (gi == gj) ? 1.0 : 0.0;                 // identity padding up to a multiple of 128
-                    } else {
-                        const bool dg = gi == gj;
-                        const double b = dg ? 1.0 : gs_base_value_t<FAM>(s[h][c], th, tl);   // np.fill_diagonal(K, 1)
-                        val = amp * b;
-                        if (dg) val = val + desc.white_noise;
-                        val = val + addc;
-                        if (dg) val = val + diag_add;
-                    }
-                    if (gi == gj) diag0[gi] = val;
-                    v[h][c] = val;
-                }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const gs_d2 o = {v[h][0], v[h][1]};
-            *reinterpret_cast<gs_d2*>(A + (int64_t)(r0 + rp + 4 * h) * ld + gj0) = o;
-        }
-    }
-}
-
-// family and dimension are uniform over the workgroup: one scalar branch per tile
-__device__ __forceinline__ void gs_build_tile128_any(double* A, int64_t ld, const double* ui, const double* uj, const double* th,
-                                                     const double* tl, int bi, int bj, int n, int d, const gsum_kernel_desc& desc,
-                                                     double diag_add, double* diag0, int w, int lane) {
-#define GS_BT(F)                                                                                                       \
-    if (d == 1) gs_build_tile128<F, true>(A, ld, ui, uj, th, tl, bi, bj, n, d, desc, diag_add, diag0, w, lane);        \
-    else gs_build_tile128<F, false>(A, ld, ui, uj, th, tl, bi, bj, n, d, desc, diag_add, diag0, w, lane)
-    if (desc.family == GSUM_RBF) { GS_BT(GSUM_RBF); }
-    else if (desc.family == GSUM_MATERN52) { GS_BT(GSUM_MATERN52); }
-    else if (desc.family == GSUM_MATERN32) { GS_BT(GSUM_MATERN32); }
-    else { GS_BT(GSUM_MATERN12); }
-#undef GS_BT
-}
-
-#define GS_B2_ROWS 32
-// One 32 x 128 tile per 256-thread workgroup: wave w takes rows 8 w .. 8 w + 7, two at a time; each lane owns two adjacent
-// columns (one 16-B store per row, 1 KiB per wave-instruction).  Grid: CROSS or tri == 0: (prow / 32 rounded up) x (pcol /
-// 128 rounded up) tiles, row-slice fastest; tri != 0: the 128-column tiles on or below the diagonal, four row slices each.
-template <bool CROSS, int FAM, bool D1>
-__global__ __launch_bounds__(256) void k_build2(double* out, int64_t ldo, const double* X, const double* Y, int n, int m,
-                                                 int prow, int pcol, int d, gsum_kernel_desc desc, double diag_add, int tri) {
-#pragma clang fp contract(off)
-    __shared__ double ui[GS_B2_ROWS * GSUM_MAX_D];
-    __shared__ double uj[128 * GSUM_MAX_D];
-    __shared__ double tab[32];
-    const int t = threadIdx.x;
-    int bi, bj;                                        // 32-row slice index, 128-column tile index
-    if (tri) {
-        const int bid = blockIdx.x >> 2;
-        int b128 = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(b128 + 1) * (b128 + 2) / 2 <= bid) ++b128;
-        while ((int64_t)b128 * (b128 + 1) / 2 > bid) --b128;
-        bj = bid - (int)((int64_t)b128 * (b128 + 1) / 2);
-        bi = 4 * b128 + (blockIdx.x & 3);
-    } else {
-        const int tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS;
-        bi = blockIdx.x % tr;
-        bj = blockIdx.x / tr;
-    }
-    const double* Yp = CROSS ? Y : X;
-    const int ny = CROSS ? m : n;
-    const int r0 = bi * GS_B2_ROWS, c0 = bj * 128;
-    if (t < 16) tab[t] = gs_exp_th[t];
-    else if (t < 32) tab[t] = gs_exp_tl[t - 16];
-    for (int idx = t; idx < 128 * d; idx += 256) {
-        const int r = idx / d, dd = idx - r * d;
-        const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
-        const int gj = c0 + r;
-        uj[idx] = gj < ny ? Yp[(int64_t)gj * d + dd] / ls : 0.0;
-        if (r < GS_B2_ROWS) {
-            const int gi = r0 + r;
-            ui[idx] = gi < n ? X[(int64_t)gi * d + dd] / ls : 0.0;
-        }
-    }
-    __syncthreads();
-    const double* th = tab;
-    const double* tl = tab + 16;
-    const int lane = t & 63, w = t >> 6;
-    const int gj0 = c0 + 2 * lane;
-    if (gj0 >= pcol) return;
-    double vj0[D1 ? 1 : GSUM_MAX_D], vj1[D1 ? 1 : GSUM_MAX_D];
-    if (D1) {
-        vj0[0] = uj[2 * lane];
-        vj1[0] = uj[2 * lane + 1];
-    } else {
-#pragma unroll
-        for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-            vj0[dd] = dd < d ? uj[(2 * lane) * d + dd] : 0.0;
-            vj1[dd] = dd < d ? uj[(2 * lane + 1) * d + dd] : 0.0;
-        }
-    }
-    // a tile is plain when no entry needs a diagonal or padding rule: then value = amplitude * base + additive
-    const bool plain = CROSS ? (r0 + GS_B2_ROWS <= n && c0 + 128 <= m)
-                             : (r0 + GS_B2_ROWS <= n && c0 + 128 <= n && (c0 + 128 <= r0 || r0 + GS_B2_ROWS <= c0));
-    const double amp = desc.amplitude, addc = desc.additive_const;
-#pragma unroll 1
-    for (int rp = 0; rp < 8; rp += 2) {
-        double s[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rr = 8 * w + rp + h;
-            if (D1) {
-                const double xi = ui[rr];
-                const double e0 = xi - vj0[0], e1 = xi - vj1[0];
-                s[h][0] = e0 * e0;
-                s[h][1] = e1 * e1;
-            } else {
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int dd = 0; dd < GSUM_MAX_D; ++dd) {
-                    if (dd < d) {
-                        const double xi = ui[rr * d + dd];
-                        const double e0 = xi - vj0[dd], e1 = xi - vj1[dd];
-                        s0 = s0 + e0 * e0;
-                        s1 = s1 + e1 * e1;
-                    }
-                }
-                s[h][0] = s0;
-                s[h][1] = s1;
-            }
-        }
-        double v[2][2];
-        if (plain) {
-            // wave-uniform short cut: every exponential of these 2 x 128 entries is exactly zero
-            const bool nz = !(gs_base_is_zero<FAM>(s[0][0]) && gs_base_is_zero<FAM>(s[0][1]) && gs_base_is_zero<FAM>(s[1][0]) &&
-                              gs_base_is_zero<FAM>(s[1][1]));
-            if (__builtin_amdgcn_ballot_w64(nz) == 0) {
-                const double z = amp * 0.0 + addc;
-                v[0][0] = v[0][1] = v[1][0] = v[1][1] = z;
-            } else {
-                bool slow[2][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) v[h][c] = amp * gs_base_value_nb<FAM>(s[h][c], th, tl, slow[h][c]) + addc;
-                if (__builtin_amdgcn_ballot_w64(slow[0][0] || slow[0][1] || slow[1][0] || slow[1][1]) != 0) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-                            if (slow[h][c]) v[h][c] = amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int gi = r0 + 8 * w + rp + h, gj = gj0 + c;
-                    double val;
-                    if (CROSS) {
-                        val = (gi < n && gj < m) ? amp * gs_base_value_t<FAM>(s[h][c], th, tl) + addc : 0.0;
-                    } else if (gi >= n || gj >= n) {
-                        val = (gi == gj) ? 1.0 : 0.0;                 // identity padding up to a multiple of 128
-                    } else {
-                        const bool dg = gi == gj;
-                        const double b = dg ? 1.0 : gs_base_value_t<FAM>(s[h][c], th, tl);   // np.fill_diagonal(K, 1)
-                        val = amp * b;
-                        if (dg) val = val + desc.white_noise;
-                        val = val + addc;
-                        if (dg) val = val + diag_add;
-                    }
-                    v[h][c] = val;
-                }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int gi = r0 + 8 * w + rp + h;
-            if (gi < prow) {
-                const gs_d2 o = {v[h][0], v[h][1]};
-                *reinterpret_cast<gs_d2*>(out + (int64_t)gi * ldo + gj0) = o;
-            }
-        }
-    }
-}
-
-// ---- general kernel trees (gsum_kernel_desc with n_ops > 0) ----------------------------------------------------------------------
-// The reference hands ANY scikit-learn kernel to its three call sites (gsum/models.py:708, 822-824, 958-960).  The flattened
-// descriptor covers the family its own tests and notebooks use and runs the templated kernels above; everything else that is a
-// Sum / Product tree over stationary leaves (RBF, Matern 1/2 3/2 5/2, RationalQuadratic), ConstantKernel and WhiteKernel is
-// evaluated entry by entry as a postfix program in scikit-learn's own evaluation order (Sum: k1 + k2, kernels.py:858-866;
-// Product: k1 * k2, :956-966), so that `RBF + RBF` or `C * RBF + C * Matern` come out bit-identical to sklearn's matrix like
-// the flattened family does; RationalQuadratic goes through pow() and is within an ulp or two of numpy's.
-// The same walk with dual numbers gives d kernel / d log(parameter) for the gradient path (sklearn's K_gradient formulas per leaf:
-// RBF :1567-1577, Matern :1740-1771, RationalQuadratic :1893-1901; product and sum rules for the operators).
-#define GS_TREE_STACK 8
-
-// want: 0 value only, 1 d / d log length_scale (isotropic), 2 d / d log length_scale[dim], 3 d / d log alpha
-__device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const double* xi, const double* xj, int d, bool diag, int want,
-                                             int dim, double& v, double& dv) {
-#pragma clang fp contract(off)
-    dv = 0.0;
-    if (diag) {                                  // np.fill_diagonal(K, 1) of the one-argument form; every leaf gradient is 0 there
-        v = 1.0;
-        return;
-    }
-    if (lf.family == GSUM_RQ) {                  // kernels.py:1886-1890: (1 + sqeuclidean(X) / (2 alpha ls^2)) ** -alpha
-        double s = 0.0;
-        for (int m = 0; m < d; ++m) {
-            const double e = xi[m] - xj[m];
-            s = s + e * e;
-        }
-        const double ls2 = lf.length_scale[0] * lf.length_scale[0];
-        const double base = 1.0 + s / ((2.0 * lf.alpha) * ls2);
-        v = pow(base, -lf.alpha);
-        if (want == 1) dv = s * v / (ls2 * base);
-        else if (want == 3) dv = v * (-lf.alpha * log(base) + s / ((2.0 * ls2) * base));
-        return;
-    }
-    double s = 0.0, dsel = 0.0;                  // sqeuclidean(X / length_scale): divide first, like pdist on the scaled points
-    for (int m = 0; m < d; ++m) {
-        const double ls = lf.anisotropic ? lf.length_scale[m] : lf.length_scale[0];
-        const double u = xi[m] / ls - xj[m] / ls;
-        const double dmm = u * u;
-        s = s + dmm;
-        if (m == dim) dsel = dmm;
-    }
-    v = gs_base_value(lf.family, s);
-    if (want == 1 || want == 2) {
-        const double dm = want == 1 ? s : dsel;
-        if (lf.family == GSUM_RBF) {
-            dv = v * dm;
-        } else if (lf.family == GSUM_MATERN52) {
-            const double tmp = sqrt(5.0 * s);
-            dv = 5.0 / 3.0 * dm * (tmp + 1.0) * gs_exp_np(-tmp);
-        } else if (lf.family == GSUM_MATERN32) {
-            dv = 3.0 * dm * gs_exp_np(-sqrt(3.0 * s));
-        } else {
-            const double den = sqrt(s);
-            dv = den != 0.0 ? v * (dm / den) : 0.0;
-        }
-    }
-}
-
-// value of the tree at (xi, xj); diag: the entry is on the diagonal of the ONE-argument form (leaves exactly 1, WhiteKernel on).
-// pr != NULL: *dout = d value / d log(parameter pr) as well.
-__device__ __forceinline__ double gs_tree_eval(const gsum_kernel_desc& t, const double* xi, const double* xj, int d, bool diag,
-                                               const gsum_grad_param* pr, double* dout) {
-#pragma clang fp contract(off)
-    double sv[GS_TREE_STACK], sd[GS_TREE_STACK];
-    int sp = 0;
-    const int code = pr ? pr->code : -1, pdim = pr ? pr->dim : 0;
-    for (int k = 0; k < t.n_ops; ++k) {
-        const int op = t.op[k];
-        if (op >= GSUM_OP_WHITE) {
-            const int c = op - GSUM_OP_WHITE;
-            const double w = diag ? t.cval[c] : 0.0;
-            sv[sp] = w;
-            sd[sp] = (code == GSUM_GRAD_TREE_WHITE && pdim == c) ? w : 0.0;
-            ++sp;
-        } else if (op >= GSUM_OP_CONST) {
-            const int c = op - GSUM_OP_CONST;
-            sv[sp] = t.cval[c];
-            sd[sp] = (code == GSUM_GRAD_TREE_CONST && pdim == c) ? t.cval[c] : 0.0;
-            ++sp;
-        } else if (op >= GSUM_OP_LEAF) {
-            const int l = op - GSUM_OP_LEAF;
-            int want = 0;
-            if (code >= GSUM_GRAD_TREE_LENGTH_ISO && (pdim >> 4) == l)
-                want = code == GSUM_GRAD_TREE_LENGTH_ISO ? 1 : (code == GSUM_GRAD_TREE_LENGTH_DIM ? 2 : 3);
-            double v, dv;
-            gs_leaf_eval(t.leaf[l], xi, xj, d, diag, want, pdim & 15, v, dv);
-            sv[sp] = v;
-            sd[sp] = dv;
-            ++sp;
-        } else {
-            const double b = sv[sp - 1], db = sd[sp - 1], a = sv[sp - 2], da = sd[sp - 2];
-            sp -= 2;
-            if (op == GSUM_OP_ADD) {
-                sv[sp] = a + b;
-                sd[sp] = da + db;
-            } else {
-                sv[sp] = a * b;
-                sd[sp] = da * b + a * db;
-            }
-            ++sp;
-        }
-    }
-    if (dout) *dout = sd[0];
-    return sv[0];
-}
-
-// kernel matrix of a tree: the tile geometry of k_build2 (32 x 128 tiles, a lane owns two adjacent columns), values through gs_tree_eval
-template <bool CROSS>
-__global__ __launch_bounds__(256) void k_build_tree(double* out, int64_t ldo, const double* X, const double* Y, int n, int m, int prow,
-                                                     int pcol, int d, gsum_kernel_desc desc, double diag_add, int tri) {
-#pragma clang fp contract(off)
-    const int t = threadIdx.x;
-    int bi, bj;
-    if (tri) {
-        const int bid = blockIdx.x >> 2;
-        int b128 = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(b128 + 1) * (b128 + 2) / 2 <= bid) ++b128;
-        while ((int64_t)b128 * (b128 + 1) / 2 > bid) --b128;
-        bj = bid - (int)((int64_t)b128 * (b128 + 1) / 2);
-        bi = 4 * b128 + (blockIdx.x & 3);
-    } else {
-        const int tr = (prow + GS_B2_ROWS - 1) / GS_B2_ROWS;
-        bi = blockIdx.x % tr;
-        bj = blockIdx.x / tr;
-    }
-    const double* Yp = CROSS ? Y : X;
-    const int ny = CROSS ? m : n;
-    const int lane = t & 63, w = t >> 6;
-    const int gj0 = bj * 128 + 2 * lane;
-    if (gj0 >= pcol) return;
-    double xj[2][GSUM_MAX_D];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xj[c][mm] = (mm < d && gj0 + c < ny) ? Yp[(int64_t)(gj0 + c) * d + mm] : 0.0;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int gi = bi * GS_B2_ROWS + 8 * w + rr;
-        if (gi >= prow) continue;
-        double xi[GSUM_MAX_D];
-#pragma unroll
-        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xi[mm] = (mm < d && gi < n) ? X[(int64_t)gi * d + mm] : 0.0;
-        double v[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int gj = gj0 + c;
-            if (CROSS) {
-                v[c] = (gi < n && gj < m) ? gs_tree_eval(desc, xi, xj[c], d, false, nullptr, nullptr) : 0.0;
-            } else if (gi >= n || gj >= n) {
-                v[c] = gi == gj ? 1.0 : 0.0;                       // identity padding
-            } else {
-                v[c] = gs_tree_eval(desc, xi, xj[c], d, gi == gj, nullptr, nullptr);
-                if (gi == gj) v[c] = v[c] + diag_add;
-            }
-        }
-        const gs_d2 o = {v[0], v[1]};
-        *reinterpret_cast<gs_d2*>(out + (int64_t)gi * ldo + gj0) = o;
-    }
-}
-
-// Border rows np..np+15 of the augmented matrix: row c = column c of RHS (n x k, row-major), zero
-// beyond k / n, and a zero 16x16 corner.
-__global__ __launch_bounds__(256) void k_set_border(double* A, int64_t ld, int n, int np, const double* Z, int k) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= np + GS_BORDER) return;
-#pragma unroll
-    for (int c = 0; c < GS_BORDER; ++c)
-        A[(int64_t)(np + c) * ld + i] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
-}
-
-// diag0[i] = A[i][i] before the factorisation touches it.
-__global__ __launch_bounds__(256) void k_save_diag(const double* A, int64_t ld, int np, double* diag0) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < np) diag0[i] = A[(int64_t)i * ld + i];
-}
-
-// Rows >= n of the padded square part become identity rows; used after a host upload.
-__global__ __launch_bounds__(256) void k_pad_identity(double* A, int64_t ld, int n, int np) {
-    int j = blockIdx.x * 256 + threadIdx.x;
-    int i = n + blockIdx.y;
-    if (j >= np || i >= np) return;
-    A[(int64_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2a: diagonal block (128x128), one workgroup.  (The round-1 routine -- the block in the registers of a 16 x 16 thread grid, an
-// LDS mailbox round trip per two columns, the explicit 128 x 128 inverse -- was removed in round 4; gs_diag_block below is what runs.)
-// LAPACK dpotf2 semantics: pivot <= 0 or NaN -> info, plus the guard of gs_pivot_guard (top of this file).
-// ------------------------------------------------------------------------------------------------
-#define GS_DV_STR 17     // padded row stride of the 16x16 diagonal inverses in LDS
-
-__device__ __forceinline__ double gs_rsqrt_nr(double p) {
-    // ~1 ulp reciprocal square root: hardware estimate + two Newton-Raphson steps
-    double r = __builtin_amdgcn_rsq(p);
-    const double h = 0.5 * p;
-    double e = __builtin_fma(-(h * r), r, 0.5);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-(h * r), r, 0.5);
-    r = __builtin_fma(r, e, r);
-    return r;
-}
-
-#define GS_DIAG_WS 9792      // LDS doubles the fused small / medium kernels reserve for the diagonal routine (76.5 KB >= its 9472)
-
-// ------------------------------------------------------------------------------------------------
-// K2a, second version (round 2): the 128x128 diagonal block as an 8 x 8 grid of 16x16 micro-blocks that live in the
-// ACCUMULATOR REGISTERS of the four waves for the whole factorisation; only the pivot recurrence of one 16x16 micro-block
-// at a time is scalar work, and it runs inside ONE wave with no barrier and no LDS round trip per column.
-//
-// Register image.  Wave w owns block rows w and 7 - w (9 micro-blocks, 72 VGPRs).  For micro-block (i, k) with current
-// value M the four registers hold  P[x](lane l) = -M[l & 15][(l >> 4) + 4 x].  Read as an MFMA accumulator that is
-// -M^T; read as the A operand of k-step x it is -M; read as the B operand of k-step x it is -M^T (all three with the
-// same k numbering kappa(x, g) = g + 4 x).  Hence, with no data movement and no negation anywhere:
-//   panel solve   L_ij^T = D_j M_ij^T :  P_ij <- mfma(A = D_j from LDS,             B = P_ij)         (D_j = L_jj^-1)
-//   update        M_ik^T -= L_kj L_ij^T:  P_ik <- mfma(A = -L_kj = P_kj dumped to LDS, B = P_ij, C = P_ik)
-// and the LDS copy of the panel ("dump": register x of lane l at [x][l], conflict-free both ways) is also the A operand
-// -L_ip the block inverse needs afterwards.
-// Pivot recurrence (gs_potf2_16): the owner wave turns its micro-block into one row per lane (lanes 0..15) with the
-// rows of the identity beside it (lanes 16..31).  Column step c: the pivot and the scaled column entries l_k come out
-// of their lanes with v_readlane into SGPRs, every lane does a[k] -= a[c] l_k -- the same instruction stream gives L in
-// lanes 0..15 and L^-T in lanes 16..31 (column operations applied to the identity), so the micro-block inverse D_j
-// costs nothing.  ~45 instructions per column instead of a barrier + mailbox round trip (~1200 cycles) per two columns.
-// Schedule per micro-block column j: [barrier] panel solve + dump [barrier] the owner of row j + 1 updates its diagonal
-// micro-block and runs the pivot recurrence at once while the other waves apply the remaining updates.
-// Semantics unchanged: LAPACK dpotf2's pivot test plus the lost-every-bit threshold (see above), the first failing column
-// reported; L in place (lower part only), L^-1 of the whole block to Linv, sum of log L_jj.
-// Workspace: 28 panel blocks (56 KB) + 8 micro-block inverses (17 KB) + 128 thresholds = 9472 doubles <= GS_DIAG_WS.
-// ------------------------------------------------------------------------------------------------
-#define GS_D2_LS 0
-#define GS_D2_DV (28 * 256)
-#define GS_D2_THR (GS_D2_DV + 8 * 16 * GS_DV_STR)
-
-__device__ __forceinline__ double gs_readlane_f64(double v, int srclane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ void gs_wave_lds_sync() {
-    // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across the point
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// Accumulation order (what the log-likelihood's last digits depend on; measured against the extended-precision values of
-// tests/golden/large_truth.json).  An entry of the factor is (a_ik - sum_p l_ip l_kp) / l_kk.  Subtracting the products
-// from a_ik one by one, as a right-looking update does, rounds every partial result at the magnitude of a_ik, although
-// the products of far-away columns are tiny and only the last few are large: on the S2 / S3 inputs (pivots ~ 1e-8 of the
-// diagonal) that put the log-likelihood 6-20 x further from the true value than LAPACK.  Here the products are summed
-// FROM ZERO in ascending p, in accumulators of their own (S), and the sum is subtracted once -- the order of a
-// left-looking dot product -- while the schedule stays right-looking.  The pivot recurrence continues the same sums.
-// Pivot recurrence of micro-block JB in one wave, entirely in the register image -- no LDS round trip, no per-lane row
-// arrays.  Pjj: the ORIGINAL block (-A_jj^T, symmetric), Sjj: the products accumulated so far (+sum_p L_jp L_jp^T).  Column
-// c = g + 4 x of a symmetric 16 x 16 matrix M sits in register x of the sixteen lanes of group g (lane & 15 = row), so
-//   e   = A[x] - S[x]                     column c of the Schur complement on group g (one subtraction of the sum)
-//   p   = readlane(e, 16 g + c)           the pivot;  1 / sqrt(p) by v_rsq + two Newton steps, uniform
-//   m   = e / sqrt(p)                     column c of L on group g;  ms = its part strictly below the diagonal, else 0
-//   S  += ms ms^T                         ONE v_mfma_f64_16x16x4 with ms as A and B operand in k-slot g (the other three
-//                                         slots are zeros): the rank-1 update of all 256 sums
-//   V   : column c scaled, V -= v_c l^T   a second MFMA (A = -ms, B = v_c): the column operations applied to the identity,
-//                                         V -> L^-T, whose transpose D_j = L_jj^-1 goes to the table row-major
-// ~35 instructions per column, two of them MFMAs, against ~70 VALU + v_readlane for a row-per-lane formulation (9.3 k
-// cycles per micro-block measured) and a barrier + LDS mailbox per two columns in round 1.
-// Ablk: the block's origin in the matrix.  Dvj: its 16 x 17 slot of the inverse table.  Returns the failing local column or -1.
-// PAIR IMAGE of the diagonal micro-blocks.  The recurrence below eliminates two columns per step (the two pivots'
-// reciprocal square roots are independent dependent-chains; done one after the other they are most of a column's ~430
-// cycles), and for that both columns of a pair must sit in the same lanes.  A diagonal micro-block M (symmetric) is
-// therefore held permuted: with rho(i) = (i >> 2) + 4 (i & 3), register x of lane l holds M[rho^-1(l & 15)][4 (l >> 4) + x]
-// -- columns 4 g .. 4 g + 3 in the sixteen lanes of group g.  Seen as an MFMA accumulator this is Pi M Pi^T for the
-// permutation Pi of rho, so rank-1 updates with vectors indexed the same way (lane & 15 = rho(row)) need nothing else:
-// the sums S_jj reach it by reading the panel dumps with a permuted lane index (gs_d2_upd_diag), A_jj by loading it so.
-__device__ __forceinline__ int gs_pair_row(int lane) { return 4 * (lane & 3) + ((lane & 15) >> 2); }   // rho^-1(lane & 15)
-#define GS_PAIR_LANE(r, c) (16 * ((c) >> 2) + ((r) >> 2) + 4 * ((r) & 3))                              // lane of entry (r, c)
-
-// v is zero outside lane row g (16 lanes): the same values in row g ^ 1, zero elsewhere.  v_permlane16_swap exchanges the odd
-// rows of its first operand with the even rows of its second; ODD = g & 1.
-__device__ __forceinline__ double gs_row_to_sibling(double v, bool ODD) {     // ODD folds after unrolling
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    if (ODD) {
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, 0u, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, 0u, false, false);
-        return __hiloint2double((int)b[1], (int)a[1]);
-    } else {
-        const auto a = __builtin_amdgcn_permlane16_swap(0u, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(0u, hi, false, false);
-        return __hiloint2double((int)b[0], (int)a[0]);
-    }
-}
-
-template <int JB>
-__device__ __forceinline__ int gs_potf2_16(const gs_d4& Ajj, const gs_d4& Sjj, double* Ablk, int64_t ld, double* Dvj,
-                                           const double* thr, double* dbuf, int lane, unsigned long long* stamps = nullptr) {
-    const int fq = lane >> 4, rr = gs_pair_row(lane);
-    unsigned long long tq0 = 0;
-    if (stamps) tq0 = __builtin_amdgcn_s_memtime();
-    gs_d4 Aa = Ajj, S = Sjj, V, Lo = {0.0, 0.0, 0.0, 0.0}, Rs = {1.0, 1.0, 1.0, 1.0};
-#pragma unroll
-    for (int x = 0; x < 4; ++x) V[x] = (rr == 4 * fq + x) ? 1.0 : 0.0;
-    const double tl = thr[16 * JB + rr];
-    int fail = -1;
-#pragma unroll
-    for (int c0 = 0; c0 < 16; c0 += 2) {
-        const int c1 = c0 + 1, g = c0 >> 2, x0 = c0 & 3, x1 = x0 + 1;
-        const bool ing = fq == g;
-        const double e0 = Aa[x0] - S[x0];     // columns c0, c1 of the Schur complement before c0 is eliminated (group g):
-        const double e1 = Aa[x1] - S[x1];     // ONE subtraction of the zero-start sums each
-        const double p0 = gs_readlane_f64(e0, GS_PAIR_LANE(c0, c0));
-        const double a10 = gs_readlane_f64(e0, GS_PAIR_LANE(c1, c0));
-        const double p1r = gs_readlane_f64(e1, GS_PAIR_LANE(c1, c1));
-        const double t0 = gs_readlane_f64(tl, GS_PAIR_LANE(c0, 0) & 15), t1 = gs_readlane_f64(tl, GS_PAIR_LANE(c1, 0) & 15);
-        // q = p0 p1 with p1 = p1r - a10^2 / p0 the second pivot: 1 / sqrt(p1) = sqrt(p0) rsqrt(q), so rsqrt(q) runs beside
-        // rsqrt(p0) instead of behind it
-        const double q = __builtin_fma(p1r, p0, -(a10 * a10));
-        if (fail < 0 && !(p0 > t0)) fail = c0;            // wave-uniform (the operands came through SGPRs); catches NaN
-        if (fail < 0 && !(q > t1 * p0)) fail = c1;        // <=> p1 <= threshold
-        const double r0 = gs_rsqrt_nr(p0), rq = gs_rsqrt_nr(q);
-        double d0 = p0 * r0;                                             // sqrt(p0) ...
-        d0 = __builtin_fma(__builtin_fma(-d0, d0, p0), 0.5 * r0, d0);    // ... corrected to ~0.5 ulp
-        double sq = q * rq;
-        sq = __builtin_fma(__builtin_fma(-sq, sq, q), 0.5 * rq, sq);
-        const double l10 = a10 * r0, r1 = d0 * rq, d1 = sq * r0;        // L[c1][c0], 1 / sqrt(p1), sqrt(p1)
-        const double m0 = e0 * r0;
-        const double ms0 = (ing && rr > c0) ? m0 : 0.0;
-        // column c1 after c0: its sum takes the product l_r,c0 l_c1,c0 first, then the one subtraction
-        const double m1 = (Aa[x1] - __builtin_fma(m0, l10, S[x1])) * r1;
-        const double ms1 = (ing && rr > c1) ? m1 : 0.0;
-        Lo[x0] = ing ? ((rr == c0) ? d0 : ms0) : Lo[x0];
-        Lo[x1] = ing ? ((rr == c1) ? d1 : ms1) : Lo[x1];
-        Rs[x0] = ing ? r0 : Rs[x0];           // the columns of V are scaled at the end (never updated after their step)
-        Rs[x1] = ing ? r1 : Rs[x1];
-        const double vc0 = ing ? V[x0] * r0 : 0.0;
-        const double vc1 = ing ? __builtin_fma(-l10, vc0, V[x1]) * r1 : 0.0;
-        // both rank-1 updates of the pair in ONE MFMA each: column c1's vector moves to the sibling lane row (g ^ 1, a
-        // different k-slot) with v_permlane16_swap, so the instruction sums ms0 ms0^T + ms1 ms1^T (two of its four k-slots)
-        const double ab = ms0 + gs_row_to_sibling(ms1, (g & 1) != 0);
-        const double vb = vc0 + gs_row_to_sibling(vc1, (g & 1) != 0);
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, ab, S, 0, 0, 0);
-        V = __builtin_amdgcn_mfma_f64_16x16x4f64(-ab, vb, V, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);    // keep the steps apart: hoisting the next steps' lane masks and v_readlane
-                                              // results ahead ran the kernel out of SGPRs (spills through v_writelane)
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int cc = 4 * fq + x;
-        if (cc <= rr) Ablk[(int64_t)rr * ld + cc] = Lo[x];                    // L_jj, lower part
-        if (cc == rr) dbuf[16 * JB + rr] = Lo[x];                             // its diagonal, for the log-determinant
-        Dvj[cc * GS_DV_STR + rr] = V[x] * Rs[x];                              // D_j[a][b] = V[b][a], row-major
-    }
-    if (stamps && lane == 0) stamps[24 + JB] = __builtin_amdgcn_s_memtime() - tq0;      // diagnostics: cycles of this recurrence
-    return fail;
-}
-
-// C (acc) += A (dumped block at `blk`: [x][lane]) * B (registers)
-__device__ __forceinline__ void gs_d2_upd(gs_d4& Cc, const double* blk, const gs_d4& Bb, int lane) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[x * 64 + lane], Bb[x], Cc, 0, 0, 0);
-}
-
-// the same for a DIAGONAL micro-block's sum, kept in the pair image: both operands are the dumped block read with the
-// pair image's lane index (row rho^-1(lane & 15) of the block)
-__device__ __forceinline__ void gs_d2_upd_diag(gs_d4& Cc, const double* blk, int lane) {
-    const int src = gs_pair_row(lane) + 16 * (lane >> 4);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const double v = blk[x * 64 + src];
-        Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, Cc, 0, 0, 0);
-    }
-}
-
-// X^T = D_J (A^T - sum)  in the register image:  P <- mfma(D_J, P + S), dumped to the panel table
-// FULL: all 28 dumps stay in LDS (the fused kernels solve rows against them afterwards).  !FULL: LDS holds only the
-// CURRENT panel column (slot = block row; a column is read in its own step only) and every dump goes straight to the
-// global table Lg -- 35 KB of LDS instead of 77, so the stand-alone kernel fits into the place ONE bulk workgroup
-// leaves behind on a busy CU.
-#define GS_LS_SLOT(FULL, row, J) ((FULL) ? ((row) * ((row) - 1) / 2 + (J)) : (row))
-template <int J, bool FULL>
-__device__ __forceinline__ void gs_d2_solve_dump(gs_d4& Pb, const gs_d4& Sb, const double (&av)[4], double* Ls, double* Lg, double* A,
-                                                 int64_t ld, int row, int lane) {
-    const gs_d4 E = Pb + Sb;
-    gs_d4 T = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int x = 0; x < 4; ++x) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], E[x], T, 0, 0, 0);
-    Pb = T;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) Ls[(GS_LS_SLOT(FULL, row, J) * 4 + x) * 64 + lane] = T[x];
-
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Lg[((row * (row - 1) / 2 + J) * 4 + x) * 64 + lane] = T[x];
-    }
-}
-
-template <int W, int J, bool FULL>
-__device__ __forceinline__ void gs_d2_trsm_dump(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W],
-                                                const double* Dv, double* Ls, double* Lg, double* A, int64_t ld, int lane) {
-    constexpr int R0 = W, R1 = 7 - W;
-    const int fr = lane & 15, fq = lane >> 4;
-    if constexpr (R1 > J) {                   // R1 >= R0: nothing to do for either row otherwise
-        double av[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = Dv[(J * 16 + fr) * GS_DV_STR + fq + 4 * x];
-        if constexpr (R0 > J) gs_d2_solve_dump<J, FULL>(P0[J], S0[J], av, Ls, Lg, A, ld, R0, lane);
-        gs_d2_solve_dump<J, FULL>(P1[J], S1[J], av, Ls, Lg, A, ld, R1, lane);
-    }
-}
-
-// after panel column J is in LDS: add its products to the sums; the owner of row J + 1 finishes the sum of its diagonal
-// micro-block first and runs the pivot recurrence on it before its other updates.  Returns the failing local column of
-// micro-block J + 1 or -1.
-// the blocks of panel column J this wave solved are final: back to the matrix.  Issued in the update phase -- by the
-// wave that runs the next pivot recurrence only after it, by the others first -- so the scattered 8-byte stores are off
-// the chain (at the end of the kernel they were 8 k cycles of tail, in the solve phase 1-1.5 k per step)
-template <int W, int J>
-__device__ __forceinline__ void gs_d2_store_col(const gs_d4 (&P0)[W + 1], const gs_d4 (&P1)[8 - W], double* A, int64_t ld, int lane) {
-    constexpr int R0 = W, R1 = 7 - W;
-    const int fr = lane & 15, fq = lane >> 4;
-    if constexpr (R0 > J) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R0 + fr) * ld + 16 * J + fq + 4 * x] = -P0[J][x];
-    }
-    if constexpr (R1 > J) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) A[(int64_t)(16 * R1 + fr) * ld + 16 * J + fq + 4 * x] = -P1[J][x];
-    }
-}
-
-template <int W, int J, bool FULL>
-__device__ __forceinline__ int gs_d2_update(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
-                                            int64_t ld, double* Dv, double* scr, const double* Ls, const double* thr, double* dbuf,
-                                            int lane, unsigned long long* stamps) {
-    constexpr int R0 = W, R1 = 7 - W, N = J + 1;
-    int fail = -1;
-    if constexpr (R0 != N && R1 != N) gs_d2_store_col<W, J>(P0, P1, A, ld, lane);
-    if constexpr (R0 == N) {
-        gs_d2_upd_diag(S0[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
-        fail = gs_potf2_16<N>(P0[N], S0[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
-    } else if constexpr (R1 == N) {
-        gs_d2_upd_diag(S1[N], Ls + GS_LS_SLOT(FULL, N, J) * 256, lane);
-        fail = gs_potf2_16<N>(P1[N], S1[N], A + (int64_t)(16 * N) * ld + 16 * N, ld, Dv + N * 16 * GS_DV_STR, thr, dbuf, lane, stamps);
-    }
-    if constexpr (R0 == N || R1 == N) gs_d2_store_col<W, J>(P0, P1, A, ld, lane);
-    if constexpr (R0 > N) {
-#pragma unroll
-        for (int k = N; k < R0; ++k) gs_d2_upd(S0[k], Ls + GS_LS_SLOT(FULL, k, J) * 256, P0[J], lane);
-        gs_d2_upd_diag(S0[R0], Ls + GS_LS_SLOT(FULL, R0, J) * 256, lane);           // the row's own diagonal micro-block
-    }
-    if constexpr (R1 > N) {
-#pragma unroll
-        for (int k = N; k < R1; ++k) gs_d2_upd(S1[k], Ls + GS_LS_SLOT(FULL, k, J) * 256, P1[J], lane);
-        gs_d2_upd_diag(S1[R1], Ls + GS_LS_SLOT(FULL, R1, J) * 256, lane);
-    }
-    return fail;
-}
-
-// the blocks of panel column K that wave W owns, from the matrix into the register image: a strictly lower block negated
-// in the standard image, a diagonal micro-block in the pair image, not negated, read from its lower triangle only
-template <int W, int K>
-__device__ __forceinline__ void gs_d2_load_col(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], const double* A, int64_t ld, int lane) {
-    constexpr int R0 = W, R1 = 7 - W;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int prow = gs_pair_row(lane);
-    if constexpr (K <= R0) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if constexpr (K < R0) {
-                P0[K][x] = -A[(int64_t)(16 * R0 + fr) * ld + 16 * K + fq + 4 * x];
-            } else {
-                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
-                P0[K][x] = A[(int64_t)(16 * R0 + hi) * ld + 16 * R0 + lo];
-            }
-        }
-    }
-    if constexpr (K <= R1) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if constexpr (K < R1) {
-                P1[K][x] = -A[(int64_t)(16 * R1 + fr) * ld + 16 * K + fq + 4 * x];
-            } else {
-                const int cc = 4 * fq + x, hi = cc > prow ? cc : prow, lo = cc > prow ? prow : cc;
-                P1[K][x] = A[(int64_t)(16 * R1 + hi) * ld + 16 * R1 + lo];
-            }
-        }
-    }
-}
-
-template <int W, int J, bool FULL>
-__device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W], gs_d4 (&S0)[W + 1], gs_d4 (&S1)[8 - W], double* A,
-                                           int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, const double* thr, double* dbuf,
-                                           int* fail_sh, int lane, unsigned long long* stamps) {
-    if constexpr (J < 7) gs_d2_load_col<W, J + 1>(P0, P1, A, ld, lane);       // next column's blocks: a step ahead of their use
-    __syncthreads();                                          // D_J (and a failure flag) visible
-    if (stamps && W == 0 && lane == 0) stamps[8 + 2 * J] = __builtin_amdgcn_s_memtime();       // diagnostics only
-    if (*fail_sh >= 0) return false;
-    gs_d2_trsm_dump<W, J, FULL>(P0, P1, S0, S1, Dv, Ls, Lg, A, ld, lane);
-    __syncthreads();                                          // panel column J visible
-    if (stamps && W == 0 && lane == 0) stamps[9 + 2 * J] = __builtin_amdgcn_s_memtime();
-    if constexpr (J < 7) {
-        const int f = gs_d2_update<W, J, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, thr, dbuf, lane, stamps);
-        if (f >= 0 && lane == 0) *fail_sh = 16 * (J + 1) + f;
-    }
-    return true;
-}
-
-// phase 1 of wave W: returns false if a pivot failed (every wave leaves at the same barrier)
-template <int W, bool FULL>
-__device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, double* thr,
-                                           double d0, double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
-    constexpr int R0 = W, R1 = 7 - W;
-    const int fr = lane & 15, fq = lane >> 4;
-    gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
-    const int prow = gs_pair_row(lane);
-
-#pragma unroll
-    for (int k = 0; k <= R0; ++k) S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k <= R1; ++k) S1[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-    // Only panel column 0 is fetched here; column k + 1 is requested at the start of step k (gs_d2_step), a whole
-    // step (7-10 k cycles) ahead of its use.  A block of the matrix is needed exactly once -- when its column is solved
-    // (or, for a diagonal micro-block, factored) -- so holding all nine of a wave's blocks from the start only cost
-    // registers: 72 of them, which is what pushed the fused kernels (capped at 256 for two evaluations per CU) into
-    // scratch.  Nothing writes a block before it is read: stores go to columns already solved.
-    gs_d2_load_col<W, 0>(P0, P1, A, ld, lane);
-    // pivot thresholds (d0 was requested before the block, so it is the oldest load in flight): waves 0 and 1 store 64
-    // each.  No barrier: the first recurrence reads entries 0..15, which its own wave wrote (LDS operations of one wave
-    // execute in order); every later reader is behind the barriers of step 0.
-    if constexpr (W < 2) thr[threadIdx.x] = d0 > 0.0 ? d0 * gs_pivot_guard : 0.0;
-    if constexpr (W == 0) {
-        gs_wave_lds_sync();
-        const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);
-        if (f >= 0 && lane == 0) *fail_sh = f;
-    }
-    if (!gs_d2_step<W, 0, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 1, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 2, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 3, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 4, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 5, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 6, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 7, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    // (the strictly lower micro-blocks went back to the matrix as they were solved, the diagonal ones from the pivot recurrence)
-    return true;
-}
-
-// One block column J of L^-1 on the matrix cores, from the panel dumps (A operand: -L_ip) and the micro-block inverses.
-template <int J>
-__device__ __forceinline__ void gs_trtri_col2(const double* Ls, const double* Dv, double* Linv, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    gs_d4 X[8];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) X[J][x] = Dv[(J * 16 + fq + 4 * x) * GS_DV_STR + fr];      // X_JJ = D_J in accumulator layout
-#pragma unroll
-    for (int i = J + 1; i < 8; ++i) {
-        gs_d4 T = {0.0, 0.0, 0.0, 0.0};                                                      // -sum_p L_ip X_pJ
-#pragma unroll
-        for (int p = J; p < i; ++p) gs_d2_upd(T, Ls + (i * (i - 1) / 2 + p) * 256, X[p], lane);
-        gs_d4 R = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const double av = Dv[(i * 16 + fr) * GS_DV_STR + 4 * s4 + fq];                 // A operand: D_i
-            R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], R, 0, 0, 0);
-        }
-        X[i] = R;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            Linv[(16 * i + fq + 4 * x) * 128 + 16 * J + fr] = (i < J) ? 0.0 : X[i][x];
-}
-
-// the whole 128 x 128 inverse: wave w builds block columns w and 7 - w
-__device__ __forceinline__ void gs_trtri_block(const double* Ls, const double* Dv, double* Linv, int w, int lane) {
-    if (w == 0) {
-        gs_trtri_col2<0>(Ls, Dv, Linv, lane);
-        gs_trtri_col2<7>(Ls, Dv, Linv, lane);
-    } else if (w == 1) {
-        gs_trtri_col2<1>(Ls, Dv, Linv, lane);
-        gs_trtri_col2<6>(Ls, Dv, Linv, lane);
-    } else if (w == 2) {
-        gs_trtri_col2<2>(Ls, Dv, Linv, lane);
-        gs_trtri_col2<5>(Ls, Dv, Linv, lane);
-    } else {
-        gs_trtri_col2<3>(Ls, Dv, Linv, lane);
-        gs_trtri_col2<4>(Ls, Dv, Linv, lane);
-    }
-}
-
-// The diagonal-block routine as a device function (k_potrf_diag, k_potrf_diag256, k_chain and the fused small / medium kernels
-// share it).  A: the 128 x 128 block (leading dimension ld), factored in place (lower part).  diag0: the block's 128 original
-// diagonal entries (pivot guard).  Returns 0 or the 1-based local column of the first bad pivot (uniform over the workgroup);
-// *logdet_out (thread 0) = sum_j log L_jj.  wsp: the caller's LDS workspace (16-B aligned); passing it in lets a fused kernel lend
-// the same bytes to its other phases.  What it leaves behind:
-//   - the substitution tables of the block stay in the caller's LDS workspace, wsp[0 .. GS_LTAB): the 28 panel dumps
-//     (-L_kj in A-operand layout) and the 8 micro-block inverses D_j.  gs_panel16 solves rows against them;
-//   - Ltab != NULL: the same GS_LTAB doubles are copied to global memory for kernels that come later;
-//   - Linv != NULL: the explicit 128 x 128 inverse is built too (phase 2; 15 k cycles that nothing on the
-//     factorisation's own path needs any more).
-#define GS_LTAB (GS_D2_DV + 8 * 16 * GS_DV_STR)          // 9344 doubles = 73 KB
-// LDS layout of the !FULL mode: 8 panel-column slots | the 8 micro-block inverses | 128 thresholds   (4352 doubles = 34 KB)
-#define GS_D2C_DV (8 * 256)
-#define GS_D2C_THR (GS_D2C_DV + 8 * 16 * GS_DV_STR)
-#define GS_D2C_WS (GS_D2C_THR + 128)
-template <bool FULL = true>
-__device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet_out,
-                                             const double* diag0, unsigned long long* stamps, double* wsp) {
-    __shared__ double dbuf[128];
-    __shared__ int fail_sh;
-    double* Ls = wsp + GS_D2_LS;
-    double* Dv = wsp + (FULL ? GS_D2_DV : GS_D2C_DV);
-    double* thr = wsp + (FULL ? GS_D2_THR : GS_D2C_THR);
-    double* scr = nullptr;
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    unsigned long long st0 = 0, sr0 = 0, st2 = 0;
-    if (stamps) {
-        st0 = __builtin_amdgcn_s_memtime();
-        sr0 = __builtin_amdgcn_s_memrealtime();
-        if (t == 0) stamps[7] = st0;
-    }
-    if (t == 0) fail_sh = -1;                           // first read behind the first barrier of step 0
-    double d0 = 0.0;
-    if (t < 128) d0 = diag0[t];                         // the thresholds' load goes out ahead of the block's (see gs_d2_wave)
-    __builtin_amdgcn_sched_barrier(0);
-    bool ok;
-    if (w == 0) ok = gs_d2_wave<0, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else if (w == 1) ok = gs_d2_wave<1, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else if (w == 2) ok = gs_d2_wave<2, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else ok = gs_d2_wave<3, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    if (!ok) return fail_sh + 1;                       // uniform: every wave read the flag behind the same barrier
-    if (stamps) st2 = __builtin_amdgcn_s_memtime();
-    if (t < 128) dbuf[t] = log(dbuf[t]);
-    if constexpr (FULL) {
-        if (Ltab) {
-            const gs_d2* src = reinterpret_cast<const gs_d2*>(wsp);
-            gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab);
-            for (int i = t; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
-        }
-        if (Linv) gs_trtri_block(Ls, Dv, Linv, w, lane);
-    } else {
-        // the panel dumps went to Ltab as they were made; only the micro-block inverses are left to export
-        const gs_d2* src = reinterpret_cast<const gs_d2*>(Dv);
-        gs_d2* dst = reinterpret_cast<gs_d2*>(Ltab + GS_D2_DV);
-        for (int i = t; i < 8 * 16 * GS_DV_STR / 2; i += 256) dst[i] = src[i];
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (w == 0) {
-        // sum of the 128 logs by one wave: two per lane, then a fixed xor tree (deterministic)
-        double sl = dbuf[lane] + dbuf[lane + 64];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sl += __shfl_xor(sl, off, 64);
-        if (lane == 0) *logdet_out = sl;
-    }
-    if (t == 0) {
-        if (stamps) {
-            const unsigned long long st3 = __builtin_amdgcn_s_memtime(), sr3 = __builtin_amdgcn_s_memrealtime();
-            stamps[0] = 0;              // (the loads are part of phase 1 in this version)
-            stamps[1] = st2 - st0;      // phase 1 (micro-block factorisation)
-            stamps[2] = st3 - st2;      // table export (+ block inverse when asked for)
-            stamps[3] = st3 - st0;      // total shader cycles
-            stamps[4] = sr3 - sr0;      // total 100 MHz ticks
-        }
-    }
-    return 0;
-}
-
-// ---- rows against a factored diagonal block: blocked substitution on the matrix cores ---------------------------
-// X L_bb^T = B for 16 rows of B (128 columns), in place, by ONE wave, from the block's substitution tables in LDS: the
-// rows are eight micro-blocks in the register image of gs_diag_block (P_k = -B_k^T), and column step j is
-//     S   <- sum_{p<j} (-L_jp) P_p        (from zero, ascending p)
-//     P_j <- D_j (P_j + S)                (X_j^T = D_j (B_j - sum_{p<j} X_p L_jp^T)^T)
-// -- the arithmetic the rows below a diagonal micro-block go through inside gs_diag_block, with no pivoting work.  Only the
-// 16 x 16 inverses D_j multiply, the off-diagonal part of L_bb enters through products with L itself: this is forward
-// substitution at micro-block granularity, backward stable up to cond(L_jj) of 16 x 16 blocks, where a product with the
-// explicit 128 x 128 inverse (round 1) loses cond(L_bb): measured against the extended-precision value of the S2 / S3
-// log-likelihoods that product was 6-20 x further from the truth than LAPACK.  144 MFMAs per 16 rows instead of 256.
-// rows: pointer to the first of the 16 rows at the block's first column; nvalid: rows that exist (others read as 0).
-__device__ __forceinline__ void gs_panel16_load(gs_d4 (&P)[8], const double* rows, int64_t ld, int nvalid, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    const bool live = fr < nvalid;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[k][x] = live ? -rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] : 0.0;
-}
-
-__device__ __forceinline__ void gs_panel16_solve(gs_d4 (&P)[8], const double* tab, int lane) {
-    const double* Ls = tab + GS_D2_LS;
-    const double* Dv = tab + GS_D2_DV;
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        gs_d4 S = {0.0, 0.0, 0.0, 0.0};                                // + sum_{p<j} L_jp X_p^T, from zero in ascending p
-#pragma unroll
-        for (int pp = 0; pp < j; ++pp) gs_d2_upd(S, Ls + (j * (j - 1) / 2 + pp) * 256, P[pp], lane);
-        const gs_d4 E = P[j] + S;                                      // -(B_j - sum)^T: one subtraction of the whole sum
-        gs_d4 T = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(Dv[(j * 16 + fr) * GS_DV_STR + fq + 4 * x], E[x], T, 0, 0, 0);
-        P[j] = T;
-    }
-}
-
-// two 16-row groups against the same tables in one pass: every table block is read from LDS once and feeds two
-// independent MFMA chains (k_lml_medium's panel phase: 25-30 % of that kernel with one group at a time, each wave waiting
-// on its own LDS reads and dependent MFMAs).  Row for row the arithmetic of gs_panel16_solve.
-__device__ __forceinline__ void gs_panel16_solve2(gs_d4 (&P)[8], gs_d4 (&Q)[8], const double* tab, int lane) {
-    const double* Ls = tab + GS_D2_LS;
-    const double* Dv = tab + GS_D2_DV;
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        gs_d4 SP = {0.0, 0.0, 0.0, 0.0}, SQ = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int pp = 0; pp < j; ++pp) {
-            const double* blk = Ls + (j * (j - 1) / 2 + pp) * 256;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const double a = blk[x * 64 + lane];
-                SP = __builtin_amdgcn_mfma_f64_16x16x4f64(a, P[pp][x], SP, 0, 0, 0);
-                SQ = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Q[pp][x], SQ, 0, 0, 0);
-            }
-        }
-        const gs_d4 EP = P[j] + SP, EQ = Q[j] + SQ;
-        gs_d4 TP = {0.0, 0.0, 0.0, 0.0}, TQ = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const double dv = Dv[(j * 16 + fr) * GS_DV_STR + fq + 4 * x];
-            TP = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, EP[x], TP, 0, 0, 0);
-            TQ = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, EQ[x], TQ, 0, 0, 0);
-        }
-        P[j] = TP;
-        Q[j] = TQ;
-    }
-}
-
-__device__ __forceinline__ void gs_panel16_store(const gs_d4 (&P)[8], double* rows, int64_t ld, int nvalid, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    if (fr < nvalid) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) rows[(int64_t)fr * ld + 16 * k + fq + 4 * x] = -P[k][x];
-    }
-}
-
-// The same two through a wave-private LDS tile (16 rows x 18 doubles): the register image wants lane (fr, fq) to hold columns fq + 4 x of
-// row fr, so gs_panel16_load's instruction x of micro-block k touches 16 rows x 32 B -- sixteen cache lines for 512 B, four times over
-// per micro-block, and the stores are 32-B fragments.  Here a micro-block goes global <-> registers as TWO 16-B-per-lane accesses of 8
-// whole 128-B lines each, and changes layout in LDS (a wave's LDS operations execute in order: no barrier).  Measured on the batch's
-// panel launches (probe builds, profiles/r04_panel_rows.log): the fragmented row traffic was 4 ms of a 61-ms call.  Same values.
-#define GS_PT_STR 18
-#define GS_PT_TILE (16 * GS_PT_STR)
-__device__ __forceinline__ void gs_panel16_load_t(gs_d4 (&P)[8], const double* rows, int64_t ld, int nvalid, int lane, double* tile) {
-    const int fr = lane & 15, fq = lane >> 4;
-    const int r0 = lane >> 3, cp = 2 * (lane & 7);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)                  // raw lines into the registers the image will occupy: all 16 loads in flight together
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const gs_d2 v = (r0 + 8 * h < nvalid) ? *reinterpret_cast<const gs_d2*>(rows + (int64_t)(r0 + 8 * h) * ld + 16 * k + cp) : gs_d2{0.0, 0.0};
-            P[k][2 * h] = v[0];
-            P[k][2 * h + 1] = v[1];
-        }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) *reinterpret_cast<gs_d2*>(tile + (r0 + 8 * h) * GS_PT_STR + cp) = gs_d2{P[k][2 * h], P[k][2 * h + 1]};
-        gs_wave_lds_sync();
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[k][x] = -tile[fr * GS_PT_STR + fq + 4 * x];
-        gs_wave_lds_sync();
-    }
-}
-
-__device__ __forceinline__ void gs_panel16_store_t(const gs_d4 (&P)[8], double* rows, int64_t ld, int nvalid, int lane, double* tile) {
-    const int fr = lane & 15, fq = lane >> 4;
-    const int r0 = lane >> 3, cp = 2 * (lane & 7);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) tile[fr * GS_PT_STR + fq + 4 * x] = -P[k][x];
-        gs_wave_lds_sync();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const gs_d2 v = *reinterpret_cast<const gs_d2*>(tile + (r0 + 8 * h) * GS_PT_STR + cp);
-            if (r0 + 8 * h < nvalid) *reinterpret_cast<gs_d2*>(rows + (int64_t)(r0 + 8 * h) * ld + 16 * k + cp) = v;
-        }
-        gs_wave_lds_sync();
-    }
-}
-
-__device__ __forceinline__ void gs_panel16(double* rows, int64_t ld, int nvalid, const double* tab, int lane) {
-    gs_d4 P[8];
-    gs_panel16_load(P, rows, ld, nvalid, lane);
-    gs_panel16_solve(P, tab, lane);
-    gs_panel16_store(P, rows, ld, nvalid, lane);
-}
-
-// global -> LDS copy of one block's substitution tables (256 threads); ends with a barrier
-__device__ __forceinline__ void gs_load_ltab(double* tab, const double* Ltab) {
-    const gs_d2* src = reinterpret_cast<const gs_d2*>(Ltab);
-    gs_d2* dst = reinterpret_cast<gs_d2*>(tab);
-    for (int i = threadIdx.x; i < GS_LTAB / 2; i += 256) dst[i] = src[i];
-    __syncthreads();
-}
-
-// the same copy without staging registers: global_load_lds_dwordx4 moves each wave's 64 x 16 B straight into LDS
-// (wave w of the workgroup's 4 takes every fourth 1-KiB piece); the caller waits (vmcnt) and synchronises
-__device__ __forceinline__ void gs_load_ltab_direct(double* tab, const double* Ltab, int w, int lane) {
-    constexpr int PIECES = GS_LTAB * 8 / 1024;                 // 73 whole 1-KiB pieces (GS_LTAB * 8 = 74752 = 73 KiB)
-    for (int pc = w; pc < PIECES; pc += 4)
-        __builtin_amdgcn_global_load_lds(Ltab + pc * 128 + 2 * lane, tab + pc * 128, 16, 0, 0);
-}
-
-// ---- the same substitution with the tables read straight from GLOBAL memory (L2 / L1 hits: every wave of a launch
-// reads the same 73 KB), software-pipelined through registers: no LDS, no barrier, one wave per workgroup.  What it
-// buys is placement, not arithmetic: beside the bulk update every CU holds three bulk workgroups and 1 KB of free LDS,
-// and a 73-KB table workgroup waited for two of them to retire on the SAME CU (rocprofv3: 100-200 us per call in the
-// first third of a factorisation, 20 us alone).  A lone wave with ~200 VGPRs and no LDS fits on any SIMD at once.
-// Step j's table blocks (j panel dumps + D_j) are fetched one to two steps ahead; bit-identical to gs_panel16_solve.
-template <int J>
-__device__ __forceinline__ void gs_ptab_fetch(gs_d4 (&buf)[8], const double* tab, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int pp = 0; pp < J; ++pp)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) buf[pp][x] = tab[GS_D2_LS + ((J * (J - 1) / 2 + pp) * 4 + x) * 64 + lane];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) buf[J][x] = tab[GS_D2_DV + (J * 16 + fr) * GS_DV_STR + fq + 4 * x];
-}
-
-template <int J>
-__device__ __forceinline__ void gs_ptab_step(gs_d4 (&P)[8], const gs_d4 (&buf)[8]) {
-    gs_d4 S = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int pp = 0; pp < J; ++pp)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) S = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[pp][x], P[pp][x], S, 0, 0, 0);
-    const gs_d4 E = P[J] + S;
-    gs_d4 T = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int x = 0; x < 4; ++x) T = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[J][x], E[x], T, 0, 0, 0);
-    P[J] = T;
-}
-
-__device__ __forceinline__ void gs_panel16_solve_g(gs_d4 (&P)[8], const double* tab, int lane) {
-    gs_d4 b0[8], b1[8], b2[8], b3[8];
-    gs_ptab_fetch<0>(b0, tab, lane);
-    gs_ptab_fetch<1>(b1, tab, lane);
-    gs_ptab_fetch<2>(b2, tab, lane);
-    gs_ptab_fetch<3>(b3, tab, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_ptab_step<0>(P, b0);
-    gs_ptab_step<1>(P, b1);
-    gs_ptab_fetch<4>(b0, tab, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_ptab_step<2>(P, b2);
-    gs_ptab_step<3>(P, b3);
-    gs_ptab_fetch<5>(b1, tab, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_ptab_step<4>(P, b0);
-    gs_ptab_fetch<6>(b2, tab, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_ptab_step<5>(P, b1);
-    gs_ptab_fetch<7>(b3, tab, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_ptab_step<6>(P, b2);
-    gs_ptab_step<7>(P, b3);
-}
-
-// rows [0, M) x 128 columns at P (leading dimension ld)  <-  rows * L_bb^-T, 16 rows per single-wave workgroup
-__global__ __launch_bounds__(64) void k_panel(double* P, int64_t ld, int M, const double* Ltab) {
-    const int lane = threadIdx.x;
-    const int r0 = blockIdx.x * 16;
-    if (r0 >= M) return;
-    __builtin_amdgcn_s_setprio(3);          // chain kernel: ahead of the bulk waves it shares the SIMD with
-    double* rows = P + (int64_t)r0 * ld;
-    gs_d4 Pr[8];
-    gs_panel16_load(Pr, rows, ld, M - r0, lane);
-    gs_panel16_solve_g(Pr, Ltab, lane);
-    gs_panel16_store(Pr, rows, ld, M - r0, lane);
-}
-
-// ---- two block columns at once ------------------------------------------------------------------------------------
-// Lsib: the 128 x 128 block L(j+1, j) as 64 micro-block dumps in A-operand layout, [(c * 8 + k) * 256 + x * 64 + lane]
-// = register image of (-L_ck) -- what k_potrf_diag256 leaves behind for the rows below.
-#define GS_LSIB (64 * 256)
-
-// P1 (register image of the rows' second 128 columns)  +=  sum_k (-L_ck) P0_k : the sibling-column update
-// B[:, j+1] -= X_j L(j+1, j)^T of these 16 rows, products in ascending k on accumulators that START as the matrix entries
-// -- element for element the arithmetic of k_gemm_nt on the same block (sign-mirrored), so the fused kernels below stay
-// bit-identical to the three-launch sequence panel / sibling update / panel.
-__device__ __forceinline__ void gs_sib_fetch(gs_d4 (&buf)[8], const double* Lsib, int c, int lane) {
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) buf[kb][x] = Lsib[((c * 8 + kb) * 4 + x) * 64 + lane];
-}
-
-__device__ __forceinline__ void gs_sib_apply(gs_d4& acc, const gs_d4 (&buf)[8], const gs_d4 (&P0)[8]) {
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[kb][x], P0[kb][x], acc, 0, 0, 0);
-}
-
-__device__ __forceinline__ void gs_sib_update(gs_d4 (&P1)[8], const gs_d4 (&P0)[8], const double* Lsib, int lane) {
-    gs_d4 ba[8], bb[8];
-    gs_sib_fetch(ba, Lsib, 0, lane);
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        gs_sib_fetch(bb, Lsib, c + 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gs_sib_apply(P1[c], ba, P0);
-        if (c + 2 < 8) gs_sib_fetch(ba, Lsib, c + 2, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gs_sib_apply(P1[c + 1], bb, P0);
-    }
-}
-
-// the same with half-size buffers (k-blocks 0..3 / 4..7 of one micro-block row at a time): 64 registers of operands in
-// flight instead of 128.  For k_panel256 in a batch: six bulk waves (72 registers each) leave 80 of a SIMD's 512 registers
-// free and every retiring bulk workgroup 144 more, so a wave of up to 224 registers starts where ONE bulk workgroup has
-// left; a bigger one needs two or three gone and keeps them away for as long as it waits for memory.
-template <int H>
-__device__ __forceinline__ void gs_sib_fetch_half(gs_d4 (&buf)[4], const double* Lsib, int c, int lane) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) buf[kb][x] = Lsib[((c * 8 + 4 * H + kb) * 4 + x) * 64 + lane];
-}
-
-template <int H>
-__device__ __forceinline__ void gs_sib_apply_half(gs_d4& acc, const gs_d4 (&buf)[4], const gs_d4 (&P0)[8]) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[kb][x], P0[4 * H + kb][x], acc, 0, 0, 0);
-}
-
-__device__ __forceinline__ void gs_sib_update_lean(gs_d4 (&P1)[8], const gs_d4 (&P0)[8], const double* Lsib, int lane) {
-    gs_d4 b0[4], b1[4];
-    gs_sib_fetch_half<0>(b0, Lsib, 0, lane);
-    gs_sib_fetch_half<1>(b1, Lsib, 0, lane);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        __builtin_amdgcn_sched_barrier(0);
-        gs_sib_apply_half<0>(P1[c], b0, P0);                    // ascending k: blocks 0..3, then 4..7
-        if (c + 1 < 8) gs_sib_fetch_half<0>(b0, Lsib, c + 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gs_sib_apply_half<1>(P1[c], b1, P0);
-        if (c + 1 < 8) gs_sib_fetch_half<1>(b1, Lsib, c + 1, lane);
-    }
-}
-
-// ---- flags of the persistent-chain schedule (the schedule itself: after k_potrf_diag256, below) ----
-#define GS_CH_GMAX 32                       // window row groups at most (W = 512)
-#define GS_FL_ABORT 0                       // 0 running, 1 a wait timed out, 2 a pivot failed (info says where)
-#define GS_FL_RESIDENT 1                    // workgroups of k_chain that have started (k_wait_flag holds the other streams back)
-#define GS_FL_BASE 16
-enum { GS_FL_T0 = 0, GS_FL_TL, GS_FL_T1, GS_FL_WTOP, GS_FL_WALL, GS_FL_UD0, GS_FL_UD1, GS_FL_UR, GS_FL_FA, GS_FL_FB, GS_FL_RP, GS_FL_KINDS };
-__host__ __device__ inline int gs_fl(int kind, int S, int s) { return GS_FL_BASE + kind * S + s; }
-__host__ __device__ inline int gs_fl_wg(int S, int s, int g) { return GS_FL_BASE + GS_FL_KINDS * S + GS_CH_GMAX * s + g; }
-__host__ __device__ inline int gs_fl_count(int S) { return (GS_FL_BASE + (GS_FL_KINDS + GS_CH_GMAX) * S + 3) / 4 * 4; }
-#define GS_CH_TIMEOUT 100000000ull          // 1 s of s_memrealtime (100 MHz)
-#define GS_CH_STAMPS 16                     // u64 per outer step (diagnostics)
-#define GS_CH_KSTAMPS 8                     // ... and first start / last end of the step's four host-enqueued launches
-#define GS_CH_LDS_DOUBLES GS_LSIB           // 128 KB: the L10 operand images (>= the diagonal routine's 75.8 KB workspace)
-
-#define GS_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ unsigned gs_flag_ld(const unsigned* f) {
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, GS_RLX_AGENT));
-}
-__device__ __forceinline__ void gs_flag_st(unsigned* f, unsigned v) { __hip_atomic_store(f, v, GS_RLX_AGENT); }
-__device__ __forceinline__ void gs_flag_add(unsigned* f) { (void)__hip_atomic_fetch_add(f, 1u, GS_RLX_AGENT); }
-__device__ __forceinline__ void gs_st_wt(double* p, double v) { __hip_atomic_store(p, v, GS_RLX_AGENT); }   // global_store_dwordx2 sc1
-__device__ __forceinline__ void gs_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// One wave polls until *f >= want (every lane loads the same word: one request).  false: the chain was aborted.  No acquire.
-__device__ __forceinline__ bool gs_poll_ge(const unsigned* f, unsigned want, unsigned* flags) {
-    if (gs_flag_ld(f) < want) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (unsigned spins = 0;; ++spins) {
-            // short naps first (a hand-off on the critical path), longer ones once the wait is clearly a long one (the chain
-            // idling behind the bulk update in the first third of a factorisation): polls are fabric traffic the bulk kernels pay for
-            if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
-            if (gs_flag_ld(f) >= want) break;
-            if ((spins & 15) == 15) {
-                if (gs_flag_ld(flags + GS_FL_ABORT)) return false;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > GS_CH_TIMEOUT) {
-                    gs_flag_st(flags + GS_FL_ABORT, 1u);
-                    return false;
-                }
-            }
-        }
-    }
-    return true;
-}
-// ONE agent-scope acquire after the poll(s) have matched: this CU's L1 drops its lines; the wave's own later loads are ordered
-// behind the invalidate in its memory pipeline (other waves: s_waitcnt vmcnt(0) + barrier first, gs_wg_wait_ge)
-__device__ __forceinline__ void gs_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-__device__ __forceinline__ bool gs_wait_ge(const unsigned* f, unsigned want, unsigned* flags) {
-    if (!gs_poll_ge(f, want, flags)) return false;
-    gs_acquire();
-    return true;
-}
-
-// the same for a whole workgroup: thread 0's wave polls and acquires, the others load behind the barrier.  `sh`: one int of LDS.
-__device__ __forceinline__ bool gs_wg_wait_ge(const unsigned* f, unsigned want, unsigned* flags, volatile int* sh) {
-    if (threadIdx.x < 64) {
-        const bool ok = gs_wait_ge(f, want, flags);
-        gs_drain();                              // the invalidate has completed before the barrier lets the other waves load
-        if (threadIdx.x == 0) *sh = ok ? 1 : 0;
-    }
-    __syncthreads();
-    const int ok = *sh;
-    __syncthreads();
-    return ok != 0;
-}
-
-__global__ void k_signal(unsigned* f, unsigned v) {
-    if (threadIdx.x == 0) gs_flag_st(f, v);
-}
-
-// one wave that waits for chain flags in stream order: everything enqueued behind it on its stream starts only then (the
-// launch boundary is the acquire).  This is how the host-enqueued kernels of the schedule meet the chain: a poll + acquire +
-// two barriers in front of EVERY workgroup of a 3000-workgroup trailing update cost 24 us per outer step (measured), and
-// gated workgroups hold their slots while they spin; one spinning wave costs nothing.
-// Also once per factorisation: nothing is dispatched before EVERY workgroup of k_chain is resident -- a k_chain wave needs a whole
-// SIMD's registers and its workgroup most of a CU's LDS, and other streams' waves that wait for a chain workgroup that found no
-// room would keep it out for good (seen: one factorisation in three timed out at n = 8192).
-__global__ __launch_bounds__(64) void k_wait_flag(const unsigned* f, unsigned want, const unsigned* f2, unsigned want2, unsigned* flags) {
-    if (gs_poll_ge(f, want, flags) && f2) (void)gs_poll_ge(f2, want2, flags);
-}
-
-// end of a persistent-chain factorisation: a chain that gave up (a wait timed out) says so through the info word
-#define GS_INFO_CHAIN_ABORT 0x7fffffff
-__global__ void k_chain_status(const unsigned* flags, int* info) {
-    if (threadIdx.x == 0 && gs_flag_ld(flags + GS_FL_ABORT) == 1u) *info = GS_INFO_CHAIN_ABORT;
-}
-
-// two-stream probe of the chain schedule's one assumption: kernels of different streams of this process run side by side
-// (a profiler that serialises dispatches breaks it).  k_probe_wait spins until k_signal's word arrives or `ticks` pass.
-__global__ __launch_bounds__(64) void k_probe_wait(const unsigned* f, const unsigned* f2, unsigned long long ticks, unsigned* out) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned seen = 0;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
-        if (gs_flag_ld(f) && gs_flag_ld(f2)) { seen = 1; break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (threadIdx.x == 0) *out = seen;
-}
-
-// rows [0, M) x 256 columns at P: both panels of an outer step in one launch, 16 rows per single-wave workgroup:
-//   X_j = B_j L_jj^-T;   B_j+1 -= X_j L(j+1, j)^T;   X_j+1 = B_j+1 L_j+1,j+1^-T
-// (k_panel, the K = 128 sibling update on k_gemm_nt, k_panel again -- without two launches and two passes over the rows)
-__device__ __forceinline__ void gs_panel256_body(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                 const double* Ltab1, unsigned long long* kst, unsigned long long* wstat, const int group,
-                                                 double* tile = nullptr) {
-    const int lane = threadIdx.x & 63;
-    const int r0 = group * 16;
-    if (r0 >= M) return;
-    const unsigned long long w_t0 = wstat ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    __builtin_amdgcn_s_setprio(3);
-    if (kst && lane == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());          // diagnostics: first start / last end of the launch
-    double* rows = P + (int64_t)r0 * ld;
-    gs_d4 P0[8], P1[8];
-    if (tile) gs_panel16_load_t(P0, rows, ld, M - r0, lane, tile); else gs_panel16_load(P0, rows, ld, M - r0, lane);
-    gs_panel16_solve_g(P0, Ltab0, lane);
-    if (tile) gs_panel16_store_t(P0, rows, ld, M - r0, lane, tile); else gs_panel16_store(P0, rows, ld, M - r0, lane);
-    __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now: 64 registers less at the peak
-    if (tile) gs_panel16_load_t(P1, rows + 128, ld, M - r0, lane, tile); else gs_panel16_load(P1, rows + 128, ld, M - r0, lane);
-    gs_sib_update_lean(P1, P0, Lsib, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gs_panel16_solve_g(P1, Ltab1, lane);
-    if (tile) gs_panel16_store_t(P1, rows + 128, ld, M - r0, lane, tile); else gs_panel16_store(P1, rows + 128, ld, M - r0, lane);
-    if (kst && lane == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
-    if (wstat && lane == 0) {                                   // diagnostics (option panel_stats): how long the panel's waves are resident
-        atomicAdd(wstat, __builtin_amdgcn_s_memrealtime() - w_t0);
-        atomicAdd(wstat + 1, 1ull);
-    }
-}
-
-__global__ __launch_bounds__(64, 2) void k_panel256(double* P, int64_t ld, int M, const double* Ltab0, const double* Lsib,
-                                                  const double* Ltab1, unsigned long long* kst, unsigned long long* wstat) {
-    __shared__ __attribute__((aligned(16))) double tile[GS_PT_TILE];
-    gs_panel256_body(P, ld, M, Ltab0, Lsib, Ltab1, kst, wstat, (int)blockIdx.x, tile);
-}
-
-// explicit inverses of the diagonal blocks from their tables, one workgroup per block (for the consumers that still
-// multiply by L_bb^-1: the back-substitution half of cho_solve)
-__global__ __launch_bounds__(256) void k_trtri_blocks(const double* Ltab, double* Linv) {
-    __shared__ __attribute__((aligned(16))) double tab[GS_LTAB];
-    gs_load_ltab(tab, Ltab + (size_t)blockIdx.x * GS_LTAB);
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gs_trtri_block(tab + GS_D2_LS, tab + GS_D2_DV, Linv + (size_t)blockIdx.x * 128 * 128, w, lane);
-}
-
-// info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).  Micro-block routine, substitution tables to Ltab.
-__global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Ltab, double* logdet, int* info, int col0,
-                                                     const double* diag0, unsigned long long* stamps) {
-    // 34 KB of LDS (one panel column at a time, dumps exported as they are made): with its 124 VGPRs the workgroup fits where ONE
-    // bulk workgroup (53 KB, 8 waves) has just retired; at 77 KB it waited for two on the same CU while lower-priority bulk
-    // workgroups kept taking the single slots (rocprofv3: 90-250 us per call beside the bulk update)
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
-    if (*info != 0) return;                    // an earlier block already failed (uniform)
-    __builtin_amdgcn_s_setprio(3);             // the chain's one workgroup: ahead of the bulk waves on its SIMDs
-    const int bad = gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
-    if (bad && threadIdx.x == 0) *info = col0 + bad;
-}
-
-// Two diagonal blocks in one launch: the 256 x 256 diagonal super-block of an outer step, by one workgroup.
-//   A00 = L00 L00^T (gs_diag_block);  L10 = A10 L00^-T (blocked substitution, two 16-row groups per wave);
-//   A11 -= L10 L10^T (lower micro-tiles, on accumulators that start as the matrix entries, ascending k: k_gemm_nt's
-//   arithmetic);  A11 = L11 L11^T (gs_diag_block).
-// Replaces diag / panel / sibling update / diag on the chain of a factorisation: four dependent launches, two of them
-// over all rows below, become one; the rows below go through k_panel256 afterwards.  L10 is also left in Lsib (operand
-// layout) for that kernel.  Tables of both blocks to Ltab[0], Ltab[GS_LTAB].
-__device__ __forceinline__ void gs_potrf_diag256_body(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                      int col0, const double* diag0, unsigned long long* stamps, double* wsd) {
-    if (*info != 0) return;
-    __builtin_amdgcn_s_setprio(3);
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    int bad = gs_diag_block<false>(A, ld, (double*)nullptr, Ltab, logdet, diag0, stamps, wsd);
-    if (bad) {
-        if (t == 0) *info = col0 + bad;
-        return;
-    }
-    __threadfence();                            // the tables just written are read back from global memory below
-    __syncthreads();
-    // ---- L10: groups w and 7 - w of the 128 rows below
-    double* A10 = A + (int64_t)128 * ld;
-    const int g0 = w, g1 = 7 - w;
-    gs_d4 Pa[8], Pb[8];
-    gs_panel16_load(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
-    gs_panel16_load(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
-    gs_panel16_solve_g(Pa, Ltab, lane);
-    gs_panel16_solve_g(Pb, Ltab, lane);
-    gs_panel16_store(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
-    gs_panel16_store(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            Lsib[((g0 * 8 + k) * 4 + x) * 64 + lane] = Pa[k][x];
-            Lsib[((g1 * 8 + k) * 4 + x) * 64 + lane] = Pb[k][x];
-        }
-    __threadfence();
-    __syncthreads();
-    // ---- A11 -= L10 L10^T: micro-tile (c, c') for c' in {g0, g1}, c >= c'.  A operand: dump of group c (-L_c,kb),
-    // B operand: own registers (image of group c').  Accumulator = -(tile) in the standard orientation.
-    double* A11 = A10 + 128;
-    auto tile = [&](int c, int cp, const gs_d4 (&Pq)[8]) {
-        gs_d4 acc;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[x] = -A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr];
-        gs_d4 buf[8];
-        gs_sib_fetch(buf, Lsib, c, lane);
-        gs_sib_apply(acc, buf, Pq);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr] = -acc[x];
-    };
-    for (int c = g0; c < 8; ++c) tile(c, g0, Pa);
-    for (int c = g1; c < 8; ++c) tile(c, g1, Pb);
-    __threadfence();
-    __syncthreads();
-    bad = gs_diag_block<false>(A11, ld, (double*)nullptr, Ltab + GS_LTAB, logdet + 1, diag0 + 128, nullptr, wsd);
-    if (bad && t == 0) *info = col0 + 128 + bad;
-}
-
-__global__ __launch_bounds__(256, 2) void k_potrf_diag256(double* A, int64_t ld, double* Ltab, double* Lsib, double* logdet, int* info,
-                                                       int col0, const double* diag0, unsigned long long* stamps) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
-    gs_potrf_diag256_body(A, ld, Ltab, Lsib, logdet, info, col0, diag0, stamps, wsd);
-}
-
-// ---- grouped chain kernels (see k_gemm_ld3g): outer step `step` of workspace `q` per entry, all workspaces of a group at fixed
-// strides from the first.  One workgroup per entry (diagonal super-block); one wave per 16 rows below it of every entry (panels).
-#define GS_WVC_MAX 24
-struct gs_wv_pool {
-    double* A; int64_t strideA, ld;          // augmented matrices, (np + 16) x ld each
-    double* Ltab; double* Lsib;              // T x GS_LTAB, (T / 2 + 1) x GS_LSIB per workspace
-    double* logdet; double* diag0;           // T, np per workspace
-    int* info;                               // 1 per workspace
-    double* res;                             // 258 per workspace (k_finalize_g)
-    int np, T;
-};
-struct gs_wv_chain_args {
-    gs_wv_pool p;
-    int n, pad;
-    short q[GS_WVC_MAX], step[GS_WVC_MAX];
-    int end[GS_WVC_MAX];                     // k_panel256g: running counts of 16-row groups
-};
-__global__ __launch_bounds__(256, 2) void k_potrf_diag256g(const gs_wv_chain_args a) {
-    __shared__ __attribute__((aligned(16))) double wsd[GS_D2C_WS];
-    const int e = (int)blockIdx.x;
-    const int64_t q = a.q[e];
-    const int b = 2 * a.step[e];
-    const int64_t c = (int64_t)b * GS_NB;
-    gs_potrf_diag256_body(a.p.A + q * a.p.strideA + c * a.p.ld + c, a.p.ld, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
-                          a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.logdet + q * a.p.T + b, a.p.info + q, (int)c,
-                          a.p.diag0 + q * a.p.np + c, (unsigned long long*)nullptr, wsd);
-}
-__global__ __launch_bounds__(64, 2) void k_panel256g(const gs_wv_chain_args a) {
-    const int bid = (int)blockIdx.x;
-    int e = 0;
-    while (e + 1 < a.n && bid >= a.end[e]) ++e;
-    const int first = e ? a.end[e - 1] : 0;
-    const int64_t q = a.q[e];
-    const int b = 2 * a.step[e];
-    const int64_t c0 = (int64_t)b * GS_NB, r2 = c0 + 2 * GS_NB;
-    const int M = a.p.np + GS_BORDER - (int)r2;
-    gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
-                     a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
-                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, bid - first);
-}
-// The same with W = 4 (or 8) waves per workgroup, each on its own 16-row group.  Single-wave workgroups are spread round-robin
-// over the CUs, and one 224-register panel wave on a SIMD is enough to keep a whole bulk workgroup (2 waves on EACH of the CU's 4
-// SIMDs) off that CU: a thin spread of panel waves costs the trailing updates of the other groups up to a third of every CU it
-// touches.  Four waves per workgroup land on ONE CU and use the evicted workgroup's room on all four SIMDs.
-template <int W, bool TR = false>
-__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_panel256gw(const gs_wv_chain_args a) {
-    __shared__ __attribute__((aligned(16))) double tiles[TR ? W * GS_PT_TILE : 2];
-    const int grp = (int)blockIdx.x * W + (int)(threadIdx.x >> 6);
-    int e = 0;
-    while (e + 1 < a.n && grp >= a.end[e]) ++e;
-    if (grp >= a.end[a.n - 1]) return;
-    const int first = e ? a.end[e - 1] : 0;
-    const int64_t q = a.q[e];
-    const int b = 2 * a.step[e];
-    const int64_t c0 = (int64_t)b * GS_NB, r2 = c0 + 2 * GS_NB;
-    const int M = a.p.np + GS_BORDER - (int)r2;
-    gs_panel256_body(a.p.A + q * a.p.strideA + r2 * a.p.ld + c0, a.p.ld, M, a.p.Ltab + (q * a.p.T + b) * GS_LTAB,
-                     a.p.Lsib + (q * (a.p.T / 2 + 1) + b / 2) * GS_LSIB, a.p.Ltab + (q * a.p.T + b + 1) * GS_LTAB,
-                     (unsigned long long*)nullptr, (unsigned long long*)nullptr, grp - first,
-                     TR ? tiles + (threadIdx.x >> 6) * GS_PT_TILE : (double*)nullptr);
-}
-// entering evaluations: border rows <- RHS^T (k_set_border), grid ((np + 16) / 256 rounded up, entries)
-__global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k) {
-    const int64_t q = a.q[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.p.np + GS_BORDER) return;
-    double* A = a.p.A + q * a.p.strideA;
-#pragma unroll
-    for (int c = 0; c < GS_BORDER; ++c)
-        A[(int64_t)(a.p.np + c) * a.p.ld + i] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
-}
-// entering evaluations: diag0 <- the diagonal before the factorisation touches it, info <- 0 (grid: (np / 256 rounded up, entries))
-__global__ __launch_bounds__(256) void k_wave_begin(const gs_wv_chain_args a) {
-    const int64_t q = a.q[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.p.np) a.p.diag0[q * a.p.np + i] = a.p.A[q * a.p.strideA + (int64_t)i * a.p.ld + i];
-    if (i == 0) a.p.info[q] = 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// PERSISTENT CHAIN (round 3): the dependent chain of ONE factorisation as one resident kernel on CUs of its own.
-//
-// One factorisation alone is bound by the chain diag -> panel -> sibling update -> diag -> panel -> look-ahead update of every
-// 256-column outer step, not by the bulk update: as host-enqueued launches every link queued behind bulk
-// workgroups for a CU slot, shared its SIMDs' matrix pipes with them (k_potrf_diag 43-96 us beside the bulk update, 31 alone)
-// and ran over ALL rows below the panel although the next diagonal blocks only need the rows just below it.  Here the chain
-// is cut down to a WINDOW of W rows under the panel and runs as ONE kernel of 1 + W / 64 workgroups that each hold a CU
-// alone (128 KB of LDS: no bulk workgroup fits beside them) and talk through flags in global memory:
-//   workgroup 0 (D role)       per outer step s (block columns k = 2 s, k + 1):  D(k) -> T0 | rows of block k + 1 solved
-//                              against it (tables in LDS) -> TL | A11 -= L10 L10^T | D(k + 1) -> T1
-//   workgroups 1.. (P role)    one wave per 16-row group of the window [r2, r2 + W): X_k = B_k L_kk^-T (after T0), sibling
-//                              update (after TL), X_k+1 (after T1), rows + operand images published; then the window's share of
-//                              the trailing update, C[window rows, next panel's columns] -= P P^T (K = 256), as 32 x 32 tasks
-//                              over the published images, the next diagonal block's tasks first (counters UD0 / UD1 / UR)
-// Everything M-proportional -- the panel of the rows below the window (k_panel256, gated on T1), the update of the next
-// panel's columns below the window (A), of the panel after it (B) and of the far region (Far) -- stays host-enqueued on two
-// streams and meets the chain through the same flags: a one-wave k_wait_flag in front of a launch holds its stream until the chain has set the flag, one-thread
-// k_signal launches tell the chain that A(s) / B(s) have finished.  The regions are a partition of the trailing update of
-// the host-enqueued schedule and every element receives the same products in the same ascending order: results are
-// bit-identical to it (tests/test_gpu_parity.py).
-//
-// Hand-off discipline (MI355X_MICROARCH.md, inter-workgroup visibility): published bytes are stored write-through (relaxed
-// agent-scope atomic stores = global_store ... sc1), every storing wave drains vmcnt, (workgroup barrier,) ONE lane stores the
-// flag / adds to the counter; a consumer polls relaxed, then ONE agent-scope acquire, s_waitcnt vmcnt(0), (barrier,) plain loads.
-// Every spin is bounded (GS_CH_TIMEOUT): on expiry flags[GS_FL_ABORT] = 1 and every party leaves at its next wait.
-// ------------------------------------------------------------------------------------------------
-// a wave-uniform pointer made opaque to the optimiser, in SGPRs: inside the persistent loops LICM otherwise hoists hundreds of
-// per-lane 64-bit table addresses (base + lane + constant) out of the loop and spills them (1000 spilled VGPRs measured)
-template <class T>
-__device__ __forceinline__ T* gs_uniform_ptr(T* p) {
-    const unsigned long long v = (unsigned long long)p;          // (readfirstlane: uniform by construction, whatever the
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);               // divergence analysis thinks)
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    p = (T*)(((unsigned long long)hi << 32) | lo);
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-struct gs_chain_args {
-    double* A; int64_t ld; int np, naug, S, W;
-    double* Ltab; double* Lsib; double* logdet; const double* diag0; int* info;
-    double* dump;                  // [2][GS_CH_GMAX][16][4][64]: operand images of the window's solved rows, by step parity
-    unsigned* flags;               // gs_fl_count(S) words, zeroed before the launch
-    const unsigned* fbwant;        // S words: how many first-256-column tiles the host-enqueued trailing update of step s counts in FB[s]
-    int test_abort;                // test hook (option "chain_test_abort"): the D role gives up at this outer step as if a wait had timed out
-    unsigned long long* stamps;    // S x GS_CH_STAMPS realtime stamps, or NULL
-};
-
-// window geometry of outer step s: Gs row groups [r2, r2 + 16 Gs), Gc column groups of the next panel
-__device__ __forceinline__ void gs_ch_geom(int np, int naug, int W, int s, int& r2, int& Gs, int& Gc) {
-    r2 = 256 * (s + 1);
-    const int wend = min(r2 + W, naug);
-    Gs = (wend - r2) / 16;
-    Gc = min(16, (naug - r2) / 16);
-}
-// tiles of the first 256 columns of outer step s's host-enqueued trailing update (k_gemm_ld3, nfirst): what FB[s] counts up to
-__host__ __device__ inline unsigned gs_ch_nfirst(int naug, int s) {
-    const int m3 = naug - 256 * (s + 2);
-    return m3 > 0 ? (unsigned)(4 * ((m3 + 127) / 128) - 2) : 0u;
-}
-// number of 32 x 32 update tasks (I, J), J <= I, with Ilo <= I < Ihi, in a window of Gs row and Gc column groups
-__device__ __forceinline__ int gs_ch_ntasks(int Gs, int Gc, int Ilo, int Ihi) {
-    const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
-    int c = 0;
-    for (int I = Ilo; I < min(Ihi, NI); ++I) c += min(I + 1, NJ);
-    return c;
-}
-
-__device__ __forceinline__ void gs_panel16_store_wt(const gs_d4 (&P)[8], double* rows, int64_t ld, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) gs_st_wt(rows + (int64_t)fr * ld + 16 * k + fq + 4 * x, -P[k][x]);
-}
-__device__ __forceinline__ void gs_image_store_wt(const gs_d4 (&P)[8], double* img, int lane) {      // img: [kb][x][lane]
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) gs_st_wt(img + (k * 4 + x) * 64 + lane, P[k][x]);
-}
-
-// ---- D role: the 256 x 256 diagonal super-block of every outer step (k_potrf_diag256's arithmetic, tables kept in LDS)
-__device__ __forceinline__ void gs_chain_diag_role(const gs_chain_args& a, double* wsd, volatile int* sh) {
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int S = a.S;
-    unsigned* fl = a.flags;
-    for (int s = 0; s < S; ++s) {
-        const int k = 2 * s;
-        const int64_t c0 = 256 * (int64_t)s, ld = a.ld;
-        double* A00 = gs_uniform_ptr(a.A + c0 * ld + c0);
-        double* A10 = gs_uniform_ptr(A00 + 128 * ld);
-        double* A11 = gs_uniform_ptr(A10 + 128);
-        double* tab0 = gs_uniform_ptr(a.Ltab + (size_t)k * GS_LTAB);
-        double* tab1 = gs_uniform_ptr(tab0 + GS_LTAB);
-        double* sib = gs_uniform_ptr(a.Lsib + (size_t)s * GS_LSIB);
-        unsigned long long* st = a.stamps ? a.stamps + (size_t)s * GS_CH_STAMPS : nullptr;
-        int pr2 = 0, pGs = 0, pGc = 0;
-        if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
-        if (st && t == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        if (a.test_abort > 0 && s == a.test_abort) {          // (tests only: exercise the give-up path of every party and of the host)
-            if (t == 0) gs_flag_st(fl + GS_FL_ABORT, 1u);
-            return;
-        }
-        if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD0, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 0, 4), fl, sh)) return;
-        if (st && t == 0) st[1] = __builtin_amdgcn_s_memrealtime();
-        int bad = gs_diag_block<true>(A00, ld, (double*)nullptr, (double*)nullptr, a.logdet + k, a.diag0 + c0, nullptr, wsd);
-        if (bad) {                                  // uniform
-            if (t == 0) {
-                *a.info = (int)c0 + bad;
-                gs_flag_st(fl + GS_FL_ABORT, 2u);
-            }
-            return;
-        }
-        // tables of block k to global memory, write-through; their flag goes out below, behind the row solves (the stores drain
-        // meanwhile: the P waves have the ~70 us until T1 for their first solve and sibling update)
-        for (int i = t; i < GS_LTAB; i += 256) gs_st_wt(tab0 + i, wsd[i]);
-        // ---- L10: row groups w and 7 - w of block row k + 1 against the tables in LDS
-        if (s > 0 && !gs_wg_wait_ge(fl + gs_fl(GS_FL_UD1, S, s - 1), (unsigned)gs_ch_ntasks(pGs, pGc, 4, 8), fl, sh)) return;
-        if (st && t == 0) st[3] = __builtin_amdgcn_s_memrealtime();
-        const int g0 = w, g1 = 7 - w;
-        gs_d4 Pa[8], Pb[8];
-        gs_panel16_load(Pa, A10 + (int64_t)(16 * g0) * ld, ld, 16, lane);
-        gs_panel16_load(Pb, A10 + (int64_t)(16 * g1) * ld, ld, 16, lane);
-        gs_panel16_solve2(Pa, Pb, wsd, lane);
-        gs_drain();
-        __syncthreads();                            // tables published; every wave is through with them: the LDS takes the images of L10
-        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T0, S, s), 1u);
-        if (st && t == 0) st[2] = __builtin_amdgcn_s_memrealtime();
-        // (L10's rows go back to the matrix from the published image, by P waves 0..7: gs_chain_panel_role)
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                wsd[((g0 * 8 + kb) * 4 + x) * 64 + lane] = Pa[kb][x];
-                wsd[((g1 * 8 + kb) * 4 + x) * 64 + lane] = Pb[kb][x];
-                gs_st_wt(sib + ((g0 * 8 + kb) * 4 + x) * 64 + lane, Pa[kb][x]);
-                gs_st_wt(sib + ((g1 * 8 + kb) * 4 + x) * 64 + lane, Pb[kb][x]);
-            }
-        __syncthreads();                            // images in LDS (the copies for the other workgroups drain behind the update)
-        if (st && t == 0) st[4] = __builtin_amdgcn_s_memrealtime();
-        // ---- A11 -= L10 L10^T: micro-tiles (c, c') for c' in {g0, g1}, c >= c' (k_gemm_nt's arithmetic: -C + sum, ascending k)
-        auto tile = [&](int c, int cp, const gs_d4 (&Pq)[8]) {
-            gs_d4 acc;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = -A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr];
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wsd[((c * 8 + kb) * 4 + x) * 64 + lane], Pq[kb][x], acc, 0, 0, 0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) A11[(int64_t)(16 * c + fq + 4 * x) * ld + 16 * cp + fr] = -acc[x];
-        };
-        for (int c = g0; c < 8; ++c) tile(c, g0, Pa);
-        for (int c = g1; c < 8; ++c) tile(c, g1, Pb);
-        gs_drain();
-        __syncthreads();
-        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_TL, S, s), 1u);
-        if (st && t == 0) st[5] = __builtin_amdgcn_s_memrealtime();
-        bad = gs_diag_block<true>(A11, ld, (double*)nullptr, (double*)nullptr, a.logdet + k + 1, a.diag0 + c0 + 128, nullptr, wsd);
-        if (bad) {
-            if (t == 0) {
-                *a.info = (int)c0 + 128 + bad;
-                gs_flag_st(fl + GS_FL_ABORT, 2u);
-            }
-            return;
-        }
-        for (int i = t; i < GS_LTAB; i += 256) gs_st_wt(tab1 + i, wsd[i]);
-        gs_drain();
-        __syncthreads();
-        if (t == 0) gs_flag_st(fl + gs_fl(GS_FL_T1, S, s), 1u);
-        if (st && t == 0) st[6] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-// ---- P role: one wave = one 16-row group of the window per outer step, then its share of the window's update tasks.
-// A 32 x 32 update task (I, J): C[rows of groups 2I, 2I+1][columns of groups 2J, 2J+1] -= P P^T over the panel's 256 columns
-// (16 k-blocks of operand images); held in four accumulators that start as -C (the bulk tiles' arithmetic).
-struct gs_utask {
-    int I, J, gi0, gj0;
-    bool va1, vb1, v01, v10, v11;
-    double* C0;
-    const double *dA0, *dA1, *dB0, *dB1;
-    gs_d4 c00, c01, c10, c11;
-};
-
-__device__ __forceinline__ bool gs_utask_decode(gs_utask& u, int tk, int Gs, int Gc, double* A, int64_t ld, int r2, const double* dump,
-                                                int lane) {
-    const int NI = (Gs + 1) / 2, NJ = (Gc + 1) / 2;
-    int I = 0, J = -1, seen = 0;
-    for (I = 0; I < NI; ++I) {
-        const int c = min(I + 1, NJ);
-        if (tk < seen + c) { J = tk - seen; break; }
-        seen += c;
-    }
-    if (J < 0) return false;
-    u.I = I; u.J = J; u.gi0 = 2 * I; u.gj0 = 2 * J;
-    u.va1 = u.gi0 + 1 < Gs;
-    u.vb1 = u.gj0 + 1 < Gc;
-    // micro-tile (a, b): rows of group gi0 + a, columns of group gj0 + b; on a diagonal task only the lower ones
-    u.v01 = u.vb1 && u.gi0 >= u.gj0 + 1;
-    u.v10 = u.va1;
-    u.v11 = u.va1 && u.vb1;
-    u.C0 = gs_uniform_ptr(A + (int64_t)(r2 + 16 * u.gi0) * ld + r2 + 16 * u.gj0);
-    u.dA0 = gs_uniform_ptr(dump + (size_t)u.gi0 * 16 * 256) + lane;
-    u.dA1 = gs_uniform_ptr(dump + (size_t)(u.va1 ? u.gi0 + 1 : u.gi0) * 16 * 256) + lane;
-    u.dB0 = gs_uniform_ptr(dump + (size_t)u.gj0 * 16 * 256) + lane;
-    u.dB1 = gs_uniform_ptr(dump + (size_t)(u.vb1 ? u.gj0 + 1 : u.gj0) * 16 * 256) + lane;
-    return true;
-}
-
-// the flags of the four row groups a task multiplies have reached `want` (1: first 128 panel columns published, 2: all 256)
-__device__ __forceinline__ bool gs_utask_poll(const gs_utask& u, unsigned* fl, int S, int s, unsigned want) {
-    if (!gs_poll_ge(fl + gs_fl_wg(S, s, u.gi0), want, fl)) return false;
-    if (u.va1 && !gs_poll_ge(fl + gs_fl_wg(S, s, u.gi0 + 1), want, fl)) return false;
-    if (!gs_poll_ge(fl + gs_fl_wg(S, s, u.gj0), want, fl)) return false;
-    if (u.vb1 && !gs_poll_ge(fl + gs_fl_wg(S, s, u.gj0 + 1), want, fl)) return false;
-    return true;
-}
-
-__device__ __forceinline__ void gs_utask_load(gs_utask& u, int64_t ld, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
-        u.c00[x] = -u.C0[ro];
-        u.c01[x] = u.v01 ? -u.C0[ro + 16] : 0.0;
-        u.c10[x] = u.v10 ? -u.C0[ro + 16 * ld] : 0.0;
-        u.c11[x] = u.v11 ? -u.C0[ro + 16 * ld + 16] : 0.0;
-    }
-}
-
-// k-blocks [kb0, kb1) in ascending order, operands one k-block ahead
-__device__ __forceinline__ void gs_utask_accumulate(gs_utask& u, int kb0, int kb1) {
-    gs_d4 a0, a1, b0, b1, na0, na1, nb0, nb1;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        a0[x] = u.dA0[(kb0 * 4 + x) * 64];
-        a1[x] = u.dA1[(kb0 * 4 + x) * 64];
-        b0[x] = u.dB0[(kb0 * 4 + x) * 64];
-        b1[x] = u.dB1[(kb0 * 4 + x) * 64];
-    }
-#pragma unroll 1
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const int kn = kb + 1 < kb1 ? kb + 1 : kb;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            na0[x] = u.dA0[(kn * 4 + x) * 64];
-            na1[x] = u.dA1[(kn * 4 + x) * 64];
-            nb0[x] = u.dB0[(kn * 4 + x) * 64];
-            nb1[x] = u.dB1[(kn * 4 + x) * 64];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            u.c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[x], u.c00, 0, 0, 0);
-            if (u.v01) u.c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b1[x], u.c01, 0, 0, 0);
-            if (u.v10) u.c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b0[x], u.c10, 0, 0, 0);
-            if (u.v11) u.c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[x], u.c11, 0, 0, 0);
-        }
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-}
-
-__device__ __forceinline__ void gs_utask_store(const gs_utask& u, int64_t ld, unsigned* fl, int S, int s, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t ro = (int64_t)(fq + 4 * x) * ld + fr;
-        gs_st_wt(u.C0 + ro, -u.c00[x]);
-        if (u.v01) gs_st_wt(u.C0 + ro + 16, -u.c01[x]);
-        if (u.v10) gs_st_wt(u.C0 + ro + 16 * ld, -u.c10[x]);
-        if (u.v11) gs_st_wt(u.C0 + ro + 16 * ld + 16, -u.c11[x]);
-    }
-    gs_drain();
-    if (lane == 0) gs_flag_add(fl + gs_fl(u.I < 4 ? GS_FL_UD0 : (u.I < 8 ? GS_FL_UD1 : GS_FL_UR), S, s));
-}
-
-// Per outer step, wave pw (its workgroup's four waves meet at two barriers: the second block's tables are staged in LDS once):
-//   rows ready -> [T0] X_k, published (group flag = 1) -> [TL] sibling update; L10's rows to the matrix (waves 0..7) ->
-//   FIRST HALF of its first update task (k-blocks 0..7 need only the X_k images; accumulators stay in registers) ->
-//   [T1] tables of block k + 1 into LDS (the four waves a quarter each) -> X_k+1, published (group flag = 2) ->
-//   second half of that task -> its other tasks in full.
-// What is left on the chain's critical path between T1 and the next diagonal block: one solve from LDS, one publish, 128 MFMAs.
-__device__ __forceinline__ void gs_chain_panel_role(const gs_chain_args& a, int pw, int NPW, int lane, double* tabl) {
-    const int fr = lane & 15, fq = lane >> 4;
-    const int wq = pw & 3;                       // wave within its workgroup
-    const int S = a.S;
-    const int64_t ld = a.ld;
-    unsigned* fl = a.flags;
-    for (int s = 0; s < S; ++s) {
-        int r2, Gs, Gc;
-        gs_ch_geom(a.np, a.naug, a.W, s, r2, Gs, Gc);
-        const int64_t c0 = 256 * (int64_t)s;
-        const double* tab0 = gs_uniform_ptr(a.Ltab + (size_t)(2 * s) * GS_LTAB);
-        const double* tab1 = gs_uniform_ptr(a.Ltab + (size_t)(2 * s + 1) * GS_LTAB);
-        const double* sib = gs_uniform_ptr(a.Lsib + (size_t)s * GS_LSIB);
-        double* dump = a.dump + (size_t)(s & 1) * GS_CH_GMAX * 16 * 256;
-        unsigned long long* st = (a.stamps && pw == 0) ? a.stamps + (size_t)s * GS_CH_STAMPS : nullptr;
-        int pr2 = 0, pGs = 0, pGc = 0;
-        if (s > 0) gs_ch_geom(a.np, a.naug, a.W, s - 1, pr2, pGs, pGc);
-        const int g = pw;
-        const bool has = g < Gs;                 // NPW = W / 16 >= Gs: a wave owns at most one row group
-        double* rows = gs_uniform_ptr(a.A + (int64_t)(r2 + 16 * (has ? g : 0)) * ld + c0);
-        double* img = gs_uniform_ptr(dump + (size_t)(has ? g : 0) * 16 * 256);
-        gs_d4 P0[8], P1[8];
-        // ---- X_k = B_k L_kk^-T  (k_panel256's arithmetic throughout)
-        if (has) {
-            if (s > 0) {
-                // these rows' entries in panel s's columns: last updated by the window tasks of step s - 1 (rows that were
-                // in that window: its groups 16 ..) or by the host-enqueued update A(s - 1) (rows below it)
-                const bool in_prev = g + 16 < pGs;
-                const unsigned* f = in_prev ? fl + gs_fl(GS_FL_UR, S, s - 1) : fl + gs_fl(GS_FL_FA, S, s - 1);
-                const unsigned want = in_prev ? (unsigned)gs_ch_ntasks(pGs, pGc, 8, 1 << 20) : 1u;
-                if (!gs_wait_ge(f, want, fl)) return;
-            }
-            if (st) st[8] = __builtin_amdgcn_s_memrealtime();
-            gs_panel16_load(P0, rows, ld, 16, lane);
-            if (!gs_wait_ge(fl + gs_fl(GS_FL_T0, S, s), 1u, fl)) return;
-            if (st) st[9] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-            gs_panel16_solve_g(P0, tab0, lane);
-            gs_panel16_store_wt(P0, rows, ld, lane);
-            gs_image_store_wt(P0, img, lane);
-            gs_drain();
-            if (lane == 0) gs_flag_st(fl + gs_fl_wg(S, s, g), 1u);
-            __builtin_amdgcn_sched_barrier(0);          // the second 128 columns are fetched only now (as k_panel256)
-            gs_panel16_load(P1, rows + 128, ld, 16, lane);
-        }
-        if (has || pw < 8) {
-            if (!gs_wait_ge(fl + gs_fl(GS_FL_TL, S, s), 1u, fl)) return;
-        }
-        if (has) {
-            gs_sib_update_lean(P1, P0, sib, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (pw < 8) {
-            // L(k+1, k) back into the matrix, from its operand image (the diagonal workgroup only publishes the image: 128
-            // scattered stores per lane off its critical path); nobody reads these rows before the factorisation ends
-            double* l10 = gs_uniform_ptr(a.A + (c0 + 128 + 16 * pw) * ld + c0);
-            const double* im = gs_uniform_ptr(sib + (size_t)pw * 8 * 256) + lane;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) l10[(int64_t)fr * ld + 16 * kb + fq + 4 * x] = -im[(kb * 4 + x) * 64];
-        }
-        if (st) st[10] = __builtin_amdgcn_s_memrealtime();
-        // ---- first half of this wave's first update task, while the diagonal workgroup factors block k + 1
-        const int ntask = gs_ch_ntasks(Gs, Gc, 0, 1 << 20);
-        gs_utask u;
-        bool early = false;
-        const bool have_task = pw < ntask && gs_utask_decode(u, pw, Gs, Gc, a.A, ld, r2, dump, lane);
-        const unsigned fb_want = s > 0 ? a.fbwant[s - 1] : 0u;     // B(s - 1): C's last host-enqueued update, counted per tile
-        if (have_task && gs_flag_ld(fl + gs_fl(GS_FL_FB, S, s > 0 ? s - 1 : 0)) >= fb_want) {      // (C is up to date already: else later, in full)
-            if (!gs_utask_poll(u, fl, S, s, 1u)) return;
-            gs_acquire();
-            gs_utask_load(u, ld, lane);
-            gs_utask_accumulate(u, 0, 8);
-            early = true;
-        }
-        // ---- tables of block k + 1 into LDS, X_k+1 = B_k+1 L_k+1,k+1^-T
-        if (!gs_wait_ge(fl + gs_fl(GS_FL_T1, S, s), 1u, fl)) return;
-        if (st) st[11] = __builtin_amdgcn_s_memrealtime();
-        __syncthreads();                             // the previous step's readers of the LDS tables are through
-        gs_load_ltab_direct(tabl, tab1, wq, lane);
-        gs_drain();
-        __syncthreads();
-        if (has) {
-            gs_panel16_solve(P1, tabl, lane);
-            gs_panel16_store_wt(P1, rows + 128, ld, lane);
-            gs_image_store_wt(P1, img + 8 * 256, lane);
-            gs_drain();
-            if (lane == 0) {
-                gs_flag_st(fl + gs_fl_wg(S, s, g), 2u);
-                if (g < 16) gs_flag_add(fl + gs_fl(GS_FL_WTOP, S, s));
-                gs_flag_add(fl + gs_fl(GS_FL_WALL, S, s));
-            }
-        }
-        if (st) st[12] = __builtin_amdgcn_s_memrealtime();
-        // ---- the window's share of the trailing update, tasks in ascending I (the next diagonal block's first)
-        for (int tk = pw; tk < ntask; tk += NPW) {
-            const bool first = tk == pw;
-            if (!first && !gs_utask_decode(u, tk, Gs, Gc, a.A, ld, r2, dump, lane)) break;
-            if (!gs_utask_poll(u, fl, S, s, 2u)) return;
-            if (s > 0 && !gs_poll_ge(fl + gs_fl(GS_FL_FB, S, s - 1), fb_want, fl)) return;
-            gs_acquire();
-            if (st && first) st[13] = __builtin_amdgcn_s_memrealtime();
-            if (first && early) {
-                gs_utask_accumulate(u, 8, 16);
-            } else {
-                gs_utask_load(u, ld, lane);
-                gs_utask_accumulate(u, 0, 16);
-            }
-            gs_utask_store(u, ld, fl, S, s, lane);
-            if (st && first) st[14] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void k_chain(gs_chain_args a) {
-    extern __shared__ __attribute__((aligned(16))) double wsd[];
-    __shared__ int sh_ok;
-    __builtin_amdgcn_s_setprio(3);
-    if (threadIdx.x == 0) gs_flag_add(a.flags + GS_FL_RESIDENT);
-    if (blockIdx.x == 0) {
-        gs_chain_diag_role(a, wsd, &sh_ok);
-    } else {
-        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        gs_chain_panel_role(a, ((int)blockIdx.x - 1) * 4 + w, ((int)gridDim.x - 1) * 4, threadIdx.x & 63, wsd);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused path for n <= 128 (the reference's own problem sizes: 5-100 points, thousands of grid points):
-// ONE workgroup per evaluation builds K, factors it, solves for the right-hand sides and reduces the Gram
-// matrix; a launch evaluates a whole row of a likelihood grid.  Same arithmetic as the general path
-// (k_build's kernel functions, gs_diag_block), per-evaluation scratch in global memory (L2-resident).
-//   scratch per evaluation: A (128x128) | W^T (16x128, in a 128x128 slot);   res per evaluation: 258 doubles as k_finalize.
-// ------------------------------------------------------------------------------------------------
-#define GS_SMALL_SCRATCH (2 * 128 * 128)
-
-__global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
-                                                    const gsum_kernel_desc* descs, double nugget, double* scratch,
-                                                    double* res) {
-#pragma clang fp contract(off)
-    __shared__ double dg0[128];
-    __shared__ double ldet;
-    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // lent to the build (us) and the solve (Wt) too:
-    double* us = wsd;                                                   // 78.6 KB of LDS in all, two evaluations per CU
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc desc = descs[blockIdx.x];
-    double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
-    double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
-    double* out = res + (int64_t)blockIdx.x * 258;
-    // ---- kernel matrix (full symmetric 128x128 tile, identity padding beyond n)
-    double* etab = us + 128 * GSUM_MAX_D;                               // exp tables th[16] | tl[16]
-    if (t < 16) etab[t] = gs_exp_th[t];
-    else if (t < 32) etab[t] = gs_exp_tl[t - 16];
-    for (int idx = t; idx < 128 * d; idx += 256) {
-        const int r = idx / d, dd = idx - r * d;
-        const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
-        us[idx] = r < n ? X[(int64_t)r * d + dd] / ls : 0.0;
-    }
-    __syncthreads();
-    // (the one tile is a diagonal tile: rows and columns are the same points; family / dimension as template parameters)
-    gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
-    __threadfence_block();
-    __syncthreads();
-    // ---- Cholesky of the block; its substitution tables stay in wsd
-    const int bad = gs_diag_block(A, 128, (double*)nullptr, (double*)nullptr, &ldet, dg0, nullptr, wsd);
-    if (bad) {
-        if (t == 0) {
-            out[256] = 0.0;
-            out[257] = (double)bad;
-        }
-        return;
-    }
-    // ---- W^T = Z^T L^-T: the right-hand sides as 16 rows of 128 points, solved by one wave against the tables
-    for (int idx = t; idx < 16 * 128; idx += 256) {
-        const int c = idx >> 7, i = idx & 127;
-        Wt[idx] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (w == 0) gs_panel16(Wt, 128, 16, wsd, lane);
-    __threadfence_block();
-    __syncthreads();
-    const int fr = lane & 15, fq = lane >> 4;
-    // ---- Gram matrix G = W^T W (16 x 16, K = 128) by wave 0
-    if (w == 0) {
-        gs_d4 g = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < 8; ++kb) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const double wv = Wt[fr * 128 + 16 * kb + 4 * s4 + fq];
-                g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) out[(fq + 4 * x) * 16 + fr] = g[x];
-        if (lane == 0) {
-            out[256] = ldet;
-            out[257] = 0.0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2b: C (+)= sign * A * B^T  on fp64 MFMA.   A: M x K, B: N x K (both row-major, K contiguous — the
-// shape every step of a row-major lower Cholesky produces), C: M x N.
-//   - 4 waves per workgroup, wave tile (WM*16) x (WN*16) of v_mfma_f64_16x16x4_f64 accumulators;
-//   - K is staged 16 doubles (one 128-B line per row) at a time: global -> registers -> LDS, two LDS
-//     stages, one barrier per chunk; the next chunk's global loads are in flight during the MFMAs;
-//   - fragment reads at row stride 17 doubles: conflict-free for the A/B lane map (lane l holds
-//     [row l&15][k l>>4]) under ds_read2_b64's 32-bank mapping (stride 18 measured 40% conflict cycles);
-//   - rows >= M / cols >= N are clamped on load and predicated on store, so the 16-row border tile
-//     and the padded tail run through the same code;
-//   - tri != 0: only tiles on or below the diagonal (SYRK of the trailing matrix);
-//   - sign must be +1 or -1 (it multiplies the staged A operand exactly).
-// In-place use (C == A, TRSM against an explicit inverse) is safe when one tile spans all N = K
-// columns: every global load of the tile's rows is finished before the epilogue stores.
-// ------------------------------------------------------------------------------------------------
-// PF: operand chunks requested ahead of the one being multiplied.  1 = the next chunk only (one memory latency per 16
-// columns of K: fine when several workgroups share a CU, 1.3-1.5 us per chunk for the lone 32 x 128 tiles of the
-// factorisation's chain -- sibling update 12.6 us, look-ahead update 21 us for 0.4 / 0.9 us of MFMA work per tile).
-// 4 = a ring of four register sets (K a multiple of 64): the same products in the same order, ~3x sooner.
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool STAMP = false, int PF = 1>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 2) void k_gemm_nt(double* C, int64_t ldc, const double* A, int64_t lda,
-                                                     const double* B, int64_t ldb, int M, int N, int K,
-                                                     int tri, int beta, double sign,
-                                                     unsigned long long* stamps = nullptr, int stagger = 0) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N;          // 256 threads
-    constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
-    constexpr int A_VECS = BM * (GS_KC / 2), B_VECS = BN * (GS_KC / 2);
-    constexpr int A_IT = (A_VECS + NT - 1) / NT, B_IT = (B_VECS + NT - 1) / NT;
-    extern __shared__ double lds[];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w % WAVES_M, wn = w / WAVES_M;
-    int bm, bn;
-    if (tri) {
-        const int bid = blockIdx.x;
-        bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
-        while ((int64_t)bm * (bm + 1) / 2 > bid) --bm;
-        bn = bid - (int)((int64_t)bm * (bm + 1) / 2);
-    } else {
-        const int tm = (M + BM - 1) / BM;
-        bm = blockIdx.x % tm;
-        bn = blockIdx.x / tm;
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    if (tri == 2) {
-        // C = U U^T for an upper-triangular U (row i is zero left of column i): a tile whose rows start at m0
-        // only needs k >= m0 (m0 <= the tile's first column-tile row too, since tiles are on or below the diagonal)
-        A += m0;
-        B += m0;
-        K -= m0;
-    }
-    // De-phase the two workgroups that share a CU.  All workgroups of a launch take the same time, so the
-    // pair that starts together stays in lockstep: both wait on their C-tile loads, both fight for the
-    // matrix pipe, both store.  The dispatcher fills every CU once before placing second workgroups, so
-    // blocks 256..511 are the late partners of blocks 0..255 (observed; speed only): they sleep `stagger` x
-    // 2048 cycles once, and every later workgroup inherits the offset of the slot it replaces.
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);       // 32 x 64 cycles
-    }
-
-    // The accumulators start as beta*C (all loads of the tile issued back to back, one wait) and the
-    // sign rides on the staged A operand, so the epilogue is stores only.  (A load-modify-store epilogue
-    // serialises 64 global round trips per thread: stores may alias the next load.)
-    const int fr = lane & 15, fq = lane >> 4;
-    gs_d4 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
-            }
-        }
-
-    gs_d2 ra[PF][A_IT], rb[PF][B_IT];
-    // one 16-B global load of the staging set: i < A_IT -> A tile, else B tile; `slot` = register set (compile-time)
-    auto gload_one = [&](int kc, int i, auto slot) {
-        constexpr int S = decltype(slot)::value;
-        if (i < A_IT) {
-            const int vv = t + i * NT;
-            if (vv < A_VECS) {
-                int row = m0 + (vv >> 3);
-                row = row < M ? row : M - 1;
-                ra[S][i] = *reinterpret_cast<const gs_d2*>(A + (int64_t)row * lda + kc * GS_KC + 2 * (vv & 7));
-            }
-        } else {
-            const int vv = t + (i - A_IT) * NT;
-            if (vv < B_VECS) {
-                int row = n0 + (vv >> 3);
-                row = row < N ? row : N - 1;
-                rb[S][i - A_IT] = *reinterpret_cast<const gs_d2*>(B + (int64_t)row * ldb + kc * GS_KC + 2 * (vv & 7));
-            }
-        }
-    };
-    auto gload = [&](int kc, auto slot) {
-#pragma unroll
-        for (int i = 0; i < A_IT + B_IT; ++i) gload_one(kc, i, slot);
-    };
-    auto swrite = [&](int stage, auto slot) {
-        constexpr int S = decltype(slot)::value;
-        double* sA = lds + stage * (BM + BN) * GS_LSTR;
-        double* sB = sA + BM * GS_LSTR;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int vv = t + it * NT;
-            if (vv < A_VECS) {          // rows are only 8-B aligned at an odd stride: two 8-byte stores
-                double* q = sA + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-                q[0] = ra[S][it][0] * sign;
-                q[1] = ra[S][it][1] * sign;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int vv = t + it * NT;
-            if (vv < B_VECS) {
-                double* q = sB + (vv >> 3) * GS_LSTR + 2 * (vv & 7);
-                q[0] = rb[S][it][0];
-                q[1] = rb[S][it][1];
-            }
-        }
-    };
-    auto multiply = [&](int stage) {
-        const double* sA = lds + stage * (BM + BN) * GS_LSTR + (wm * WM * 16 + fr) * GS_LSTR + fq;
-        const double* sB = lds + stage * (BM + BN) * GS_LSTR + BM * GS_LSTR + (wn * WN * 16 + fr) * GS_LSTR + fq;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 4; ++ks) {
-            double af[WM], bf[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 16 * GS_LSTR + ks * 4];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 16 * GS_LSTR + ks * 4];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-
-    const int nk = K / GS_KC;
-    // STAMP build only (diagnostics, separate instantiation): shader-cycle sums of the loop phases
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
-    auto stamp = [&](int i) {
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long now;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (i >= 0) ph[i] += now - tq;
-            tq = now;
-        }
-    };
-    if constexpr (PF == 1) {
-        stamp(-1);
-        gload(0, I0{});
-        swrite(0, I0{});
-        __syncthreads();
-        stamp(0);                                   // prologue: C loads issued, first chunk staged
-        for (int c = 0; c < nk; ++c) {
-            // Next chunk's operands: issued in one burst ahead of the MFMAs.  (Spreading them over the k-steps
-            // was measured and is no better: under load each load instruction blocks in-order issue for ~300
-            // cycles wherever it sits; the CU's vector-memory path, ~7-10 B/clk, is the ceiling for this tile.)
-            if (c + 1 < nk) gload(c + 1, I0{});
-            stamp(1);                               // global load issue
-            multiply(c & 1);
-            stamp(2);                               // fragment reads + MFMAs
-            if (c + 1 < nk) swrite((c + 1) & 1, I0{});
-            stamp(3);                               // wait for the global loads, LDS stores
-            __syncthreads();
-            stamp(4);                               // barrier
-        }
-    } else {
-        static_assert(PF == 1 || PF == 4, "ring of four register sets");
-        using I1 = std::integral_constant<int, 1 % PF>;
-        using I2 = std::integral_constant<int, 2 % PF>;
-        using I3 = std::integral_constant<int, 3 % PF>;
-        // nk is a multiple of 4 (the launcher checks K % 64 == 0).  Branch-free body: loads past the end re-read the last
-        // chunk and the last LDS store goes to the stage nobody reads again -- a branch around a load makes the
-        // compiler's wait-count bookkeeping drain every outstanding load at the join.
-        auto clampk = [&](int kc) { return kc < nk ? kc : nk - 1; };
-        gload(0, I0{});
-        gload(clampk(1), I1{});
-        gload(clampk(2), I2{});
-        gload(clampk(3), I3{});
-        swrite(0, I0{});
-        __syncthreads();
-        auto iter = [&](int c, auto slot, auto next) {
-            gload(clampk(c + 4), slot);             // this set went to LDS in the previous iteration
-            multiply(c & 1);
-            swrite((c + 1) & 1, next);              // requested three iterations ago
-            __syncthreads();
-        };
-        for (int c = 0; c < nk; c += 4) {
-            iter(c, I0{}, I1{});
-            iter(c + 1, I1{}, I2{});
-            iter(c + 2, I2{}, I3{});
-            iter(c + 3, I3{}, I0{});
-        }
-    }
-    if (STAMP && stamps && lane == 0) {
-        unsigned long long* o = stamps + ((int64_t)blockIdx.x * (NT / 64) + w) * 5;
-        for (int i = 0; i < 5; ++i) o[i] = ph[i];
-    }
-    // accumulator map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][x];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused path for 128 < n <= GS_MEDIUM_MAX (4096) when MANY evaluations are asked for (a likelihood grid on a few hundred
-// to a couple of thousand points): ONE workgroup per evaluation runs the whole bordered pipeline on its own matrix
-// in HBM (288 GB holds thousands of them), so a launch keeps 256 evaluations in flight, one per CU, with no
-// inter-workgroup dependency and no per-step kernel launches.  Same building blocks as the general path: k_build's
-// kernel functions, gs_diag_block, and a 128x128x(K = 128) MFMA tile routine with the accumulation order of
-// k_gemm_nt (the trailing update is a plain right-looking sweep: per element it subtracts the same products in the
-// same ascending-k order as the two-level schedule, so the factor is bit-identical to the general path's).
-// Per-evaluation scratch: A (np x ld, ld = np + 16) | Linv (T x 128 x 128) | diag0 (np) | W^T (16 x np).
-// ------------------------------------------------------------------------------------------------
-#define GS_MEDIUM_MAX 4096
-__device__ int gs_medium_lazy = 64;                 // option "medium_lazy": depth of the grouping of the fused sweep's trailing updates (1: one K = 256 update of every
-                                                    // trailing tile per outer step; 2: K = 512 every other step; >= 16: LEFT-LOOKING at n <= 4096 -- a tile is read and
-                                                    // written once, when its panel is next, with all the panels before it in one pass: the default, this sweep is HBM-bound)
-
-// C (M x N, both <= 128) = beta C + sign A B^T with A: M x K, B: N x K, K a multiple of 16; 256 threads (2 x 2 waves of
-// 64 x 64).  Operand chunks go global -> LDS directly (global_load_lds_dwordx4) in k_gemm_ld3's layout: XOR-swizzled
-// k-pairs, even / odd rows in regions one double apart (no bank conflicts), the sign carried by negated accumulators.
-// LDS: 2 stages x 2 operands x (128 x 16 + 2) doubles.  Ends with a workgroup barrier after the stores (fenced).
-#define GS_TILE_LD_DOUBLES (2 * 2 * (128 * GS_KC + 2))
-__device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
-                                           int M, int N, int K, int beta, double sign, double* lds) {
-    constexpr int WM = 4, WN = 4;
-    constexpr int OPER = 128 * GS_KC + 2, STAGE = 2 * OPER, HALF = 64 * GS_KC + 1;
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = w & 1, wn = w >> 1;
-    const int fr = lane & 15, fq = lane >> 4;
-    const bool neg = sign < 0.0;
-    gs_d4 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = (wm * WM + i) * 16 + fq + 4 * x;
-                const double c = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
-                acc[i][j][x] = neg ? -c : c;
-            }
-        }
-    // this wave stages tile rows [32 w, 32 w + 32) of both operands: per parity h two loads of 8 rows each
-    const int lrow = lane >> 3, lg = lane & 7;
-    const double* srcA[2][2];
-    const double* srcB[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r = 32 * w + 16 * q + 2 * lrow + h;
-            const int kp = lg ^ ((r >> 1) & 7);
-            const int ra = r < M ? r : M - 1, rb = r < N ? r : N - 1;
-            srcA[h][q] = A + (int64_t)ra * lda + 2 * kp;
-            srcB[h][q] = B + (int64_t)rb * ldb + 2 * kp;
-        }
-    auto stage_load = [&](int kc, int stage) {
-        double* base = lds + stage * STAGE;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                double* dstA = base + h * HALF + (16 * w + 8 * q) * GS_KC;
-                double* dstB = base + OPER + h * HALF + (16 * w + 8 * q) * GS_KC;
-                __builtin_amdgcn_global_load_lds(srcA[h][q] + kc * GS_KC, dstA, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(srcB[h][q] + kc * GS_KC, dstB, 16, 0, 0);
-            }
-    };
-    const int swz = (fr >> 1) & 7;
-    const int rsel = (fr & 1) * HALF + (fr >> 1) * GS_KC;
-    int goff[GS_KC / 4];
-#pragma unroll
-    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
-    const int nk = K / GS_KC;
-    __syncthreads();                                     // the previous user of `lds` is done with it
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < nk; ++c) {
-        if (c + 1 < nk) stage_load(c + 1, (c + 1) & 1);
-        const double* sA = lds + (c & 1) * STAGE + wm * WM * 8 * GS_KC + rsel;
-        const double* sB = lds + (c & 1) * STAGE + OPER + wn * WN * 8 * GS_KC + rsel;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 4; ++ks) {
-            double af[WM], bf[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = (wm * WM + i) * 16 + fq + 4 * x;
-                if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
-            }
-        }
-    __threadfence_block();
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
-                                                     const gsum_kernel_desc* descs, double nugget, double* scratch,
-                                                     int64_t scratch_stride, double* res, unsigned long long* stamps = nullptr) {
-    extern __shared__ double lds[];                 // max(GS_DIAG_WS, GS_TILE_LD_DOUBLES) doubles, lent in turn to the kernel
-                                                    // build, the diagonal-block routine and the tile routine: 77.6 KB in
-                                                    // all, so TWO evaluations share a CU
-    __shared__ double ldet_blk;
-    __shared__ double ldet_sum;
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc desc = descs[blockIdx.x];
-    const int np = (n + 127) / 128 * 128, T = np / 128;
-    const int64_t ld = np + GS_BORDER;
-    double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
-    double* diag0 = A + (int64_t)np * ld + (int64_t)T * 128 * 128;     // (the T x 128 x 128 slot before it held exported tables
-                                                                       // while the right-hand sides had a sweep of their own)
-    double* Wt = diag0 + np;                        // 16 x np, row-major
-    double* out = res + (int64_t)blockIdx.x * 258;
-    // diagnostics (option "diag_stamps"): shader cycles of workgroup 0 per phase -> stamps[40..47] =
-    // {build, diagonal blocks, panel solves, sibling tiles, trailing tiles, W step, Gram + rest, total}
-    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0, tstart = 0;
-    const bool stamping = stamps != nullptr && blockIdx.x == 0 && t == 0;
-    auto phase = [&](int i) {
-        if (stamping) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            if (i >= 0) ph[i] += now - tq; else tstart = now;
-            tq = now;
-        }
-    };
-    phase(-1);
-    // ---- kernel matrix: lower 128x128 tiles, identity padding (k_build's arithmetic)
-    {
-#pragma clang fp contract(off)
-        double* ui = lds;
-        double* uj = lds + 128 * GSUM_MAX_D;
-        double* etab = lds + 2 * 128 * GSUM_MAX_D;      // exp tables th[16] | tl[16] (first read behind the loop's barriers)
-        if (t < 16) etab[t] = gs_exp_th[t];
-        else if (t < 32) etab[t] = gs_exp_tl[t - 16];
-        for (int bi = 0; bi < T; ++bi)
-            for (int bj = 0; bj <= bi; ++bj) {
-                __syncthreads();
-                for (int idx = t; idx < 128 * d; idx += 256) {
-                    const int r = idx / d, dd = idx - r * d;
-                    const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
-                    const int gi = bi * 128 + r, gj = bj * 128 + r;
-                    ui[idx] = gi < n ? X[(int64_t)gi * d + dd] / ls : 0.0;
-                    uj[idx] = gj < n ? X[(int64_t)gj * d + dd] / ls : 0.0;
-                }
-                __syncthreads();
-                gs_build_tile128_any(A, ld, ui, uj, etab, etab + 16, bi, bj, n, d, desc, nugget, diag0, w, lane);
-            }
-    }
-    if (t == 0) ldet_sum = 0.0;
-    __threadfence_block();
-    __syncthreads();
-    phase(0);
-    const int fr = lane & 15, fq = lane >> 4;
-    // ---- right-looking blocked Cholesky, two block columns per trailing update (K = 256: the trailing tiles are read
-    // and written once per 256 eliminated columns, which is what this HBM-resident sweep is bound by)
-    int grp = 0;                                    // outer steps of the current group already applied to the NEXT panel's columns only
-    for (int b = 0; b < T; b += 2) {
-        const bool two = b + 1 < T;
-        for (int s = 0; s < (two ? 2 : 1); ++s) {
-            const int c = b + s;
-            // (no table export: every consumer of block c's tables -- the panel below, right-hand-side rows included -- reads
-            // them from LDS before the next block overwrites them)
-            const int bad = gs_diag_block(A + (int64_t)c * 128 * ld + c * 128, ld, (double*)nullptr, (double*)nullptr,
-                                          &ldet_blk, diag0 + c * 128, nullptr, lds);
-            if (bad) {
-                if (t == 0) {
-                    out[256] = 0.0;
-                    out[257] = (double)(c * 128 + bad);
-                }
-                return;
-            }
-            if (t == 0) ldet_sum += ldet_blk;
-            __threadfence_block();
-            __syncthreads();
-            phase(1);
-            // The 16 right-hand-side rows are rows of the bordered matrix: block column c of W^T = Z^T L^-T is brought up to
-            // date here (left-looking over the columns already done, on the matrix cores straight from global memory: wave w
-            // owns point-columns [32 w, 32 w + 32) of the block) and then SOLVED WITH THE PANEL below, against the tables
-            // gs_diag_block has just left in LDS.  As a separate sweep after the factorisation every block cost a reload of its
-            // 73-KB table, two barriers and a lone wave solving while three waited: 12-15 % of the kernel at n <= 1024.
-            {
-                gs_d4 acc[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pc = c * 128 + (2 * w + h) * 16 + fr;        // accumulator column = point index
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const int rr = fq + 4 * x;                         // accumulator row = right-hand side
-                        acc[h][x] = (rr < k && pc < n) ? Z[(int64_t)pc * k + rr] : 0.0;
-                    }
-                }
-                // minus W^T[:, c'] L[c, c']^T, ascending k; eight k-steps requested at a time before their MFMAs
-                const double* wrow = Wt + (int64_t)fr * np + fq;
-                const double* l0 = A + (int64_t)(c * 128 + (2 * w) * 16 + fr) * ld + fq;
-                const double* l1 = l0 + (int64_t)16 * ld;
-                for (int kk0 = 0; kk0 < c * 128; kk0 += 32) {
-                    double av[8], bv0[8], bv1[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        av[u] = -wrow[kk0 + 4 * u];
-                        bv0[u] = l0[kk0 + 4 * u];
-                        bv1[u] = l1[kk0 + 4 * u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv0[u], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv1[u], acc[1], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) Wt[(int64_t)(fq + 4 * x) * np + c * 128 + (2 * w + h) * 16 + fr] = acc[h][x];
-            }
-            __threadfence_block();
-            __syncthreads();
-            phase(5);
-            // panel: rows below <- rows * L_cc^-T by blocked substitution against the tables in lds, two 16-row groups per
-            // wave and pass; the last group is the right-hand-side rows
-            {
-                const int ngr = (T - c - 1) * 8;        // 16-row groups of the matrix below the block; group ngr = W^T[:, c]
-                double* pan = A + ((int64_t)(c + 1) * 128) * ld + c * 128;
-                for (int br = w; br <= ngr; br += 8) {
-                    double* ra = br < ngr ? pan + (int64_t)(16 * br) * ld : Wt + c * 128;
-                    const int64_t lda_ = br < ngr ? ld : np;
-                    if (br + 4 <= ngr) {
-                        double* rb = br + 4 < ngr ? pan + (int64_t)(16 * (br + 4)) * ld : Wt + c * 128;
-                        const int64_t ldb_ = br + 4 < ngr ? ld : np;
-                        gs_d4 Pg[8], Qg[8];
-                        gs_panel16_load(Pg, ra, lda_, 16, lane);
-                        gs_panel16_load(Qg, rb, ldb_, 16, lane);
-                        gs_panel16_solve2(Pg, Qg, lds, lane);
-                        gs_panel16_store(Pg, ra, lda_, 16, lane);
-                        gs_panel16_store(Qg, rb, ldb_, 16, lane);
-                    } else {
-                        gs_panel16(ra, lda_, 16, lds, lane);
-                    }
-                }
-            }
-            __threadfence_block();
-            if (stamping || stamps) __syncthreads();        // (diagnostic runs only: a barrier so that the phases separate)
-            phase(2);
-            if (s == 0 && two)                      // sibling block column b + 1: the first panel only (K = 128)
-                for (int i = b + 1; i < T; ++i)
-                    gs_tile128(A + (int64_t)i * 128 * ld + (b + 1) * 128, ld, A + (int64_t)i * 128 * ld + b * 128, ld,
-                               A + (int64_t)(b + 1) * 128 * ld + b * 128, ld, 128, 128, 128, 1, -1.0, lds);
-            phase(3);
-        }
-        const int Kp = two ? 256 : 128, first = b + (two ? 2 : 1);
-        // The batch factorisation's pairing of trailing updates (lazy_far = 2) inside this sweep: after an even outer step only the NEXT two block columns take
-        // this panel's update (K = 256); the step after it applies both panels to every tile right of them in one K = 512 pass -- the trailing tiles, which this
-        // HBM-resident sweep reads and writes once per update, are then touched half as often.  Same products in the same ascending-k order per element.
-        // gs_medium_lazy = depth of the grouping (1: none, 2: pairs, d: the far tiles are touched once per d outer steps, with K = 256 d)
-        const int depth = gs_medium_lazy;
-        const bool more = depth > 1 && two && first + 1 < T && grp + 1 < depth;      // a full two-block panel follows and the group is not complete
-        const int gb = b - 2 * grp;                                                  // first block column of the group: [gb, b + 2) are (grp + 1) x 256 contiguous columns
-        const int Kg = 256 * grp + Kp;
-        const int jlast = more ? first + 1 : T - 1;                                  // near update: the next panel's two block columns only
-        for (int i = first; i < T; ++i)
-            for (int j = first; j <= min(i, jlast); ++j)
-                gs_tile128(A + (int64_t)i * 128 * ld + j * 128, ld, A + (int64_t)i * 128 * ld + gb * 128, ld,
-                           A + (int64_t)j * 128 * ld + gb * 128, ld, 128, 128, Kg, 1, -1.0, lds);
-        grp = more ? grp + 1 : 0;
-        phase(4);
-    }
-    __threadfence_block();
-    __syncthreads();                               // W^T complete (its last block was solved by whichever wave had the group)
-    // ---- Gram matrix G = W^T W by wave 0 (ascending k), log-det, info
-    if (w == 0) {
-        gs_d4 g = {0.0, 0.0, 0.0, 0.0};
-        for (int s4 = 0; s4 < np / 4; ++s4) {
-            const double wv = Wt[(int64_t)fr * np + 4 * s4 + fq];
-            g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) out[(fq + 4 * x) * 16 + fr] = g[x];
-        if (lane == 0) {
-            out[256] = ldet_sum;
-            out[257] = 0.0;
-        }
-    }
-    phase(6);
-    if (stamping) {
-        for (int i = 0; i < 7; ++i) stamps[40 + i] = ph[i];
-        stamps[47] = tq - tstart;
-    }
-}
-
-template <int NACC>
-__global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
-    gs_d4 acc[NACC];
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = gs_d4{0.0, 0.0, 0.0, 0.0};
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (sum == 1.2345e301) out[blockIdx.x * blockDim.x + threadIdx.x] = sum;          // keeps the chain alive
-}
-
-// (body of k_gemm_ld3 / k_gemm_ld3g: `bid_in` is the tile's index within ITS product -- the workgroup id of a plain launch, the
-// offset into its entry's tile range for a grouped one)
-template <int NST>
-__device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                                 int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                 unsigned long long* kst, int nfirst, unsigned* first_done, const int bid_in) {
-    constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
-    constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
-    constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
-    extern __shared__ double lds[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (kst && t == 0) atomicMin(kst, __builtin_amdgcn_s_memrealtime());             // diagnostics: first start / last end of the launch
-    // (Tried in round 3, measured, not kept: de-phasing naps for the second and third workgroup of a CU -- no gain, the
-    // co-resident workgroups are not in lock step; three LDS stages with two workgroups per CU -- 3 % slower alone, 7 % slower
-    // pipelined.  A K = 256 launch at M = 7936 spends ~30-45 us on its C reads and ~25 us on its C stores of ~300; the K loop alone
-    // runs at 66 TF/s, the clock-limited rate under this kernel: profiles/r03_bulk_cphase.log.)
-    const int wm = w % WAVES_M, wn = w / WAVES_M;
-    int bm, bn;
-    bool first_cols = false;
-    if (tri && nfirst > 0) {
-        // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
-        // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
-        const int bid = bid_in;
-        if (bid < nfirst) {
-            if (bid < 2) { bm = 0; bn = bid; }
-            else { bm = 1 + (bid - 2) / 4; bn = (bid - 2) % 4; }
-            first_cols = true;
-        } else {
-            const int f = bid - nfirst;
-            bm = (int)((3.0 + sqrt(1.0 + 4.0 * (double)f)) * 0.5);
-            while ((int64_t)(bm - 1) * (bm - 2) > f) --bm;
-            while ((int64_t)bm * (bm - 1) <= f) ++bm;
-            bn = 4 + f - (bm - 1) * (bm - 2);
-        }
-    } else if (tri) {
-        // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1.
-        // (An XCD-aware order -- rows padded to multiples of 8 slots so that workgroup id and column tile agree modulo 8
-        // and each XCD's L2 keeps one eighth of the B-side panel -- was measured: rocprofv3 FETCH_SIZE of the exclusive
-        // M = 8192 launch 813 -> 610 MB, its rate unchanged (55.0 vs 55.6 TF/s), the 16-in-flight pipeline 3 % SLOWER
-        // (266.6 vs 274 evals/s: with sixteen queues dispatching at once workgroup ids no longer map to XCDs round-robin,
-        // and the padding slots cost launches).  The kernel is not fetch-bound; the plain order stays.)
-        const int bid = bid_in;
-        bm = (int)((sqrt(4.0 * (double)bid + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(bm + 1) * (bm + 2) <= bid) ++bm;
-        while ((int64_t)bm * (bm + 1) > bid) --bm;
-        bn = bid - (int)((int64_t)bm * (bm + 1));
-    } else {
-        const int tm = (M + BM - 1) / BM;
-        bm = bid_in % tm;
-        bn = bid_in / tm;
-        first_cols = bid_in < nfirst;        // column-major tile order: the first 4 tm ids are the first 256 columns
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-    if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
-        if (first_cols && t == 0) gs_flag_add(first_done);
-        return;
-    }
-    if (tri == 2) {
-        A += m0;
-        B += m0;
-        K -= m0;
-    }
-    const int fr = lane & 15, fq = lane >> 4;
-    const bool neg = sign < 0.0;
-    gs_d4 acc[WM][WN];
-    // Lower-triangle launches: a wave whose 32 x 32 block lies strictly ABOVE the diagonal (5 of the 8 waves of a diagonal block's
-    // right-hand tile, 1 of 8 in its left-hand tile) neither loads, multiplies nor stores it -- nothing reads the strict upper triangle
-    // of a workspace matrix -- and leaves the matrix pipes to the CU's other workgroups: 0.75 / (tm + 1) of a launch's MFMAs (1.3 % at
-    // tm = 57 row tiles, 4.4 % at 16).  It still stages its share of the operands and keeps the barriers.
-    const bool idle = tri == 1 && __builtin_amdgcn_readfirstlane(m0 + wm * WM * 16 + WM * 16 - 1 < n0 + wn * WN * 16);
-    // interior tiles (all but the last row / column of a ragged matrix): the 16 C loads -- and the 16 stores at the end -- go out back to back, without a
-    // compare and a branch each (same-process A/B, profiles/r03_bulk_interior_tiles_ab.log: batch +0.8 %, K = 256 / 512 steady state at M = 7936 +2 / +1.5 %,
-    // M = 4096 -1.1 %, one factorisation unchanged; bit-identical)
-    const bool full = m0 + BM <= M && n0 + BN <= N;
-    if (idle) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j] = gs_d4{0.0, 0.0, 0.0, 0.0};
-    } else if (full && beta) {
-        const double* c0 = C + (int64_t)(m0 + wm * WM * 16 + fq) * ldc + n0 + wn * WN * 16 + fr;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) acc[i][j][x] = c0[(int64_t)(16 * i + 4 * x) * ldc + 16 * j];
-    } else {
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wn * WN + j) * 16 + fr;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;      // sign applied below, behind the wait
-            }
-        }
-    }
-    // staging: A has 16 eight-row slices (2 per wave: rows [16 w, 16 w + 16) by parity), B has 8 (1 per wave: wave w
-    // takes parity w & 1 of rows [16 (w >> 1), 16 (w >> 1) + 16))
-    const int lrow = lane >> 3, lg = lane & 7;
-    const double* srcA[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 16 * w + 2 * lrow + h;
-        const int kp = lg ^ ((r >> 1) & 7);
-        int ra = m0 + r;
-        ra = ra < M ? ra : M - 1;
-        srcA[h] = A + (int64_t)ra * lda + 2 * kp;
-    }
-    const int hb = w & 1, gb = w >> 1;
-    const double* srcB;
-    {
-        const int r = 16 * gb + 2 * lrow + hb;
-        const int kp = lg ^ ((r >> 1) & 7);
-        int rb = n0 + r;
-        rb = rb < N ? rb : N - 1;
-        srcB = B + (int64_t)rb * ldb + 2 * kp;
-    }
-    auto stage_load = [&](int kc, int stage) {
-        double* base = lds + stage * STAGE;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_global_load_lds(srcA[h] + kc * GS_KC, base + h * HALFA + 8 * w * GS_KC, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(srcB + kc * GS_KC, base + OPA + hb * HALFB + 8 * gb * GS_KC, 16, 0, 0);
-    };
-    const int swz = (fr >> 1) & 7;
-    const int rselA = (fr & 1) * HALFA + (fr >> 1) * GS_KC, rselB = (fr & 1) * HALFB + (fr >> 1) * GS_KC;
-    int goff[GS_KC / 4];
-#pragma unroll
-    for (int ks = 0; ks < GS_KC / 4; ++ks) goff[ks] = (((2 * ks + (fq >> 1)) ^ swz) << 1) + (fq & 1);
-    const int nk = K / GS_KC;
-    // NST stages of LDS: chunk c + NST - 1 is requested while chunk c is multiplied.  Every wave issues exactly three
-    // LDS-direct loads per stage, so "all but the newest NST - 2 stages have landed" is vmcnt(3 (NST - 2)).
-    // (NST = 3: 74 KB per workgroup, two per CU; the operands of a K = 256 trailing update mostly MISS the L2 -- the panel is
-    // 16 MB, FETCH_SIZE ~ the operand bytes -- and come from the Infinity Cache in 1-2 us, more than one chunk of a shared CU.)
-    stage_load(0, 0);
-    if (NST == 3 && nk > 1) stage_load(1, 1);
-    // The C values were requested first and are used (negated) only from here on: with the negation next to the loads the compiler put its
-    // wait for them in front of the third LDS-direct load of stage 0, which then paid a memory latency of its own in every tile's prologue.
-    // (same-process A/B, profiles/r03_bulk_prologue_ab.log: +1 % on the kernel at K = 256, +0.2-0.3 % on the pipelined batch; bit-identical)
-    __builtin_amdgcn_sched_barrier(0);
-    if (NST == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (neg) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) acc[i][j][x] = -acc[i][j][x];
-    }
-    __syncthreads();
-    if constexpr (NST == 2) {
-        // Fragments one k-step ahead, in two register sets: the LDS reads of step ks + 1 are issued BEFORE the four MFMAs of step ks, and the last
-        // step of a chunk is multiplied behind the barrier, after the next chunk's loads and first reads have gone out -- a wave never sits between "MFMAs issued" and
-        // "next fragments arrived" with nothing to issue (the compiler's own schedule reused one register set: read, wait, multiply, four times per
-        // chunk).  Same products, same order per accumulator: bit-identical.  +7 registers (63 of the 72 this kernel may use).  Same-process A/B
-        // (profiles/r03_bulk_kloop_ab.log): pipelined batch +1.25 % (294.4-295.0 against 290.8-291.5 evals/s), K = 512 steady state +1.6 %, M = 4096 +1.2 %,
-        // one factorisation -0.9 % time; K = 256 at M = 7936 unchanged (that launch is held by its C phases).
-        static_assert(GS_KC == 16, "the pipelined K loop is written for four k-steps per chunk");
-        double afA[WM], bfA[WN], afB[WM], bfB[WN];
-        auto ldf = [&](double (&af)[WM], double (&bf)[WN], const double* sA, const double* sB, int ks) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
-        };
-        auto mm = [&](const double (&af)[WM], const double (&bf)[WN]) {
-            if (idle) return;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        };
-        const double* sA = lds + wm * WM * 8 * GS_KC + rselA;
-        const double* sB = lds + OPA + wn * WN * 8 * GS_KC + rselB;
-        if (nk > 1) stage_load(1, 1);
-        if (nk > 0) ldf(afA, bfA, sA, sB, 0);
-        // `arrived` is an empty statement that reads a fragment set: the compiler's wait for that set lands THERE, i.e. before the next set's reads are
-        // issued -- placed in front of the MFMAs (its own choice) the wait came out as lgkmcnt(0) and covered the reads just issued as well.
-        auto arrived = [&](const double (&af)[WM], const double (&bf)[WN]) {
-            static_assert(WM == 2 && WN == 2, "two row and two column fragments per wave");
-            asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(bf[0]), "v"(bf[1]));
-        };
-        for (int c = 0; c < nk; ++c) {
-            __builtin_amdgcn_sched_barrier(0);
-            arrived(afA, bfA);
-            ldf(afB, bfB, sA, sB, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(afA, bfA);
-            __builtin_amdgcn_sched_barrier(0);
-            arrived(afB, bfB);
-            ldf(afA, bfA, sA, sB, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(afB, bfB);
-            __builtin_amdgcn_sched_barrier(0);
-            arrived(afA, bfA);
-            ldf(afB, bfB, sA, sB, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(afA, bfA);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                // (waits for the LDS reads above too: this stage may be overwritten from here on)
-            if (c + 1 < nk) {                               // the next chunk's first fragments are requested BEFORE the last four MFMAs of this one ...
-                sA = lds + ((c + 1) & 1) * STAGE + wm * WM * 8 * GS_KC + rselA;
-                sB = lds + ((c + 1) & 1) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
-                ldf(afA, bfA, sA, sB, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mm(afB, bfB);                                   // k-step 3 of chunk c
-            // ... and the LDS-direct loads of chunk c + 2 behind them: their address arithmetic and M0 writes no longer stand between the barrier and
-            // the MFMAs (same-process A/B, profiles/r03_bulk_dma_order_ab.log: batch +0.7 %, M = 4096 +2.2 %, K = 256 / 512 steady state +1.5 / +0.7 %;
-            // one MFMA group later still is no better and costs M = 4096 1.7 %).
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 2 < nk) stage_load(c + 2, c & 1);
-        }
-    } else {
-    for (int c = 0; c < nk; ++c) {
-        if (c + NST - 1 < nk) stage_load(c + NST - 1, (c + NST - 1) % NST);
-        const double* sA = lds + (c % NST) * STAGE + wm * WM * 8 * GS_KC + rselA;
-        const double* sB = lds + (c % NST) * STAGE + OPA + wn * WN * 8 * GS_KC + rselB;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 4; ++ks) {
-            double af[WM], bf[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = sA[i * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = sB[j * 8 * GS_KC + goff[ks]];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (NST == 3 && c + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk c + 1 has landed; c + 2 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    }
-    // The store addresses are re-derived from the thread index HERE, behind an opaque copy of it: computed once in the prologue they
-    // stay live across the K loop, and this kernel must fit 72 VGPRs -- six bulk waves then leave a SIMD exactly the room in which one
-    // chain / panel wave (224) fits as soon as ONE bulk workgroup retires (tests/test_host_logic.py::test_kernel_register_budgets).
-    int t2 = threadIdx.x;
-    asm volatile("" : "+v"(t2));
-    const int lane2 = t2 & 63, w2 = t2 >> 6;
-    const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
-    if (idle) {
-        // (nothing to store)
-    } else if (!first_cols && m0 + BM <= M && n0 + BN <= N) {
-        double* c0 = C + (int64_t)(m0 + wm2 * WM * 16 + fq2) * ldc + n0 + wn2 * WN * 16 + fr2;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) c0[(int64_t)(16 * i + 4 * x) * ldc + 16 * j] = neg ? -acc[i][j][x] : acc[i][j][x];
-    } else if (!first_cols) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int col = n0 + (wn2 * WN + j) * 16 + fr2;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
-                    if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
-                }
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int col = n0 + (wn2 * WN + j) * 16 + fr2;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
-                    if (row < M && col < N) gs_st_wt(C + (int64_t)row * ldc + col, neg ? -acc[i][j][x] : acc[i][j][x]);
-                }
-            }
-    }
-    if (first_cols) {                         // published to the chain kernel: every wave drains, then one lane counts the tile
-        gs_drain();
-        __syncthreads();
-        if (t == 0) gs_flag_add(first_done);
-    }
-    if (kst && t == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
-}
-
-
-template <int NST>
-__global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                                      int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                      unsigned long long* kst, int nfirst, unsigned* first_done) {
-    gs_gemm_ld3_body<NST>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, nfirst, first_done, (int)blockIdx.x);
-}
-
-// ---- grouped launches: the same outer step of SEVERAL evaluations in one launch -------------------------------------------------
-// A batch of evaluations (a likelihood grid) used to run as up to 20 independent HIP streams, one evaluation each, and counted on
-// the runtime giving every stream a hardware queue of its own (GPU_MAX_HW_QUEUES) -- 24 live streams collapsed it, a process with an
-// RCCL communicator had to run a different policy, and no per-launch profile described the step.  Round 4: the evaluations of a
-// group advance in lock step and ONE launch carries the tiles of all of them.  An entry names its product by offsets from its
-// evaluation's workspace (all workspaces of a group are `strideA` doubles apart, same order, same leading dimension); the entry of a
-// workgroup is found from the running tile counts in the kernel arguments (scalar loads: the workgroup id is uniform).  The tile
-// arithmetic is gs_gemm_ld3_body's: results are bit-identical to the one-evaluation launches.
-#define GS_WV_MAX 24
-struct gs_wv_gemm_entry {
-    int64_t offC, offA, offB;      // doubles from the evaluation's workspace base
-    int M, N, K, tri;
-    int q, pad;                    // workspace index within the group
-};
-struct gs_wv_gemm_args {
-    double* base; int64_t strideA, ld;
-    int n, pad;
-    int end[GS_WV_MAX];            // running tile counts: entry e owns block ids [end[e - 1], end[e])
-    gs_wv_gemm_entry e[GS_WV_MAX];
-};
-__device__ __forceinline__ void gs_gemm_ld3g_body(const gs_wv_gemm_args& a) {
-    const int bid = (int)blockIdx.x;
-    int e = 0;
-    while (e + 1 < a.n && bid >= a.end[e]) ++e;
-    const int first = e ? a.end[e - 1] : 0;
-    const gs_wv_gemm_entry& en = a.e[e];
-    double* W = a.base + (int64_t)en.q * a.strideA;
-    gs_gemm_ld3_body<2>(W + en.offC, a.ld, W + en.offA, a.ld, W + en.offB, a.ld, en.M, en.N, en.K, en.tri, 1, -1.0,
-                        (unsigned long long*)nullptr, 0, (unsigned*)nullptr, bid - first);
-}
-// k_gemm_ld3g: the big ("far") trailing updates, one after the other on the batch schedule's bulk stream.  k_gemm_ld3n: the same
-// code under a name of its own for the small "near" updates that run on the groups' chain streams BESIDE them -- so that a
-// per-kernel profile (rocprofv3 --stats) keeps the two roles apart and the far updates' launch times add up to the step time.
-__global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
-__global__ __launch_bounds__(512, 7) void k_gemm_ld3n(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
-
-// Read-out of the bordered factorisation: G = -(corner), sum of the per-block log-det partials.
-// res[0..255] = G (16x16 row-major), res[256] = sum_i log L_ii, res[257] = info.
-__global__ __launch_bounds__(256) void k_finalize(const double* A, int64_t ld, int np, const double* logdet,
-                                                   int T, const int* info, double* res) {
-    const int t = threadIdx.x;
-    const int r = t >> 4, c = t & 15;
-    res[t] = -A[(int64_t)(np + r) * ld + np + c];
-    if (t == 0) {
-        double s = 0.0;
-        for (int i = 0; i < T; ++i) s += logdet[i];
-        res[256] = s;
-        res[257] = (double)(*info);
-    }
-}
-
-// the same for the finished evaluations of a group (one workgroup per entry)
-__global__ __launch_bounds__(256) void k_finalize_g(const gs_wv_chain_args a) {
-    const int64_t q = a.q[blockIdx.x];
-    const int t = threadIdx.x;
-    const int r = t >> 4, c = t & 15;
-    const double* A = a.p.A + q * a.p.strideA;
-    double* res = a.p.res + q * 258;
-    res[t] = -A[(int64_t)(a.p.np + r) * a.p.ld + a.p.np + c];
-    if (t == 0) {
-        double s = 0.0;
-        for (int i = 0; i < a.p.T; ++i) s += a.p.logdet[q * a.p.T + i];
-        res[256] = s;
-        res[257] = (double)a.p.info[q];
-    }
-}
-
-// out[r] = sum_j B[r][j]^2 over ncols; one wave per row, fixed summation order.
-// Row sums of squares of B (nrows x ncols) AND, in the same pass over B, its product with the 16 rows of W (ldw apart):
-//   ss[row] = sum_j B[row][j]^2,   vw[row * 16 + c] = sum_j B[row][j] W[c][j].
-// predict reads V^T (m x n, 268 MB at m = 2048, n = 16384) for both: as k_rowsumsq + a 16-column GEMM on the 32 x 128 tile
-// (64 workgroups looping over K = n: 0.79 ms, latency-bound) that was two passes and 0.9 ms; this is one streaming pass.
-// One wave per GS_VW_ROWS rows (W -- 2 MB, L2-resident -- is re-read once per wave, not once per row).
-#define GS_VW_ROWS 2
-__global__ __launch_bounds__(256) void k_rowsumsq_vw(const double* B, int64_t ldb, int nrows, int ncols, const double* W, int64_t ldw,
-                                                     double* ss, double* vw) {
-    constexpr int R = GS_VW_ROWS;
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (row0 >= nrows) return;
-    const double* p[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) p[r] = B + (int64_t)(row0 + r < nrows ? row0 + r : nrows - 1) * ldb;
-    double s[R], acc[R][16];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        s[r] = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
-    }
-    for (int j = lane; j < ncols; j += 64) {
-        double b[R], wv[16];
-#pragma unroll
-        for (int r = 0; r < R; ++r) b[r] = p[r][j];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) wv[c] = W[(int64_t)c * ldw + j];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s[r] += b[r] * b[r];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) acc[r][c] += b[r] * wv[c];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_down(s[r], off, 64);
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[r][c] += __shfl_down(acc[r][c], off, 64);
-        if (lane == 0 && row0 + r < nrows) {
-            ss[row0 + r] = s[r];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) vw[(int64_t)(row0 + r) * 16 + c] = acc[r][c];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_rowsumsq(const double* B, int64_t ldb, int nrows, int ncols, double* out) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    const double* p = B + (int64_t)row * ldb;
-    double s = 0.0;
-    for (int j = lane; j < ncols; j += 64) s += p[j] * p[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) out[row] = s;
-}
-
-// ---- back-substitution half of cho_solve (models.py:479): x^T L = w^T on the 16 border rows, right-looking from the
-// last block column to the first.  Rows = right-hand sides (16), columns = points; everything on the matrix cores
-// straight from global memory (the factor is read exactly once: HBM-bound, 4 n^2 bytes).
-// One 16 x 128 panel times a 128 x 128 row-major matrix:  out[a][j] = sum_k P[a][k] M[k][j].  P comes from LDS
-// (16 rows, stride 129), M from global memory (leading dimension ldm); wave w owns columns [32 w, 32 w + 32).
-__device__ __forceinline__ void gs_panel_times_block(const double* P, const double* M, int64_t ldm, gs_d4 (&o)[2], int w, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    o[0] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-    o[1] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-    for (int s4 = 0; s4 < 32; ++s4) {
-        const int kk = 4 * s4 + fq;
-        const double av = P[fr * 129 + kk];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const double bv = M[(int64_t)kk * ldm + (2 * w + h) * 16 + fr];
-            o[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o[h], 0, 0, 0);
-        }
-    }
-}
-
-// X_c^T = W_c^T L_cc^-1 for the LAST block column (c0 = its first column), in place on the border rows.
-__global__ __launch_bounds__(256) void k_back_first(double* Brow, int64_t ld, const double* Linv, int c0) {
-    __shared__ double P[16 * 129];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    for (int idx = t; idx < 16 * 128; idx += 256) P[(idx >> 7) * 129 + (idx & 127)] = Brow[(int64_t)(idx >> 7) * ld + c0 + (idx & 127)];
-    __syncthreads();
-    gs_d4 o[2];
-    gs_panel_times_block(P, Linv, 128, o, w, lane);
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + c0 + (2 * w + h) * 16 + fr] = o[h][x];
-}
-
-// Step c (block column c holds the finished X_c^T): workgroup g < c subtracts X_c^T L[c rows, g cols] from W_g^T; the
-// workgroup of block column c - 1 then finishes it, X_{c-1}^T = W_{c-1}^T L_{c-1,c-1}^-1 (nothing else touches it later).
-__global__ __launch_bounds__(256) void k_back_step(const double* A, int64_t ld, double* Brow, const double* Linv, int c) {
-    __shared__ double P[16 * 129];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int g = blockIdx.x, c0 = c * 128, g0 = g * 128;
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int idx = t; idx < 16 * 128; idx += 256) P[(idx >> 7) * 129 + (idx & 127)] = -Brow[(int64_t)(idx >> 7) * ld + c0 + (idx & 127)];
-    gs_d4 acc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[h][x] = Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr];
-    __syncthreads();
-    const double* Lblk = A + (int64_t)c0 * ld + g0;                 // rows of block c, columns of block g
-    for (int s4 = 0; s4 < 32; ++s4) {
-        const int kk = 4 * s4 + fq;
-        const double av = P[fr * 129 + kk];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const double bv = Lblk[(int64_t)kk * ld + (2 * w + h) * 16 + fr];
-            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[h], 0, 0, 0);
-        }
-    }
-    if (g != c - 1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr] = acc[h][x];
-        return;
-    }
-    __syncthreads();                                                // every wave is done reading P
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[(fq + 4 * x) * 129 + (2 * w + h) * 16 + fr] = acc[h][x];
-    __syncthreads();
-    gs_d4 o[2];
-    gs_panel_times_block(P, Linv + (size_t)g * 128 * 128, 128, o, w, lane);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) Brow[(int64_t)(fq + 4 * x) * ld + g0 + (2 * w + h) * 16 + fr] = o[h][x];
-}
-
-// upper triangle <- lower triangle, in place (rows are written coalesced; the strided reads hit L2 for the sizes this serves)
-__global__ __launch_bounds__(256) void k_mirror_lower(double* A, int64_t ld, int n) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j < n && j > i) A[(int64_t)i * ld + j] = A[(int64_t)j * ld + i];
-}
-
-// Mirror the lower triangle into the upper one / zero the upper one, into a dense n x n buffer.
-__global__ __launch_bounds__(256) void k_export(const double* A, int64_t ld, int n, double* out, int zero_upper) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= n) return;
-    double v;
-    if (j <= i) v = A[(int64_t)i * ld + j];
-    else v = zero_upper ? 0.0 : A[(int64_t)j * ld + i];
-    out[(int64_t)i * n + j] = v;
-}
-
-// Coefficient covariance -> partial-sum covariance, in place (models.py:1343-1354 with helpers.py:149-182):
-//   A_ij *= factor * ref_r[i] ref_c[j] * S(ratio_r[i] ratio_c[j]),
-//   S(x) = (x^start - x^(end+1)) / (1 - x) - sum_{e excluded, start <= e <= end} x^e;   end < 0: infinite sum, x^(end+1) = 0.
-// Same operation order as the reference's array expression; pow() is within an ulp of numpy's.
-__global__ __launch_bounds__(256) void k_scale_series(double* A, int64_t ld, int rows, int cols, const double* ref_r,
-                                                       const double* ratio_r, const double* ref_c, const double* ratio_c,
-                                                       gsum_series_scale sc) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= cols || i >= rows) return;
-    const double x = ratio_r[i] * ratio_c[j];
-    const double hi = sc.end < 0 ? 0.0 : pow(x, (double)(sc.end + 1));
-    double sum = (pow(x, (double)sc.start) - hi) / (1.0 - x);
-    for (int e = 0; e < sc.n_excluded; ++e) {
-        const int ex = sc.excluded[e];
-        if (ex >= sc.start && (sc.end < 0 || ex <= sc.end)) sum -= pow(x, (double)ex);
-    }
-    const double refm = ref_r[i] * ref_c[j];
-    A[(int64_t)i * ld + j] = (refm * sum) * (sc.factor * A[(int64_t)i * ld + j]);
-}
-
-// out = L Z for the lower-triangular factor (row-major, leading dimension ld), Z and out n x 16 (zero-padded
-// columns): the sampling transform y = mean + L z of a multivariate normal.  One wave per row: lanes stride over the
-// row's columns j <= i (coalesced 8-B loads of L, which is read exactly once: HBM-bound, n^2/2 x 8 B), 16
-// accumulators per lane, then a butterfly reduction.  Z (n x 128 B) stays in L2.
-__global__ __launch_bounds__(256) void k_tri_multiply(const double* L, int64_t ld, int n, const double* Z, double* out) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
-    double acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
-    const double* row = L + (int64_t)i * ld;
-    for (int j = lane; j <= i; j += 64) {
-        const double l = row[j];
-        const gs_d2* z = reinterpret_cast<const gs_d2*>(Z + (int64_t)j * 16);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const gs_d2 v = z[q];
-            acc[2 * q] = __builtin_fma(l, v[0], acc[2 * q]);
-            acc[2 * q + 1] = __builtin_fma(l, v[1], acc[2 * q + 1]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double v = acc[c];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[c] = v;
-    }
-    if (lane < 16) {
-        double v = acc[0];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
-        out[(int64_t)i * 16 + lane] = v;
-    }
-}
-
-// Vt[c][j] = sum_{k >= j} U[j][k] Wt[c][k] for an upper-triangular U (row-major, n x n) and 16 rows Wt: V^T = W^T U^T of
-// the gradient path.  One wave per row of U (read once, coalesced: HBM-bound, 4 n^2 bytes), 16 accumulators per lane,
-// butterfly reduction.  (As a 16 x n x n GEMM on 16 x 256 tiles this had 32 workgroups with K = n each: 3.7 ms at n = 8192.)
-__global__ __launch_bounds__(256) void k_upper_times_rows(const double* U, int64_t ldu, int n, const double* Wt, int64_t ldw,
-                                                           double* Vt, int64_t ldv) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    double acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
-    const double* row = U + (int64_t)j * ldu;
-    for (int k = (j & ~63) + lane; k < n; k += 64) {
-        const double u = k >= j ? row[k] : 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(u, Wt[(int64_t)c * ldw + k], acc[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double v = acc[c];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[c] = v;
-    }
-    if (lane < 16) {
-        double v = acc[0];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
-        Vt[(int64_t)lane * ldv + j] = v;
-    }
-}
-
-// ---- gradient path (models.py:957-958, 1041-1056) ------------------------------------------------
-__global__ __launch_bounds__(256) void k_set_identity(double* A, int64_t ld, int np) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j < np) A[(int64_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
-}
-
-struct gs_grad_params { gsum_grad_param p[GSUM_MAX_GRAD]; };
-
-// d kernel(X)_ij / d theta_p for one log-hyperparameter (scikit-learn's K_gradient; kernels.py of sklearn 1.x:
-// RBF.__call__, Matern.__call__, ConstantKernel, WhiteKernel, Product / Sum rules), evaluated on the fly.
-// s = sum_m D_m, D_m = ((x_im - x_jm) / l_m)^2;  dm = s for an isotropic length scale, D_dim otherwise.
-__device__ __forceinline__ double gs_kernel_grad(const gsum_kernel_desc& desc, const gsum_grad_param& pr, double s, double dm,
-                                                 bool diag) {
-    switch (pr.code) {
-        case GSUM_GRAD_AMPLITUDE: return desc.amplitude * (diag ? 1.0 : gs_base_value(desc.family, s));
-        case GSUM_GRAD_WHITE: return diag ? pr.weight : 0.0;
-        case GSUM_GRAD_ADDITIVE: return pr.weight;
-        default: break;
-    }
-    if (diag) return 0.0;
-    double g;
-    if (desc.family == GSUM_RBF) {
-        g = gs_base_value(GSUM_RBF, s) * dm;
-    } else if (desc.family == GSUM_MATERN52) {
-        const double tmp = sqrt(5.0 * s);
-        g = 5.0 / 3.0 * dm * (tmp + 1.0) * gs_exp_np(-tmp);
-    } else if (desc.family == GSUM_MATERN32) {
-        g = 3.0 * dm * gs_exp_np(-sqrt(3.0 * s));
-    } else {
-        const double den = sqrt(s);
-        g = den != 0.0 ? gs_base_value(GSUM_MATERN12, s) * (dm / den) : 0.0;
-    }
-    return desc.amplitude * g;
-}
-
-// One wave per row i of dR_p (grid.y = p): Q_p[i][c] = sum_j dR_p,ij V[j][c] (V^T given as 16 rows: coalesced loads)
-// and trow_p[i] = sum_{j<=i} (2 - [i == j]) Rinv_ij dR_p,ij, so that sum_i trow = tr(R^-1 dR_p) from the lower
-// triangle of R^-1 alone.  dR is never stored: n^2 kernel-gradient evaluations per parameter, HBM traffic = the
-// lower triangle of R^-1 once per parameter.
-// TREE: the descriptor is a Sum / Product tree (n_ops > 0).  Two instantiations: with the tree walk in the same kernel the flattened
-// form -- every kernel the reference itself constructs -- ran at 218 registers instead of 146 (two waves per SIMD instead of three) and the
-// whole gradient evaluation 5 % slower.
-template <bool TREE>
-__global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, int d, gsum_kernel_desc desc, gs_grad_params prm,
-                                                        const double* Rinv, int64_t ldr, const double* Vt, int64_t ldv,
-                                                        double* Q, double* trow) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int p = blockIdx.y;
-    if (i >= n) return;
-    const gsum_grad_param pr = prm.p[p];
-    double xi[GSUM_MAX_D], inv_ls[GSUM_MAX_D];
-#pragma unroll
-    for (int m = 0; m < GSUM_MAX_D; ++m) {
-        inv_ls[m] = 1.0 / (desc.anisotropic ? desc.length_scale[m < d ? m : 0] : desc.length_scale[0]);
-        xi[m] = m < d ? X[(int64_t)i * d + m] : 0.0;
-    }
-    double acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
-    double tr = 0.0;
-    for (int j = lane; j < n; j += 64) {
-        double s = 0.0, dsel = 0.0;
-#pragma unroll
-        for (int m = 0; m < GSUM_MAX_D; ++m) {
-            if (m < d) {
-                const double u = (xi[m] - X[(int64_t)j * d + m]) * inv_ls[m];
-                const double dmm = u * u;
-                s += dmm;
-                if (m == pr.dim) dsel = dmm;
-            }
-        }
-        const double dm = pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel;
-        double g;
-        if constexpr (TREE) {                    // a general tree: the same walk as the kernel build, with dual numbers
-            double xj[GSUM_MAX_D];
-#pragma unroll
-            for (int m = 0; m < GSUM_MAX_D; ++m) xj[m] = m < d ? X[(int64_t)j * d + m] : 0.0;
-            (void)gs_tree_eval(desc, xi, xj, d, i == j, &pr, &g);
-        } else {
-            g = gs_kernel_grad(desc, pr, s, dm, i == j);
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(g, Vt[(int64_t)c * ldv + j], acc[c]);
-        if (j <= i) tr = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g, tr);
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double v = acc[c];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[c] = v;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tr += __shfl_xor(tr, off, 64);
-    if (lane < 16) {
-        double v = acc[0];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
-        Q[((int64_t)p * n + i) * 16 + lane] = v;
-    }
-    if (lane == 0) trow[(int64_t)p * n + i] = tr;
-}
-
-// H_p = V^T Q_p (16 x 16) and sum_i trow_p[i], in two deterministic stages.  Stage 1 (grid: chunks x P): chunk c
-// reduces rows [c * rows_per, (c + 1) * rows_per) into part[(p * chunks + c) * 257 ...]; stage 2 (grid: P) adds the
-// chunks in index order.
-__global__ __launch_bounds__(256) void k_grad_reduce1(const double* Vt, int64_t ldv, const double* Q, const double* trow, int n,
-                                                       int rows_per, double* part) {
-    __shared__ double red[256];
-    const int t = threadIdx.x, a = t >> 4, b = t & 15, c = blockIdx.x, p = blockIdx.y;
-    const int lo = c * rows_per, hi = min(n, lo + rows_per);
-    const double* Qp = Q + (int64_t)p * n * 16;
-    double h = 0.0;
-    for (int i = lo; i < hi; ++i) h = __builtin_fma(Vt[(int64_t)a * ldv + i], Qp[(int64_t)i * 16 + b], h);
-    double* o = part + ((int64_t)p * gridDim.x + c) * 257;
-    o[t] = h;
-    double ts = 0.0;
-    for (int i = lo + t; i < hi; i += 256) ts += trow[(int64_t)p * n + i];
-    red[t] = ts;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-        if (t < w) red[t] += red[t + w];
-        __syncthreads();
-    }
-    if (t == 0) o[256] = red[0];
-}
-
-__global__ __launch_bounds__(256) void k_grad_reduce2(const double* part, int chunks, double* out) {
-    const int t = threadIdx.x, p = blockIdx.x;
-    const double* src = part + (int64_t)p * chunks * 257;
-    double h = 0.0;
-    for (int c = 0; c < chunks; ++c) h += src[(int64_t)c * 257 + t];
-    out[(int64_t)p * 257 + t] = h;
-    if (t == 0) {
-        double ts = 0.0;
-        for (int c = 0; c < chunks; ++c) ts += src[(int64_t)c * 257 + 256];
-        out[(int64_t)p * 257 + 256] = ts;
-    }
-}
-
-// ---- probes ------------------------------------------------------------------------------------
-// pseudo-random fill in [-1, 1) (integer hash), so benchmark operands are not zeros (DVFS reads high on zeros)
-__global__ __launch_bounds__(256) void k_fill_random(double* p, int64_t n, unsigned seed) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + seed;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z ^= z >> 31;
-        p[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
-    }
-}
-
-// NACC independent accumulators held in VGPRs (inline asm: hipcc would otherwise shuttle them through
-// AGPRs every iteration), back-to-back v_mfma_f64_16x16x4_f64.  NACC = 1 measures dependent latency.
-template <int NACC>
-__global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters, unsigned long long* stamps) {
-    gs_d4 acc[NACC];
-#pragma unroll
-    for (int u = 0; u < NACC; ++u) acc[u] = (gs_d4){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 1e-4;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int rep = 0; rep < 16 / NACC; ++rep)
-#pragma unroll
-            for (int u = 0; u < NACC; ++u)
-                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int u = 0; u < NACC; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) {     // diagnostic stamps go to their own buffer, never into results
-        const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        stamps[2 * wv] = c1 - c0;
-        stamps[2 * wv + 1] = r1 - r0;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_probe_store(gs_d2* out, int64_t nvec) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    gs_d2 v = {1.0, 2.0};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) out[i] = v;
-}
-
-// one wave spinning for `ticks` of the 100 MHz real-time counter: the queue-concurrency probe (gs_probe_queues)
-__global__ __launch_bounds__(64) void k_probe_spin(unsigned long long ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
-}
-
+#include "kernels/common.hip.h"
+#include "kernels/build.hip.h"
+#include "kernels/diag.hip.h"
+#include "kernels/panel.hip.h"
+#include "kernels/chain.hip.h"
+#include "kernels/gemm_nt.hip.h"
+#include "kernels/fused.hip.h"
+#include "kernels/tile.hip.h"
+#include "kernels/solve.hip.h"
+#include "kernels/grad.hip.h"
+#include "kernels/probes.hip.h"

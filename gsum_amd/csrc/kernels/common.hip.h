@@ -1,0 +1,24 @@
+// shared definitions: block size, pivot guard, vector types
+// (part of gsum_kernels.hip.h: included from there, in order; gfx950 only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "gsum_hip.h"
+
+#define GS_NB 128
+// pivot test: LAPACK's dpotf2 rule (p <= 0 or NaN -> info) with a guard of 2 eps: a pivot p of column j also counts as not positive
+// when p <= gs_pivot_guard * A_jj (the original diagonal entry).  Rounds 1-2 shipped 8 eps.  Measured in round 3
+// (tools/gpu_info_sweep.py, the duplicated-point cases of the test suite): with 0 an exactly singular matrix (n = 2048 Matern-5/2,
+// one point duplicated, no nugget) factorises on the device with a pivot of +1e-17 where numpy.linalg.cholesky raises; with 4 eps
+// and more the device refuses 2-D Matern-5/2 matrices that are singular to working precision and that LAPACK still factorises;
+// 1 and 2 eps reproduce LAPACK's outcome on all of them.  Option "pivot_guard_ulps" / GSUM_PIVOT_GUARD_ULPS.
+__device__ double gs_pivot_guard = 2.0 * 2.220446049250313e-16;
+#define GS_BORDER 16
+#define GS_KC 16                  // K chunk staged through LDS (16 doubles = one 128-B line per row)
+#define GS_LSTR (GS_KC + 1)       // odd LDS row stride (17 doubles): the compiler pairs fragment reads into
+                                  // ds_read2_b64, which banks mod 32 dwords -> rows 2 dwords apart, no conflicts
+
+typedef double gs_d4 __attribute__((ext_vector_type(4)));
+typedef double gs_d2 __attribute__((ext_vector_type(2)));
+

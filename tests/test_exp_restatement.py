@@ -2,7 +2,7 @@
 routine numpy's float64 exp dispatches to on AVX512 hosts (Intel SVML __svml_exp8_ha), because that
 routine is not correctly rounded and a single differing ulp in one kernel value moves the uniform-grid
 log-likelihood by 6e-10.  This CPU test pins the restatement: a Python model of
-gs_exp_np (gsum_amd/csrc/gsum_kernels.hip.h) with exactly rounded FMAs must equal np.exp bit for bit.
+gs_exp_np (gsum_amd/csrc/kernels/build.hip.h) with exactly rounded FMAs must equal np.exp bit for bit.
 The same check runs against the device in tests/test_gpu_parity.py::test_kernel_matrix_matches_sklearn."""
 import math
 import re
@@ -18,7 +18,7 @@ H = float.fromhex
 
 def _device_constants():
     """Read the tables / coefficients straight from the HIP source, so the test pins what ships."""
-    src = open(f"{ROOT}/gsum_amd/csrc/gsum_kernels.hip.h").read()
+    src = open(f"{ROOT}/gsum_amd/csrc/kernels/build.hip.h").read()
     th = re.search(r"gs_exp_th\[16\] = \{(.*?)\};", src, re.S).group(1)
     tl = re.search(r"gs_exp_tl\[16\] = \{(.*?)\};", src, re.S).group(1)
     body = src[src.index("double gs_exp_np(double x)"):src.index("double gs_base_value")]
