@@ -1,0 +1,204 @@
+// C ABI: value + gradient pieces (gsum_lml_grad[_batch])
+// (part of gsum_capi.hip: included from there, in order -- one translation unit)
+#pragma once
+// Gradient pieces on top of one fused evaluation (see include/gsum_hip.h).  After the factorisation the workspace
+// holds L, the 128x128 inverses of its diagonal blocks and W^T = RHS^T L^-T in the border rows; then
+//   U = L^-T      right-looking sweep over block columns on an identity (rows below the current block are still
+//                 zero and are skipped: n^3 / 3 flops, the GEMMs of the prediction path)
+//   R^-1 = U U^T  one lower-tile SYRK launch whose tiles start their K loop at their own first row (n^3 / 3 flops)
+//   V^T = W^T U^T (16 x n), then the fused kernel-gradient contractions, one grid row per hyperparameter.
+static int gs_grad_check(gsum_ctx* ctx, const gsum_grad_param* params, int32_t n_params, int32_t d, int32_t k) {
+    if (n_params < 1 || n_params > GSUM_MAX_GRAD) GS_FAIL("n_params must be 1..GSUM_MAX_GRAD");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    for (int p = 0; p < n_params; ++p) {
+        const int code = params[p].code, dim = params[p].dim;
+        if (code >= GSUM_GRAD_TREE_CONST && code <= GSUM_GRAD_TREE_ALPHA) {          // parameters of a kernel tree
+            if (code <= GSUM_GRAD_TREE_WHITE ? (dim < 0 || dim >= GSUM_MAX_OPS) : (dim < 0 || (dim >> 4) >= GSUM_MAX_LEAVES || (dim & 15) >= d))
+                GS_FAIL("gradient parameter of a kernel tree: slot / leaf / dimension out of range");
+            continue;
+        }
+        if (code < GSUM_GRAD_AMPLITUDE || code > GSUM_GRAD_ADDITIVE) GS_FAIL("unknown gradient parameter code");
+        if (code == GSUM_GRAD_LENGTH_DIM && (dim < 0 || dim >= d)) GS_FAIL("gradient parameter dim out of range");
+    }
+    return 0;
+}
+
+// One evaluation with gradient pieces, enqueued on slot `sl` (ctx->cur); results land in the slot's pinned buffers (hres: the
+// fused evaluation's 258 doubles, hgrad: P x 257) when its main stream has drained.
+//   solo: the single-evaluation schedule -- the U = L^-T sweep trails the look-ahead factorisation panel by panel on a stream
+//         of its own, V^T runs beside the SYRK on the panel stream;
+//  !solo: everything in order on the slot's main stream (a batch hides latencies with its other evaluations: gs_lml_on's rule).
+static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, double nugget,
+                           bool solo) {
+    const int64_t n = ctx->in->n;
+    const int d = ctx->in->d;
+    ctx->cur = sl;
+    ctx->chain_events_needed = 1;          // the sweep below trails the factorisation by its evP events (host-enqueued schedule)
+    const int rc_eval = gs_eval_enqueue(ctx, desc, nugget);
+    ctx->chain_events_needed = 0;
+    if (rc_eval) return -1;
+    gsum_mat* m = sl->ws;
+    const int64_t np = m->np, ld = m->ld, ldg = np + GS_BORDER;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int chunks = (int)std::min<int64_t>(128, (n + 63) / 64), rows_per = (int)((n + chunks - 1) / chunks);
+    const size_t o_u = 0, o_r = up((size_t)np * ldg * 8), o_v = o_r + up((size_t)np * ldg * 8), o_q = o_v + up((size_t)16 * ldg * 8),
+                 o_t = o_q + up((size_t)P * n * 16 * 8), o_o = o_t + up((size_t)P * n * 8), o_p = o_o + up((size_t)P * 257 * 8),
+                 total = o_p + up((size_t)P * chunks * 257 * 8);
+    if (gs_reserve(ctx, &sl->gws, &sl->gws_cap, total)) return -1;
+    if (!sl->hgrad) GS_CHECK(hipHostMalloc((void**)&sl->hgrad, (size_t)GSUM_MAX_GRAD * 257 * sizeof(double), hipHostMallocDefault));
+    char* base = (char*)sl->gws;
+    double *U = (double*)(base + o_u), *Ri = (double*)(base + o_r), *Vt = (double*)(base + o_v), *Q = (double*)(base + o_q),
+           *trow = (double*)(base + o_t), *dout = (double*)(base + o_o), *part = (double*)(base + o_p);
+    hipStream_t s = sl->sm;
+    // U = L^-T.  Solo: on a stream of its own, trailing the factorisation: block columns c, c + 1 of the sweep need the factor's
+    // columns c0 .. c0 + 255 and their tables, which are final once the panel chain of that outer step has run (event
+    // evP[c] of the look-ahead schedule).  One factorisation alone is bound by its panel chain, with most of the chip idle
+    // behind it -- the sweep's GEMMs (n^3 / 3 flops) fill that time instead of following it (5.5 ms at n = 8192).
+    const bool trail = solo && ctx->lookahead != 0 && ctx->batch_active < 3;       // the condition under which gs_potrf records evP
+    hipStream_t su = s;
+    if (solo) {
+        if (!sl->su) {
+            // the sweep runs beside the factorisation's main and panel streams: it takes the context's fourth stream (the third group's chain
+            // stream of a batch, idle here) -- a stream created now would share a command-processor pipe with one of those two
+            // (round 4 found the single gradient evaluation at 19.7 ms instead of 14.2 that way)
+            if (sl == &ctx->slots[0] && ctx->wave.g[2].sc) { sl->su = ctx->wave.g[2].sc; sl->own_su = false; }
+            else GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evU, hipEventDisableTiming));
+        }
+        su = sl->su;
+        GS_CHECK(hipEventRecord(sl->evU, s));                                  // everything enqueued so far (nothing of U is in use)
+        if (!trail) GS_CHECK(hipStreamWaitEvent(su, sl->evU, 0));              // no per-panel events: the sweep follows the factorisation
+    }
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, su, U, ldg, (int)np);
+    GS_CHECK(hipGetLastError());
+    // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
+    for (int c = 0; c < m->T; c += 2) {
+        const bool two = c + 1 < m->T;
+        const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
+        if (trail) GS_CHECK(hipStreamWaitEvent(su, sl->evP[c], 0));
+        if (gs_trsm_rows(ctx, su, m, c, U + c0, ldg, c1)) return -1;
+        if (two) {
+            // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
+            if (gs_gemm(ctx, su, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+            if (gs_trsm_rows(ctx, su, m, c + 1, U + c1, ldg, r2)) return -1;
+        }
+        if (r2 < np && gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+            return -1;
+    }
+    hipStream_t sv = s;
+    if (solo) {
+        GS_CHECK(hipEventRecord(sl->evU, su));
+        GS_CHECK(hipStreamWaitEvent(s, sl->evU, 0));
+        // V^T = W^T U^T needs only U: it runs on the panel stream beside the SYRK
+        GS_CHECK(hipEventRecord(sl->evFork, s));
+        if (gs_panel_stream(ctx, sl)) return -1;
+        GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
+        sv = sl->sp;
+    }
+    hipLaunchKernelGGL(k_upper_times_rows, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, sv, U, ldg, (int)np, m->A + np * ld, ld, Vt, ldg);
+    GS_CHECK(hipGetLastError());
+    if (solo) {
+        if (gs_potrf_events(ctx, sl, 1)) return -1;
+        GS_CHECK(hipEventRecord(sl->evP[0], sl->sp));
+    }
+    if (gs_gemm(ctx, s, GS_BULK, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
+    if (solo) GS_CHECK(hipStreamWaitEvent(s, sl->evP[0], 0));
+    gs_grad_params prm;
+    memset(&prm, 0, sizeof prm);
+    for (int p = 0; p < P; ++p) prm.p[p] = params[p];
+    if (desc->n_ops > 0) {
+        hipLaunchKernelGGL(k_grad_contract<true>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+                       prm, Ri, ldg, Vt, ldg, Q, trow);
+    } else {
+        hipLaunchKernelGGL(k_grad_contract<false>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+                       prm, Ri, ldg, Vt, ldg, Q, trow);
+    }
+    GS_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_reduce1, dim3((unsigned)chunks, (unsigned)P), dim3(256), 0, s, Vt, ldg, Q, trow, (int)n, rows_per, part);
+    GS_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_reduce2, dim3((unsigned)P), dim3(256), 0, s, part, chunks, dout);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(sl->hgrad, dout, (size_t)P * 257 * 8, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+// wait for the gradient evaluation pending on a slot (index sl->pending) and copy its pieces out
+static int gs_grad_harvest(gsum_ctx* ctx, gs_slot* sl, int P, double* G_out, double* sld_out, int64_t* info_out, double* trace_out,
+                           double* H_out) {
+    const int i = sl->pending, k = ctx->in->k;
+    if (i < 0) return 0;
+    if (gs_eval_harvest(ctx, sl, G_out, sld_out, info_out)) return -1;      // synchronises the stream
+    for (int p = 0; p < P; ++p) {
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) H_out[(((size_t)i * P + p) * k + a) * k + b] = sl->hgrad[(size_t)p * 257 + a * 16 + b];
+        trace_out[(size_t)i * P + p] = sl->hgrad[(size_t)p * 257 + 256];
+    }
+    return 0;
+}
+
+int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_param* params, int32_t n_params,
+                  const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget, double* G_out,
+                  double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
+    if (!ctx || !desc || !params || !G_out || !sld_out || !info_out || !trace_out || !H_out) return -2;
+    if (gs_grad_check(ctx, params, n_params, d, k)) return -2;
+    int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
+    if (rc) return rc;
+    ctx->in = &ctx->op;
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    gs_slot* sl = &ctx->slots[0];
+    ctx->batch_active = 1;
+    if (gs_grad_enqueue(ctx, sl, desc, params, n_params, nugget, true)) return -1;
+    sl->pending = 0;
+    return gs_grad_harvest(ctx, sl, n_params, G_out, sld_out, info_out, trace_out, H_out);
+}
+
+// The same for a list of kernels with ONE hyperparameter structure (params: n_desc x n_params entries, the weights are per kernel) on one set of inputs (the restarts of a multi-start fit,
+// models.py:641-662; a grid of gradients): independent evaluations pipelined over slots like gsum_lml_resident's, each entirely on
+// its slot's main stream.  Outputs are the single-evaluation outputs stacked: G (n, k, k), sld (n), info (n), trace (n, P), H (n, P, k, k).
+int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_desc, const gsum_grad_param* params, int32_t n_params,
+                        const double* X, int64_t n, int32_t d, const double* RHS, int32_t k, double nugget, double* G_out,
+                        double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
+    if (!ctx || !descs || !params || !G_out || !sld_out || !info_out || !trace_out || !H_out || n_desc < 1) return -2;
+    for (int i = 0; i < n_desc; ++i) {
+        if (gs_grad_check(ctx, params + (size_t)i * n_params, n_params, d, k)) return -2;
+        for (int p = 0; p < n_params; ++p)
+            if (params[(size_t)i * n_params + p].code != params[p].code || params[(size_t)i * n_params + p].dim != params[p].dim)
+                GS_FAIL("gsum_lml_grad_batch: every kernel must have the same hyperparameter structure");
+    }
+    int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
+    if (rc) return rc;
+    ctx->in = &ctx->op;
+    for (int i = 0; i < n_desc; ++i)
+        if (gs_check_desc(ctx, &descs[i], d)) return -2;
+    if (n_desc == 1) {
+        gs_slot* sl = &ctx->slots[0];
+        ctx->batch_active = 1;
+        if (gs_grad_enqueue(ctx, sl, &descs[0], params, n_params, nugget, true)) return -1;
+        sl->pending = 0;
+        return gs_grad_harvest(ctx, sl, n_params, G_out, sld_out, info_out, trace_out, H_out);
+    }
+    // slots: every one owns a workspace matrix and U, R^-1 (3 n^2 doubles in all): within 70 % of the free memory, 8 at most
+    const int64_t np = gs_padded_order(ctx, n);
+    size_t free_b = 0, total_b = 0;
+    GS_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const double per_slot = 3.2 * (double)(np + GS_BORDER) * (double)(np + GS_BORDER) * 8.0;
+    int S = (int)std::min<double>(8.0, std::max(1.0, 0.7 * (double)free_b / per_slot));
+    S = std::max(1, std::min(S, (int)n_desc));
+    S = std::min(S, ctx->batch_slots);                              // one stream each: the context's four streams sit on four pipes
+    if (gs_need_slots(ctx, S)) return -1;
+    ctx->batch_active = std::max(S, 3);        // the batch schedule (no look-ahead, no intra-evaluation events) for every member
+    for (int i = 0; i < n_desc && !rc; ++i) {
+        gs_slot* sl = &ctx->slots[i % S];
+        rc = gs_grad_harvest(ctx, sl, n_params, G_out, sld_out, info_out, trace_out, H_out);
+        if (!rc) rc = gs_grad_enqueue(ctx, sl, &descs[i], params + (size_t)i * n_params, n_params, nugget, false);
+        if (!rc) sl->pending = i;
+    }
+    for (int q = 0; q < S; ++q) {
+        const int r2 = gs_grad_harvest(ctx, &ctx->slots[q], n_params, G_out, sld_out, info_out, trace_out, H_out);
+        if (!rc) rc = r2;
+    }
+    ctx->cur = &ctx->slots[0];
+    ctx->batch_active = 1;
+    return rc;
+}
+

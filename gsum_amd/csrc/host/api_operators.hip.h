@@ -1,0 +1,425 @@
+// C ABI, operator level: kernel build, potrf, triangular solves, predictive pieces, series scaling
+// (part of gsum_capi.hip: included from there, in order -- one translation unit)
+#pragma once
+static int gs_upload_X(gsum_ctx* ctx, gs_inputs* I, const double* X, int64_t n, int d) {
+    if (!X || n <= 0) GS_FAIL("X is NULL or empty");
+    if (gs_reserve(ctx, &I->X, &I->X_cap, (size_t)n * d * sizeof(double))) return -1;
+    GS_CHECK(hipMemcpyAsync(I->X, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
+    I->n = n;
+    I->d = d;
+    return 0;
+}
+
+static int gs_upload_Z(gsum_ctx* ctx, gs_inputs* I, const double* Z, int64_t n, int k) {
+    if (k < 0 || k > GSUM_MAX_RHS) GS_FAIL("k must be 0..GSUM_MAX_RHS");
+    if (k > 0 && !Z) GS_FAIL("RHS is NULL");
+    if (gs_reserve(ctx, &I->Z, &I->Z_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
+    if (k > 0) GS_CHECK(hipMemcpyAsync(I->Z, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
+    I->k = k;
+    return 0;
+}
+
+static int gs_check_series(gsum_ctx* ctx, const gsum_series_scale* sc);
+
+// kernel(X[, Y]) -> host, optionally scaled like TruncationProcess.cov on the device before it leaves (sc != NULL)
+static int gs_kernel_build_host(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
+                                double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x, const double* ref_y,
+                                const double* ratio_y, double* out) {
+    if (!ctx) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (!X || !out || n <= 0) GS_FAIL("bad argument");
+    const bool cross = Y != nullptr;
+    const int64_t cols = cross ? m : n;
+    if (cols <= 0) GS_FAIL("bad argument");
+    if (sc && (gs_check_series(ctx, sc) || !ref_x || !ratio_x || (cross && (!ref_y || !ratio_y)))) {
+        if (ctx->err.empty()) ctx->err = "series scaling needs ref / ratio for both point sets";
+        return -2;
+    }
+    const int64_t ldo = (cols + 1) / 2 * 2;
+    const size_t xb = (size_t)n * d * sizeof(double), yb = cross ? (size_t)m * d * sizeof(double) : 0;
+    const size_t ob = (size_t)n * ldo * sizeof(double), vb = sc ? (size_t)2 * (n + cols) * sizeof(double) : 0;
+    const size_t off_y = (xb + 255) / 256 * 256, off_o = off_y + (yb + 255) / 256 * 256, off_v = off_o + (ob + 255) / 256 * 256;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, off_v + vb)) return -1;
+    char* base = (char*)ctx->scratch;
+    double* dXl = (double*)base;
+    double* dYl = (double*)(base + off_y);
+    double* dO = (double*)(base + off_o);
+    hipStream_t s = ctx->cur->sm;
+    GS_CHECK(hipMemcpyAsync(dXl, X, xb, hipMemcpyHostToDevice, s));
+    if (cross) GS_CHECK(hipMemcpyAsync(dYl, Y, yb, hipMemcpyHostToDevice, s));
+    if (cross ? gs_launch_build<true>(ctx, s, dO, ldo, dXl, dYl, n, m, n, ldo, d, desc, 0.0, 0)
+              : gs_launch_build<false>(ctx, s, dO, ldo, dXl, nullptr, n, n, n, ldo, d, desc, diag_add, 0))
+        return -1;
+    if (sc) {
+        double* v = (double*)(base + off_v);
+        double *d_ref_r = v, *d_rat_r = v + n, *d_ref_c = v + 2 * n, *d_rat_c = v + 2 * n + cols;
+        GS_CHECK(hipMemcpyAsync(d_ref_r, ref_x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_rat_r, ratio_x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_ref_c, cross ? ref_y : ref_x, (size_t)cols * 8, hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(d_rat_c, cross ? ratio_y : ratio_x, (size_t)cols * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((cols + 255) / 256), (unsigned)n), dim3(256), 0, s, dO, ldo, (int)n, (int)cols,
+                           d_ref_r, d_rat_r, d_ref_c, d_rat_c, *sc);
+        GS_CHECK(hipGetLastError());
+    }
+    GS_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), dO, (size_t)ldo * sizeof(double),
+                              (size_t)cols * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int gsum_kernel_build(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                      const double* Y, int64_t m, double diag_add, double* out) {
+    return gs_kernel_build_host(ctx, desc, X, n, d, Y, m, diag_add, nullptr, nullptr, nullptr, nullptr, nullptr, out);
+}
+
+int gsum_kernel_build_series(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Y, int64_t m,
+                             double diag_add, const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                             const double* ref_y, const double* ratio_y, double* out) {
+    if (!ctx || !sc) return -2;
+    return gs_kernel_build_host(ctx, desc, X, n, d, Y, m, diag_add, sc, ref_x, ratio_x, ref_y, ratio_y, out);
+}
+
+int gsum_kernel_build_dev(gsum_ctx* ctx, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                          double diag_add, gsum_mat** out) {
+    if (!ctx || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
+    gsum_mat* m = nullptr;
+    if (gs_mat_alloc(ctx, n, &m)) return -1;
+    if (gs_build_into(ctx, ctx->cur->sm, m, desc, ctx->op.X, d, diag_add, ctx->build_lower_only) ||
+        gs_set_border(ctx, ctx->cur->sm, m, nullptr, 0)) {
+        gs_mat_release(m);
+        return -1;
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    *out = m;
+    return 0;
+}
+
+int gsum_mat_from_host(gsum_ctx* ctx, const double* Ah, int64_t n, gsum_mat** out) {
+    if (!ctx || !out || !Ah) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    gsum_mat* m = nullptr;
+    if (gs_mat_alloc(ctx, n, &m)) return -1;
+    hipError_t e = hipMemcpy2DAsync(m->A, (size_t)m->ld * sizeof(double), Ah, (size_t)n * sizeof(double),
+                                    (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, ctx->cur->sm);
+    if (e == hipSuccess && m->np > n) {
+        hipLaunchKernelGGL(k_pad_identity, dim3((unsigned)((m->np + 255) / 256), (unsigned)(m->np - n)), dim3(256), 0,
+                           ctx->cur->sm, m->A, m->ld, (int)n, (int)m->np);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess || gs_set_border(ctx, ctx->cur->sm, m, nullptr, 0)) {
+        gs_mat_release(m);
+        if (e != hipSuccess) ctx->err = std::string("upload failed: ") + hipGetErrorString(e);
+        return -1;
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    *out = m;
+    return 0;
+}
+
+int gsum_potrf_lower(gsum_ctx* ctx, gsum_mat* A, int64_t* info) {
+    if (!ctx || !A || !info) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (A->factored) GS_FAIL("matrix is already factorised");
+    if (gs_potrf(ctx, A)) return -1;
+    if (gs_finalize(ctx, A)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    *info = (int64_t)ctx->cur->hres[257];
+    if (*info == GS_INFO_CHAIN_ABORT) {
+        ctx->chain_persist = 0;
+        ++ctx->chain_aborts;
+        A->factored = false;
+        ctx->err = "the persistent chain schedule timed out (streams of this process do not run side by side); the matrix is "
+                   "destroyed -- rebuild it and factorise again: the schedule is now switched off (option chain_persist = 0)";
+        return GSUM_ERR_CHAIN_ABORT;        // a runtime failure the caller can recover from: rebuild the matrix, factorise again
+    }
+    if (*info > A->n) *info = A->n;     // cannot happen (identity padding), kept as a guard
+    A->factored = (*info == 0);
+    return 0;
+}
+
+// Forward substitution on the border rows against an existing factor (right-looking, block by block):
+//   W_c = Z_c L_cc^-T ;  Z[:, rest] -= W_c L[rest, c]^T ;  corner accumulates -W W^T.
+static int gs_border_solve(gsum_ctx* ctx, gsum_mat* m) {
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    double* Brow = A + m->np * ld;
+    for (int k = 0; k < m->T; ++k) {
+        const int64_t c0 = (int64_t)k * GS_NB, r0 = c0 + GS_NB;
+        if (gs_trsm_rows(ctx, ctx->cur->sm, m, k, Brow + c0, ld, GS_BORDER)) return -1;
+        if (gs_gemm(ctx, ctx->cur->sm, 2, Brow + r0, ld, Brow + c0, ld, A + r0 * ld + c0, ld, GS_BORDER, naug - r0, GS_NB, 0, 1,
+                    -1.0))
+            return -1;
+    }
+    return 0;
+}
+
+// border rows <- (L^-1 RHS)^T, corner <- -W^T W; skipped when the rows already hold the solve of the same RHS (predict is
+// called again and again with the same training residual: T x 2 dependent launches saved per call)
+static int gs_border_prepare(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int k) {
+    const size_t cnt = (size_t)n * k;
+    if (L->solved_k == k && L->solved_rhs.size() == cnt && !memcmp(L->solved_rhs.data(), RHS, cnt * sizeof(double))) return 0;
+    L->solved_k = -1;
+    if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
+    if (gs_set_border(ctx, ctx->cur->sm, L, ctx->op.Z, k)) return -1;
+    if (gs_border_solve(ctx, L)) return -1;
+    L->solved_rhs.assign(RHS, RHS + cnt);
+    L->solved_k = k;
+    return 0;
+}
+
+int gsum_forward_gram(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* G,
+                      double* sum_log_diag) {
+    if (!ctx || !L || !G || !sum_log_diag) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("forward_gram needs a factorised matrix");
+    if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    GS_CHECK(hipMemsetAsync(ctx->cur->dinfo, 0, sizeof(int), ctx->cur->sm));
+    if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
+    if (gs_finalize(ctx, L)) return -1;
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) G[i * k + j] = ctx->cur->hres[i * 16 + j];
+    *sum_log_diag = ctx->cur->hres[256];
+    return 0;
+}
+
+int gsum_forward_solve(gsum_ctx* ctx, gsum_mat* L, const double* RHS, int64_t n, int32_t k, double* W) {
+    if (!ctx || !L || !W) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("forward_solve needs a factorised matrix");
+    if (n != L->n) GS_FAIL("RHS has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
+    std::vector<double> rows((size_t)k * n);
+    GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), L->A + L->np * L->ld, (size_t)L->ld * sizeof(double),
+                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) W[i * k + c] = rows[(size_t)c * n + i];
+    return 0;
+}
+
+// scipy.linalg.cho_solve((L, True), B) = L^-T (L^-1 B): the forward half is gs_border_solve (border rows = W^T), the
+// backward half runs right-looking from the last block column to the first, in place on the border rows:
+//   X_c^T = W_c^T L_cc^-1 ;  W^T[:, cols < c0] -= X_c^T L[c rows, cols < c0]        (k_back_first / k_back_step)
+int gsum_cho_solve(gsum_ctx* ctx, gsum_mat* L, const double* B, int64_t n, int32_t k, double* X) {
+    if (!ctx || !L || !B || !X) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("cho_solve needs a factorised matrix");
+    if (n != L->n) GS_FAIL("B has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    hipStream_t s = ctx->cur->sm;
+    if (gs_border_prepare(ctx, L, B, n, k)) return -1;
+    L->solved_k = -1;                  // the back-substitution below overwrites the border rows in place
+    if (gs_need_linv(ctx, s, L)) return -1;
+    double* Brow = L->A + L->np * L->ld;
+    const int T = L->T;
+    hipLaunchKernelGGL(k_back_first, dim3(1), dim3(256), 0, s, Brow, L->ld, L->Linv + (size_t)(T - 1) * GS_NB * GS_NB, (T - 1) * GS_NB);
+    GS_CHECK(hipGetLastError());
+    for (int c = T - 1; c >= 1; --c) {
+        hipLaunchKernelGGL(k_back_step, dim3((unsigned)c), dim3(256), 0, s, L->A, L->ld, Brow, L->Linv, c);
+        GS_CHECK(hipGetLastError());
+    }
+    std::vector<double> rows((size_t)k * n);
+    GS_CHECK(hipMemcpy2DAsync(rows.data(), (size_t)n * sizeof(double), Brow, (size_t)L->ld * sizeof(double),
+                              (size_t)n * sizeof(double), (size_t)k, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) X[i * k + c] = rows[(size_t)c * n + i];
+    return 0;
+}
+
+int gsum_tri_multiply(gsum_ctx* ctx, gsum_mat* L, const double* Z, int64_t n, int32_t k, double* out) {
+    if (!ctx || !L || !Z || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (!L->factored) GS_FAIL("tri_multiply needs a factorised matrix");
+    if (n != L->n) GS_FAIL("Z has the wrong number of rows");
+    if (k < 1 || k > GSUM_MAX_RHS) GS_FAIL("k must be 1..GSUM_MAX_RHS");
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)2 * n * 16 * 8)) return -1;
+    double* dZ16 = ctx->scratch;
+    double* dOut = dZ16 + (size_t)n * 16;
+    hipStream_t s = ctx->cur->sm;
+    std::vector<double> pad((size_t)n * 16, 0.0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) pad[(size_t)i * 16 + c] = Z[i * k + c];
+    GS_CHECK(hipMemcpyAsync(dZ16, pad.data(), pad.size() * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_tri_multiply, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, L->A, L->ld, (int)n, dZ16, dOut);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(pad.data(), dOut, pad.size() * 8, hipMemcpyDeviceToHost, s));
+    GS_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < k; ++c) out[i * k + c] = pad[(size_t)i * 16 + c];
+    return 0;
+}
+
+// V^T = kernel(Xs, X) L^-T, one row per new point (m x np, row-major): the same right-looking sweep as
+// the factorisation's panel step, with the rows of kernel(Xs, X) in the role of the rows below the panel.
+static int gs_check_series(gsum_ctx* ctx, const gsum_series_scale* sc) {
+    if (sc->start < 0 || (sc->end >= 0 && sc->end < sc->start)) GS_FAIL("series scale: end must be >= start >= 0");
+    if (sc->n_excluded < 0 || sc->n_excluded > GSUM_MAX_EXCLUDED) GS_FAIL("series scale: too many excluded orders");
+    return 0;
+}
+
+int gsum_mat_scale_series(gsum_ctx* ctx, gsum_mat* A, const gsum_series_scale* sc, const double* ref, const double* ratio) {
+    if (!ctx || !A || !sc || !ref || !ratio) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (A->factored) GS_FAIL("scale_series needs an unfactored matrix");
+    if (gs_check_series(ctx, sc)) return -2;
+    const int64_t n = A->n;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)2 * n * 8)) return -1;
+    double* dref = ctx->scratch;
+    double* drat = dref + n;
+    hipStream_t s = ctx->cur->sm;
+    GS_CHECK(hipMemcpyAsync(dref, ref, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    GS_CHECK(hipMemcpyAsync(drat, ratio, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A->A, A->ld, (int)n, (int)n,
+                       dref, drat, dref, drat, *sc);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                            int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                            const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                            const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW, double* cov_out);
+
+int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                       int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                       double* colsumsq, double* VtW, double* cov_out) {
+    return gs_predict_terms(ctx, L, desc, X, n, d, Xs, m, RHS, k, nullptr, nullptr, nullptr, nullptr, nullptr, colsumsq,
+                            VtW, cov_out);
+}
+
+int gsum_predict_terms_series(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                              int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                              const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                              const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW,
+                              double* cov_out) {
+    if (!ctx || !sc || !ref_x || !ratio_x || !ref_s || !ratio_s) return -2;
+    if (gs_check_series(ctx, sc)) return -2;
+    return gs_predict_terms(ctx, L, desc, X, n, d, Xs, m, RHS, k, sc, ref_x, ratio_x, ref_s, ratio_s, colsumsq, VtW,
+                            cov_out);
+}
+
+static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
+                            int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
+                            const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,
+                            const double* ref_s, const double* ratio_s, double* colsumsq, double* VtW, double* cov_out) {
+    if (!ctx || !L || !X || !Xs || !colsumsq) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    if (gs_check_desc(ctx, desc, d)) return -2;
+    if (!L->factored) GS_FAIL("predict_terms needs a factorised matrix");
+    if (n != L->n || m <= 0) GS_FAIL("bad shapes");
+    if (k < 0 || k > GSUM_MAX_RHS || (k > 0 && (!RHS || !VtW))) GS_FAIL("bad RHS / k");
+    const int64_t np = L->np, ld = L->ld, ldb = np + GS_BORDER;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_xs = 0, o_bt = up((size_t)m * d * 8), o_vw = o_bt + up((size_t)m * ldb * 8),
+                 o_ss = o_vw + up((size_t)m * 16 * 8), o_cv = o_ss + up((size_t)m * 8),
+                 o_sc = o_cv + (cov_out ? up((size_t)m * m * 8) : 0),
+                 total = o_sc + (sc ? up((size_t)2 * (n + m) * 8) : 0);
+    if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, total)) return -1;
+    char* base = (char*)ctx->scratch;
+    double *dXs = (double*)(base + o_xs), *Bt = (double*)(base + o_bt), *dVW = (double*)(base + o_vw),
+           *dSS = (double*)(base + o_ss), *dCov = (double*)(base + o_cv);
+    GS_CHECK(hipMemcpyAsync(dXs, Xs, (size_t)m * d * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+    if (gs_launch_build<true>(ctx, ctx->cur->sm, Bt, ldb, dXs, ctx->op.X, m, n, m, np, d, desc, 0.0, 0)) return -1;
+    if (sc) {
+        // rows of Bt are the new points, columns the conditioning points
+        double* v = (double*)(base + o_sc);
+        double *d_ref_s = v, *d_rat_s = v + m, *d_ref_x = v + 2 * m, *d_rat_x = v + 2 * m + n;
+        GS_CHECK(hipMemcpyAsync(d_ref_s, ref_s, (size_t)m * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_rat_s, ratio_s, (size_t)m * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_ref_x, ref_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        GS_CHECK(hipMemcpyAsync(d_rat_x, ratio_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->cur->sm));
+        hipLaunchKernelGGL(k_scale_series, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m,
+                           (int)n, d_ref_s, d_rat_s, d_ref_x, d_rat_x, *sc);
+        GS_CHECK(hipGetLastError());
+    }
+    // V^T = kernel(Xs, X) L^-T by a right-looking sweep, two block columns per trailing update (K = 256) like the
+    // factorisation: the trailing part of Bt is read and written once per 256 eliminated columns instead of once per 128
+    // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work)
+    const int sib_cfg = m >= 1024 ? GS_BULK : 1;
+    bool deferred = false;                               // the columns right of the next panel still owe the previous panel's update
+    for (int c = 0; c < L->T; c += 2) {
+        const bool two = c + 1 < L->T;
+        const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
+        if (gs_trsm_rows(ctx, ctx->cur->sm, L, c, Bt + c0, ldb, m)) return -1;
+        if (two) {
+            if (gs_gemm(ctx, ctx->cur->sm, sib_cfg, Bt + c1, ldb, Bt + c0, ldb, L->A + c1 * ld + c0, ld, m, GS_NB, GS_NB, 0, 1, -1.0))
+                return -1;
+            if (gs_trsm_rows(ctx, ctx->cur->sm, L, c + 1, Bt + c1, ldb, m)) return -1;
+        }
+        if (r2 >= np) continue;
+        // The batch factorisation's lazy far updates (lazy_far = 2) applied to this sweep: after an even step only the next panel's 256 columns take
+        // this panel's update (K = 256); the step after it applies both panels to everything to its right in ONE K = 512 launch -- half as many passes
+        // over the trailing part of Bt, each at the tile kernel's better K = 512 rate.  Same products in the same ascending-k order per element.
+        const bool pair = ctx->predict_lazy && two && m >= 1024 && np >= ctx->lazy_min_np && c + 3 < L->T && r2 + 2 * GS_NB <= np;
+        if (!deferred && pair) {
+            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
+            deferred = true;
+        } else if (deferred) {
+            const int64_t cp = c0 - 2 * GS_NB;            // the previous panel's first column: [cp, r2) is 512 columns wide
+            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + cp, ldb, L->A + r2 * ld + cp, ld, m, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
+            deferred = false;
+        } else if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+            return -1;
+    }
+    std::vector<double> vw;
+    if (k > 0) {
+        // row sums of squares and V^T W in ONE pass over V^T (k_rowsumsq_vw)
+        if (gs_border_prepare(ctx, L, RHS, n, k)) return -1;
+        hipLaunchKernelGGL(k_rowsumsq_vw, dim3((unsigned)((m + 4 * GS_VW_ROWS - 1) / (4 * GS_VW_ROWS))), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np,
+                           L->A + np * ld, ld, dSS, dVW);
+        GS_CHECK(hipGetLastError());
+        vw.resize((size_t)m * 16);
+        GS_CHECK(hipMemcpyAsync(vw.data(), dVW, (size_t)m * 16 * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
+    } else {
+        hipLaunchKernelGGL(k_rowsumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->cur->sm, Bt, ldb, (int)m, (int)np, dSS);
+        GS_CHECK(hipGetLastError());
+    }
+    GS_CHECK(hipMemcpyAsync(colsumsq, dSS, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
+    if (cov_out) {
+        // V^T V is symmetric: lower tiles only (half the flops of the square product), then mirrored in place
+        if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, dCov, m, Bt, ldb, Bt, ldb, m, m, (int)np, 1, 0, 1.0)) return -1;
+        hipLaunchKernelGGL(k_mirror_lower, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->cur->sm, dCov, m, (int)m);
+        GS_CHECK(hipGetLastError());
+        GS_CHECK(hipMemcpyAsync(cov_out, dCov, (size_t)m * m * 8, hipMemcpyDeviceToHost, ctx->cur->sm));
+    }
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    for (int64_t j = 0; j < m && k > 0; ++j)
+        for (int c = 0; c < k; ++c) VtW[j * k + c] = vw[(size_t)j * 16 + c];
+    return 0;
+}
+
+int gsum_mat_to_host(gsum_ctx* ctx, const gsum_mat* A, double* out) {
+    if (!ctx || !A || !out) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = A->n;
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)n * n * sizeof(double))) return -1;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->cur->sm, A->A, A->ld, (int)n,
+                       ctx->scratch, A->factored ? 1 : 0);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(out, ctx->scratch, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->cur->sm));
+    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    return 0;
+}
+
+int64_t gsum_mat_n(const gsum_mat* A) { return A ? A->n : -1; }
+
+void gsum_mat_free(gsum_ctx* ctx, gsum_mat* A) {
+    if (!A) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->cur->sm);
+        if (ctx->cur->sp) (void)hipStreamSynchronize(ctx->cur->sp);
+    }
+    gs_mat_release(A);
+}
+

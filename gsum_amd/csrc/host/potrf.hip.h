@@ -1,0 +1,516 @@
+// K2: the schedules of ONE factorisation -- host-enqueued look-ahead, persistent chain (k_chain) -- and the read-out
+// (part of gsum_capi.hip: included from there, in order -- one translation unit)
+#pragma once
+// ---- K2: two-level blocked right-looking Cholesky with look-ahead --------------------------------
+// Outer step = a 256-column panel made of two 128-column sub-steps (block columns b, b+1):
+//   diag(b)   : L_bb, L_bb^-1                                  (k_potrf_diag, one workgroup)
+//   trsm(b)   : rows below  <-  rows * L_bb^-T                 (MFMA GEMM against the explicit inverse)
+//   col(b+1)  : block column b+1 -= P_b P_b[b+1]^T             (K = 128, only 128 columns wide)
+//   diag(b+1), trsm(b+1)
+//   la        : next panel's 256 columns -= P P[next]^T        (K = 256)   } P = both sub-panels,
+//   bulk      : everything right of it  -= P P^T, lower tiles  (K = 256)   } 256 contiguous columns
+// The trailing matrix is read and written once per 256 eliminated columns: K = 256 doubles the flops
+// per byte of C traffic over a plain nb = 128 sweep (the K = 128 update was memory-side bound).  With
+// look-ahead, everything but `bulk` runs on the high-priority panel stream, so the panel chain of step
+// s+1 overlaps bulk(s).  Both streams are joined on the main stream at the end.
+static int gs_potrf_events(gsum_ctx* ctx, gs_slot* sl, int T) {
+    if ((int)sl->evP.size() < T + 1) {
+        size_t old = sl->evP.size();
+        sl->evP.resize(T + 1);
+        sl->evM.resize(T + 1);
+        sl->evA.resize(T + 1);
+        for (size_t i = old; i < sl->evP.size(); ++i) {
+            GS_CHECK(hipEventCreateWithFlags(&sl->evP[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evM[i], hipEventDisableTiming));
+            GS_CHECK(hipEventCreateWithFlags(&sl->evA[i], hipEventDisableTiming));
+        }
+    }
+    return 0;
+}
+
+// The high-priority panel stream exists only on slots that run a look-ahead schedule.
+static int gs_panel_stream(gsum_ctx* ctx, gs_slot* sl) {
+    if (!sl->sp) GS_CHECK(hipStreamCreateWithPriority(&sl->sp, hipStreamNonBlocking, ctx->prio_hi));
+    return 0;
+}
+
+static int gs_diag(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
+    gs_slot* sl = ctx->cur;
+    const int64_t c = (int64_t)b * GS_NB;
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, (double)GS_NB * GS_NB * GS_NB / 3.0);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB, m->logdet + b,
+                       sl->dinfo, (int)c, m->diag0 + c, stamps);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// P (M rows x 128 columns, leading dimension ldp)  <-  P L_bb^-T for diagonal block b of the factor m: blocked
+// substitution against the block's tables (k_panel).
+static int gs_trsm_rows(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
+    if (M <= 0) return 0;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, (double)M * GS_NB * GS_NB);
+    hipLaunchKernelGGL(k_panel, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// blocks b, b + 1 (b even) of the factor in one launch, and the rows below them in one launch (see the kernels)
+static int gs_diag256(gsum_ctx* ctx, hipStream_t s, gsum_mat* m, int b) {
+    gs_slot* sl = ctx->cur;
+    const int64_t c = (int64_t)b * GS_NB;
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_DIAG, 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
+    hipLaunchKernelGGL(k_potrf_diag256, dim3(1), dim3(256), 0, s, m->A + c * m->ld + c, m->ld, m->Ltab + (size_t)b * GS_LTAB,
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->logdet + b, sl->dinfo, (int)c, m->diag0 + c, stamps);
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int gs_panel256(gsum_ctx* ctx, hipStream_t s, const gsum_mat* m, int b, double* P, int64_t ldp, int64_t M) {
+    if (M <= 0) return 0;
+    const int rec = gs_prof_begin(ctx, s, GS_PROF_PANEL, 4.0 * (double)M * GS_NB * GS_NB);
+    hipLaunchKernelGGL(k_panel256, dim3((unsigned)((M + 15) / 16)), dim3(64), 0, s, P, ldp, (int)M, m->Ltab + (size_t)b * GS_LTAB,
+                       m->Lsib + (size_t)(b / 2) * GS_LSIB, m->Ltab + (size_t)(b + 1) * GS_LTAB, ctx->kst_ptr, ctx->panel_stats);
+    ctx->kst_ptr = nullptr;
+    gs_prof_end(ctx, s, rec);
+    GS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the explicit 128 x 128 inverses of the diagonal blocks, for the consumers that want them (cho_solve's back-substitution)
+static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
+    if (m->have_linv) return 0;
+    hipLaunchKernelGGL(k_trtri_blocks, dim3((unsigned)m->T), dim3(256), 0, s, m->Ltab, m->Linv);
+    GS_CHECK(hipGetLastError());
+    m->have_linv = true;
+    return 0;
+}
+
+// ---- persistent-chain schedule (see k_chain) ------------------------------------------------------------------------
+// Do kernels of two streams of this process run side by side?  The chain kernel waits for flags that host-enqueued kernels
+// on other streams set, and they wait for its flags: under a tool that serialises dispatches (rocprofv3's kernel trace does)
+// that would stall until the in-kernel timeout.  One spinning wave on one stream, the word it waits for written from another;
+// 20 ms at most, once per context.
+// The probe is the schedule's own triangle: a kernel that spins on the CHAIN's stream (sp) while the main stream (sm) and the
+// auxiliary stream (sa) each deliver a word to it.  (Round 3 probed sm against sa only; with more high-priority streams in the
+// process than hardware queues of that priority -- the groups' chain streams of a batch call created first -- sp and sa came to share
+// a queue, the probe passed and the first single factorisation timed out: found by bench.py's own single-evaluation leg.)
+static int gs_chain_probe(gsum_ctx* ctx, gs_slot* sl) {
+    if (ctx->chain_probe != 0) return 0;
+    unsigned* d = (unsigned*)ctx->dstamps + 64;                 // words 64.. of the 64 x u64 stamp buffer: unused by the stamps' 8 x u64
+    GS_CHECK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned), sl->sm));
+    GS_CHECK(hipEventRecord(sl->evFork, sl->sm));
+    GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
+    GS_CHECK(hipStreamWaitEvent(sl->sa, sl->evFork, 0));
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, sl->sp, (const unsigned*)d, (const unsigned*)(d + 1), 2000000ull, d + 2);     // <= 20 ms
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sm, d, 1u);
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sl->sa, d + 1, 1u);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipStreamSynchronize(sl->sp));
+    GS_CHECK(hipStreamSynchronize(sl->sa));
+    GS_CHECK(hipStreamSynchronize(sl->sm));
+    unsigned seen = 0;
+    GS_CHECK(hipMemcpy(&seen, d + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    ctx->chain_probe = seen ? 1 : -1;
+    return 0;
+}
+
+// the second high-priority stream of the persistent-chain schedule (rest of the panel, near update)
+static int gs_aux_stream(gsum_ctx* ctx, gs_slot* sl) {
+    if (!sl->sa) {
+        GS_CHECK(hipStreamCreateWithPriority(&sl->sa, hipStreamNonBlocking, ctx->prio_hi));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evC, hipEventDisableTiming));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evS, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
+    if (gs_aux_stream(ctx, sl)) return -1;
+    const int S = m->T / 2;
+    if (!m->cflags) GS_CHECK(hipMalloc((void**)&m->cflags, (size_t)(gs_fl_count(S) + S + 4) * sizeof(unsigned)));    // flags | fbwant[S]
+    if (!m->cdump) GS_CHECK(hipMalloc((void**)&m->cdump, (size_t)2 * GS_CH_GMAX * 16 * 256 * sizeof(double)));
+    if (!m->cstamps) {       // S x 16 chain stamps | S x 4 launch starts (preset to all ones: atomicMin) | S x 4 launch ends
+        GS_CHECK(hipMalloc((void**)&m->cstamps, (size_t)S * (GS_CH_STAMPS + GS_CH_KSTAMPS) * sizeof(unsigned long long)));
+        GS_CHECK(hipMemset(m->cstamps, 0, (size_t)S * (GS_CH_STAMPS + GS_CH_KSTAMPS) * sizeof(unsigned long long)));
+    }
+    if (!ctx->lds_attr_done.count((const void*)k_chain)) {
+        GS_CHECK(hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(GS_CH_LDS_DOUBLES * sizeof(double))));
+        ctx->lds_attr_done.insert((const void*)k_chain);
+    }
+    return 0;
+}
+
+static bool gs_chain_wanted(const gsum_ctx* ctx, const gsum_mat* m) {
+    if (ctx->chain_persist == 0 || ctx->chain_events_needed) return false;
+    if (m->T < 4 || (m->T & 1)) return false;
+    return ctx->chain_persist > 0 || m->np >= ctx->chain_min_np;
+}
+
+// Outer step s (panel columns [c0, c0 + 256), trailing matrix from r2 = c0 + 256), K = 256 everywhere:
+//   k_chain            diagonal super-block, the window rows [r2, r2 + W) of the panel, C[window rows][r2, r2 + 256)
+//   sa: rest(s)        rows >= r2 + W of the panel (k_panel256, gated on T1[s])                       -> evP[s]
+//       A(s)           C[rows >= r2 + W][r2, r2 + 256)            gated on the window's first 16 row groups and on FB[s - 1]  -> FA[s]
+//   sm: B(s) + Far(s)  lower tiles of C[rows, columns >= r2 + 256] in one launch, gated on the whole window, after rest(s); the tiles
+//                      of its first 256 columns (B) first, counted in FB[s]
+static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
+    gs_slot* sl = ctx->cur;
+    const int T = m->T, S = T / 2;
+    const int W = ctx->chain_rows >= 512 ? 512 : 256;
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    unsigned* fl = m->cflags;
+    hipStream_t sm = sl->sm, sp = sl->sp, sa = sl->sa;
+    GS_CHECK(hipMemsetAsync(fl, 0, (size_t)gs_fl_count(S) * sizeof(unsigned), sm));
+    // The per-step table fbwant[] (how many first-column tiles of step s's trailing update the chain waits for) is part of what the
+    // chain kernel reads: it is computed and uploaded HERE, in stream order ahead of the launch (round 3 uploaded it after the launch
+    // with a synchronous copy on the null stream -- nothing ordered the two, and a delayed host could have let the chain read a stale
+    // table: ADVICE round 3).  The host copy lives in the matrix object: it outlives the asynchronous copy.
+    struct Plan { int kind; unsigned fb; };          // kind 0: banded B + Far, 1: near-512 (even, lazy), 2: B then Far K = 512 (odd, lazy)
+    std::vector<Plan> plan((size_t)S, Plan{0, 0u});
+    const bool lazy = ctx->chain_lazy > 0 || (ctx->chain_lazy < 0 && m->np >= 10240);
+    const bool near256 = lazy && ctx->chain_lazy != 1;        // 2 / auto: only the next-but-one panel's 256 columns are "near" (the batch schedule's lazy_far = 2)
+    const int NB = 1;                 // (row bands of the trailing update on streams of their own were measured in round 3 and removed in round 4:
+                                      //  2 / 3 / 4 bands 5.84 / 5.87 / 6.79 ms against 5.45 with one at n = 8192)
+    int64_t bound[6];
+    bound[0] = 0;
+    for (int p = 1; p < NB; ++p) bound[p] = (int64_t)(std::sqrt((double)p / NB) * (double)m->np / 256.0 + 0.5) * 256;
+    bound[NB] = naug;
+    auto first_tiles_of = [&](int s) {               // tiles of the first 256 trailing columns over all bands of step s
+        const int64_t r3 = 256 * (int64_t)(s + 2);
+        unsigned cnt = 0;
+        for (int p = 0; p < NB; ++p) {
+            const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
+            if (lo >= hi) continue;
+            if (lo > r3) cnt += 4u * (unsigned)((hi - lo + 127) / 128);               // rectangle: all its first four column tiles
+            else cnt += 4u * (unsigned)((hi - lo + 127) / 128) - 2u;                   // the triangle that starts at r3
+        }
+        return cnt;
+    };
+    {
+        bool deferred = false;
+        for (int s = 0; s + 1 < S; ++s) {
+            const int64_t r3 = 256 * (int64_t)(s + 2), m3 = naug - r3;
+            if (m3 <= 0) continue;
+            const unsigned tm = (unsigned)((m3 + 127) / 128);
+            if (deferred) {
+                plan[s] = Plan{2, near256 ? 4u * tm - 2u : 4u * tm};
+                deferred = false;
+            } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
+                plan[s] = Plan{1, 4u * tm};
+                deferred = true;
+            } else {
+                plan[s] = Plan{0, first_tiles_of(s)};
+            }
+        }
+    }
+    unsigned* fbw = fl + gs_fl_count(S);
+    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0);
+    if (m->fbwant_key != fb_key) {
+        GS_CHECK(hipStreamSynchronize(sm));                      // (a previous upload from the same host buffer has completed)
+        m->fbwant_host.resize((size_t)S);
+        for (int s = 0; s < S; ++s) m->fbwant_host[s] = plan[s].fb;
+        GS_CHECK(hipMemcpyAsync(fbw, m->fbwant_host.data(), m->fbwant_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, sm));
+        m->fbwant_key = fb_key;
+    }
+    GS_CHECK(hipEventRecord(sl->evFork, sm));
+    GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
+    GS_CHECK(hipStreamWaitEvent(sa, sl->evFork, 0));
+    gs_chain_args ca;
+    ca.A = A; ca.ld = ld; ca.np = (int)m->np; ca.naug = (int)naug; ca.S = S; ca.W = W;
+    ca.Ltab = m->Ltab; ca.Lsib = m->Lsib; ca.logdet = m->logdet; ca.diag0 = m->diag0; ca.info = sl->dinfo;
+    ca.dump = m->cdump; ca.flags = fl; ca.fbwant = fl + gs_fl_count(S); ca.stamps = ctx->chain_stamps ? m->cstamps : nullptr;
+    ca.test_abort = ctx->chain_test_abort;
+    ctx->chain_test_abort = 0;
+    {
+        const int rec = gs_prof_begin(ctx, sp, GS_PROF_DIAG, (double)T * GS_NB * GS_NB * GS_NB / 3.0);
+        hipLaunchKernelGGL(k_chain, dim3((unsigned)(1 + W / 64)), dim3(256), GS_CH_LDS_DOUBLES * sizeof(double), sp, ca);
+        gs_prof_end(ctx, sp, rec);
+        GS_CHECK(hipGetLastError());
+    }
+    // nothing of the other streams is dispatched before every workgroup of the chain is resident (see k_wait_flag); the main
+    // stream follows sa through evP[0]
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, sa, (const unsigned*)(fl + GS_FL_RESIDENT), (unsigned)(1 + W / 64),
+                       (const unsigned*)nullptr, 0u, fl);
+    GS_CHECK(hipGetLastError());
+    // the stream waits for chain flags (one spinning wave; see k_wait_flag)
+    auto wait1 = [&](hipStream_t st, int kind, int s, unsigned want) {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want, (const unsigned*)nullptr, 0u, fl);
+    };
+    auto wait2 = [&](hipStream_t st, int kind, int s, unsigned want, int kind2, int s2, unsigned want2) {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want,
+                           (const unsigned*)(fl + gs_fl(kind2, S, s2)), want2, fl);
+    };
+    unsigned long long* kst0 = nullptr;          // launch stamps (diagnostics): a (first start, last end) pair per launch, four per step
+    if (ctx->chain_stamps) {
+        // a launch writes kst[0] (atomicMin) and kst[1] (atomicMax): interleave (start, end) pairs, starts preset to all ones
+        kst0 = m->cstamps + (size_t)S * GS_CH_STAMPS;
+        std::vector<unsigned long long> init((size_t)S * GS_CH_KSTAMPS);
+        for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+        GS_CHECK(hipMemcpyAsync(kst0, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, sm));
+        GS_CHECK(hipStreamSynchronize(sm));      // (diagnostic mode only: the host vector goes out of scope)
+    }
+    auto kstamp = [&](int s, int which) { ctx->kst_ptr = kst0 ? kst0 + ((size_t)s * 4 + which) * 2 : nullptr; };
+    // B and Far are ONE launch on the main stream (k_gemm_ld3, nfirst): B's tiles take the first block ids, start on an empty chip
+    // the moment the previous trailing update ends, are stored write-through and counted in FB[s]; Far's tiles follow in the same
+    // grid.  sa keeps rest -> A, ~70 us per step.  (Measured on the way: rest / A / B on sa with B waiting for Far(s - 1) by event:
+    // the cycle rest -> A -> B -> rest, ~135 us, bound steps 11-20, 5.61 ms; the panel on a stream of its own with two more events
+    // per step made every cross-stream wait 60-90 us, 6.9 ms; B as its own launch in front of Far on the main stream idled the chip
+    // for ~45 us per step in the first third, 5.83 ms.)
+    // LAZY FAR UPDATES (chain_lazy; the batch schedule's idea, worth far more here): one factorisation alone runs its trailing
+    // updates exclusively, and an exclusive K = 256 launch spends 15-20 % of its time on C reads and stores nothing else hides
+    // (47.5 TF/s at M = 7936 against 55 at K = 512: profiles/r03_bulk_cphase.log).  So even steps update only the 512 columns the
+    // next two panels live in ("near", K = 256, rectangular) and the following odd step applies both panels to everything right of
+    // them in ONE K = 512 pass after its own B columns.  Per element the same products in the same order: bit-identical.
+    // ROW BANDS (chain_bands): the trailing update B + Far of a step is cut into row bands with boundaries fixed in absolute
+    // coordinates (equal areas of the whole triangle: X_p = n sqrt(p / NB), rounded to 256), band p on stream p.  A tile of the
+    // trailing matrix depends on its own previous version and on the panel only, so band p of step s + 1 may start when band p
+    // of step s is done, whatever the other bands do: the launches of one step no longer end at a chip-wide barrier, and one
+    // band's tail overlaps another's bulk -- what sixteen evaluations in flight do for a batch (52 TF/s of Cholesky flops there
+    // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
+    hipStream_t sbd[1] = {sm};
+    for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
+        const int k = 2 * s;
+        const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
+        const int Gs = (int)((wend - r2) / 16);
+        if (mr > 0) {
+            wait1(sa, GS_FL_T1, s, 1u);
+            kstamp(s, 0);
+            if (gs_panel256(ctx, sa, m, k, A + wend * ld + c0, ld, mr)) return -1;
+        }
+        // the whole window solved (operands of the trailing update, and of A): the panel of step s is complete ...
+        wait1(sa, GS_FL_WALL, s, (unsigned)Gs);
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_RP, S, s), 1u);
+        // ... and, for A, B(s - 1) (the same region of C)
+        if (mr > 0) {
+            if (s > 0) wait1(sa, GS_FL_FB, s - 1, plan[s - 1].fb);
+            kstamp(s, 1);
+            if (gs_gemm(ctx, sa, GS_BULK, A + wend * ld + r2, ld, A + wend * ld + c0, ld, A + r2 * ld + c0, ld, mr, 256, 256, 0, 1, -1.0)) return -1;
+        }
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, sa, fl + gs_fl(GS_FL_FA, S, s), 1u);
+        GS_CHECK(hipGetLastError());
+        const int64_t r3 = r2 + 256, m3 = naug - r3;
+        if (m3 <= 0) continue;
+        unsigned* fbp = fl + gs_fl(GS_FL_FB, S, s);
+        double* P3 = A + r3 * ld + c0;               // panel rows r3.., this step's 256 columns
+        if (plan[s].kind == 0) {
+            for (int p = 0; p < NB; ++p) {
+                const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
+                if (lo >= hi) continue;
+                hipStream_t sb = sbd[p];
+                wait1(sb, GS_FL_RP, s, 1u);
+                double* Plo = A + lo * ld + c0;          // panel rows of this band
+                if (lo > r3) {
+                    // rectangle: rows [lo, hi) x columns [r3, lo); its first 256 columns are B's
+                    ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128));
+                    ctx->first_done = fbp;
+                    if (p == NB - 1) kstamp(s, 3);
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + r3, ld, Plo, ld, P3, ld, hi - lo, lo - r3, 256, 0, 1, -1.0)) return -1;
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
+                } else {
+                    // the band the trailing matrix starts in: a triangle from r3, first-256-column tiles first
+                    ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128) - 2);
+                    ctx->first_done = fbp;
+                    if (p == NB - 1) kstamp(s, 3); else kstamp(s, 2);
+                    if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
+                }
+            }
+            continue;
+        }
+        wait1(sm, GS_FL_RP, s, 1u);
+        ctx->first_tiles = (int)plan[s].fb;
+        ctx->first_done = fbp;
+        if (plan[s].kind == 1) {
+            // near region only: rows >= r3, columns [r3, r3 + 512) -- or just [r3, r3 + 256); algorithmic work = the lower trapezoid
+            const double wn = near256 ? 256.0 : 512.0;
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * wn - wn * (wn - 1.0));
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, near256 ? 256 : 512, 256, 0, 1, -1.0)) return -1;
+        } else if (near256) {
+            // everything from column r3 on takes the previous panel and this one together (512 contiguous panel columns), the tiles of its first 256 columns first
+            double* P4 = A + r3 * ld + (c0 - 256);
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P4, ld, P4, ld, m3, m3, 512, 1, 1, -1.0)) return -1;
+        } else {
+            // columns [r3, r3 + 256): this panel only (they had the previous one as "near") ...
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * 256.0 - 256.0 * 255.0);
+            kstamp(s, 2);
+            if (gs_gemm(ctx, sm, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, std::min<int64_t>(256, m3), 256, 0, 1, -1.0)) return -1;
+            // ... everything right of them: the previous panel and this one together (512 contiguous panel columns)
+            const int64_t r4 = r3 + 256, m4 = naug - r4;
+            if (m4 > 0) {
+                double* P4 = A + r4 * ld + (c0 - 256);
+                kstamp(s, 3);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, 512, 1, 1, -1.0)) return -1;
+            }
+        }
+    }
+    GS_CHECK(hipEventRecord(sl->evC, sp));
+    GS_CHECK(hipEventRecord(sl->evS, sa));
+    GS_CHECK(hipStreamWaitEvent(sm, sl->evC, 0));
+    GS_CHECK(hipStreamWaitEvent(sm, sl->evS, 0));
+    // a chain that gave up (flags[0] == 1) reports through the info word: INT_MAX is no LAPACK index
+    hipLaunchKernelGGL(k_chain_status, dim3(1), dim3(64), 0, sm, (const unsigned*)fl, sl->dinfo);
+    GS_CHECK(hipGetLastError());
+    m->factored = true;
+    return 0;
+}
+
+static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
+    const int T = m->T;
+    gs_slot* sl = ctx->cur;
+    if (gs_potrf_events(ctx, sl, T)) return -1;
+    m->have_linv = false;                      // (explicit block inverses: built on demand, gs_need_linv)
+    m->have_ltab = true;
+    m->solved_k = -1;
+    const int64_t ld = m->ld, naug = m->np + GS_BORDER;
+    double* A = m->A;
+    GS_CHECK(hipMemsetAsync(sl->dinfo, 0, sizeof(int), sl->sm));
+    {
+        const int rec = gs_prof_begin(ctx, sl->sm, GS_PROF_OTHER, 0.0);
+        hipLaunchKernelGGL(k_save_diag, dim3((unsigned)((m->np + 255) / 256)), dim3(256), 0, sl->sm, A, ld, (int)m->np, m->diag0);
+        gs_prof_end(ctx, sl->sm, rec);
+    }
+    GS_CHECK(hipGetLastError());
+    // look-ahead shortens ONE factorisation; with several in flight the others already fill the GPU and the
+    // extra look-ahead launches only cost (measured: 3 in flight without look-ahead beats 4 with)
+    // Only slot 0 ever runs a look-ahead schedule (the gradient batch's other slots run everything on their one stream).
+    const bool la = ctx->lookahead != 0 && ctx->batch_active < 3 && sl == &ctx->slots[0];
+    ctx->bulk_pad_now = false;
+    if (la && gs_panel_stream(ctx, sl)) return -1;
+    if (la && gs_chain_wanted(ctx, m)) {
+        if (gs_chain_resources(ctx, sl, m)) return -1;
+        if (gs_chain_probe(ctx, sl)) return -1;
+        if (ctx->chain_probe > 0) return gs_potrf_chain(ctx, m);
+    }
+    hipStream_t sp = la ? sl->sp : sl->sm;
+    hipStream_t sm = sl->sm, sb = sl->sm;
+    if (la) {
+        GS_CHECK(hipEventRecord(sl->evFork, sm));
+        GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
+    }
+    // panel GEMMs (TRSM against the block inverse, sibling column) stay on the low-latency 32x128 tile in every mode.
+    // (In a batch the LDS-direct 128x128 tile is 1 % cheaper overall, but then one kernel symbol would serve two
+    // roles and rocprofv3's per-kernel average would no longer be the bulk update's.)
+    const int ccfg = 1;
+    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
+    int prev = -1;                                   // outer step whose bulk update is still in flight
+    bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
+    for (int k = 0; k < T; k += 2) {
+        const bool two = k + 1 < T;
+        const int64_t c0 = (int64_t)k * GS_NB, c1 = c0 + GS_NB;
+        const int64_t r2 = two ? c1 + GS_NB : c1;   // first row / column of the trailing matrix
+        const int Kp = two ? 2 * GS_NB : GS_NB;
+        double* Pa = A + c1 * ld + c0;              // rows below diagonal block k, border included
+        if (two && (ctx->chain_fused > 0 || (ctx->chain_fused < 0 && ctx->batch_active >= 3))) {
+            // both diagonal blocks in one launch, then both panels of the rows below in one
+            if (gs_diag256(ctx, sp, m, k)) return -1;
+            if (gs_panel256(ctx, sp, m, k, A + r2 * ld + c0, ld, naug - r2)) return -1;
+        } else {
+            // ---- sub-step a
+            if (gs_diag(ctx, sp, m, k)) return -1;
+            if (gs_trsm_rows(ctx, sp, m, k, Pa, ld, naug - c1)) return -1;
+            if (two) {
+                // block column k+1 (rows c1..) -= P_a P_a[first 128 rows]^T, then its own diag + trsm
+                if (gs_gemm(ctx, sp, ccfg, A + c1 * ld + c1, ld, Pa, ld, Pa, ld, naug - c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                if (gs_diag(ctx, sp, m, k + 1)) return -1;
+                double* Pb = A + r2 * ld + c1;
+                if (gs_trsm_rows(ctx, sp, m, k + 1, Pb, ld, naug - r2)) return -1;
+            }
+        }
+        // ---- trailing update with the whole panel: rows r2.., columns c0..c0+Kp-1
+        double* P = A + r2 * ld + c0;
+        const int64_t mrest = naug - r2;            // >= 16 (the border)
+        if (!la) {
+            // Batch mode (latency is irrelevant, the bulk kernel's fixed per-launch cost is not): lazy far updates.
+            // Even outer steps update only the 512 columns the next two panels live in (K = 256) and defer the rest;
+            // the following odd step applies both panels to the deferred region in ONE pass (K = 512: half the C
+            // traffic and launch overhead there).  Every element still subtracts the same products in the same
+            // ascending-k order, so results do not change.
+            const int64_t w2 = 2 * GS_NB;
+            // measured (lazy_far = 1 against none): -2.3 % per evaluation at n = 8192, neutral at 7000, +8 % (extra launches) at 4096 and below;
+            // lazy_far = 2 against 1 at n = 8192, same process: 303.4-303.8 against 297.6-298.7 evals/s (+1.9 %), profiles/r03_lazy_far2_ab.log
+            const bool full_next = ctx->lazy_far && m->np >= ctx->lazy_min_np && two && r2 + 2 * w2 <= m->np;   // a full panel follows, and one more
+            if (!deferred && full_next) {
+                // near region only: rows >= r2, columns [r2, r2 + 512) -- or, lazy_far = 2, just the next panel's 256 columns: the panel after that then
+                // takes both updates in the K = 512 launch below, which moves two thirds of the near region's flops out of skinny K = 256 launches and
+                // saves one launch per pair of steps; algorithmic work = the lower trapezoid
+                const int64_t wn = ctx->lazy_far == 2 ? w2 : 2 * w2;
+                ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * wn - (double)wn * (wn - 1));
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+                deferred = true;
+                continue;
+            }
+            if (deferred && ctx->lazy_far == 2) {
+                // everything from column r2 on: the previous panel and this one together (contiguous 512 columns), lower triangle
+                double* P2 = A + r2 * ld + (c0 - w2);
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P2, ld, P2, ld, mrest, mrest, (int)(w2 + Kp), 1, 1, -1.0)) return -1;
+                deferred = false;
+                continue;
+            }
+            if (deferred) {
+                // columns [r2, r2 + 256): this panel only (they had the previous one as "near")
+                ctx->next_algo_flops = (double)Kp * (2.0 * (double)mrest * w2 - (double)w2 * (w2 - 1));
+                if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, w2, Kp, 0, 1, -1.0)) return -1;
+                // everything right of them: the previous panel and this one together (contiguous 512 columns)
+                const int64_t rf = r2 + w2, mf = naug - rf;
+                double* P2 = A + rf * ld + (c0 - w2);
+                if (gs_gemm(ctx, sm, GS_BULK, A + rf * ld + rf, ld, P2, ld, P2, ld, mf, mf, (int)(w2 + Kp), 1, 1, -1.0)) return -1;
+                deferred = false;
+                continue;
+            }
+            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
+            continue;
+        }
+        GS_CHECK(hipEventRecord(sl->evP[k], sp));
+        if (r2 < m->np) {
+            const int64_t wn = std::min<int64_t>(2 * GS_NB, m->np - r2);     // width of the next panel
+            // look-ahead columns: need the previous bulk update to have finished with THEM (evA: see below)
+            if (prev >= 0) GS_CHECK(hipStreamWaitEvent(sp, sl->evA[prev], 0));
+            if (gs_gemm(ctx, sp, ccfg, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, wn, Kp, 0, 1, -1.0)) return -1;
+            const int64_t r3 = r2 + wn, m3 = naug - r3;
+            double* P3 = A + r3 * ld + c0;
+            GS_CHECK(hipStreamWaitEvent(sb, sl->evP[k], 0));
+            // The bulk update goes out in two launches: first the 256 columns the panel AFTER the next one lives in, then
+            // everything right of them.  The next step's look-ahead update waits for the first only, so the chain is a
+            // whole outer step ahead of the bulk stream instead of starting when the previous bulk update ends: in the
+            // first third of a factorisation (bulk-bound) the chain then hides under the bulk update completely.
+            const int64_t wa = std::min<int64_t>(2 * GS_NB, m->np - r3);
+            if (ctx->la_depth2 && wa > 0 && m3 > wa) {
+                ctx->next_algo_flops = (double)Kp * (2.0 * (double)m3 * wa - (double)wa * (wa - 1));
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, wa, Kp, 0, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(sl->evA[k], sb));
+                const int64_t r4 = r3 + wa, m4 = naug - r4;
+                double* P4 = A + r4 * ld + c0;
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r4 * ld + r4, ld, P4, ld, P4, ld, m4, m4, Kp, 1, 1, -1.0)) return -1;
+            } else {
+                if (gs_bulk_la(ctx, sb, GS_BULK, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, m3, Kp, 1, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(sl->evA[k], sb));
+            }
+            GS_CHECK(hipEventRecord(sl->evM[k], sb));
+            prev = k;
+        } else {
+            // last panel: only the 16x16 corner (the Gram matrix) is left
+            GS_CHECK(hipStreamWaitEvent(sm, sl->evP[k], 0));
+            if (gs_gemm(ctx, sm, GS_BULK, A + r2 * ld + r2, ld, P, ld, P, ld, mrest, mrest, Kp, 1, 1, -1.0)) return -1;
+        }
+    }
+    m->factored = true;
+    return 0;
+}
+
+static int gs_finalize(gsum_ctx* ctx, gsum_mat* m) {
+    const int rec = gs_prof_begin(ctx, ctx->cur->sm, GS_PROF_OTHER, 0.0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, ctx->cur->sm, m->A, m->ld, (int)m->np, m->logdet, m->T, ctx->cur->dinfo,
+                       ctx->cur->dres);
+    gs_prof_end(ctx, ctx->cur->sm, rec);
+    GS_CHECK(hipGetLastError());
+    GS_CHECK(hipMemcpyAsync(ctx->cur->hres, ctx->cur->dres, 258 * sizeof(double), hipMemcpyDeviceToHost, ctx->cur->sm));
+    return 0;
+}
+

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The far (bulk-stream) launches of one batch call, restated from gs_wave_bulk_plan / gs_lml_wave (gsum_capi.hip): for every
+"""The far (bulk-stream) launches of one batch call, restated from gs_wave_bulk_plan / gs_lml_wave (csrc/host/wave.hip.h): for every
 k_gemm_ld3g launch its members, M, K, algorithmic flops and algorithmic HBM bytes.
    algorithmic bytes of a member = its C lower triangle read and written once (16 B per element of M (M + 1) / 2) + its M x K panel
    rows read once (both operands of the symmetric product are those rows)."""
