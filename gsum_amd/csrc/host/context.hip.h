@@ -127,7 +127,9 @@ struct gsum_ctx {
     int chain_stamps = 0;            // record the chain kernel's per-step realtime stamps (gsum_debug_chain_stamps)
     int chain_probe = 0;             // two-stream concurrency probe: 0 not run, 1 streams run side by side, -1 they do not (a
                                      // profiler serialises dispatches): the chain schedule would deadlock until its timeout
-    int chain_events_needed = 0;     // the gradient path trails the factorisation by evP events: host-enqueued schedule only
+    int chain_events_needed = 0;     // 1: a caller trails the factorisation by evP events (host-enqueued schedule only); 2: the gradient
+                                     // path: either schedule, it trails the persistent chain by the chain's own flags
+    bool last_potrf_chain = false;   // the last gs_potrf took the persistent-chain schedule
     int chain_aborts = 0;            // factorisations whose chain kernel timed out (the schedule is then switched off)
     int chain_test_abort = 0;        // test hook: the chain gives up at this outer step of its NEXT factorisation (one shot)
     unsigned long long* kst_ptr = nullptr;   // diagnostics: start / end stamp pair of the NEXT bulk (cfg 7) / k_panel256 launch

@@ -147,7 +147,7 @@ static int gs_chain_resources(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m) {
 }
 
 static bool gs_chain_wanted(const gsum_ctx* ctx, const gsum_mat* m) {
-    if (ctx->chain_persist == 0 || ctx->chain_events_needed) return false;
+    if (ctx->chain_persist == 0 || ctx->chain_events_needed == 1) return false;
     if (m->T < 4 || (m->T & 1)) return false;
     return ctx->chain_persist > 0 || m->np >= ctx->chain_min_np;
 }
@@ -382,11 +382,15 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     // Only slot 0 ever runs a look-ahead schedule (the gradient batch's other slots run everything on their one stream).
     const bool la = ctx->lookahead != 0 && ctx->batch_active < 3 && sl == &ctx->slots[0];
     ctx->bulk_pad_now = false;
+    ctx->last_potrf_chain = false;
     if (la && gs_panel_stream(ctx, sl)) return -1;
     if (la && gs_chain_wanted(ctx, m)) {
         if (gs_chain_resources(ctx, sl, m)) return -1;
         if (gs_chain_probe(ctx, sl)) return -1;
-        if (ctx->chain_probe > 0) return gs_potrf_chain(ctx, m);
+        if (ctx->chain_probe > 0) {
+            ctx->last_potrf_chain = true;
+            return gs_potrf_chain(ctx, m);
+        }
     }
     hipStream_t sp = la ? sl->sp : sl->sm;
     hipStream_t sm = sl->sm, sb = sl->sm;
