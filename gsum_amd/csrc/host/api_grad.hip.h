@@ -110,7 +110,7 @@ static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* d
         GS_CHECK(hipStreamWaitEvent(sl->sp, sl->evFork, 0));
         sv = sl->sp;
     }
-    hipLaunchKernelGGL(k_upper_times_rows, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, sv, U, ldg, (int)np, m->A + np * ld, ld, Vt, ldg);
+    hipLaunchKernelGGL(k_upper_times_rows, dim3((unsigned)((np + 15) / 16)), dim3(256), 0, sv, U, ldg, (int)np, m->A + np * ld, ld, Vt, ldg);
     GS_CHECK(hipGetLastError());
     if (solo) {
         if (gs_potrf_events(ctx, sl, 1)) return -1;
@@ -122,10 +122,10 @@ static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* d
     memset(&prm, 0, sizeof prm);
     for (int p = 0; p < P; ++p) prm.p[p] = params[p];
     if (desc->n_ops > 0) {
-        hipLaunchKernelGGL(k_grad_contract<true>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+        hipLaunchKernelGGL((k_grad_contract<true, 1>), dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
     } else {
-        hipLaunchKernelGGL(k_grad_contract<false>, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
+        hipLaunchKernelGGL((k_grad_contract<false, 2>), dim3((unsigned)((n + 7) / 8), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
     }
     GS_CHECK(hipGetLastError());

@@ -44,66 +44,82 @@ __device__ __forceinline__ double gs_kernel_grad(const gsum_kernel_desc& desc, c
 // TREE: the descriptor is a Sum / Product tree (n_ops > 0).  Two instantiations: with the tree walk in the same kernel the flattened
 // form -- every kernel the reference itself constructs -- ran at 218 registers instead of 146 (two waves per SIMD instead of three) and the
 // whole gradient evaluation 5 % slower.
-template <bool TREE>
+// R rows of dR_p per wave (round 4): the 16 loads of V^T (and X_j) per column j then feed R x 16 FMAs -- with one row per wave those
+// L1-served loads bound the kernel (1.3 ms per parameter at n = 8192).  Per row the same terms in the same order as before.
+template <bool TREE, int R>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, int d, gsum_kernel_desc desc, gs_grad_params prm,
                                                         const double* Rinv, int64_t ldr, const double* Vt, int64_t ldv,
                                                         double* Q, double* trow) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     const int p = blockIdx.y;
-    if (i >= n) return;
+    if (i0 >= n) return;
     const gsum_grad_param pr = prm.p[p];
-    double xi[GSUM_MAX_D], inv_ls[GSUM_MAX_D];
+    double xi[R][GSUM_MAX_D], inv_ls[GSUM_MAX_D];
 #pragma unroll
     for (int m = 0; m < GSUM_MAX_D; ++m) {
         inv_ls[m] = 1.0 / (desc.anisotropic ? desc.length_scale[m < d ? m : 0] : desc.length_scale[0]);
-        xi[m] = m < d ? X[(int64_t)i * d + m] : 0.0;
-    }
-    double acc[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
-    double tr = 0.0;
+        for (int r = 0; r < R; ++r) xi[r][m] = (m < d && i0 + r < n) ? X[(int64_t)(i0 + r) * d + m] : 0.0;
+    }
+    double acc[R][16], tr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        tr[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
+    }
     for (int j = lane; j < n; j += 64) {
-        double s = 0.0, dsel = 0.0;
+        double xj[GSUM_MAX_D];
 #pragma unroll
-        for (int m = 0; m < GSUM_MAX_D; ++m) {
-            if (m < d) {
-                const double u = (xi[m] - X[(int64_t)j * d + m]) * inv_ls[m];
-                const double dmm = u * u;
-                s += dmm;
-                if (m == pr.dim) dsel = dmm;
+        for (int m = 0; m < GSUM_MAX_D; ++m) xj[m] = m < d ? X[(int64_t)j * d + m] : 0.0;
+        double g[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = i0 + r;
+            double s = 0.0, dsel = 0.0;
+#pragma unroll
+            for (int m = 0; m < GSUM_MAX_D; ++m) {
+                if (m < d) {
+                    const double u = (xi[r][m] - xj[m]) * inv_ls[m];
+                    const double dmm = u * u;
+                    s += dmm;
+                    if (m == pr.dim) dsel = dmm;
+                }
             }
-        }
-        const double dm = pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel;
-        double g;
-        if constexpr (TREE) {                    // a general tree: the same walk as the kernel build, with dual numbers
-            double xj[GSUM_MAX_D];
-#pragma unroll
-            for (int m = 0; m < GSUM_MAX_D; ++m) xj[m] = m < d ? X[(int64_t)j * d + m] : 0.0;
-            (void)gs_tree_eval(desc, xi, xj, d, i == j, &pr, &g);
-        } else {
-            g = gs_kernel_grad(desc, pr, s, dm, i == j);
+            const double dm = pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel;
+            if constexpr (TREE) (void)gs_tree_eval(desc, xi[r], xj, d, i == j, &pr, &g[r]);      // a general tree: the kernel build's walk, with dual numbers
+            else g[r] = gs_kernel_grad(desc, pr, s, dm, i == j);
+            if (i < n && j <= i) tr[r] = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g[r], tr[r]);
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(g, Vt[(int64_t)c * ldv + j], acc[c]);
-        if (j <= i) tr = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g, tr);
+        for (int c = 0; c < 16; ++c) {
+            const double v = Vt[(int64_t)c * ldv + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][c] = __builtin_fma(g[r], v, acc[r][c]);
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double v = acc[c];
+    for (int r = 0; r < R; ++r) {
+        if (i0 + r >= n) break;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[c] = v;
+        for (int c = 0; c < 16; ++c) {
+            double v = acc[r][c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[r][c] = v;
+        }
+        double t = tr[r];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane < 16) {
+            double v = acc[r][0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[r][c] : v;
+            Q[((int64_t)p * n + i0 + r) * 16 + lane] = v;
+        }
+        if (lane == 0) trow[(int64_t)p * n + i0 + r] = t;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tr += __shfl_xor(tr, off, 64);
-    if (lane < 16) {
-        double v = acc[0];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
-        Q[((int64_t)p * n + i) * 16 + lane] = v;
-    }
-    if (lane == 0) trow[(int64_t)p * n + i] = tr;
 }
 
 // H_p = V^T Q_p (16 x 16) and sum_i trow_p[i], in two deterministic stages.  Stage 1 (grid: chunks x P): chunk c

@@ -164,30 +164,43 @@ __global__ __launch_bounds__(256) void k_tri_multiply(const double* L, int64_t l
 // butterfly reduction.  (As a 16 x n x n GEMM on 16 x 256 tiles this had 32 workgroups with K = n each: 3.7 ms at n = 8192.)
 __global__ __launch_bounds__(256) void k_upper_times_rows(const double* U, int64_t ldu, int n, const double* Wt, int64_t ldw,
                                                            double* Vt, int64_t ldv) {
+    // FOUR rows of U per wave (round 4): a lane's 16 loads of W^T per k then feed 64 FMAs instead of 16 -- with one row per wave the kernel
+    // was bound by those (L1-served) loads, 1.7 ms at n = 8192 for 268 MB of U.  Per row the same terms in the same order as before.
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    double acc[16];
+    const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (j0 >= n) return;
+    double acc[4][16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
-    const double* row = U + (int64_t)j * ldu;
-    for (int k = (j & ~63) + lane; k < n; k += 64) {
-        const double u = k >= j ? row[k] : 0.0;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = __builtin_fma(u, Wt[(int64_t)c * ldw + k], acc[c]);
+        for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
+    const double* row = U + (int64_t)j0 * ldu;
+    for (int k = (j0 & ~63) + lane; k < n; k += 64) {
+        double u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = (j0 + r < n && k >= j0 + r) ? row[(int64_t)r * ldu + k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double w = Wt[(int64_t)c * ldw + k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_fma(u[r], w, acc[r][c]);
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double v = acc[c];
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[c] = v;
-    }
-    if (lane < 16) {
-        double v = acc[0];
+        for (int c = 0; c < 16; ++c) {
+            double v = acc[r][c];
 #pragma unroll
-        for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[c] : v;
-        Vt[(int64_t)lane * ldv + j] = v;
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[r][c] = v;
+        }
+        if (lane < 16 && j0 + r < n) {
+            double v = acc[r][0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[r][c] : v;
+            Vt[(int64_t)lane * ldv + j0 + r] = v;
+        }
     }
 }
 
