@@ -76,6 +76,8 @@ int gsum_init(int device, gsum_ctx** out) {
     ctx->wave.sb = ctx->cur->sm;
     if ((e = hipMalloc((void**)&ctx->dstamps, 64 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
     (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
+#ifdef GSUM_LAB
+    // (lab build only: the product library reads no environment variable -- its ten options are set through gsum_set_option)
     const char* la = getenv("GSUM_LOOKAHEAD");
     if (la) ctx->lookahead = atoi(la);
     const char* pg = getenv("GSUM_PIVOT_GUARD_ULPS");
@@ -85,6 +87,7 @@ int gsum_init(int device, gsum_ctx** out) {
     }
     const char* cp = getenv("GSUM_CHAIN_PERSIST");
     if (cp) ctx->chain_persist = atoi(cp) < 0 ? -1 : (atoi(cp) != 0);
+#endif
     *out = ctx;
     return 0;
 }

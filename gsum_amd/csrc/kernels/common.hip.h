@@ -12,7 +12,7 @@
 // (tools/gpu_info_sweep.py, the duplicated-point cases of the test suite): with 0 an exactly singular matrix (n = 2048 Matern-5/2,
 // one point duplicated, no nugget) factorises on the device with a pivot of +1e-17 where numpy.linalg.cholesky raises; with 4 eps
 // and more the device refuses 2-D Matern-5/2 matrices that are singular to working precision and that LAPACK still factorises;
-// 1 and 2 eps reproduce LAPACK's outcome on all of them.  Option "pivot_guard_ulps" / GSUM_PIVOT_GUARD_ULPS.
+// 1 and 2 eps reproduce LAPACK's outcome on all of them.  Option "pivot_guard_ulps" (lab build: also GSUM_PIVOT_GUARD_ULPS).
 __device__ double gs_pivot_guard = 2.0 * 2.220446049250313e-16;
 #define GS_BORDER 16
 #define GS_KC 16                  // K chunk staged through LDS (16 doubles = one 128-B line per row)

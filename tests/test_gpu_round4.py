@@ -263,3 +263,33 @@ def test_mixed_calls_on_one_context_stay_bit_stable():
     rec = json.loads([line for line in run.stdout.splitlines() if line.startswith("{")][-1])
     assert rec["chain_aborts"] == 0 and rec["chain_probe"] == 1
     assert all(rec["calls"].get(k, 0) > 0 for k in ("batch", "single", "grad", "gradbatch", "factorize", "two")), rec
+
+
+def test_launch_list_restatement_matches_the_library(lab):
+    """tools/wave_plan.py restates the far launches of a batch call (members, M, K per launch) to price the PMC traffic of
+    profiles/r04_gemm_pmc.json in algorithmic bytes.  Its flops must be the library's own record of a profiled call, launch for launch in
+    total: same count, same sum."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from wave_plan import far_launches
+    from sklearn.gaussian_process.kernels import RBF
+    ctx = lab
+    n = 3000
+    X = 0.1 * np.arange(n)[:, None]
+    Z = np.concatenate([np.random.RandomState(0).randn(n, 3), np.ones((n, 1))], axis=1)
+    ctx.set_inputs(X, Z)
+    old = ctx.get_option("medium_path")
+    try:
+        ctx.set_option("medium_path", 0)
+        descs = [gsum_amd.describe_kernel(RBF(0.2 + 0.001 * i), 1) for i in range(11)]
+        ctx.lml_resident(descs, 1e-10)
+        ctx.set_option("profile_gemm", 1)
+        ctx.kernel_profile()
+        ctx.lml_resident(descs, 1e-10)
+        prof = ctx.kernel_profile()
+    finally:
+        ctx.set_option("profile_gemm", 0)
+        ctx.set_option("medium_path", old)
+    plan = far_launches(n, [4, 4, 3])
+    assert prof["bulk_update"]["launches"] == len(plan)
+    assert prof["bulk_update"]["flops"] == float(sum(x["flops"] for x in plan))

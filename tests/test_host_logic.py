@@ -523,3 +523,16 @@ def test_describe_gradients_equals_describing_the_clones():
         for a, b in zip(got, want):
             assert len(a) == len(b) == len(kern.theta)
             assert all(bytes(x) == bytes(y) for x, y in zip(a, b)), kern
+
+
+def test_product_library_reads_no_environment_variable():
+    """"Runtime configuration: none".  The product library's schedules are set through gsum_set_option alone; the GSUM_*
+    overrides of rounds 1-3 (look-ahead, chain schedule, pivot guard) are compiled into the lab build only, and nothing reads
+    GPU_MAX_HW_QUEUES."""
+    import subprocess
+    lib = os.path.join(ROOT, "gsum_amd", "libgsum_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    text = subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True).stdout
+    for name in ("GSUM_LOOKAHEAD", "GSUM_CHAIN_PERSIST", "GSUM_PIVOT_GUARD_ULPS", "GPU_MAX_HW_QUEUES"):
+        assert name not in text, name
