@@ -89,6 +89,7 @@ struct gsum_ctx {
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
+    int grad_batch_wave = 1;         // gradient batches: the factorisations on the grouped schedule (gs_grad_batch_wave)
     int batch_slots = 4;             // gradient evaluations kept in flight by gsum_lml_grad_batch, one stream each: the context's four
                                      // streams on four pipes (n = 8192: 14.3 / 13.3 / 12.4 / 12.2 / 12.4 ms each with 2 / 3 / 4 / 5 / 8;
                                      // value-only batches do not use slots: gs_lml_wave)

@@ -130,6 +130,16 @@ static int gs_wave_fill_chain(const gs_wave_group* g, gs_wv_chain_args* a, bool 
     return run;
 }
 
+// how many workspace matrices of this order the groups may hold: within 70 % of what is free (plus what the groups already hold)
+static int gs_wave_fit(gsum_ctx* ctx, int64_t n, int64_t np) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    double held = 0.0;
+    for (int i = 0; i < GS_WV_GROUPS; ++i)
+        if (ctx->wave.g[i].cap && ctx->wave.g[i].n == n) held += ctx->wave.g[i].cap * gs_wave_ws_bytes(np);
+    return (int)std::min<double>(1e6, (0.7 * (double)free_b + held) / gs_wave_ws_bytes(np));
+}
+
 static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out, double* sld_out,
                        int64_t* info_out) {
     const int64_t n = ctx->in->n, np = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB), ld = np + GS_BORDER, naug = np + GS_BORDER;
@@ -141,13 +151,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
         B = (n_kernels + G - 1) / G;
     }
     {
-        // group workspaces within 70 % of what is free (plus what the groups already hold)
-        size_t free_b = 0, total_b = 0;
-        GS_CHECK(hipMemGetInfo(&free_b, &total_b));
-        double held = 0.0;
-        for (int i = 0; i < GS_WV_GROUPS; ++i)
-            if (ctx->wave.g[i].cap && ctx->wave.g[i].n == n) held += ctx->wave.g[i].cap * gs_wave_ws_bytes(np);
-        const int fit = (int)std::min<double>(1e6, (0.7 * (double)free_b + held) / gs_wave_ws_bytes(np));
+        const int fit = gs_wave_fit(ctx, n, np);
         if (fit < 1) GS_FAIL("not enough device memory for one workspace matrix");
         if (G * B > fit) {
             G = std::max(1, std::min(G, fit));
@@ -189,7 +193,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
     // latency-bound last steps is paced by the other's 5-ms updates; 80 evaluations on 2 x 10: 315 evals/s in phase, 305 / 300
     // with the second group 4 / 8 macro-steps behind (the chains of the first and last macro-steps then run with nothing beside them).
     const int shift = !several_rounds ? 0 : (ctx->wave_shift > 0 ? std::min(ctx->wave_shift, S) : 0);
-    for (int i = 0; i < G; ++i) {
+    for (int i = 0; i < GS_WV_GROUPS; ++i) {           // (all groups: after the call cnt / first_eval say which members a group's workspaces hold)
         gs_wave_group* g = &wv->g[i];
         g->active = false;
         g->cnt = g->step = 0;
