@@ -185,6 +185,37 @@ def golden_lml(n, r):
     return None
 
 
+def gradient_leg(ctx, X, Z, n):
+    """value + analytic gradient pieces of one evaluation (what every L-BFGS step of `fit` costs: gsum_lml_grad)
+    and of eight kernels in one call (the restarts of a multi-start fit advance in lock step: gsum_lml_grad_batch), same inputs as the
+    headline workload; C * RBF + fixed WhiteKernel, two free hyperparameters."""
+    import gsum_amd
+    from gsum_amd.kernels import describe_gradient, describe_kernel
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    base = C(1.0) * RBF(0.2) + WhiteKernel(1e-10, noise_level_bounds="fixed")
+    kernels = [base.clone_with_theta(base.theta + 0.01 * i) for i in range(8)]
+    descs, prms = [describe_kernel(k, 1) for k in kernels], [describe_gradient(k, 1) for k in kernels]
+    ctx.lml_grad(descs[0], prms[0], X, Z, 1e-10)
+    single = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one = ctx.lml_grad(descs[0], prms[0], X, Z, 1e-10)
+        single.append(time.perf_counter() - t0)
+    ctx.lml_grad_batch(descs, prms, X, Z, 1e-10)
+    batch = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        many = ctx.lml_grad_batch(descs, prms, X, Z, 1e-10)
+        batch.append(time.perf_counter() - t0)
+    same = bool(np.array_equal(many[0][0], one[0]) and np.array_equal(many[4][0], one[4]) and np.array_equal(many[3][0], one[3]))
+    flops = float(n) ** 3                    # n^3 / 3 each for the factorisation, U = L^-T and R^-1 = U U^T
+    return {"workload": f"value + gradient pieces, n = {n}, 2 free hyperparameters (C * RBF + fixed White)",
+            "single_ms": min(single) * 1e3, "batch_of_8_ms_each": min(batch) * 1e3 / 8,
+            "single_tflops": flops / min(single) / 1e12, "batch_tflops": 8 * flops / min(batch) / 1e12,
+            "flops": "n^3 per evaluation (factorisation, U = L^-T, R^-1 = U U^T: n^3 / 3 each); host wall time, uploads included",
+            "batch_equals_single_bit_for_bit": same}
+
+
 def n2048_leg(ctx):
     """BASELINE configs[1]: n = 2048 1-D RBF, 4 orders -- K build + Cholesky + logpdf on one MI355X.
     One evaluation alone (the multi-kernel path with the persistent chain) and 1024 evaluations of a 512 x 2 (ell, ratio)
@@ -475,9 +506,10 @@ def main():
     except Exception as exc:                 # no lab library on this box: the in-situ per-launch figure stands alone
         print(f"[bench] exclusive microbenchmark skipped: {exc}", file=sys.stderr)
 
-    reuse = ell_grid = pred = cfg2 = None
+    reuse = ell_grid = pred = cfg2 = grad = None
     if rank == 0 and world == 1 and args.extras:
         cfg2 = n2048_leg(ctx)
+        grad = gradient_leg(ctx, X, Z, n)
         ctx.set_inputs(X, Z)                 # (the leg above used the operator-level inputs; the resident set is untouched, but be explicit)
         orders = np.arange(r)
         gp = gsum_amd.TruncationGP(kernel=RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None)
@@ -606,6 +638,7 @@ def main():
             "ell_ratio_grid": ell_grid,
             "predict": pred,
             "n2048": cfg2,
+            "gradient": grad,
             "lml_sample": float(allvals[0]),
         }
         ref_v = golden_lml(n, r)
