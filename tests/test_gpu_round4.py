@@ -293,3 +293,39 @@ def test_launch_list_restatement_matches_the_library(lab):
     plan = far_launches(n, [4, 4, 3])
     assert prof["bulk_update"]["launches"] == len(plan)
     assert prof["bulk_update"]["flops"] == float(sum(x["flops"] for x in plan))
+
+
+def test_gradient_batch_on_grouped_factorisations(ctx):
+    """Round 4: gsum_lml_grad_batch factorises its kernels in ONE grouped call and runs the gradient stages on the factors the groups'
+    workspaces hold.  Every member equals the single call bit for bit, in its position -- also when the batch is larger than one round of
+    the groups (chunks) and when one member is not positive definite (its info says so, its neighbours are untouched)."""
+    from gsum_amd.kernels import describe_gradient, describe_kernel
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    n = 1500
+    rng = np.random.RandomState(5)
+    X = np.sort(rng.rand(n, 1), axis=0) * 150.0
+    Z = np.concatenate([rng.randn(n, 4), np.ones((n, 1))], axis=1)
+    good = [C(1.0 + 0.1 * i) * RBF(0.2 + 0.02 * i) + WhiteKernel(1e-8, noise_level_bounds="fixed") for i in range(6)]
+    bad = C(1.0) * RBF(4000.0) + WhiteKernel(1e-300, noise_level_bounds="fixed")          # numerically singular
+    kernels = good[:3] + [bad] + good[3:]
+    descs = [describe_kernel(k, 1) for k in kernels]
+    prms = [describe_gradient(k, 1) for k in kernels]
+    old = {k: ctx.get_option(k) for k in ("wave_groups", "wave_size")}
+    try:
+        singles = [ctx.lml_grad(d, p, X, Z, 0.0) for d, p in zip(descs, prms)]
+        assert singles[3][2] > 0 and all(s[2] == 0 for i, s in enumerate(singles) if i != 3)
+        for groups, size in ((3, 8), (2, 1), (1, 2)):                      # one round; chunks of two
+            ctx.set_option("wave_groups", groups)
+            ctx.set_option("wave_size", size)
+            G, sld, info, tr, H = ctx.lml_grad_batch(descs, prms, X, Z, 0.0)
+            for i, s in enumerate(singles):
+                assert info[i] == s[2]
+                if s[2] != 0:
+                    continue
+                np.testing.assert_array_equal(G[i], s[0])
+                assert sld[i] == s[1]
+                np.testing.assert_array_equal(tr[i], s[3])
+                np.testing.assert_array_equal(H[i], s[4])
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
