@@ -576,8 +576,10 @@ def main():
                                       " (BASELINE configs[1], S2)" if (n, r) == (2048, 4) else " (not a BASELINE size: rehearsal)"),
                        "n": n, "orders": r,
                        "evals_per_gpu": K, "mode": "full-recompute", "evals_in_flight_per_gpu": in_flight,
-                       "batch_schedule": f"{groups} groups x up to {gsize} evaluations, one launch per kernel class and outer step; "
-                                         f"{ctx.get_option('wave_streams')} streams; GPU_MAX_HW_QUEUES "
+                       "batch_schedule": ("fewer than three evaluations per call: one after the other on the single-factorisation schedule "
+                                          "(persistent chain); " if K < 3 else
+                                          f"{groups} groups x up to {gsize} evaluations, one launch per kernel class and outer step; ")
+                                         + f"{ctx.get_option('wave_streams')} streams; GPU_MAX_HW_QUEUES "
                                          + ("unset" if "GPU_MAX_HW_QUEUES" not in os.environ else os.environ["GPU_MAX_HW_QUEUES"])},
             "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)",
                         "ms_per_step_median": elapsed / K * 1e3, "ms_per_step_min": min(all_elapsed) / K * 1e3,
