@@ -333,6 +333,117 @@ def predict_leg(ctx, n, m, reps=3):
             "finite": bool(np.isfinite(mean).all() and np.isfinite(std).all()), "std_mean": float(np.mean(std))}
 
 
+def inproc_main(args):
+    """`bench.py --inproc N`: the contract's workload and JSON keys with the N GPUs driven from ONE process through the C ABI's device
+    group (include/gsum_hip.h: gsum_init_multi, gsum_group_set_inputs, gsum_group_lml_resident) -- what a single-process caller of the
+    reference (docs/notebooks/correlated_EFT_publication.ipynb:1444-1459) gets from `log_marginal_likelihood_grid(devices=...)`.  Weak
+    scaling like --gpus N: every device evaluates its own K grid points (block partition, gsum_shard_range), the gather of the grid
+    (--gather rccl: one in-place ncclAllGather over the devices) is inside the timed region."""
+    import torch
+    import gsum_amd
+    from sklearn.gaussian_process.kernels import RBF
+    from gsum_amd.conjugate import lml_from_gram_batch
+
+    n, r, K, W, N = args.n, args.orders, args.steps, args.warmup, args.inproc
+    ids = [int(v) for v in args.devices.split(",")] if args.devices else list(range(N))
+    if len(ids) != N:
+        raise SystemExit(f"--inproc {N} but --devices lists {len(ids)}")
+    repeated = len(set(ids)) != len(ids)
+    gather = "host" if repeated else args.gather              # RCCL wants one rank per GPU
+    grp = gsum_amd.HipGroup(ids, own=True) if repeated else gsum_amd.default_group(ids)
+    ctx0 = grp.contexts[0]
+    X, y = make_workload(n, r)
+    c = gsum_amd.coefficients(y, 0.5, 1.0, np.arange(r))
+    Z = np.concatenate([c, np.ones((n, 1))], axis=1)
+    jac = float(np.sum(np.arange(r)) * np.log(0.5) * n)
+    grp.set_inputs(X, Z)                                      # X, RHS resident in the HBM of every device from here on
+    if args.groups > 0:
+        grp.set_option("wave_groups", args.groups)
+    if args.group_size > 0:
+        grp.set_option("wave_size", args.group_size)
+    total = N * K
+    ells = np.linspace(0.19, 0.21, total) if total > 1 else np.array([0.2])
+    descs = ctx0.desc_array([gsum_amd.describe_kernel(RBF(float(e)), 1) for e in ells])
+
+    def evaluate(batch, how):
+        G, sld, info = grp.lml_resident(batch, 1e-10, gather=how)
+        out = lml_from_gram_batch(G, sld, n, 0.0, 0.0, 1, 1) - jac
+        out[np.asarray(info) != 0] = -np.inf
+        return out
+
+    def sync_all():
+        for d in set(ids):
+            torch.cuda.synchronize(d)
+
+    evaluate(descs, gather)                                   # set-up: workspaces on every device, the communicators
+    for _ in range(max(0, -(-W // max(1, K)))):
+        evaluate(descs, gather)
+
+    def timed_region(profile_every=0):
+        ctx0.set_option("profile_gemm", profile_every)
+        ctx0.kernel_profile()
+        sync_all()
+        t0 = time.perf_counter()
+        vals = evaluate(descs, gather)
+        sync_all()
+        el = time.perf_counter() - t0
+        return el, vals, ctx0.kernel_profile()
+
+    regions = [timed_region() for _ in range(max(1, args.repeats))]
+    prof_elapsed, _, prof = timed_region(1)
+    ctx0.set_option("profile_gemm", 0)
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, allvals, _ = regions[order[(len(order) - 1) // 2]]
+    all_elapsed = [reg[0] for reg in regions]
+    gemm_ms, gemm_flops, gemm_launches = (prof["bulk_update"][k] for k in ("ms", "flops", "launches"))
+    launch_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # every device's first grid point again, as a single evaluation on device 0 (another schedule, another GPU): bit-identical or rc 3
+    firsts = [int(gsum_amd.shard_range(total, rk, N)[0]) for rk in range(N)]
+    G1, s1, i1 = zip(*[ctx0.lml_resident([descs[i]], 1e-10) for i in firsts])
+    redo = lml_from_gram_batch(np.concatenate(G1), np.concatenate(s1), n, 0.0, 0.0, 1, 1) - jac
+    got_first = np.array([allvals[i] for i in firsts])
+    rank_check = {"what": "grid point 0 of every device's block: gathered value vs a single evaluation of the same descriptor on the "
+                          "first device", "ranks": N, "bit_identical": bool(np.array_equal(redo, got_first)),
+                  "max_rel": float(np.max(np.abs(redo - got_first) / np.abs(redo)))}
+    gpu_lml_02 = float(lml_from_gram_batch(*ctx0.lml_resident([gsum_amd.describe_kernel(RBF(0.2), 1)], 1e-10)[:2], n, 0.0, 0.0, 1, 1)[0] - jac)
+    ref_v = golden_lml(n, r)
+    ref_rel = None if ref_v is None else abs(gpu_lml_02 - ref_v) / abs(ref_v)
+    groups, gsize = ctx0.get_option("wave_groups"), ctx0.get_option("wave_size")
+    out = {"metric": "lml_evals_per_sec", "value": total / elapsed, "unit": "evals/s", "n_gpus": N, "steps": K, "warmup": W,
+           "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": f"full-recompute lml eval: n={n} 1-D RBF(ell~0.2) dx=0.5ell, nugget 1e-10, {r} orders"
+                                  + (" (BASELINE configs[2], S3)" if (n, r) == (8192, 6) else " (not the headline size: rehearsal)"),
+                      "n": n, "orders": r, "evals_per_gpu": K, "mode": "full-recompute",
+                      "parallelism": f"inproc{N}: ONE process, the library's device group -- one gsum_ctx and one host thread per GPU "
+                                     f"(devices {ids}), descriptors block-partitioned (gsum_shard_range), gather = {gather}"
+                                     + (" (a device is listed twice: contexts of their own, RCCL not applicable)" if repeated else ""),
+                      "batch_schedule": f"{groups} groups x up to {min(gsize, -(-K // groups))} evaluations per device and call; "
+                                        f"{ctx0.get_option('wave_streams')} streams per device"},
+           "repeats": {"n": len(all_elapsed), "stat": "median region (lower median)", "ms_per_step_median": elapsed / K * 1e3,
+                       "ms_per_step_min": min(all_elapsed) / K * 1e3, "ms_per_step_max": max(all_elapsed) / K * 1e3,
+                       "evals_per_s_all": [total / e for e in all_elapsed]},
+           "roofline": {"kernel": "k_gemm_ld3g on the first device of the group (every device runs the same launches)", "bound": "mfma",
+                        "achieved": launch_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": launch_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "launches": gemm_launches,
+                        "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches), "sum_launch_ms": gemm_ms, "region_ms": elapsed * 1e3,
+                        "busy_share_of_region": gemm_ms * 1e-3 / prof_elapsed},
+           "group": {"devices": ids, "rccl": grp.get("rccl"), "rccl_gathers": grp.get("rccl_gathers"),
+                     "devices_used": grp.get("devices_used"), "pipes_ok": [c_.get_option("pipes_ok") for c_ in grp.contexts]},
+           "rank_check": rank_check,
+           "parity": {"gpu": gpu_lml_02, "reference": ref_v, "rel": ref_rel, "bound": PARITY_BOUND,
+                      "status": "checked" if ref_rel is not None else "unchecked: no committed reference value for this size",
+                      "what": "TruncationGP.log_marginal_likelihood(log 0.2, ratio=0.5) on the first device vs the reference's committed "
+                              "value (tests/golden/large_lml.json)"},
+           "gathered": {"length": int(len(allvals)), "expected": int(total), "finite": bool(np.isfinite(allvals).all())},
+           "lml_sample": float(allvals[0])}
+    print(json.dumps(out), flush=True)
+    rc = 0
+    if (ref_rel is not None and not ref_rel <= PARITY_BOUND) or not rank_check["bit_identical"] or not np.isfinite(allvals).all():
+        rc = 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,8 +457,17 @@ def main():
     ap.add_argument("--repeats", type=int, default=10,
                     help="the timed K-step region is run this many times back to back; value / ms_per_step are the "
                          "median region, min and max are reported beside it")
-    ap.add_argument("--groups", type=int, default=0, help="groups of the batch schedule (0 = library default, 2)")
-    ap.add_argument("--group-size", type=int, default=0, help="evaluations per group (0 = library default, 10)")
+    ap.add_argument("--groups", type=int, default=0, help="groups of the batch schedule (0 = library default, 3)")
+    ap.add_argument("--group-size", type=int, default=0, help="evaluations per group at most (0 = library default, 8)")
+    ap.add_argument("--inproc", type=int, default=0,
+                    help="N > 0: the same weak-scaling workload over N GPUs from THIS process -- the library's device group "
+                         "(gsum_init_multi / gsum_group_lml_resident: one context and one host thread per GPU inside the library), "
+                         "no torch.distributed; prints the same JSON keys as --gpus N")
+    ap.add_argument("--devices", default="", help="--inproc: comma-separated device indices (default 0 .. N-1; an index may repeat "
+                                                  "to rehearse the fan-out on one GPU: contexts of their own then)")
+    ap.add_argument("--gather", default="rccl", choices=["host", "rccl"],
+                    help="--inproc: how the grid comes together -- host: every device's thread writes its block into the caller's "
+                         "arrays; rccl (default): additionally one in-place ncclAllGather between the devices inside the timed region")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--device", type=int, default=None, help="GPU index override (rehearsal: several ranks on one GPU)")
     ap.add_argument("--config", default="lml", choices=["lml", "predict"],
@@ -355,6 +475,8 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0: skip the legs outside the contract (grids, predict)")
     args = ap.parse_args()
 
+    if args.inproc > 0:
+        raise SystemExit(inproc_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
 
@@ -669,6 +791,13 @@ def main():
                              "rel_vs_reference": ref_rel, "reference_what": ref_what,
                              "what": "TruncationGP.log_marginal_likelihood(log 0.2, ratio=0.5) of the workload on rank 0's GPU vs the "
                                      "reference's committed value (no CPU leg at N > 1 / --cpu-evals 0)"}
+        # never exit 0 with no numeric gate having run and nothing said about it
+        cpu_checked = out["parity"].get("cpu") is not None and out["parity"].get("host_exp_is_svml", False)
+        out["parity"]["status"] = ("checked" if (ref_rel is not None or cpu_checked) else
+                                   "unchecked: no committed reference value for this size and no CPU leg that can be compared "
+                                   "(--cpu-evals 0, N > 1, or a host whose numpy exp is not SVML)")
+        if out["parity"]["status"] != "checked":
+            print("[bench] parity UNCHECKED: " + out["parity"]["status"], file=sys.stderr)
         if ref_rel is not None and not ref_rel <= PARITY_BOUND:
             rc = 3
         if pred is not None and pred.get("parity") is not None and not pred["parity"].get("ok", False):

@@ -299,3 +299,89 @@ def cpu_context() -> CpuContext:
     if _cpu_ctx is None:
         _cpu_ctx = CpuContext()
     return _cpu_ctx
+
+
+class CpuGroup:
+    """``backend='cpu'`` counterpart of :class:`gsum_amd._lib.HipGroup`: ``world`` CPU contexts behind the same fan-out interface
+    (``contexts``, ``map``, ``lml_resident``, ``lml_batch``, ``allgather``), so the sharding logic of ``devices=`` runs -- and is
+    tested -- without a GPU.  Every member counts its own calls."""
+
+    def __init__(self, world: int):
+        if world < 1:
+            raise ValueError("a group needs at least one member")
+        self.contexts = [CpuContext() for _ in range(int(world))]
+        self.devices = list(range(int(world)))
+        self.gathers = 0
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def map(self, fn):
+        import threading
+        world = len(self.contexts)
+        out, errs = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                out[r] = fn(r, self.contexts[r])
+            except BaseException as exc:        # noqa: BLE001 -- re-raised on the calling thread
+                errs[r] = exc
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(1, world)]
+        for t in threads:
+            t.start()
+        run(0)
+        for t in threads:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return out
+
+    def set_inputs(self, X, rhs):
+        for c in self.contexts:
+            c.set_inputs(X, rhs)
+
+    def _sharded(self, call, descs, k):
+        from .grid import shard_range
+        nk, world = len(descs), len(self.contexts)
+        G, sld, info = np.full((nk, k, k), np.nan), np.full(nk, np.nan), np.full(nk, -1, dtype=np.int64)
+
+        def block(r, ctx):
+            lo, hi = shard_range(nk, r, world)
+            if hi > lo:
+                G[lo:hi], sld[lo:hi], info[lo:hi] = call(ctx, list(descs[lo:hi]))
+        self.map(block)
+        return G, sld, info
+
+    def lml_resident(self, descs, nugget, gather="host"):
+        k = self.contexts[0].resident_shape()[2]
+        out = self._sharded(lambda ctx, part: ctx.lml_resident(part, nugget), descs, k)
+        return self._gathered(out, gather)
+
+    def lml_batch(self, descs, X, rhs, nugget, gather="host"):
+        out = self._sharded(lambda ctx, part: ctx.lml_batch(part, X, rhs, nugget), descs, np.shape(rhs)[1])
+        return self._gathered(out, gather)
+
+    def _gathered(self, out, gather):
+        if gather not in ("host", "rccl"):
+            raise KeyError(gather)
+        if gather == "rccl":
+            self.gathers += 1                   # no devices to exchange between: the host arrays already are the gathered grid
+        return out
+
+    def allgather(self, a, rows=None):
+        self.gathers += 1
+        return np.array(a, dtype=np.float64)
+
+    def get(self, name):
+        return {"rccl": 0, "rccl_gathers": self.gathers, "devices_used": len(self.contexts)}.get(name, -1)
+
+
+_cpu_groups = {}
+
+
+def cpu_group(world: int) -> CpuGroup:
+    g = _cpu_groups.get(int(world))
+    if g is None:
+        g = _cpu_groups[int(world)] = CpuGroup(world)
+    return g

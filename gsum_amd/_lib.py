@@ -191,8 +191,21 @@ PROTOTYPES = {
     "gsum_lml_resident_shard": (C.c_int, [_p, _kp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _ip, _ip, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
     "gsum_kernel_profile": (C.c_int, [_p, _dp, _dp, _ip]),
+    "gsum_init_multi": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_p)]),
+    "gsum_group_adopt": (C.c_int, [C.c_int, C.POINTER(_p), C.POINTER(_p)]),
+    "gsum_group_destroy": (None, [_p]),
+    "gsum_group_size": (C.c_int32, [_p]),
+    "gsum_group_ctx": (_p, [_p, C.c_int32]),
+    "gsum_group_last_error": (C.c_char_p, [_p]),
+    "gsum_group_get": (C.c_int64, [_p, C.c_char_p]),
+    "gsum_group_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
+    "gsum_group_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip, C.c_int32]),
+    "gsum_lml_batch_multi": (C.c_int, [_p, _kp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_double,
+                                       _dp, _dp, _ip, C.c_int32]),
+    "gsum_group_allgather": (C.c_int, [_p, _dp, C.c_int64, C.c_int64]),
 }
 LAB_PROTOTYPES = {
+    "gsum_debug_pipe_probe": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_int32)]),
     "gsum_debug_diag_stamps": (C.c_int, [_p, _ip]),
     "gsum_debug_chain_stamps": (C.c_int, [_p, _dp, C.c_int32, C.POINTER(C.c_int32)]),
     "gsum_probe_mfma_f64": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -241,6 +254,22 @@ def _f64(a, shape=None):
 
 def _ptr(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+_pipes_warned = False
+
+
+def _warn_pipes(ctx):
+    """Once per process: gsum_init's pairwise stream probe found two of the context's streams taking turns."""
+    global _pipes_warned
+    if _pipes_warned or int(ctx._lib.gsum_get_option(ctx._h, b"pipes_ok")) != 0:
+        return
+    _pipes_warned = True
+    import warnings
+    pm = int(ctx._lib.gsum_get_option(ctx._h, b"pipe_overlap_permille"))
+    warnings.warn(f"gsum_amd: two of the context's four HIP streams on device {ctx.device} do not run side by side (overlap {pm / 10:.0f} % "
+                  "of a 100-us probe kernel): they share a command-processor pipe, or a tool serialises dispatches.  Results are "
+                  "unaffected; batches run 3-6 % and single factorisations 30-70 % slower (DESIGN.md section 4.1).", RuntimeWarning, stacklevel=3)
 
 
 class ChainAborted(RuntimeError):
@@ -295,6 +324,7 @@ class HipContext:
             raise RuntimeError(f"gsum_init(device={device}) failed: {msg.decode() if msg else rc}")
         self._h = h
         self.device = int(device)
+        _warn_pipes(self)
 
     # -- plumbing ------------------------------------------------------------
     def _check(self, rc):
@@ -309,7 +339,8 @@ class HipContext:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            self._lib.gsum_destroy(self._h)
+            if not getattr(self, "_borrowed", False):        # a member of an owning HipGroup is destroyed with its group
+                self._lib.gsum_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -323,7 +354,7 @@ class HipContext:
 
     def get_option(self, name: str) -> int:
         v = int(self._lib.gsum_get_option(self._h, name.encode()))
-        if v < 0 and name not in ("chain_persist", "chain_probe", "medium_min_batch", "wave_shift"):
+        if v < 0 and name not in ("chain_persist", "chain_probe", "medium_min_batch", "wave_shift", "pipes_ok", "pipe_overlap_permille"):
             raise ValueError(f"unknown option: {name}")
         return v
 
@@ -641,6 +672,14 @@ class HipContext:
         return {name: dict(ms=float(ms[i]), flops=float(fl[i]), launches=int(cnt[i]))
                 for i, name in enumerate(self.PROFILE_CLASSES)}
 
+    def pipe_probe(self, extra: int = 0) -> np.ndarray:
+        """(4 + extra)^2 matrix of pairwise overlaps (fraction of a 100-us kernel) of the context's four streams and ``extra``
+        streams created for the call (lab build)."""
+        n = 4 + int(extra)
+        out = (C.c_int32 * (n * n))()
+        self._check(self._lib.gsum_debug_pipe_probe(self._h, int(extra), out))
+        return np.array(out[:], dtype=float).reshape(n, n) / 1000.0
+
     def probe_mfma_f64(self, iters=10000, waves_per_simd=1, n_acc=8):
         """dict(tflops, cycles_per_mfma, clock_ghz) of a register-resident fp64 MFMA loop."""
         v = np.zeros(3)
@@ -667,14 +706,199 @@ class HipContext:
         return Cm
 
 
+GATHER_FLAGS = {"host": 0, "rccl": 1}          # GSUM_GATHER_RCCL
+
+
+class HipGroup:
+    """Several GPUs from ONE process: a ``gsum_group`` over one context per device (include/gsum_hip.h, "multi-GPU from ONE caller
+    thread").  ``devices``: a list of device indices, or "all".  By default the group adopts the process-wide contexts
+    (``default_context(d)``), so a model fitted on device 0 and a group that includes device 0 share that context's streams and
+    workspaces; ``own=True`` opens contexts of its own with ``gsum_init_multi``.  The sharded calls return arrays equal, bit for
+    bit, to the one-device call; ``gather="rccl"`` additionally exchanges the result rows between the devices with an in-place
+    ``ncclAllGather`` and checks every rank's copy against rank 0's."""
+
+    def __init__(self, devices="all", lab: bool = False, own: bool = False):
+        self._lib = load_library(lab=lab)
+        self.lab = bool(lab)
+        self._h = None
+        h = _p()
+        if own or devices == "all" or devices is None:
+            ids = None if (devices == "all" or devices is None) else [int(d) for d in devices]
+            arr = (C.c_int * len(ids))(*ids) if ids else None
+            rc = self._lib.gsum_init_multi(len(ids) if ids else 0, arr, C.byref(h))
+            if rc != 0:
+                msg = self._lib.gsum_group_last_error(None)
+                raise RuntimeError(f"gsum_init_multi({devices}) failed: {msg.decode() if msg else rc}")
+            self._h = h
+            self.contexts = []
+            for i in range(int(self._lib.gsum_group_size(h))):
+                c = HipContext.__new__(HipContext)
+                c._lib, c.lab, c._borrowed = self._lib, self.lab, True
+                c._h = _p(self._lib.gsum_group_ctx(h, i))
+                c.device = ids[i] if ids else i
+                self.contexts.append(c)
+                _warn_pipes(c)
+        else:
+            ids = [int(d) for d in devices]
+            if len(set(ids)) != len(ids):
+                raise ValueError("a device may appear once in a group (own=True opens separate contexts on one device)")
+            self.contexts = [(lab_context if lab else default_context)(d) for d in ids]
+            arr = (_p * len(ids))(*[c._h for c in self.contexts])
+            rc = self._lib.gsum_group_adopt(len(ids), arr, C.byref(h))
+            if rc != 0:
+                msg = self._lib.gsum_group_last_error(None)
+                raise RuntimeError(f"gsum_group_adopt failed: {msg.decode() if msg else rc}")
+            self._h = h
+        self.devices = [c.device for c in self.contexts]
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.gsum_group_last_error(self._h)
+            text = msg.decode() if msg else f"error {rc}"
+            raise (ValueError if rc == -2 else RuntimeError)(text)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.gsum_group_destroy(self._h)
+            self._h = None
+            for c in self.contexts:
+                if getattr(c, "_borrowed", False):
+                    c._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get(self, name: str) -> int:
+        return int(self._lib.gsum_group_get(self._h, name.encode()))
+
+    def set_option(self, name: str, value: int):
+        for c in self.contexts:
+            c.set_option(name, value)
+
+    def set_inputs(self, X, rhs):
+        X, rhs = _f64(X), _f64(rhs)
+        self._check(self._lib.gsum_group_set_inputs(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(rhs), rhs.shape[1]))
+
+    def lml_resident(self, descs, nugget: float, gather: str = "host"):
+        """``HipContext.lml_resident`` with the descriptors block-partitioned over the group's devices (gsum_shard_range)."""
+        n, _, k = self.contexts[0].resident_shape()
+        if n == 0:
+            raise ValueError("gsum_group_set_inputs has not been called")
+        nk = len(descs)
+        G, sld, info = np.empty((nk, k, k)), np.empty(nk), np.zeros(nk, dtype=np.int64)
+        self._check(self._lib.gsum_group_lml_resident(self._h, HipContext._desc_array(descs), nk, float(nugget), _ptr(G), _ptr(sld),
+                                                      info.ctypes.data_as(_ip), GATHER_FLAGS[gather]))
+        return G, sld, info
+
+    def lml_batch(self, descs, X, rhs, nugget: float, gather: str = "host"):
+        """``HipContext.lml_batch`` over the group's devices (gsum_lml_batch_multi)."""
+        X, rhs = _f64(X), _f64(rhs)
+        n, d = X.shape
+        k = rhs.shape[1]
+        nk = len(descs)
+        G, sld, info = np.empty((nk, k, k)), np.empty(nk), np.zeros(nk, dtype=np.int64)
+        self._check(self._lib.gsum_lml_batch_multi(self._h, HipContext._desc_array(descs), nk, _ptr(X), n, d, _ptr(rhs), k, float(nugget),
+                                                   _ptr(G), _ptr(sld), info.ctypes.data_as(_ip), GATHER_FLAGS[gather]))
+        return G, sld, info
+
+    def allgather(self, a, rows=None):
+        """In-place RCCL all-gather of a row-partitioned float64 array (leading axis; rank r's rows are
+        ``gsum_shard_range(rows, r, len(group))``) through the devices; returns rank 0's gathered copy, which the library has
+        compared with every other rank's."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        rows = a.shape[0] if rows is None else int(rows)
+        width = a.size // rows if rows else 1
+        out = a.copy()
+        self._check(self._lib.gsum_group_allgather(self._h, _ptr(out), rows, width))
+        return out
+
+    def map(self, fn):
+        """``[fn(rank, context) for ...]`` with one Python thread per device (ctypes releases the GIL inside library calls); the
+        first exception is re-raised."""
+        world = len(self.contexts)
+        if world == 1:
+            return [fn(0, self.contexts[0])]
+        out, errs = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                out[r] = fn(r, self.contexts[r])
+            except BaseException as exc:        # noqa: BLE001 -- re-raised below on the calling thread
+                errs[r] = exc
+        threads = [threading.Thread(target=run, args=(r,), name=f"gsum-dev{self.devices[r]}") for r in range(1, world)]
+        for t in threads:
+            t.start()
+        run(0)
+        for t in threads:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return out
+
+
 _default_ctx = {}
 _lab_ctx = {}
+_groups = {}
+
+
+def device_count() -> int:
+    """GPUs the HIP runtime shows this process (0 without one); does not create a context."""
+    import ctypes.util
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = C.CDLL(name)
+        except OSError:
+            continue
+        cnt = C.c_int(0)
+        return int(cnt.value) if hip.hipGetDeviceCount(C.byref(cnt)) == 0 else 0
+    return 0
+
+
+def resolve_devices(devices):
+    """``devices=`` argument of the model classes -> list of device indices ("all": every visible GPU)."""
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError('devices must be "all", an int or a sequence of device indices')
+        n = device_count()
+        if n < 1:
+            raise RuntimeError("devices='all': no HIP device visible (the 'hip' backend has no CPU fallback)")
+        return list(range(n))
+    if isinstance(devices, (int, np.integer)):
+        return [int(devices)]
+    ids = [int(d) for d in devices]
+    if not ids:
+        raise ValueError("devices must not be empty")
+    return ids
+
+
+def default_group(devices="all", lab: bool = False) -> HipGroup:
+    """Process-wide group over ``devices`` (adopting ``default_context`` of each)."""
+    ids = tuple(resolve_devices(devices))
+    key = (ids, bool(lab))
+    g = _groups.get(key)
+    if g is None or g._h is None or any(c._h is None for c in g.contexts):
+        g = HipGroup(list(ids), lab=lab)
+        _groups[key] = g
+    return g
 
 
 def _close_default_contexts():
     # Streams with a CU mask must be gone before the C++ finalisers of the HIP runtime / a profiler run (rocprofv3
     # segfaults in __cxa_finalize on a process that exits with one alive): destroy the contexts first.  DeviceMatrix
     # objects still alive only lose their handle (their frees become no-ops).
+    for grp in list(_groups.values()):               # groups first: they borrow the contexts below
+        try:
+            grp.close()
+        except Exception:
+            pass
+    _groups.clear()
     for ctx in list(_default_ctx.values()) + list(_lab_ctx.values()):
         try:
             ctx.close()

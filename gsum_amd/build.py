@@ -20,7 +20,7 @@ SRC = os.path.join(HERE, "csrc", "gsum_capi.hip")
 KERNEL_PARTS = ("common", "build", "diag", "panel", "chain", "gemm_nt", "fused", "tile", "solve", "grad", "probes")
 DEPS = [SRC, os.path.join(HERE, "csrc", "gsum_kernels.hip.h"), os.path.join(ROOT, "include", "gsum_hip.h"),
         os.path.join(ROOT, "include", "gsum_hip_debug.h")] + [os.path.join(HERE, "csrc", "kernels", f"{p}.hip.h") for p in KERNEL_PARTS]
-HOST_PARTS = ("context", "gemm", "matrices", "potrf", "api_context", "api_operators", "api_fused", "wave", "api_lml", "api_grad", "api_measure")
+HOST_PARTS = ("context", "gemm", "matrices", "potrf", "api_context", "api_operators", "api_fused", "wave", "api_lml", "api_multi", "api_grad", "api_measure")
 DEPS += [os.path.join(HERE, "csrc", "host", f"{p}.hip.h") for p in HOST_PARTS]
 OUT = os.path.join(HERE, "libgsum_hip.so")
 OUT_LAB = os.path.join(HERE, "libgsum_hip_lab.so")
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     out = OUT_LAB if lab else OUT
     if not force and up_to_date(out):
         return out
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-pthread",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")] + (["-DGSUM_LAB"] if lab else []) + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -280,6 +280,7 @@ class ConjugateGaussianProcess:
         self.batch_restarts = True   # multi-start fits advance in lock step, objective evaluations batched on the device
         self._ctx = None
         self._L_dev = None          # device-resident Cholesky factor of kernel_(X_train_) + nugget
+        self._replicas = {}         # ... and its copies on the other devices of predict(devices=...) (id(context) -> factor)
         self._corr = None
         self._corr_L = None
         self._gram = None
@@ -520,12 +521,13 @@ class ConjugateGaussianProcess:
         return self.cov_factor_, describe_kernel(self.kernel_, d).without_white()      # kernel_(X, Xp), both given: no white noise
 
     # -- fit (models.py:630-738) -------------------------------------------------------------------
-    def _constrained_optimization(self, obj_func, initial_theta, bounds):
-        """models.py:884-900."""
+    def _constrained_optimization(self, obj_func, initial_theta, bounds, warn=None):
+        """models.py:884-900.  ``warn``: where the convergence message goes instead of ``warnings.warn`` (the lock-step restarts
+        collect theirs and emit them from the calling thread: ``warnings.catch_warnings`` is process-global state)."""
         if self.optimizer == "fmin_l_bfgs_b":
             theta_opt, func_min, info = fmin_l_bfgs_b(obj_func, initial_theta, bounds=bounds)
             if info["warnflag"] != 0:
-                warnings.warn("fmin_l_bfgs_b terminated abnormally with the  state: %s" % info, ConvergenceWarning)
+                (warn or warnings.warn)("fmin_l_bfgs_b terminated abnormally with the  state: %s" % info, ConvergenceWarning)
         elif callable(self.optimizer):
             theta_opt, func_min = self.optimizer(obj_func, initial_theta, bounds=bounds)
         else:
@@ -595,14 +597,12 @@ class ConjugateGaussianProcess:
 
         optima = [None] * n
 
-        caught = [[] for _ in range(n)]       # ConvergenceWarnings of a start: recorded in its thread, re-emitted by the caller's
+        caught = [[] for _ in range(n)]       # convergence messages of a start: collected in its thread, emitted by the caller's
 
         def run(i):
             try:
-                with warnings.catch_warnings(record=True) as rec:
-                    warnings.simplefilter("always")
-                    optima[i] = self._constrained_optimization(make_obj(i), starts[i], bounds)
-                caught[i] = list(rec)
+                optima[i] = self._constrained_optimization(make_obj(i), starts[i], bounds,
+                                                           warn=lambda msg, cat, i=i: caught[i].append((msg, cat)))
             except BaseException as exc:   # noqa: BLE001
                 with cond:
                     if state["error"] is None:
@@ -630,9 +630,9 @@ class ConjugateGaussianProcess:
             raise
         if state["error"] is not None:
             raise state["error"]
-        for rec in caught:                 # (warnings.catch_warnings is per thread only by accident: emit from the calling thread)
-            for w in rec:
-                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        for rec in caught:                 # in start order, from the calling thread (no catch_warnings in the workers: its
+            for msg, cat in rec:           # save / restore of warnings.filters is process-global and the starts end out of order)
+                warnings.warn(msg, cat)
         return optima
 
     def _calibrate_kernel(self):
@@ -688,6 +688,9 @@ class ConjugateGaussianProcess:
         desc = describe_kernel(self.kernel_, Xd.shape[1])
         if self._L_dev is not None:
             self._L_dev.free()
+        for rep in self._replicas.values():
+            rep.free()
+        self._replicas = {}
         self._L_dev, info = ctx.factorize(desc, Xd, diag_add=self.nugget)
         if info != 0:
             self._L_dev.free()
@@ -754,10 +757,37 @@ class ConjugateGaussianProcess:
         return y_mean
 
     # -- predict (models.py:753-845) ------------------------------------------------
-    def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False):
-        return self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, False)[0]
+    def predict(self, X, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, devices=None):
+        """``devices`` (additive; ``"all"`` or a list of GPU indices): the new points are cut into one block per device
+        (``gsum_shard_range``), every device factorises its own copy of the training matrix once (kept until the next ``fit``) and
+        the blocks run side by side, one host thread per device -- columns of the predictive covariance are independent per new
+        point (models.py:836), so mean and standard deviation equal the one-device call; ``return_cov`` needs all columns on one
+        device and is refused."""
+        return self._predict_core(X, return_std, return_cov, Xc, y, pred_noise, False, devices=devices)[0]
 
-    def _predict_core(self, X, return_std, return_cov, Xc, y, pred_noise, want_basis):
+    def _group(self, devices):
+        """The device group of ``devices=`` (process-wide, adopting the default contexts; ``backend='cpu'``: as many CPU contexts)."""
+        if self.backend == "cpu":
+            from ._cpu import cpu_group          # no devices to count: "all" means two members, a list as many as it names
+            return cpu_group(2 if isinstance(devices, str) else (1 if np.isscalar(devices) else len(devices)))
+        from ._lib import default_group
+        return default_group(devices)
+
+    def _replica_factor(self, ctx, desc, Xc):
+        """The factor of the training matrix on another device's context (built there once per fit)."""
+        if ctx is self._context():
+            return self._L_dev
+        key = id(ctx)
+        L = self._replicas.get(key)
+        if L is None or getattr(L, "_h", True) is None:
+            L, info = ctx.factorize(desc, Xc, diag_add=self.nugget)
+            if info != 0:
+                L.free()
+                raise np.linalg.LinAlgError("Matrix is not positive definite")
+            self._replicas[key] = L
+        return L
+
+    def _predict_core(self, X, return_std, return_cov, Xc, y, pred_noise, want_basis, devices=None):
         """predict, plus (want_basis) the conditional basis 1 - R_no R^-1 1 of models.py:1168 from the same
         triangular solve: one more right-hand-side column."""
         if return_std and return_cov:
@@ -765,13 +795,19 @@ class ConjugateGaussianProcess:
         if not self._fit:
             return self.underlying_properties(X=X, return_std=return_std, return_cov=return_cov), None
         self._check_decomposition()
+        if devices is not None and return_cov:
+            raise ValueError("return_cov needs every new point on one device: call predict without devices=")
         ctx = self._context()
         X = np.asarray(X, dtype=float)
         desc = describe_kernel(self.kernel_, X.shape[1])
         own = None
+        fitted_inputs = Xc is None
         if Xc is None:
             Xc = np.asarray(self.X_train_, dtype=float)
             L = self._L_dev
+        elif devices is not None:
+            Xc = np.asarray(Xc, dtype=float)
+            L = None
         else:
             Xc = np.asarray(Xc, dtype=float)
             own, info = ctx.factorize(desc, Xc, diag_add=self.nugget)             # models.py:807
@@ -790,18 +826,48 @@ class ConjugateGaussianProcess:
             n_curves = resid.shape[1]
             if want_basis:
                 resid = np.concatenate([resid, self.basis(Xc)], axis=1)
-            m_parts, colsumsq, VtV = [], None, None
-            for lo in range(0, resid.shape[1], GSUM_MAX_RHS):
-                want_cov = return_cov and lo == 0
-                css, VtW, cv = ctx.predict_terms(L, desc, Xc, X, rhs=resid[:, lo:lo + GSUM_MAX_RHS], want_cov=want_cov)
-                m_parts.append(VtW)
-                colsumsq = css
-                VtV = cv if want_cov else VtV
+
+            def terms(ctx_, L_, Xs, want_cov_):
+                parts, css, cv_ = [], None, None
+                for lo in range(0, resid.shape[1], GSUM_MAX_RHS):
+                    wc = want_cov_ and lo == 0
+                    css, VtW, cv = ctx_.predict_terms(L_, desc, Xc, Xs, rhs=resid[:, lo:lo + GSUM_MAX_RHS], want_cov=wc)
+                    parts.append(VtW)
+                    cv_ = cv if wc else cv_
+                return np.concatenate(parts, axis=1), css, cv_
+
+            if devices is None:
+                shifts, colsumsq, VtV = terms(ctx, L, X, return_cov)
+            else:
+                from .grid import shard_range
+                grp = self._group(devices)
+                world = len(grp)
+
+                def block(r, ctx_r):
+                    lo, hi = shard_range(X.shape[0], r, world)
+                    if hi == lo:
+                        return np.empty((0, resid.shape[1])), np.empty(0)
+                    if fitted_inputs:
+                        L_r, mine = self._replica_factor(ctx_r, desc, Xc), None
+                    else:
+                        L_r, info = ctx_r.factorize(desc, Xc, diag_add=self.nugget)          # models.py:807, on this block's device
+                        mine = L_r
+                        if info != 0:
+                            L_r.free()
+                            raise np.linalg.LinAlgError("Matrix is not positive definite")
+                    try:
+                        return terms(ctx_r, L_r, X[lo:hi], False)[:2]
+                    finally:
+                        if mine is not None:
+                            mine.free()
+                blocks = grp.map(block)
+                shifts = np.concatenate([b[0] for b in blocks], axis=0)
+                colsumsq = np.concatenate([b[1] for b in blocks])
+                VtV = None
         finally:
             if own is not None:
                 own.free()
         # R_no R^-1 (y - m) = (L^-1 R_on)^T (L^-1 (y - m))                         models.py:831-832
-        shifts = np.concatenate(m_parts, axis=1)
         cond_basis = self.basis(X) - shifts[:, n_curves:] if want_basis else None
         m_pred = np.squeeze(m_new[:, None] + shifts[:, :n_curves])
         if return_std or return_cov:

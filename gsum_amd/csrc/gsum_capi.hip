@@ -20,5 +20,6 @@
 #include "host/api_fused.hip.h"
 #include "host/wave.hip.h"
 #include "host/api_lml.hip.h"
+#include "host/api_multi.hip.h"
 #include "host/api_grad.hip.h"
 #include "host/api_measure.hip.h"

@@ -44,16 +44,17 @@ int gsum_init(int device, gsum_ctx** out) {
     }
     gsum_ctx* ctx = new gsum_ctx();
     ctx->device = device;
-    auto fail = [&](const char* what, hipError_t err) {
+    auto fail = [&](const char* what, hipError_t err) {     // gsum_destroy: the streams, events and buffers created so far go with it
         g_init_error = std::string(what) + ": " + hipGetErrorString(err);
-        delete ctx;
+        gsum_destroy(ctx);
         return -1;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     (void)hipDeviceGetStreamPriorityRange(&ctx->prio_lo, &ctx->prio_hi);   // hi = numerically lowest
     if (gs_need_slots(ctx, 1)) {
         g_init_error = ctx->err;
-        delete ctx;
+        ++ctx->n_slots_ready;               // the slot that failed half-way: gsum_destroy frees what it did create
+        gsum_destroy(ctx);
         return -1;
     }
     ctx->cur = &ctx->slots[0];
@@ -68,7 +69,7 @@ int gsum_init(int device, gsum_ctx** out) {
     // (torch, RCCL) created before.  A fourth group of a batch (option wave_groups = 4) creates a fifth stream and shares a pipe.
     if (gs_panel_stream(ctx, ctx->cur) || gs_aux_stream(ctx, ctx->cur)) {
         g_init_error = ctx->err;
-        delete ctx;
+        gsum_destroy(ctx);
         return -1;
     }
     if ((e = hipStreamCreateWithPriority(&ctx->wave.g[2].sc, hipStreamNonBlocking, ctx->prio_hi)) != hipSuccess) return fail("hipStreamCreateWithPriority", e);
@@ -76,6 +77,14 @@ int gsum_init(int device, gsum_ctx** out) {
     ctx->wave.sb = ctx->cur->sm;
     if ((e = hipMalloc((void**)&ctx->dstamps, 64 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
     (void)hipMemset(ctx->dstamps, 0, 64 * sizeof(unsigned long long));
+    {   // are the four streams on four pipes?  (observable: gsum_get_option "pipes_ok" / "pipe_overlap_permille"; the binding warns once)
+        const hipStream_t four[4] = {ctx->cur->sm, ctx->cur->sp, ctx->cur->sa, ctx->wave.g[2].sc};
+        if (gs_pipe_probe(ctx, four, 4, nullptr)) {
+            g_init_error = ctx->err;
+            gsum_destroy(ctx);
+            return -1;
+        }
+    }
 #ifdef GSUM_LAB
     // (lab build only: the product library reads no environment variable -- its ten options are set through gsum_set_option)
     const char* la = getenv("GSUM_LOOKAHEAD");
@@ -144,6 +153,8 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
     if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
     if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
+    if (!strcmp(name, "pipes_ok")) return ctx->pipes_ok;
+    if (!strcmp(name, "pipe_overlap_permille")) return ctx->pipe_overlap_permille;
     if (!strcmp(name, "profile_gemm")) return ctx->profile_gemm;
     if (!strcmp(name, "small_path")) return ctx->small_path;
     if (!strcmp(name, "medium_path")) return ctx->medium_path;

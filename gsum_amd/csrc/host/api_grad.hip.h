@@ -201,7 +201,9 @@ static int gs_grad_batch_wave(gsum_ctx* ctx, const gsum_kernel_desc* descs, int 
     if (gs_need_slots(ctx, S)) return -1;
     // the slots' gradient buffers first (U, R^-1, ...: 3.2 n^2 doubles each), then as many members per chunk as ONE round of the groups holds
     {
-        const int64_t npg = gs_padded_order(ctx, n);
+        // (the wave pool pads to 256, gs_padded_order to 128 when the chain schedule is off or the order small: the larger of the two, or
+        // gs_grad_post would re-reserve -- hipFree + hipMalloc, a device-wide synchronisation -- per slot inside the batch)
+        const int64_t npg = std::max<int64_t>(gs_padded_order(ctx, n), (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB));
         const size_t want = (size_t)(3.3 * (double)(npg + GS_BORDER) * (double)(npg + GS_BORDER) * 8.0);
         for (int q = 0; q < S; ++q)
             if (gs_reserve(ctx, &ctx->slots[q].gws, &ctx->slots[q].gws_cap, want)) return -1;

@@ -15,6 +15,24 @@ int gsum_timers(gsum_ctx* ctx, double* ms, int32_t n) {
 }
 
 #ifdef GSUM_LAB
+// The pairwise stream probe of gsum_init on the context's four streams plus `extra` (0..4) streams created now: out holds the
+// (4 + extra)^2 overlaps in 1/1000 of the probe kernels' length.  A stream created after the first four shares a pipe with one of
+// them: this is how the probe itself is validated (tests/test_gpu_round5.py) and how profiles/r05_pipe_probe.log was taken.
+int gsum_debug_pipe_probe(gsum_ctx* ctx, int32_t extra, int32_t* out) {
+    if (!ctx || !out || extra < 0 || extra > 4) return -2;
+    GS_CHECK(hipSetDevice(ctx->device));
+    hipStream_t all[8] = {ctx->slots[0].sm, ctx->slots[0].sp, ctx->slots[0].sa, ctx->wave.g[2].sc};
+    const int n = 4 + extra;
+    for (int i = 4; i < n; ++i) GS_CHECK(hipStreamCreateWithPriority(&all[i], hipStreamNonBlocking, ctx->prio_hi));
+    for (int i = 0; i < n * n; ++i) out[i] = i / n == i % n ? 1000 : -1;
+    const int keep_ok = ctx->pipes_ok, keep_pm = ctx->pipe_overlap_permille;
+    const int rc = gs_pipe_probe(ctx, all, n, out);
+    ctx->pipes_ok = keep_ok;
+    ctx->pipe_overlap_permille = keep_pm;
+    for (int i = 4; i < n; ++i) (void)hipStreamDestroy(all[i]);
+    return rc;
+}
+
 // Realtime stamps (100 MHz ticks, relative to the first) of the last persistent-chain factorisation on slot 0's workspace
 // (option "chain_stamps" = 1): GS_CH_STAMPS = 16 per outer step -- D role 0 step begins, 1 its diagonal block is up to date,
 // 2 T0 set, 3 block row k + 1 up to date, 4 TL set, 5 sibling update done, 6 T1 set; P wave 0: 8 rows ready, 9 T0 seen,

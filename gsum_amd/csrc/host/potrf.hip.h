@@ -119,6 +119,39 @@ static int gs_chain_probe(gsum_ctx* ctx, gs_slot* sl) {
     return 0;
 }
 
+// Pairwise stream probe: do the streams the schedules run side by side really run side by side?  For every pair (a, b) a 100-us
+// single-wave kernel on a, then one on b; each stamps its start and end with the real-time counter.  On different command-processor
+// pipes the second starts a few microseconds (the host's enqueue gap) after the first and the two overlap almost completely; two
+// queues on ONE pipe, or dispatches serialised by a tool, take turns: the overlap is ~0.  (The assumption probed is the one DESIGN.md
+// section 4.1 measured: queue -> pipe = creation index mod 4; gsum_init creates the context's four streams back to back.)  ~1 ms, once per
+// context and again when a batch adds a stream (a fourth group).  out_permille (optional): n x n overlaps in 1/1000 of the kernel length.
+static int gs_pipe_probe(gsum_ctx* ctx, const hipStream_t* streams, int n, int* out_permille) {
+    const unsigned long long T = 10000ull;                       // 100 us
+    unsigned long long* d = ctx->dstamps + 16;                   // words 16..19 of the 64 x u64 stamp buffer
+    int worst = 1000;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) {
+            if (streams[a] == streams[b]) continue;
+            unsigned long long h[4] = {0, 0, 0, 0};
+            int best = 0;
+            for (int attempt = 0; attempt < 2 && best < 500; ++attempt) {      // (a host hiccup between the two enqueues: once more)
+                hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(64), 0, streams[a], T, d);
+                hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(64), 0, streams[b], T, d + 2);
+                GS_CHECK(hipGetLastError());
+                GS_CHECK(hipStreamSynchronize(streams[a]));
+                GS_CHECK(hipStreamSynchronize(streams[b]));
+                GS_CHECK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+                const long long ov = (long long)std::min(h[1], h[3]) - (long long)std::max(h[0], h[2]);
+                best = std::max(best, (int)std::max<long long>(0, std::min<long long>(1000, ov * 1000 / (long long)T)));
+            }
+            if (out_permille) out_permille[a * n + b] = out_permille[b * n + a] = best;
+            worst = std::min(worst, best);
+        }
+    ctx->pipe_overlap_permille = worst;
+    ctx->pipes_ok = worst >= 500 ? 1 : 0;
+    return 0;
+}
+
 // the second high-priority stream of the persistent-chain schedule (rest of the panel, near update)
 static int gs_aux_stream(gsum_ctx* ctx, gs_slot* sl) {
     if (!sl->sa) {

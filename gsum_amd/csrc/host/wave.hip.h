@@ -58,7 +58,16 @@ static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
             gs_slot* s0 = &ctx->slots[0];
             if (i == 0) { if (gs_panel_stream(ctx, s0)) return -1; g->sc = s0->sp; }
             else if (i == 1) { if (gs_aux_stream(ctx, s0)) return -1; g->sc = s0->sa; }
-            else { GS_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, ctx->prio_hi)); g->own_sc = true; }
+            else {
+                GS_CHECK(hipStreamCreateWithPriority(&g->sc, hipStreamNonBlocking, ctx->prio_hi));
+                g->own_sc = true;
+                // a stream created now (a fourth group) sits on a pipe one of the first four already uses: probe again, so that
+                // "pipes_ok" describes the streams this batch runs on
+                hipStream_t all[GS_WV_GROUPS + 1] = {wv->sb};
+                int cnt = 1;
+                for (int q = 0; q <= i; ++q) all[cnt++] = wv->g[q].sc;
+                if (gs_pipe_probe(ctx, all, cnt, nullptr)) return -1;
+            }
         }
         if (!g->evChain) {
             GS_CHECK(hipEventCreateWithFlags(&g->evChain, hipEventDisableTiming));

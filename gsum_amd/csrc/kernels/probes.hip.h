@@ -48,6 +48,17 @@ __global__ __launch_bounds__(256) void k_probe_store(gs_d2* out, int64_t nvec) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) out[i] = v;
 }
 
+// one wave that stamps its start, spins for `ticks` of the 100 MHz real-time counter and stamps its end: the pairwise stream probe of
+// gsum_init (gs_pipe_probe): two such kernels on two streams overlap in time iff the streams' queues are served side by side
+__global__ __launch_bounds__(64) void k_probe_stamp(unsigned long long ticks, unsigned long long* out2) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (threadIdx.x == 0) {
+        out2[0] = t0;
+        out2[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // one wave spinning for `ticks` of the 100 MHz real-time counter: the queue-concurrency probe (gs_probe_queues)
 __global__ __launch_bounds__(64) void k_probe_spin(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -81,7 +81,11 @@ def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None
     (rows, cols, scales) for BASELINE config 4's (cbar, ratio) scan), flattened in C order, which is the order
     ``log_marginal_likelihood_grid`` shards in.  ``n_rows`` / ``n_cols`` are optional and only checked.
     ``partition="theta"`` (factor-reuse scans, see :func:`owned_points`): every rank owns whole columns of the surface; the gather
-    then moves the theta axis to the front and exchanges equal blocks of thetas (still one all-gather).
+    then moves the theta axis to the front and exchanges equal blocks of thetas (still one all-gather) -- pass it whenever
+    ``evaluate`` runs ``mode="reuse"``:
+    ``lml_grid_distributed(functools.partial(gp.log_marginal_likelihood_grid, thetas, ratios, mode="reuse"), partition="theta")``.
+    An evaluated point is finite or -inf, never NaN: a NaN inside the slice this rank is about to send means ``evaluate`` filled a
+    different partition than the one gathered, and raises instead of returning a surface with holes.
     """
     dist = _dist()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
@@ -93,6 +97,7 @@ def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None
         by_theta = np.ascontiguousarray(np.moveaxis(surface, 1, 0))                 # (cols, rows[, scales])
         width = by_theta[0].size
         jlo, jhi = shard_range(by_theta.shape[0], rank, world)
+        _no_holes(by_theta[jlo:jhi], partition, rank)
         if dist is None or world == 1:
             return surface
         full = _gather_rows(by_theta[jlo:jhi].reshape(-1), by_theta.shape[0], width, group).reshape(by_theta.shape)
@@ -100,7 +105,14 @@ def lml_grid_distributed(evaluate, n_rows: int | None = None, n_cols: int | None
     if partition != "flat":
         raise ValueError('partition must be "flat" or "theta"')
     lo, hi = shard_range(total, rank, world)
+    _no_holes(surface.reshape(-1)[lo:hi], partition, rank)
     return gather_flat(surface.reshape(-1)[lo:hi], total, group).reshape(surface.shape)
+
+
+def _no_holes(own, partition, rank):
+    if np.isnan(own).any():
+        raise ValueError(f"rank {rank}: the slice of partition={partition!r} it is about to gather still holds NaN -- evaluate() filled "
+                         'another partition (mode="reuse" scans shard whole thetas: pass partition="theta")')
 
 
 def predict_distributed(predict, Xnew, n_curves, group=None):

@@ -29,7 +29,7 @@ class TruncationGP:
         self.ref = self._per_point("ref", ref)
         self.ratio = self._per_point("ratio", ratio)
         self.kernel, self.excluded = kernel, excluded
-        self.ratio_kws = dict(ratio_kws or {})
+        self.ratio_kws = {} if ratio_kws is None else ratio_kws          # the caller's dict, like models.py:1326
         self.coeffs_process = self._coeffs_process_class(kernel=kernel, **kwargs)
         self.X_train_ = self.y_train_ = self.orders_ = self.dX_ = self.dy_ = self.coeffs_ = None
         self._fit, self._log_like = False, None
@@ -45,11 +45,14 @@ class TruncationGP:
         if callable(value):
             return value
 
-        def constant(X, **override):
+        def constant(X, *positional, **override):           # the reference: lambda X, ratio=ratio: ratio * np.ones(X.shape[0])
             extra = set(override) - {name}
             if extra:
                 raise TypeError(f"{name}() got an unexpected keyword argument {sorted(extra)[0]!r}")
-            return override.get(name, value) * np.ones(np.shape(X)[0])
+            if len(positional) > 1 or (positional and name in override):
+                raise TypeError(f"{name}() takes the points and at most one value")
+            v = positional[0] if positional else override.get(name, value)
+            return v * np.ones(np.shape(X)[0])
         return constant
 
     def _series(self, X, start, end, factor=1.0):
@@ -219,7 +222,7 @@ class TruncationGP:
         return coeff_log_like - det_factor
 
     def log_marginal_likelihood_grid(self, thetas, ratio_kws_list, scales=None, X=None, y=None, orders=None, mode="full",
-                                     shard=None):
+                                     shard=None, devices=None, gather="host", _ctx=None):
         """Likelihood surface over (ratio settings) x (thetas) [x (prior scales)].
 
         ``scales=None``: ``out[i, j]`` equals ``self.log_marginal_likelihood(thetas[j], **ratio_kws_list[i])``.
@@ -237,14 +240,23 @@ class TruncationGP:
         a contiguous block of the flattened grid in mode "full", a block of whole thetas in mode
         "reuse" (``gsum_amd.grid.owned_points``; ``lml_grid_distributed(..., partition=...)`` or
         :meth:`log_marginal_likelihood_grid_distributed` gathers accordingly).
+        ``devices="all"`` / ``devices=[0, 1, ...]`` uses several GPUs from THIS process (the reference's caller is one process:
+        notebook :1444-1459): the same shards, one per device, each on a host thread of its own with that device's context
+        (``gsum_amd.HipGroup``), merged into one surface that equals the one-device result bit for bit.  ``gather="rccl"``
+        additionally exchanges the shards between the devices with one in-place ``ncclAllGather`` (``gsum_group_allgather``;
+        every rank's gathered surface is compared with rank 0's) instead of merging on the host only.
         """
+        if devices is not None:
+            if shard is not None:
+                raise ValueError("shard= (one process per GPU) and devices= (one process, several GPUs) exclude each other")
+            return self._grid_over_devices(thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather)
         X = self.X_train_ if X is None else X
         y = self.y_train_ if y is None else y
         orders = self.orders_ if orders is None else orders
         Xd = np.asarray(X, dtype=float)
         gp = self.coeffs_process
         base = gp._active_kernel()
-        ctx = gp._context()
+        ctx = gp._context() if _ctx is None else _ctx
         ni, nj = len(ratio_kws_list), len(thetas)
         if scales is None:
             ns, scale_vals = 1, None
@@ -353,6 +365,33 @@ class TruncationGP:
             raise ValueError('mode must be "full" or "reuse"')
         return shaped(out)
 
+
+    def _grid_over_devices(self, thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather):
+        if mode not in ("full", "reuse"):
+            raise ValueError('mode must be "full" or "reuse"')
+        if gather not in ("host", "rccl"):
+            raise ValueError('gather must be "host" or "rccl"')
+        grp = self.coeffs_process._group(devices)
+        world = len(grp)
+        parts = grp.map(lambda r, ctx: np.asarray(self.log_marginal_likelihood_grid(
+            thetas, ratio_kws_list, scales=scales, X=X, y=y, orders=orders, mode=mode, shard=(r, world), _ctx=ctx), dtype=np.float64))
+        from .grid import owned_points
+        out = parts[0].copy()
+        ns = out.shape[2] if out.ndim == 3 else 1
+        flat = out.reshape(-1)
+        for r in range(1, world):                # the shards are disjoint and cover the grid (gsum_shard_range)
+            mine = owned_points(out.shape[0], out.shape[1], ns, r, world, partition="theta" if mode == "reuse" else "flat")
+            flat[mine] = parts[r].reshape(-1)[mine]
+        if gather == "rccl" and out.size:
+            # the exchange step on the devices: rank r's block of the surface (flat C-order block in mode "full", whole thetas in
+            # mode "reuse": the partitions of gsum_amd.grid.owned_points) travels through ITS device's gather buffer
+            if mode == "reuse":
+                by_theta = np.ascontiguousarray(np.moveaxis(out, 1, 0))
+                full = grp.allgather(by_theta.reshape(by_theta.shape[0], -1)).reshape(by_theta.shape)
+                out = np.ascontiguousarray(np.moveaxis(full, 0, 1))
+            else:
+                out = grp.allgather(out.reshape(-1, 1)).reshape(out.shape)
+        return out
 
     def log_marginal_likelihood_grid_distributed(self, thetas, ratio_kws_list, scales=None, mode="full", group=None, **kwargs):
         """``log_marginal_likelihood_grid`` with the grid sharded over the ranks of the initialised ``torch.distributed`` group

@@ -12,8 +12,9 @@
  * device objects are opaque handles owned by the library.  Return value 0 = success, < 0 = API / runtime error (message:
  * gsum_last_error).  A matrix that is not positive definite is NOT an error: *info > 0 (LAPACK's 1-based index of the first
  * bad pivot) reports it -- what numpy.linalg.cholesky turns into LinAlgError.  A gsum_ctx is bound to ONE GPU and is not
- * thread-safe; every function is synchronous at return.  Diagnostics, probes and schedule experiments are NOT part of this
- * contract: include/gsum_hip_debug.h, built only into libgsum_hip_lab.so (-DGSUM_LAB).
+ * thread-safe (a gsum_group holds one per GPU and drives them from threads of its own); every function is synchronous at return.
+ * Diagnostics, probes and schedule experiments are NOT part of this contract: include/gsum_hip_debug.h, built only into
+ * libgsum_hip_lab.so (-DGSUM_LAB).
  */
 #ifndef GSUM_HIP_H
 #define GSUM_HIP_H
@@ -98,7 +99,11 @@ const char* gsum_last_error(gsum_ctx* ctx);             /* NULL ctx: error of a 
  *                                  the order allows;  "lookahead" 0 | 1  look-ahead in the host-enqueued schedule
  *   "pivot_guard_ulps" 0..1024     a pivot p <= guard * eps * A_jj counts as not positive (default 2; process-wide)
  * gsum_get_option reads these back, plus "wave_streams" (streams the last batch call used: groups + 1), "chain_probe",
- * "chain_aborts" (give-ups of the persistent-chain schedule; the fused path re-runs itself, see GSUM_ERR_CHAIN_ABORT). */
+ * "chain_aborts" (give-ups of the persistent-chain schedule; the fused path re-runs itself, see GSUM_ERR_CHAIN_ABORT), and
+ * "pipes_ok" / "pipe_overlap_permille": gsum_init runs a 100-us kernel on every pair of the context's four streams; 1 = every pair
+ * overlapped (>= half its length; the smallest overlap in 1/1000), 0 = some pair took turns -- two of the streams share a
+ * command-processor pipe or a tool serialises dispatches: results are unaffected, a batch runs 3-6 % and a single factorisation
+ * 30-70 % slower. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 int64_t gsum_get_option(gsum_ctx* ctx, const char* name);
 
@@ -180,10 +185,40 @@ int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_
  * c = ceil(total / world).  gsum_lml_resident_shard evaluates this rank's descriptors into THEIR positions of full-length
  * arrays, so that a host holding its own RCCL communicator all-gathers in place:
  *     ncclAllGather(sld + lo, sld, c, ncclDouble, comm, stream)          (tests/c_host/shard_host_rccl.c)
- * The library opens no communicator itself.  Replaces the serial loop docs/notebooks/correlated_EFT_publication.ipynb:1457-1459. */
+ * A host with its own communicator gathers like that; the group calls below carry the same step inside the library.  Replaces the serial loop docs/notebooks/correlated_EFT_publication.ipynb:1457-1459. */
 int gsum_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
 int gsum_lml_resident_shard(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, int32_t rank, int32_t world,
                             double nugget, double* G_out, double* sld_out, int64_t* info_out, int64_t* lo, int64_t* hi);
+
+/* ---- multi-GPU from ONE caller thread: a group of contexts (gsum_init over a device list; 8e) ------------------
+ * The reference's user is a single Python process (the notebook above; gsum/models.py:1485-1507), so the node's GPUs are also reachable
+ * without one process per GPU: gsum_init_multi opens one gsum_ctx per listed device (device_ids == NULL: devices 0 .. n_devices - 1;
+ * n_devices <= 0: every visible GPU), and the calls below cut the descriptor list with gsum_shard_range, run each device's block on a
+ * host thread of its own inside the library and write results straight into the caller's full-length arrays -- equal, bit for bit, to
+ * the one-device call.  flags = GSUM_GATHER_RCCL adds the path's one exchange step on the devices: the packed result rows (G, sld, info)
+ * are staged to each device's gather buffer at their positions, exchanged with one in-place ncclAllGather per device
+ * (ncclCommInitAll over the group's devices, opened on the first such call; librccl.so is loaded then, not linked), read back from
+ * rank 0 and checked byte for byte against every other rank's copy.  gsum_group_allgather is that step for any row-partitioned host
+ * array (rows x width doubles; rank r's rows are gsum_shard_range(rows, r, world)).  gsum_group_ctx lends a member context for the
+ * operator-level calls (predict: new points sharded over devices); a member is used by one thread at a time.
+ * gsum_group_get: "rccl" (0 not opened, 1 open, -1 unavailable), "rccl_gathers", "devices_used" (devices with work in the last scan). */
+typedef struct gsum_group gsum_group;
+#define GSUM_GATHER_RCCL 1
+int gsum_init_multi(int n_devices, const int* device_ids, gsum_group** out);
+/* ... or over contexts the caller opened (one per GPU) and keeps: gsum_group_destroy then leaves them alive (destroy the group first) */
+int gsum_group_adopt(int n_ctx, gsum_ctx* const* ctxs, gsum_group** out);
+void gsum_group_destroy(gsum_group* group);
+int32_t gsum_group_size(const gsum_group* group);
+gsum_ctx* gsum_group_ctx(gsum_group* group, int32_t i);                 /* borrowed: destroyed with the group */
+const char* gsum_group_last_error(gsum_group* group);                   /* NULL group: error of a failed gsum_init_multi */
+int64_t gsum_group_get(gsum_group* group, const char* name);
+int gsum_group_set_inputs(gsum_group* group, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);   /* every device */
+int gsum_group_lml_resident(gsum_group* group, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                            double* G_out, double* sld_out, int64_t* info_out, int32_t flags);
+/* gsum_lml_batch over the group's devices: X and RHS uploaded to every device (0.5 MB at n = 8192), descriptors block-partitioned */
+int gsum_lml_batch_multi(gsum_group* group, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n, int32_t d,
+                         const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out, int64_t* info_out, int32_t flags);
+int gsum_group_allgather(gsum_group* group, double* buf, int64_t rows, int64_t width);
 
 /* ---- measurement -------------------------------------------------------------------------------------------------------- */
 /* HIP-event times (ms) of the last single fused evaluation: K build, Cholesky (incl. fused solve), read-out + D2H, total */

@@ -25,6 +25,10 @@ extern "C" {
  * round-2 kernel: [7] start, [8 + 2j], [9 + 2j] wave 0 behind the two barriers of micro-block column j, [24 + j] cycles
  * of the pivot recurrence of micro-block j). */
 int gsum_debug_diag_stamps(gsum_ctx* ctx, int64_t* out64);
+/* the pairwise stream probe of gsum_init (option "pipes_ok") on the context's four streams plus `extra` (0..4) streams created for the
+ * call: out = (4 + extra)^2 overlaps of the pairs' two 100-us kernels in 1/1000 of their length (diagonal 1000).  A pair on one
+ * command-processor pipe takes turns (~0); DESIGN.md section 4.1. */
+int gsum_debug_pipe_probe(gsum_ctx* ctx, int32_t extra, int32_t* out);
 /* diagnostic: per-outer-step realtime stamps of the last persistent-chain factorisation (options "chain_stamps" = 1,
  * "chain_persist"; gsum_potrf_lower / a single fused evaluation on a matrix whose order is a multiple of 256): out holds
  * 24 values per step in 100 MHz ticks relative to the first stamp (-1: not written); [16..23] = first start / last end of the

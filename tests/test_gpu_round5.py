@@ -1,0 +1,195 @@
+"""Round-5 GPU tests (``-m gpu``): the device group of the C ABI (gsum_init_multi / gsum_lml_batch_multi / the in-library RCCL gather),
+``devices=`` on the model classes, the stream probe of gsum_init, the product library's factor against LAPACK."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+import gsum_amd  # noqa: E402
+from gsum_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return gsum_amd.default_context(0)
+
+
+def _scan_inputs(n, k=5, n_theta=13):
+    X = 0.1 * np.arange(n)[:, None]
+    rng = np.random.RandomState(5)
+    Z = np.concatenate([rng.randn(n, k - 1), np.ones((n, 1))], axis=1)
+    descs = [gsum_amd.describe_kernel(RBF(0.15 + 0.01 * j), 1) for j in range(n_theta)]
+    return X, Z, descs
+
+
+@pytest.mark.parametrize("n", [100, 700, 2300])
+def test_group_scan_equals_the_one_device_call(ctx, n):
+    """gsum_lml_batch_multi / gsum_group_lml_resident over [0] and over every visible GPU: G, sum log diag and info equal the
+    one-context call bit for bit, with the host merge and with the in-library RCCL gather (ncclCommInitAll over the group's devices;
+    world 1 on a one-GPU box, where the collective still runs through RCCL).  Replaces the serial loop over grid points,
+    docs/notebooks/correlated_EFT_publication.ipynb:1457-1459."""
+    X, Z, descs = _scan_inputs(n)
+    want = ctx.lml_batch(descs, X, Z, 1e-10)
+    for devices in ([0], "all"):
+        grp = gsum_amd.default_group(devices)
+        assert len(grp) == (1 if devices == [0] else gsum_amd.device_count())
+        for gather in ("host", "rccl"):
+            got = grp.lml_batch(descs, X, Z, 1e-10, gather=gather)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (devices, gather)
+        grp.set_inputs(X, Z)
+        got = grp.lml_resident(descs, 1e-10, gather="rccl")
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert grp.get("rccl") == 1 and grp.get("rccl_gathers") >= 2
+        assert grp.get("devices_used") == min(len(grp), len(descs))
+
+
+def test_group_threads_on_two_contexts_of_one_device(ctx):
+    """The fan-out itself -- one host thread per member, each block written into its positions of the caller's arrays -- on a box
+    with one GPU: a group that OWNS two contexts on device 0 (gsum_init_multi with device_ids {0, 0}).  Bit-identical to the
+    one-context call; the RCCL gather refuses a device listed twice with a message instead of hanging in ncclCommInitAll."""
+    X, Z, descs = _scan_inputs(900, n_theta=9)
+    want = ctx.lml_batch(descs, X, Z, 1e-10)
+    grp = gsum_amd.HipGroup([0, 0], own=True)
+    try:
+        assert len(grp) == 2
+        got = grp.lml_batch(descs, X, Z, 1e-10)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert grp.get("devices_used") == 2
+        # fewer descriptors than members: the second block is empty
+        got = grp.lml_batch(descs[:1], X, Z, 1e-10)
+        assert np.array_equal(got[1], want[1][:1]) and grp.get("devices_used") == 1
+        with pytest.raises(RuntimeError, match="twice"):
+            grp.lml_batch(descs, X, Z, 1e-10, gather="rccl")
+        # a failed evaluation is a value, not an error: a matrix that is not positive definite reports its pivot in every block
+        bad = [gsum_amd.describe_kernel(RBF(50.0), 1)] * 4
+        info = grp.lml_batch(bad, X, Z, 0.0)[2]
+        assert np.all(info > 0) and np.array_equal(info, ctx.lml_batch(bad, X, Z, 0.0)[2])
+        # errors name the member
+        with pytest.raises(ValueError, match="rank"):
+            grp.lml_batch(descs, X[:, [0] * 9], Z, 1e-10)
+    finally:
+        grp.close()
+
+
+def test_group_allgather_of_a_row_partitioned_array():
+    grp = gsum_amd.default_group("all")
+    a = np.random.RandomState(0).randn(37, 3)
+    out = grp.allgather(a)
+    assert np.array_equal(out, a)
+    assert grp.allgather(np.empty((0, 4))).shape == (0, 4)
+
+
+def _fitted(n, r=4, kernel=None, **kw):
+    X = 0.1 * np.arange(n)[:, None]
+    K = RBF(0.2)(X) + 1e-10 * np.eye(n)
+    c = np.linalg.cholesky(K) @ np.random.RandomState(0).randn(n, r)
+    y = gsum_amd.partials(c, ratio=0.5, ref=1.0, orders=np.arange(r))
+    gp = gsum_amd.TruncationGP(kernel=kernel or RBF(0.2), ratio=0.5, ref=1.0, center=0, disp=0, df=1, scale=1, optimizer=None, **kw)
+    gp.fit(X, y, orders=np.arange(r))
+    return gp, X, y
+
+
+@pytest.mark.parametrize("mode", ["full", "reuse"])
+def test_grid_over_devices_equals_the_plain_grid(mode):
+    """``log_marginal_likelihood_grid(devices=...)``: the surface of the single-process caller (notebook :1444-1459) from a group
+    of GPUs equals the one-device surface bit for bit -- [0], every visible GPU, host merge and RCCL gather, with and without the
+    prior-scale axis of BASELINE config 4."""
+    gp, X, y = _fitted(500)
+    thetas = [np.log([ls]) for ls in np.linspace(0.12, 0.3, 7)]
+    ratios = list(np.linspace(0.3, 0.7, 5))
+    want = gp.log_marginal_likelihood_grid(thetas, ratios, mode=mode)
+    want_s = gp.log_marginal_likelihood_grid(thetas[:2], ratios, scales=[0.5, 1.0, 2.0], mode=mode)
+    for devices in ([0], "all"):
+        for gather in ("host", "rccl"):
+            got = gp.log_marginal_likelihood_grid(thetas, ratios, mode=mode, devices=devices, gather=gather)
+            assert np.array_equal(got, want), (devices, gather)
+        got = gp.log_marginal_likelihood_grid(thetas[:2], ratios, scales=[0.5, 1.0, 2.0], mode=mode, devices=devices, gather="rccl")
+        assert np.array_equal(got, want_s)
+    with pytest.raises(ValueError):
+        gp.log_marginal_likelihood_grid(thetas, ratios, devices=[0], shard=(0, 1))
+
+
+def test_predict_over_devices_equals_the_plain_predict():
+    """``predict(devices=...)``: new points cut into one block per device, each device holding its own copy of the factor; columns
+    of the predictive covariance are independent per new point (models.py:836)."""
+    n = 700
+    rng = np.random.RandomState(3)
+    X = rng.rand(n, 2) * [6.0, 9.0]
+    y = rng.randn(n, 3)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, "fixed"), center=0, disp=0, df=1,
+                                           scale=1, optimizer=None).fit(X, y)
+    Xs = rng.rand(301, 2) * [6.0, 9.0]
+    mean, std = gp.predict(Xs, return_std=True)
+    for devices in ([0], "all"):
+        m2, s2 = gp.predict(Xs, return_std=True, devices=devices)
+        assert np.array_equal(m2, mean) and np.array_equal(s2, std)
+        m3 = gp.predict(Xs, devices=devices, Xc=X[::2], y=y[::2])
+        assert np.array_equal(m3, gp.predict(Xs, Xc=X[::2], y=y[::2]))
+    with pytest.raises(ValueError):
+        gp.predict(Xs, return_cov=True, devices=[0])
+
+
+def test_streams_of_a_context_run_side_by_side(ctx):
+    """gsum_init's pairwise stream probe (option "pipes_ok"): the context's four streams overlap pairwise; the lab entry shows the
+    same matrix, and what a stream created later -- on a pipe one of the four already uses -- looks like (recorded, asserted only
+    for shape: the mapping of queues to pipes is the runtime's)."""
+    assert ctx.get_option("pipes_ok") == 1, ctx.get_option("pipe_overlap_permille")
+    assert ctx.get_option("pipe_overlap_permille") >= 500
+    lab = gsum_amd.lab_context(0)
+    assert lab.get_option("pipes_ok") == 1
+    m = lab.pipe_probe(extra=2)
+    assert m.shape == (6, 6) and np.allclose(m, m.T) and np.all(m[:4, :4] >= 0.5)
+    from conftest import record_parity
+    record_parity("pipe_probe_overlap", float(m[:4, :4].min()), bound=0.5, later_streams=[float(m[:4, 4].min()), float(m[:4, 5].min())])
+
+
+def test_product_library_factor_against_lapack(ctx):
+    """gsum_potrf_lower of the PRODUCT library (the building-block tests of test_gpu_parity.py run on the lab build of the same
+    sources) against numpy.linalg.cholesky, factor against factor: n = 1000 in full, n = 8192 on sampled rows (LAPACK's factor of
+    the 8192 matrix takes seconds on the host).  Replaces models.py:711, 809, 969."""
+    for n, rows in ((1000, None), (8192, np.random.RandomState(0).choice(8192, 24, replace=False))):
+        X = 0.1 * np.arange(n)[:, None]
+        desc = gsum_amd.describe_kernel(RBF(0.2), 1)
+        K = RBF(0.2)(X) + 1e-6 * np.eye(n)
+        want = np.linalg.cholesky(K)
+        A = ctx.kernel_matrix_dev(desc, X, diag_add=1e-6)
+        try:
+            assert ctx.potrf(A) == 0
+            got = A.to_host()
+        finally:
+            A.free()
+        assert np.all(np.triu(got, 1) == 0.0)
+        sel = slice(None) if rows is None else np.sort(rows)
+        err = np.abs(got[sel] - want[sel]).max()
+        assert err < 1e-9, err                       # cond(K) ~ 1e6: two backward-stable factors agree to ~ eps * cond
+        back = got[sel] @ got.T - K[sel]
+        assert np.abs(back).max() < 1e-12
+
+
+def test_rccl_c_host_drives_its_devices_concurrently():
+    """tests/c_host/shard_host_rccl.c, round 5: one pthread per device runs that device's block (gsum_lml_resident_shard), so the
+    devices of a C host work at the same time; the recipe's three in-place ncclAllGather calls follow.  And the same scan through
+    the library's own group entry (gsum_lml_batch_multi with GSUM_GATHER_RCCL) from C."""
+    from test_host_logic import _build_rccl_host
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "shard_host_rccl")
+        res = _build_rccl_host(exe)
+        if res is None:
+            pytest.skip("gcc or the RCCL headers are not on this box")
+        assert res.returncode == 0, res.stderr
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "gsum_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        run = subprocess.run([exe, "1500", "13"], capture_output=True, text=True, timeout=600, env=env)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "threads" in run.stdout and "group entry: yes" in run.stdout, run.stdout
