@@ -268,8 +268,8 @@ def _warn_pipes(ctx):
     import warnings
     pm = int(ctx._lib.gsum_get_option(ctx._h, b"pipe_overlap_permille"))
     warnings.warn(f"gsum_amd: two of the context's four HIP streams on device {ctx.device} do not run side by side (overlap {pm / 10:.0f} % "
-                  "of a 100-us probe kernel): they share a command-processor pipe, or a tool serialises dispatches.  Results are "
-                  "unaffected; batches run 3-6 % and single factorisations 30-70 % slower (DESIGN.md section 4.1).", RuntimeWarning, stacklevel=3)
+                  "of a 100-us probe kernel) although gsum_init replaced the offending stream eight times: a tool serialises dispatches, "
+                  "or the process holds more streams than the GPU has hardware queues.  Results are unaffected; batches run 3-6 % and single factorisations 30-70 % slower (DESIGN.md section 4.1).", RuntimeWarning, stacklevel=3)
 
 
 class ChainAborted(RuntimeError):
@@ -354,7 +354,7 @@ class HipContext:
 
     def get_option(self, name: str) -> int:
         v = int(self._lib.gsum_get_option(self._h, name.encode()))
-        if v < 0 and name not in ("chain_persist", "chain_probe", "medium_min_batch", "wave_shift", "pipes_ok", "pipe_overlap_permille"):
+        if v < 0 and name not in ("chain_persist", "chain_probe", "medium_min_batch", "wave_shift", "pipes_ok", "pipe_overlap_permille", "pipe_heals"):
             raise ValueError(f"unknown option: {name}")
         return v
 

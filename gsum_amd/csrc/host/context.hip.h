@@ -131,6 +131,7 @@ struct gsum_ctx {
     int pipes_ok = -1;               // pairwise stream probe of gsum_init (gs_pipe_probe): 1 every pair of the context's four streams ran side by
                                      // side, 0 some pair took turns (two streams on one command-processor pipe, or a tool that serialises
                                      // dispatches: a batch loses 3-6 %, a single factorisation 30-70 %), -1 not run
+    int pipe_heals = 0;              // streams gsum_init replaced because they took turns with another of the four
     int pipe_overlap_permille = -1;  // ... the smallest overlap of a pair's two 100-us kernels, in 1/1000 of their length
     int chain_events_needed = 0;     // 1: a caller trails the factorisation by evP events (host-enqueued schedule only); 2: the gradient
                                      // path: either schedule, it trails the persistent chain by the chain's own flags

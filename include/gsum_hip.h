@@ -100,9 +100,10 @@ const char* gsum_last_error(gsum_ctx* ctx);             /* NULL ctx: error of a 
  *   "pivot_guard_ulps" 0..1024     a pivot p <= guard * eps * A_jj counts as not positive (default 2; process-wide)
  * gsum_get_option reads these back, plus "wave_streams" (streams the last batch call used: groups + 1), "chain_probe",
  * "chain_aborts" (give-ups of the persistent-chain schedule; the fused path re-runs itself, see GSUM_ERR_CHAIN_ABORT), and
- * "pipes_ok" / "pipe_overlap_permille": gsum_init runs a 100-us kernel on every pair of the context's four streams; 1 = every pair
- * overlapped (>= half its length; the smallest overlap in 1/1000), 0 = some pair took turns -- two of the streams share a
- * command-processor pipe or a tool serialises dispatches: results are unaffected, a batch runs 3-6 % and a single factorisation
+ * "pipes_ok" / "pipe_overlap_permille" / "pipe_heals": gsum_init runs a 100-us kernel on every pair of the context's four streams and
+ * replaces a stream that takes turns with another (two streams on one hardware queue: seen for the second context of a process) by a
+ * new one, up to eight times ("pipe_heals"); 1 = every pair overlaps (>= half its length; the smallest overlap in 1/1000), 0 = some
+ * pair still takes turns (e.g. a tool serialises dispatches): results are unaffected, a batch runs 3-6 % and a single factorisation
  * 30-70 % slower. */
 int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value);
 int64_t gsum_get_option(gsum_ctx* ctx, const char* name);
