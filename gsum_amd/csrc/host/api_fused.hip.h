@@ -120,8 +120,11 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lml_small, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n, ctx->in->d, ctx->in->Z, k,
-                           (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), (double*)(base + o_res));
+        bool tree = false;                        // a tree among this launch's descriptors: the instantiation that can walk one
+        for (int e = 0; e < cnt; ++e) tree = tree || kernels[lo + e].n_ops > 0;
+        hipLaunchKernelGGL(tree ? k_lml_small<true> : k_lml_small<false>, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n,
+                           ctx->in->d, ctx->in->Z, k, (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr),
+                           (double*)(base + o_res));
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));
@@ -157,16 +160,19 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
     const size_t shmem = (size_t)std::max<int>(GS_TILE_LD_DOUBLES, GS_DIAG_WS) * sizeof(double);
-    if (!ctx->lds_attr_done.count((const void*)k_lml_medium)) {
-        GS_CHECK(hipFuncSetAttribute((const void*)k_lml_medium, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        ctx->lds_attr_done.insert((const void*)k_lml_medium);
-    }
+    for (const void* fn : {(const void*)k_lml_medium<false>, (const void*)k_lml_medium<true>})
+        if (!ctx->lds_attr_done.count(fn)) {
+            GS_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            ctx->lds_attr_done.insert(fn);
+        }
     if (gs_reserve_pinned(ctx, (size_t)CH * 258 * 8)) return -1;
     double* hres = ctx->hbatch;
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lml_medium, dim3(cnt), dim3(256), shmem, s, ctx->in->X, (int)n, ctx->in->d, ctx->in->Z, k,
+        bool tree = false;
+        for (int e = 0; e < cnt; ++e) tree = tree || kernels[lo + e].n_ops > 0;
+        hipLaunchKernelGGL(tree ? k_lml_medium<true> : k_lml_medium<false>, dim3(cnt), dim3(256), shmem, s, ctx->in->X, (int)n, ctx->in->d, ctx->in->Z, k,
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res),
                            ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
         GS_CHECK(hipGetLastError());

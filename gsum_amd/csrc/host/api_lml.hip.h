@@ -9,9 +9,9 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     if (!ctx->in->X) GS_FAIL("gsum_set_inputs has not been called");
     for (int i = 0; i < n_kernels; ++i)
         if (gs_check_desc(ctx, &kernels[i], ctx->in->d)) return -2;
-    bool any_tree = false;                       // the one-workgroup-per-evaluation kernels build the flattened form only
-    for (int i = 0; i < n_kernels; ++i) any_tree = any_tree || kernels[i].n_ops > 0;
-    if (ctx->in->n <= GS_NB && ctx->small_path && !any_tree) {
+    // (kernel trees take the one-workgroup-per-evaluation paths too since round 5: k_lml_small<true> / k_lml_medium<true> walk the
+    // postfix program in their build step -- the reference's own workloads are 5 ... 20 points on 8000-point grids, models.py:958-960)
+    if (ctx->in->n <= GS_NB && ctx->small_path) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_small(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }
@@ -21,7 +21,7 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     // path up to 40 % too early: n = 2048, 96 evaluations 17.5 ms fused against 12.4 grouped)
     const int med_min = ctx->medium_min_batch > 0 ? ctx->medium_min_batch
                                                   : (ctx->in->n <= 256 ? 2 : std::max(4, (int)(ctx->in->n / 16)));
-    if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min && !any_tree) {
+    if (ctx->in->n <= GS_MEDIUM_MAX && ctx->medium_path && n_kernels >= med_min) {
         ctx->cur = &ctx->slots[0];
         return gs_lml_medium(ctx, kernels, n_kernels, nugget, G_out, sld_out, info_out);
     }

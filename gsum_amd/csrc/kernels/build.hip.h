@@ -557,6 +557,43 @@ __device__ __forceinline__ double gs_tree_eval(const gsum_kernel_desc& t, const 
     return sv[0];
 }
 
+// One 128 x 128 tile of a tree's matrix inside the one-workgroup-per-evaluation kernels (k_lml_small / k_lml_medium): the geometry
+// and the diagonal / padding rules of gs_build_tile128's general branch (wave w takes rows w, w + 4, ...; a lane two adjacent
+// columns; identity padding beyond n; the diagonal's values also to diag0), the values through gs_tree_eval on the points themselves
+// (a tree's leaves divide by their own length scales) -- so the matrix equals k_build_tree's bit for bit.  `desc` stays where it
+// is (global memory, uniform address: scalar loads), the program is walked with dynamic indices.
+__device__ __forceinline__ void gs_build_tile128_tree(double* A, int64_t ld, const double* X, int bi, int bj, int n, int d,
+                                                      const gsum_kernel_desc& desc, double diag_add, double* diag0, int w, int lane) {
+#pragma clang fp contract(off)
+    const int r0 = bi * 128, gj0 = bj * 128 + 2 * lane;
+    double xj[2][GSUM_MAX_D];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xj[c][mm] = (mm < d && gj0 + c < n) ? X[(int64_t)(gj0 + c) * d + mm] : 0.0;
+#pragma unroll 1
+    for (int rp = w; rp < 128; rp += 4) {
+        const int gi = r0 + rp;
+        double xi[GSUM_MAX_D];
+#pragma unroll
+        for (int mm = 0; mm < GSUM_MAX_D; ++mm) xi[mm] = (mm < d && gi < n) ? X[(int64_t)gi * d + mm] : 0.0;
+        double v[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int gj = gj0 + c;
+            if (gi >= n || gj >= n) {
+                v[c] = gi == gj ? 1.0 : 0.0;                       // identity padding
+            } else {
+                v[c] = gs_tree_eval(desc, xi, xj[c], d, gi == gj, nullptr, nullptr);
+                if (gi == gj) v[c] = v[c] + diag_add;
+            }
+            if (gi == gj) diag0[gi] = v[c];
+        }
+        const gs_d2 o = {v[0], v[1]};
+        *reinterpret_cast<gs_d2*>(A + (int64_t)gi * ld + gj0) = o;
+    }
+}
+
 // kernel matrix of a tree: the tile geometry of k_build2 (32 x 128 tiles, a lane owns two adjacent columns), values through gs_tree_eval
 template <bool CROSS>
 __global__ __launch_bounds__(256) void k_build_tree(double* out, int64_t ldo, const double* X, const double* Y, int n, int m, int prow,

@@ -10,8 +10,12 @@
 // ------------------------------------------------------------------------------------------------
 #define GS_SMALL_SCRATCH (2 * 128 * 128)
 
+// TREE: the instantiation the host launches when a call carries a Sum / Product tree (n_ops > 0): such an evaluation builds its matrix
+// with gs_build_tile128_tree, every other evaluation of the call with the flattened code; a call of flattened descriptors only runs the
+// TREE = false kernel, whose register budget the postfix walk never touches.
+template <bool TREE>
 __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
-                                                    const gsum_kernel_desc* descs, double nugget, double* scratch,
+                                                    const gsum_kernel_desc* __restrict__ descs, double nugget, double* scratch,
                                                     double* res) {
 #pragma clang fp contract(off)
     __shared__ double dg0[128];
@@ -20,7 +24,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     double* us = wsd;                                                   // 78.6 KB of LDS in all, two evaluations per CU
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc desc = descs[blockIdx.x];
+    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 616 B of scratch per lane
     double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
     double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
     double* out = res + (int64_t)blockIdx.x * 258;
@@ -35,7 +39,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     }
     __syncthreads();
     // (the one tile is a diagonal tile: rows and columns are the same points; family / dimension as template parameters)
-    gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
+    if (TREE && descs[blockIdx.x].n_ops > 0) gs_build_tile128_tree(A, 128, X, 0, 0, n, d, descs[blockIdx.x], nugget, dg0, w, lane);
+    else gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
     __threadfence_block();
     __syncthreads();
     // ---- Cholesky of the block; its substitution tables stay in wsd
@@ -190,8 +195,9 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
     __syncthreads();
 }
 
+template <bool TREE>
 __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
-                                                     const gsum_kernel_desc* descs, double nugget, double* scratch,
+                                                     const gsum_kernel_desc* __restrict__ descs, double nugget, double* scratch,
                                                      int64_t scratch_stride, double* res, unsigned long long* stamps = nullptr) {
     extern __shared__ double lds[];                 // max(GS_DIAG_WS, GS_TILE_LD_DOUBLES) doubles, lent in turn to the kernel
                                                     // build, the diagonal-block routine and the tile routine: 77.6 KB in
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     __shared__ double ldet_sum;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc desc = descs[blockIdx.x];
+    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 616 B of scratch per lane
     const int np = (n + 127) / 128 * 128, T = np / 128;
     const int64_t ld = np + GS_BORDER;
     double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                     uj[idx] = gj < n ? X[(int64_t)gj * d + dd] / ls : 0.0;
                 }
                 __syncthreads();
-                gs_build_tile128_any(A, ld, ui, uj, etab, etab + 16, bi, bj, n, d, desc, nugget, diag0, w, lane);
+                if (TREE && descs[blockIdx.x].n_ops > 0) gs_build_tile128_tree(A, ld, X, bi, bj, n, d, descs[blockIdx.x], nugget, diag0, w, lane);
+                else gs_build_tile128_any(A, ld, ui, uj, etab, etab + 16, bi, bj, n, d, desc, nugget, diag0, w, lane);
             }
     }
     if (t == 0) ldet_sum = 0.0;

@@ -41,7 +41,7 @@ def test_rccl_c_host_gathers_the_sharded_scan(n, n_theta):
         run = subprocess.run([exe, str(n), str(n_theta)], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "gathered == unsharded on every rank: yes" in run.stdout, run.stdout
-    assert "(RCCL, ncclCommInitAll)" in run.stdout
+    assert "(RCCL, ncclCommInitAll" in run.stdout and "group entry: yes" in run.stdout
 
 
 @pytest.mark.parametrize("variant", ["b20", "b3"])

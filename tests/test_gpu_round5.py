@@ -202,3 +202,93 @@ def test_rccl_c_host_drives_its_devices_concurrently():
         run = subprocess.run([exe, "1500", "13"], capture_output=True, text=True, timeout=600, env=env)
         assert run.returncode == 0, run.stdout + run.stderr
         assert "threads" in run.stdout and "group entry: yes" in run.stdout, run.stdout
+
+
+# ---- kernel trees on the one-workgroup-per-evaluation paths (missing 3) ---------------------------------------------------
+TREES = ["RBF(0.2) + RBF(2.5) + WhiteKernel(1e-8)", "C(2.0) * RBF(0.3) + C(0.5) * Matern(0.8, nu=2.5) + WhiteKernel(1e-6)",
+         "RBF(0.25) * Matern(1.5, nu=1.5) + WhiteKernel(1e-7)", "RationalQuadratic(0.4, alpha=1.3) + RBF(0.2) + WhiteKernel(1e-6)"]
+
+
+@pytest.mark.parametrize("expr", TREES)
+@pytest.mark.parametrize("n,d", [(5, 1), (97, 2), (128, 1), (300, 1), (700, 2)])
+def test_tree_kernels_on_the_fused_paths_equal_the_general_path(ctx, expr, n, d):
+    """A Sum / Product tree on k_lml_small<true> (n <= 128) and k_lml_medium<true> (n <= 4096) gives G, sum log diag and info equal,
+    bit for bit, to the grouped multi-kernel schedule (k_build_tree + the blocked factorisation) -- the reference accepts any kernel
+    (models.py:146-147, 958-960) and its own workloads are 5 ... 20 points on 8000-point grids; mixed calls (flattened and tree
+    descriptors in one launch) too."""
+    from conftest import tree_kernel
+    rng = np.random.RandomState(n)
+    X = rng.rand(n, d) * (0.12 * n if d == 1 else np.sqrt(n) * 0.4)
+    Z = np.concatenate([rng.randn(n, 3), np.ones((n, 1))], axis=1)
+    kern = tree_kernel(expr)
+    descs = [gsum_amd.describe_kernel(kern.clone_with_theta(kern.theta + dt), d) for dt in np.linspace(-0.15, 0.15, 5)]
+    assert all(dd.is_tree for dd in descs)
+    mixed = descs[:2] + [gsum_amd.describe_kernel(RBF(0.3) + WhiteKernel(1e-6), d)] + descs[2:]
+    ctx.set_inputs(X, Z)
+    ctx.set_option("medium_min_batch", 1)
+    try:
+        got = ctx.lml_resident(mixed, 1e-10)
+        ctx.set_option("small_path", 0)
+        ctx.set_option("medium_path", 0)
+        want = ctx.lml_resident(mixed, 1e-10)
+    finally:
+        ctx.set_option("small_path", 1)
+        ctx.set_option("medium_path", 1)
+        ctx.set_option("medium_min_batch", -1)
+    assert np.all(want[2] == 0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_tree_kernel_golden_through_the_small_path():
+    """tests/golden/tree_kernels.json (values of the reference itself, n = 60): the likelihood of every case through a CALL OF SEVERAL
+    evaluations, i.e. k_lml_small<true> (tests/test_gpu_parity.py::test_tree_kernels_golden makes the single calls)."""
+    from conftest import load_golden, tree_kernel
+    ctx = gsum_amd.default_context(0)
+    done = 0
+    for case in load_golden("tree_kernels.json"):
+        X, y = np.array(case["X"]), np.array(case["y"])
+        kern = tree_kernel(case["expr"])
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, nugget=case["nugget"], **case["priors"])
+        descs = [gsum_amd.describe_kernel(kern.clone_with_theta(np.array(ev["theta"])), case["dim"]) for ev in case["evals"]]
+        assert all(dd.is_tree for dd in descs)
+        G, sld, info = ctx.lml_batch(descs * 3, X, gp._rhs(X, y), gp.nugget)
+        lml = gp._lml_gram_batch(G, sld, X.shape[0])
+        assert np.all(info == 0)
+        vtol = max(1e-10, 3e-17 * case["cond"])
+        for q, ev in enumerate(case["evals"]):
+            assert lml[q] == lml[q + len(descs)] == lml[q + 2 * len(descs)]
+            assert lml[q] == pytest.approx(ev["lml"], rel=vtol), case["expr"]
+            done += 1
+    assert done >= 6
+
+
+def test_notebook_grid_with_a_tree_kernel_stays_on_the_fast_path():
+    """The notebook's 80 x 100 scan (n = 5, 8000 evaluations) with RBF(0.2) + RBF(2.5) + White: within 1.5 x of the flattened
+    kernel's time (round 4: a tree fell off the one-workgroup path onto the 256-padded multi-kernel schedule, per evaluation)."""
+    import time
+    from conftest import load_golden, record_parity
+    g = load_golden("notebook_grid.json")
+    X, y = np.array(g["X_train"]), np.array(g["y_train"])
+    flat = RBF(0.2) + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+    tree = RBF(0.2) + RBF(2.5, length_scale_bounds="fixed") + WhiteKernel(g["nugget"], noise_level_bounds="fixed")
+    times = {}
+    for name, kern in (("flat", flat), ("tree", tree)):
+        gp = gsum_amd.TruncationGP(kernel=kern, ref=g["ref"], ratio=0.5, center=0, disp=0, df=1, scale=1, optimizer=None)
+        gp.fit(X, y, orders=np.array(g["orders"]))
+        thetas = [[t] for t in np.log(g["ls_vals"])]
+        gp.log_marginal_likelihood_grid(thetas, g["ratio_vals"], mode="full")
+        best = np.inf
+        for _ in range(3):
+            t0 = time.perf_counter()
+            grid = gp.log_marginal_likelihood_grid(thetas, g["ratio_vals"], mode="full")
+            best = min(best, time.perf_counter() - t0)
+        assert grid.shape == (80, 100) and np.isfinite(grid).all()
+        times[name] = best
+        if name == "tree":           # spot check against the oracle's scikit-learn arithmetic
+            from oracle import gsum_oracle as orc
+            for (i, j) in ((0, 0), (36, 39), (79, 99)):
+                want = orc.trunc_lml(kern, np.array(thetas[j]), X, y, np.array(g["orders"]), ratio=g["ratio_vals"][i], ref=g["ref"])
+                assert abs(grid[i, j] - want) <= 1e-10 * abs(want)
+    record_parity("notebook_grid_tree_vs_flat_ms", flat_ms=times["flat"] * 1e3, tree_ms=times["tree"] * 1e3, bound=1.5)
+    assert times["tree"] <= 1.5 * times["flat"], times
