@@ -149,6 +149,7 @@ void gsum_destroy(gsum_ctx* ctx) {
         if (sl->sa) (void)hipStreamDestroy(sl->sa);
         if (sl->evC) (void)hipEventDestroy(sl->evC);
         if (sl->evS) (void)hipEventDestroy(sl->evS);
+        if (sl->evN) (void)hipEventDestroy(sl->evN);
     }
     gs_wave_release(ctx, true);
     for (gs_inputs* I : {&ctx->op, &ctx->res}) {
@@ -193,6 +194,8 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "wave_shift")) return ctx->wave_shift;
     if (!strcmp(name, "wave_min")) return ctx->wave_min;
     if (!strcmp(name, "chain_rows")) return ctx->chain_rows;
+    if (!strcmp(name, "chain_deep")) return ctx->chain_deep;
+    if (!strcmp(name, "chain_depth")) return ctx->chain_depth;
     if (!strcmp(name, "lazy_far")) return ctx->lazy_far;
     if (!strcmp(name, "panel_wave_ticks") || !strcmp(name, "panel_waves")) {         // read-back of option panel_stats (synchronises)
         if (!ctx->panel_stats) return -1;
@@ -234,6 +237,9 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_min_np")) ctx->chain_min_np = (int)std::max<int64_t>(512, value);
     else if (!strcmp(name, "chain_rows")) ctx->chain_rows = value >= 512 ? 512 : 256;
     else if (!strcmp(name, "chain_lazy")) ctx->chain_lazy = value < 0 ? -1 : (int)std::min<int64_t>(2, value);
+    else if (!strcmp(name, "chain_deep")) ctx->chain_deep = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(name, "chain_depth")) ctx->chain_depth = (int)std::max<int64_t>(2, std::min<int64_t>(8, value));
+    else if (!strcmp(name, "chain_deep_rows")) ctx->chain_deep_rows = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_test_abort")) ctx->chain_test_abort = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));

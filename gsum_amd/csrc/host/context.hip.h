@@ -45,6 +45,7 @@ struct gs_slot {
     hipEvent_t evU = nullptr;
     hipStream_t sa = nullptr;        // persistent-chain schedule: the panel of the rows below the window and the near updates A, B
     hipEvent_t evC = nullptr, evS = nullptr;     // ... its joins (chain kernel / stream sa -> main stream)
+    hipEvent_t evN = nullptr;                    // ... and of the near-band stream of the deep schedule (the context's fourth stream)
     std::vector<hipEvent_t> evP, evM, evA;
     hipEvent_t evFork = nullptr;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -142,6 +143,16 @@ struct gsum_ctx {
     unsigned long long* panel_stats = nullptr;   // diagnostics (option panel_stats): {sum of wave lifetimes in 10-ns ticks, waves} of every k_panel256 launch
     int first_tiles = 0;                  // the NEXT bulk (cfg 7) launch: its first-256-column tiles first, counted in *first_done (k_gemm_ld3)
     unsigned* first_done = nullptr;
+    int second_c2 = 0;                    // ... and a second counted group behind them: its column tiles 4 .. second_c2 - 1, counted in *second_done
+    unsigned* second_done = nullptr;
+    int chain_deep = -1;                  // persistent-chain schedule: trailing updates grouped `chain_depth` panels deep while the far region is large
+                                          // (gs_potrf_chain: near band on the context's fourth stream, ONE K = 256 x depth far launch per macro-step);
+                                          // -1 (default): from padded order 10240 up, 0 never, 1 whenever a macro-step fits.  Measured
+                                          // (profiles/r05_chain_deep.log): n = 16384 27.70 -> 27.07 ms, 12288 13.12 -> 12.88, 8192 5.23 -> 5.43-5.51
+                                          // (depth 2: 5.18), 4096 unchanged -- the head is bound by the chip's aggregate rate, not by waits: the
+                                          // K = 1024 launches run at 53 TF/s beside the near launches (65 alone) and those at K = 256
+    int chain_depth = 4;
+    int chain_deep_rows = 4096;           // ... as long as the far region of the macro-step has at least this many rows
     // Inputs on the device.  `res` is written by gsum_set_inputs ONLY and read by gsum_lml_resident; every other entry
     // point (operator level, gsum_lml_batch, gsum_lml_grad) uploads into `op`.  `in` is the set the fused path reads.
     gs_inputs op, res;

@@ -60,10 +60,13 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
             blocks = ((M + 127) / 128) * ((N + 63) / 64);
         }
         hipLaunchKernelGGL(k_gemm_ld3<2>, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri,
-                           beta, sign, ctx->kst_ptr, tri == 2 ? 0 : ctx->first_tiles, ctx->first_done);
+                           beta, sign, ctx->kst_ptr, tri == 2 ? 0 : ctx->first_tiles, ctx->first_done,
+                           (tri == 1 && ctx->first_tiles > 0) ? ctx->second_c2 : 0, ctx->second_done);
         ctx->kst_ptr = nullptr;
         ctx->first_tiles = 0;
         ctx->first_done = nullptr;
+        ctx->second_c2 = 0;
+        ctx->second_done = nullptr;
         GS_CHECK(hipGetLastError());
         return 0;
     }

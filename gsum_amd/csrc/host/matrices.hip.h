@@ -27,7 +27,7 @@ static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
     gsum_mat* m = new gsum_mat();
     m->n = n;
     m->np = gs_padded_order(ctx, n);
-    m->ld = m->np + GS_BORDER;          // row stride 64 KiB + 128 B at n = 8192: no channel aliasing
+    m->ld = GS_LD(m->np);               // (see GS_LD_EXTRA: not np + 16)
     m->T = (int)(m->np / GS_NB);
     hipError_t e = hipMalloc((void**)&m->A, (size_t)(m->np + GS_BORDER) * m->ld * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&m->Linv, (size_t)m->T * GS_NB * GS_NB * sizeof(double));

@@ -225,9 +225,42 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         }
         return cnt;
     };
+    // DEEP GROUPING (round 5; the batch schedule's wave_depth on ONE factorisation): while the far region is large the trailing update
+    // runs `depth` panels deep.  Macro-step of panels a .. a + L - 1:
+    //   step s < a + L - 1   N(s), the NEAR BAND: C[rows >= 256 (s + 2)][column blocks s + 2 .. a + L] -= P_s P_s^T (K = 256), one rectangular
+    //                        launch on the context's fourth stream, its first 256 columns first and counted in FB[s] (kind 3);
+    //   step a + L - 1       Far: everything from column block a + L + 1 on takes all L panels in ONE K = 256 L launch on the main stream; its
+    //                        first 256 columns are counted in FB[s], the columns of the next macro-step's band right behind them in FF[s],
+    //                        which that macro-step's first near launch waits for (kind 4).
+    // Column block c receives Far of every earlier macro-step, N(a) .. N(c - 2) and then panel c - 1 from the chain / A(c - 1), which wait
+    // for FB[c - 2] as before: the same products in the same ascending order per element, so the factor is bit-identical.  What changes is
+    // what the chain waits for: inside a macro-step only the small near launches -- the far launches (K = 1024: 65 TF/s alone against 47 at
+    // K = 256) follow one another on the main stream and no chain step queues behind a whole one.
+    std::vector<int> macro_a((size_t)S, -1), macro_L((size_t)S, 0);          // per step: first panel and length of its macro-step (deep steps only)
+    auto second_count = [](int64_t mrows, int c2) {                          // mirrors gs_gemm_ld3_body: tiles in column tiles 4 .. c2 - 1
+        const int64_t tm = (mrows + 127) / 128, bm0 = c2 / 2 - 1, cum0 = (bm0 - 1) * (bm0 - 2);
+        return (unsigned)(tm <= bm0 ? (tm >= 2 ? (tm - 1) * (tm - 2) : 0) : cum0 + (tm - bm0) * (c2 - 4));
+    };
+    const bool deep_on = ctx->chain_events_needed == 0 && ctx->wave.g[2].sc != nullptr &&
+                         (ctx->chain_deep > 0 || (ctx->chain_deep < 0 && m->np >= 10240));
+    const int depth = std::max(2, std::min(8, ctx->chain_depth));
+    int s_plain = 0;                                                         // first step of the per-step (kind 0 / 1 / 2) schedule
+    if (deep_on)
+        for (int a = 0; a + depth <= S - 1; a += depth) {
+            const int64_t rF = 256 * (int64_t)(a + depth + 1), mF = naug - rF;
+            if (mF < std::max<int64_t>(ctx->chain_deep_rows, 256 + GS_BORDER)) break;
+            for (int i = 0; i < depth; ++i) {
+                const int s = a + i;
+                macro_a[s] = a;
+                macro_L[s] = depth;
+                if (i + 1 < depth) plan[s] = Plan{3, 4u * (unsigned)((naug - 256 * (int64_t)(s + 2) + 127) / 128)};
+                else plan[s] = Plan{4, 4u * (unsigned)((mF + 127) / 128) - 2u};
+            }
+            s_plain = a + depth;
+        }
     {
         bool deferred = false;
-        for (int s = 0; s + 1 < S; ++s) {
+        for (int s = s_plain; s + 1 < S; ++s) {
             const int64_t r3 = 256 * (int64_t)(s + 2), m3 = naug - r3;
             if (m3 <= 0) continue;
             const unsigned tm = (unsigned)((m3 + 127) / 128);
@@ -243,7 +276,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         }
     }
     unsigned* fbw = fl + gs_fl_count(S);
-    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0);
+    const int fb_key = (W * 2 + (lazy ? 1 : 0)) * 8 + NB + (near256 ? 1024 : 0) + 4096 * (s_plain * 16 + depth);
     if (m->fbwant_key != fb_key) {
         GS_CHECK(hipStreamSynchronize(sm));                      // (a previous upload from the same host buffer has completed)
         m->fbwant_host.resize((size_t)S);
@@ -254,6 +287,11 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     GS_CHECK(hipEventRecord(sl->evFork, sm));
     GS_CHECK(hipStreamWaitEvent(sp, sl->evFork, 0));
     GS_CHECK(hipStreamWaitEvent(sa, sl->evFork, 0));
+    hipStream_t sn = ctx->wave.g[2].sc;               // the near band's stream (deep steps only): the context's fourth stream
+    if (s_plain > 0) {
+        if (!sl->evN) GS_CHECK(hipEventCreateWithFlags(&sl->evN, hipEventDisableTiming));
+        GS_CHECK(hipStreamWaitEvent(sn, sl->evFork, 0));
+    }
     gs_chain_args ca;
     ca.A = A; ca.ld = ld; ca.np = (int)m->np; ca.naug = (int)naug; ca.S = S; ca.W = W;
     ca.Ltab = m->Ltab; ca.Lsib = m->Lsib; ca.logdet = m->logdet; ca.diag0 = m->diag0; ca.info = sl->dinfo;
@@ -331,6 +369,37 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
         if (m3 <= 0) continue;
         unsigned* fbp = fl + gs_fl(GS_FL_FB, S, s);
         double* P3 = A + r3 * ld + c0;               // panel rows r3.., this step's 256 columns
+        if (plan[s].kind == 3) {
+            // near band of a deep macro-step: rows >= r3, column blocks s + 2 .. a + L (the strict upper part of its top square is computed
+            // and never read, like the kind-1 launches'); the first near launch of a macro-step waits for the previous far launch's band tiles
+            const int a0 = macro_a[s], L = macro_L[s];
+            const int64_t wband = 256 * (int64_t)(a0 + L + 1) - r3;
+            if (s == a0 && a0 > 0)
+                wait1(sn, GS_FL_FF, a0 - 1, second_count(naug - 256 * (int64_t)(a0 + 1), 4 * L));
+            wait1(sn, GS_FL_RP, s, 1u);
+            ctx->first_tiles = (int)plan[s].fb;
+            ctx->first_done = fbp;
+            ctx->next_algo_flops = 256.0 * (2.0 * (double)m3 * (double)wband - (double)wband * ((double)wband - 1.0));
+            kstamp(s, 2);
+            if (gs_gemm(ctx, sn, 7, A + r3 * ld + r3, ld, P3, ld, P3, ld, m3, wband, 256, 0, 1, -1.0)) return -1;
+            continue;
+        }
+        if (plan[s].kind == 4) {
+            // the far launch of a deep macro-step: all its L panels (contiguous columns 256 a ...) on everything from column block a + L + 1 on
+            const int a0 = macro_a[s], L = macro_L[s];
+            const int64_t rF = 256 * (int64_t)(a0 + L + 1), mF = naug - rF;
+            double* PF = A + rF * ld + 256 * (int64_t)a0;
+            wait1(sm, GS_FL_RP, s, 1u);
+            ctx->first_tiles = (int)plan[s].fb;
+            ctx->first_done = fbp;
+            if (s + 1 < S && plan[s + 1].kind == 3) {             // another deep macro-step follows: count its band's tiles for its first near launch
+                ctx->second_c2 = 4 * macro_L[s + 1];
+                ctx->second_done = fl + gs_fl(GS_FL_FF, S, s);
+            }
+            kstamp(s, 3);
+            if (gs_gemm(ctx, sm, GS_BULK, A + rF * ld + rF, ld, PF, ld, PF, ld, mF, mF, 256 * L, 1, 1, -1.0)) return -1;
+            continue;
+        }
         if (plan[s].kind == 0) {
             for (int p = 0; p < NB; ++p) {
                 const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
@@ -387,6 +456,10 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     GS_CHECK(hipEventRecord(sl->evS, sa));
     GS_CHECK(hipStreamWaitEvent(sm, sl->evC, 0));
     GS_CHECK(hipStreamWaitEvent(sm, sl->evS, 0));
+    if (s_plain > 0) {
+        GS_CHECK(hipEventRecord(sl->evN, sn));
+        GS_CHECK(hipStreamWaitEvent(sm, sl->evN, 0));
+    }
     // a chain that gave up (flags[0] == 1) reports through the info word: INT_MAX is no LAPACK index
     hipLaunchKernelGGL(k_chain_status, dim3(1), dim3(64), 0, sm, (const unsigned*)fl, sl->dinfo);
     GS_CHECK(hipGetLastError());

@@ -41,7 +41,7 @@ static void gs_wave_release(gsum_ctx* ctx, bool streams) {
 
 static double gs_wave_ws_bytes(int64_t np) {
     const double T = (double)(np / GS_NB);
-    return (double)(np + GS_BORDER) * (double)(np + GS_BORDER) * 8.0 + T * GS_LTAB * 8.0 + (T / 2 + 1) * GS_LSIB * 8.0 +
+    return (double)(np + GS_BORDER) * (double)GS_LD(np) * 8.0 + T * GS_LTAB * 8.0 + (T / 2 + 1) * GS_LSIB * 8.0 +
            (T + (double)np + 258.0) * 8.0 + 4.0;
 }
 
@@ -49,7 +49,7 @@ static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
     gs_wave* wv = &ctx->wave;
     if (!wv->sb) wv->sb = ctx->slots[0].sm;
     const int T = (int)(np / GS_NB);
-    const int64_t ld = np + GS_BORDER;
+    const int64_t ld = GS_LD(np);
     for (int i = 0; i < G; ++i) {
         gs_wave_group* g = &wv->g[i];
         if (!g->sc) {
@@ -151,7 +151,7 @@ static int gs_wave_fit(gsum_ctx* ctx, int64_t n, int64_t np) {
 
 static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_kernels, double nugget, double* G_out, double* sld_out,
                        int64_t* info_out) {
-    const int64_t n = ctx->in->n, np = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB), ld = np + GS_BORDER, naug = np + GS_BORDER;
+    const int64_t n = ctx->in->n, np = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB), ld = GS_LD(np), naug = np + GS_BORDER;
     const int k = ctx->in->k, d = ctx->in->d, S = (int)(np / (2 * GS_NB));
     int G = std::max(1, std::min(GS_WV_GROUPS, ctx->wave_groups));
     int B = std::max(1, std::min(GS_WVC_MAX, ctx->wave_size));

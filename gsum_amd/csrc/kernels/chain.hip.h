@@ -6,7 +6,8 @@
 #define GS_FL_ABORT 0                       // 0 running, 1 a wait timed out, 2 a pivot failed (info says where)
 #define GS_FL_RESIDENT 1                    // workgroups of k_chain that have started (k_wait_flag holds the other streams back)
 #define GS_FL_BASE 16
-enum { GS_FL_T0 = 0, GS_FL_TL, GS_FL_T1, GS_FL_WTOP, GS_FL_WALL, GS_FL_UD0, GS_FL_UD1, GS_FL_UR, GS_FL_FA, GS_FL_FB, GS_FL_RP, GS_FL_KINDS };
+enum { GS_FL_T0 = 0, GS_FL_TL, GS_FL_T1, GS_FL_WTOP, GS_FL_WALL, GS_FL_UD0, GS_FL_UD1, GS_FL_UR, GS_FL_FA, GS_FL_FB, GS_FL_RP, GS_FL_FF, GS_FL_KINDS };
+// (FF[s]: tiles of the deep schedule's far launch at the end of the macro-step that closes with step s, over the columns of the NEXT macro-step's near band)
 __host__ __device__ inline int gs_fl(int kind, int S, int s) { return GS_FL_BASE + kind * S + s; }
 __host__ __device__ inline int gs_fl_wg(int S, int s, int g) { return GS_FL_BASE + GS_FL_KINDS * S + GS_CH_GMAX * s + g; }
 __host__ __device__ inline int gs_fl_count(int S) { return (GS_FL_BASE + (GS_FL_KINDS + GS_CH_GMAX) * S + 3) / 4 * 4; }

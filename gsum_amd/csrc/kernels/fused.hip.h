@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 616 B of scratch per lane
     const int np = (n + 127) / 128 * 128, T = np / 128;
-    const int64_t ld = np + GS_BORDER;
+    const int64_t ld = GS_LD(np);
     double* A = scratch + (int64_t)blockIdx.x * scratch_stride;
     double* diag0 = A + (int64_t)np * ld + (int64_t)T * 128 * 128;     // (the T x 128 x 128 slot before it held exported tables
                                                                        // while the right-hand sides had a sweep of their own)

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
 template <int NST>
 __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                  int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                 unsigned long long* kst, int nfirst, unsigned* first_done, const int bid_in) {
+                                                 unsigned long long* kst, int nfirst, unsigned* first_done, const int bid_in,
+                                                 const int c2 = 0, unsigned* second_done = nullptr) {
     constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
@@ -36,7 +37,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     // runs at 66 TF/s, the clock-limited rate under this kernel: profiles/r03_bulk_cphase.log.)
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
-    bool first_cols = false;
+    bool first_cols = false, second_cols = false;
     if (tri && nfirst > 0) {
         // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
         // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
@@ -45,6 +46,33 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
             if (bid < 2) { bm = 0; bn = bid; }
             else { bm = 1 + (bid - 2) / 4; bn = (bid - 2) % 4; }
             first_cols = true;
+        } else if (c2 > 4) {
+            // A SECOND counted group (the deep single-factorisation schedule, gs_potrf_chain): column tiles 4 .. c2 - 1 of every row that
+            // has them -- the columns of the next macro-step's panels -- come right behind the first four and are counted in
+            // *second_done; then the rest.  Row bm holds column tiles 0 .. 2 bm + 1: rows 2 .. c2 / 2 - 2 hold 2 (bm - 1) tiles of the
+            // group ((bm - 1)(bm - 2) before row bm), rows from bm0 = c2 / 2 - 1 on all c2 - 4.
+            int f = bid - nfirst;
+            const int tmr = (M + BM - 1) / BM, bm0 = c2 / 2 - 1, cum0 = (bm0 - 1) * (bm0 - 2);
+            const int nsecond = tmr <= bm0 ? (tmr >= 2 ? (tmr - 1) * (tmr - 2) : 0) : cum0 + (tmr - bm0) * (c2 - 4);
+            if (f < nsecond) {
+                if (f < cum0) {
+                    bm = (int)((3.0 + sqrt(1.0 + 4.0 * (double)f)) * 0.5);
+                    while ((int64_t)(bm - 1) * (bm - 2) > f) --bm;
+                    while ((int64_t)bm * (bm - 1) <= f) ++bm;
+                    bn = 4 + f - (bm - 1) * (bm - 2);
+                } else {
+                    bm = bm0 + (f - cum0) / (c2 - 4);
+                    bn = 4 + (f - cum0) % (c2 - 4);
+                }
+                second_cols = true;
+            } else {
+                f -= nsecond;                                   // rows bm = c2 / 2 + q hold 2 (q + 1) tiles from c2 on: q (q + 1) before them
+                int q = (int)((sqrt(1.0 + 4.0 * (double)f) - 1.0) * 0.5);
+                while ((int64_t)q * (q + 1) > f) --q;
+                while ((int64_t)(q + 1) * (q + 2) <= f) ++q;
+                bm = c2 / 2 + q;
+                bn = c2 + f - q * (q + 1);
+            }
         } else {
             const int f = bid - nfirst;
             bm = (int)((3.0 + sqrt(1.0 + 4.0 * (double)f)) * 0.5);
@@ -73,6 +101,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     const int m0 = bm * BM, n0 = bn * BN;
     if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
         if (first_cols && t == 0) gs_flag_add(first_done);
+        if (second_cols && t == 0) gs_flag_add(second_done);
         return;
     }
     if (tri == 2) {
@@ -270,7 +299,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
     if (idle) {
         // (nothing to store)
-    } else if (!first_cols && m0 + BM <= M && n0 + BN <= N) {
+    } else if (!(first_cols || second_cols) && m0 + BM <= M && n0 + BN <= N) {
         double* c0 = C + (int64_t)(m0 + wm2 * WM * 16 + fq2) * ldc + n0 + wn2 * WN * 16 + fr2;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -278,7 +307,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) c0[(int64_t)(16 * i + 4 * x) * ldc + 16 * j] = neg ? -acc[i][j][x] : acc[i][j][x];
-    } else if (!first_cols) {
+    } else if (!(first_cols || second_cols)) {      // (counted tiles: write-through stores below -- their readers do not wait for this launch to end)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -303,10 +332,10 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
                 }
             }
     }
-    if (first_cols) {                         // published to the chain kernel: every wave drains, then one lane counts the tile
+    if (first_cols || second_cols) {          // published to the chain kernel / the near stream: every wave drains, then one lane counts the tile
         gs_drain();
         __syncthreads();
-        if (t == 0) gs_flag_add(first_done);
+        if (t == 0) gs_flag_add(first_cols ? first_done : second_done);
     }
     if (kst && t == 0) atomicMax(kst + 1, __builtin_amdgcn_s_memrealtime());
 }
@@ -315,8 +344,8 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
 template <int NST>
 __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                       int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
-                                                      unsigned long long* kst, int nfirst, unsigned* first_done) {
-    gs_gemm_ld3_body<NST>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, nfirst, first_done, (int)blockIdx.x);
+                                                      unsigned long long* kst, int nfirst, unsigned* first_done, int c2, unsigned* second_done) {
+    gs_gemm_ld3_body<NST>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, nfirst, first_done, (int)blockIdx.x, c2, second_done);
 }
 
 // ---- grouped launches: the same outer step of SEVERAL evaluations in one launch -------------------------------------------------

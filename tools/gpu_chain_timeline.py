@@ -24,6 +24,10 @@ ctx.set_inputs(X, Z)
 ctx.set_option("chain_rows", W)
 if len(sys.argv) > 3:
     ctx.set_option("chain_lazy", int(sys.argv[3]))
+if len(sys.argv) > 4:
+    ctx.set_option("chain_deep", int(sys.argv[4]))
+if len(sys.argv) > 5:
+    ctx.set_option("chain_depth", int(sys.argv[5]))
 plain = []
 for _ in range(6):
     ctx.lml_resident([desc], 1e-10)
@@ -46,7 +50,7 @@ w("  P wave 0: T1->pub = second tables seen -> its 16 rows solved and published 
 w("  host-enqueued launches: rest = panel of the rows below the window (k_panel256), A = near update, B+Far = trailing update "
   "(one launch, first-256-column tiles first): [first workgroup start, last workgroup end]")
 w("")
-w(" s |   begin   wait   D(k)    L10    sib  D(k+1) |  T1->pub  task  hand-off |  step || rest              A                 B+Far")
+w(" s |   begin   wait   D(k)    L10    sib  D(k+1) |  T1->pub  task  hand-off |  step || rest              A                 near band / B     B+Far / far")
 for s in range(st.shape[0]):
     d = st[s]
     nxt = st[s + 1] if s + 1 < st.shape[0] else None
@@ -58,7 +62,7 @@ for s in range(st.shape[0]):
         return "      -         " if np.isnan(a) or np.isnan(b) else f"[{a:7.1f},{b:7.1f}]"
 
     w(f"{s:2d} | {begin:7.1f} {ready - begin:6.1f} {rowready - ready:6.1f} {img - rowready:6.1f} {sibdone - img:6.1f} {t1 - sibdone:6.1f} |"
-      f"  {d[12] - d[11]:6.1f} {d[14] - d[13]:6.1f}  {hand:7.1f} | {step:6.1f} || {rng(d[16], d[17])} {rng(d[18], d[19])} {rng(d[22], d[23])}")
+      f"  {d[12] - d[11]:6.1f} {d[14] - d[13]:6.1f}  {hand:7.1f} | {step:6.1f} || {rng(d[16], d[17])} {rng(d[18], d[19])} {rng(d[20], d[21])} {rng(d[22], d[23])}")
 S = st.shape[0]
 late = [st[s + 1, 0] - st[s, 0] for s in range(S - 9, S - 1)]
 dk = [st[s, 3] - st[s, 1] for s in range(1, S)]
