@@ -752,8 +752,10 @@ class ConjugateGaussianProcess:
         y_mean = self.mean(X)
         if return_cov:
             return y_mean, self.cov(X)
-        if return_std:
-            return y_mean, np.sqrt(np.diag(self.cov(X)))
+        if return_std:                               # diag of the one-argument kernel: one number (leaves exactly 1, WhiteKernel noise in)
+            X = np.asarray(X, dtype=float)
+            factor, desc = self._cov_parts(X.shape[1])
+            return y_mean, np.sqrt(np.full(X.shape[0], factor * desc.one_arg_diagonal()))
         return y_mean
 
     # -- predict (models.py:753-845) ------------------------------------------------

@@ -344,32 +344,60 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
     }
     // V^T = kernel(Xs, X) L^-T by a right-looking sweep, two block columns per trailing update (K = 256) like the
     // factorisation: the trailing part of Bt is read and written once per 256 eliminated columns instead of once per 128
-    // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work)
+    // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work).
+    // The rows of Bt (the new points) never meet: from 1024 rows up the sweep runs as TWO independent half-sweeps on two of the
+    // context's streams, so that the latency-bound panel launch of one half (64 of them on the critical path at n = 16384) runs
+    // beside the trailing update of the other (round 5; one stream: 11.6 ms at n = 16384, m = 2048).
     const int sib_cfg = m >= 1024 ? GS_BULK : 1;
+    const int n_half = (m >= 1024 && ctx->predict_split && ctx->cur->sa) ? 2 : 1;
+    hipStream_t hs[2] = {ctx->cur->sm, ctx->cur->sa};
+    if (n_half == 2) {
+        if (gs_need_lsib(ctx, ctx->cur->sm, L)) return -1;                 // (before the fork: both halves read the images)
+        GS_CHECK(hipEventRecord(ctx->cur->evFork, ctx->cur->sm));
+        GS_CHECK(hipStreamWaitEvent(hs[1], ctx->cur->evFork, 0));
+    }
+    const int64_t m_lo = n_half == 2 ? (m / 2 + 127) / 128 * 128 : m;       // rows of the first half: whole 128-row tiles
     bool deferred = false;                               // the columns right of the next panel still owe the previous panel's update
     for (int c = 0; c < L->T; c += 2) {
         const bool two = c + 1 < L->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
-        if (gs_trsm_rows(ctx, ctx->cur->sm, L, c, Bt + c0, ldb, m)) return -1;
-        if (two) {
-            if (gs_gemm(ctx, ctx->cur->sm, sib_cfg, Bt + c1, ldb, Bt + c0, ldb, L->A + c1 * ld + c0, ld, m, GS_NB, GS_NB, 0, 1, -1.0))
-                return -1;
-            if (gs_trsm_rows(ctx, ctx->cur->sm, L, c + 1, Bt + c1, ldb, m)) return -1;
-        }
-        if (r2 >= np) continue;
         // The batch factorisation's lazy far updates (lazy_far = 2) applied to this sweep: after an even step only the next panel's 256 columns take
         // this panel's update (K = 256); the step after it applies both panels to everything to its right in ONE K = 512 launch -- half as many passes
         // over the trailing part of Bt, each at the tile kernel's better K = 512 rate.  Same products in the same ascending-k order per element.
         const bool pair = ctx->predict_lazy && two && m >= 1024 && np >= ctx->lazy_min_np && c + 3 < L->T && r2 + 2 * GS_NB <= np;
-        if (!deferred && pair) {
-            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
-            deferred = true;
-        } else if (deferred) {
-            const int64_t cp = c0 - 2 * GS_NB;            // the previous panel's first column: [cp, r2) is 512 columns wide
-            if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + cp, ldb, L->A + r2 * ld + cp, ld, m, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
-            deferred = false;
-        } else if (gs_gemm(ctx, ctx->cur->sm, GS_BULK, Bt + r2, ldb, Bt + c0, ldb, L->A + r2 * ld + c0, ld, m, np - r2, (int)(r2 - c0), 0, 1, -1.0))
-            return -1;
+        const bool was_deferred = deferred;
+        for (int h = 0; h < n_half; ++h) {
+            hipStream_t st = hs[h];
+            const int64_t row0 = h == 0 ? 0 : m_lo, mh = n_half == 1 ? m : (h == 0 ? m_lo : m - m_lo);
+            double* Bh = Bt + row0 * ldb;
+            if (mh <= 0) continue;
+            if (two && ctx->predict_panel256) {
+                // both panels of the pair and the sibling update between them in ONE launch, 16 rows per wave (k_panel256: the factorisation's
+                // own panel step; rounds 1-4 ran k_panel, a K = 128 GEMM and k_panel again here: 3 dependent launches per pair, 896 launches
+                // of ~12 us on the sweep's critical path at n = 16384)
+                if (gs_need_lsib(ctx, st, L)) return -1;
+                if (gs_panel256(ctx, st, L, c, Bh + c0, ldb, mh)) return -1;
+            } else {
+                if (gs_trsm_rows(ctx, st, L, c, Bh + c0, ldb, mh)) return -1;
+                if (two) {
+                    if (gs_gemm(ctx, st, sib_cfg, Bh + c1, ldb, Bh + c0, ldb, L->A + c1 * ld + c0, ld, mh, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                    if (gs_trsm_rows(ctx, st, L, c + 1, Bh + c1, ldb, mh)) return -1;
+                }
+            }
+            if (r2 >= np) continue;
+            if (!was_deferred && pair) {
+                if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + c0, ldb, L->A + r2 * ld + c0, ld, mh, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
+            } else if (was_deferred) {
+                const int64_t cp = c0 - 2 * GS_NB;            // the previous panel's first column: [cp, r2) is 512 columns wide
+                if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + cp, ldb, L->A + r2 * ld + cp, ld, mh, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
+            } else if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + c0, ldb, L->A + r2 * ld + c0, ld, mh, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+                return -1;
+        }
+        if (r2 < np) deferred = (!was_deferred && pair);
+    }
+    if (n_half == 2) {
+        GS_CHECK(hipEventRecord(ctx->cur->evS, hs[1]));
+        GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evS, 0));
     }
     std::vector<double> vw;
     if (k > 0) {

@@ -20,7 +20,7 @@ struct gsum_mat {
                                // that multiplies by L_bb^-1 (gsum_cho_solve's back-substitution)
     double* Ltab = nullptr;    // T x GS_LTAB substitution tables of the diagonal blocks
     double* Lsib = nullptr;    // (T / 2 + 1) x GS_LSIB: L(j+1, j) of every outer step in operand layout (k_potrf_diag256 -> k_panel256)
-    bool have_ltab = false, have_linv = false;
+    bool have_ltab = false, have_linv = false, have_lsib = false;   // (have_lsib: Lsib holds the images of THIS factor: gs_need_lsib)
     std::vector<double> solved_rhs;     // host copy of the right-hand sides whose forward solve W^T = (L^-1 RHS)^T the border rows
     int solved_k = -1;                  // hold (-1: none): a repeated predict / forward_gram with the same RHS skips the solve
     double* logdet = nullptr;  // T per-block sums of log L_ii
@@ -99,6 +99,8 @@ struct gsum_ctx {
     std::string err;
     int lookahead = 1;
     double next_algo_flops = -1.0;   // profile only: algorithmic flops of the next cfg-5 launch when not M(M+1)K / 2MNK
+    int predict_split = 1;           // ... in two independent half-sweeps (rows of the new points) on two streams from 1024 rows up
+    int predict_panel256 = 1;        // the predictive sweep's panel pairs as ONE k_panel256 launch (0: k_panel, K = 128 GEMM, k_panel)
     int predict_lazy = 1;            // the predictive sweep V^T = K* L^-T with the same pairing of trailing updates (K = 512 every other step)
     int lazy_min_np = 4352;          // smallest padded order the lazy far updates are used at (profiles/r03_lazy_threshold.log, 20 in flight: +3 % at 4352,
                                      // +3.7 / +4.8 / +5.3 / +6 / +6 % at 5120 / 6144 / 7168 / 8192 / 12288; neutral at 4096, -0.5 ... -3 % at 1536 ... 3072)

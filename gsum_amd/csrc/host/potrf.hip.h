@@ -90,6 +90,16 @@ static int gs_need_linv(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
     return 0;
 }
 
+// the operand images of the sibling blocks L(k + 1, k), for k_panel256 on a finished factor (the predictive sweep): built from the factor
+// itself, whatever schedule produced it
+static int gs_need_lsib(gsum_ctx* ctx, hipStream_t s, gsum_mat* m) {
+    if (m->have_lsib || m->T < 2) return 0;
+    hipLaunchKernelGGL(k_make_lsib, dim3((unsigned)(m->T / 2)), dim3(256), 0, s, (const double*)m->A, m->ld, m->Lsib);
+    GS_CHECK(hipGetLastError());
+    m->have_lsib = true;
+    return 0;
+}
+
 // ---- persistent-chain schedule (see k_chain) ------------------------------------------------------------------------
 // Do kernels of two streams of this process run side by side?  The chain kernel waits for flags that host-enqueued kernels
 // on other streams set, and they wait for its flags: under a tool that serialises dispatches (rocprofv3's kernel trace does)
@@ -472,6 +482,7 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     gs_slot* sl = ctx->cur;
     if (gs_potrf_events(ctx, sl, T)) return -1;
     m->have_linv = false;                      // (explicit block inverses: built on demand, gs_need_linv)
+    m->have_lsib = false;                      // (sibling images for consumers of the finished factor: gs_need_lsib)
     m->have_ltab = true;
     m->solved_k = -1;
     const int64_t ld = m->ld, naug = m->np + GS_BORDER;

@@ -146,6 +146,20 @@ __global__ __launch_bounds__(256) void k_trtri_blocks(const double* Ltab, double
     gs_trtri_block(tab + GS_D2_LS, tab + GS_D2_DV, Linv + (size_t)blockIdx.x * 128 * 128, w, lane);
 }
 
+// The operand images of the sibling blocks L(k + 1, k), k even, from the FACTOR in the matrix -- what k_potrf_diag256 / k_chain leave behind
+// as a by-product (-L10 in gs_panel16_load's register layout: [row group][k-block][x][lane]); for consumers of k_panel256 on a factor whose
+// schedule did not produce them (the unfused host-enqueued schedule of small orders): the predictive sweep.  One workgroup per pair.
+__global__ __launch_bounds__(256) void k_make_lsib(const double* A, int64_t ld, double* Lsib) {
+    const int s = blockIdx.x;
+    const double* L10 = A + ((int64_t)(2 * s + 1) * GS_NB) * ld + (int64_t)(2 * s) * GS_NB;
+    double* img = Lsib + (size_t)s * GS_LSIB;
+    for (int i = threadIdx.x; i < 8 * 8 * 4 * 64; i += 256) {
+        const int lane = i & 63, x = (i >> 6) & 3, kb = (i >> 8) & 7, c = i >> 11;
+        const int fr = lane & 15, fq = lane >> 4;
+        img[i] = -L10[(int64_t)(16 * c + fr) * ld + 16 * kb + fq + 4 * x];
+    }
+}
+
 // info: global failure flag (0 = ok so far; >0 = LAPACK-style 1-based failing column).  Micro-block routine, substitution tables to Ltab.
 __global__ __launch_bounds__(256) void k_potrf_diag(double* A, int64_t ld, double* Ltab, double* logdet, int* info, int col0,
                                                      const double* diag0, unsigned long long* stamps) {

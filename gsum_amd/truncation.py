@@ -87,13 +87,26 @@ class TruncationGP:
         Xp = np.asarray(Xp, dtype=float)
         return gp._context().kernel_matrix(desc, X, Xp, series=(sc, ref_x, ratio_x, self.ref(Xp), self.ratio(Xp, **self.ratio_kws)))
 
+    def _cov_diag(self, X, start=0, end=np.inf, two_arg=False):
+        """``np.diag(self.cov(X[, X], start, end))`` in O(m) on the host: every stationary leaf is exactly 1 at zero distance, so the
+        kernel's diagonal is one number -- with the WhiteKernel terms in for the one-argument call (``cov(X)``, models.py:1344 before
+        Xp is replaced) and without them when both arguments are given (``cov(X, X)``: models.py:1443, 1466) -- times the reference's
+        own elementwise factors ``ref_i^2 S(ratio_i^2)`` (:1345-1348).  The m x m matrix (2 GiB at m = 16384) is never formed."""
+        gp = self.coeffs_process
+        X = np.asarray(X, dtype=float)
+        factor, desc = gp._cov_parts(X.shape[1])
+        kd = (desc.without_white() if two_arg else desc).one_arg_diagonal()
+        ref, ratio = self.ref(X), self.ratio(X, **self.ratio_kws)
+        return (ref * ref) * geometric_sum(x=ratio * ratio, start=start, end=end, excluded=self.excluded) * (factor * kd)
+
     def underlying_properties(self, X, order, return_std=False, return_cov=False):
         """Truncation error beyond ``order``: prior mean [and covariance / its diagonal] of the orders order + 1 .. inf."""
         y_mean = self.mean(X, start=order + 1)
         if not (return_cov or return_std):
             return y_mean
-        y_cov = self.cov(X, start=order + 1)
-        return y_mean, (y_cov if return_cov else np.sqrt(np.diag(y_cov)))
+        if return_cov:
+            return y_mean, self.cov(X, start=order + 1)
+        return y_mean, np.sqrt(self._cov_diag(X, start=order + 1))
 
     # -- fit (models.py:1367-1387) -------------------------------------------------------------------
     def fit(self, X, y, orders, dX=None, dy=None):
@@ -175,24 +188,26 @@ class TruncationGP:
             m_new = self.mean(X=X, start=0, end=order)
             shift, red_diag, red = self._condition(X, Xc, np.asarray(y, dtype=float) - m_old, 0, order, return_cov)
             m_pred = m_pred + m_new + shift
-            if want_var:
-                K_nn = self.cov(start=0, end=order, X=X, Xp=X)
-                K_pred = K_pred + (K_nn - red if return_cov else np.diag(K_nn) - red_diag)
+            if return_cov:
+                K_pred = K_pred + (self.cov(start=0, end=order, X=X, Xp=X) - red)
+            elif return_std:                      # the diagonal alone, O(m): no m x m matrix is built or moved
+                K_pred = K_pred + (self._cov_diag(X, 0, order, two_arg=True) - red_diag)
         if kind == 'both' or kind == 'trunc':
             # truncation error                                                         models.py:1455-1476
             m_new_trunc = self.mean(X=X, start=order + 1, end=np.inf)
-            K_nn_trunc = self.cov(X=X, Xp=X, start=order + 1, end=np.inf) if want_var else None
+            K_nn_trunc = self.cov(X=X, Xp=X, start=order + 1, end=np.inf) if return_cov else None
+            d_nn_trunc = self._cov_diag(X, order + 1, np.inf, two_arg=True) if return_std else None
             if self.dX_ is not None:                                                   # constrained
                 m_old_trunc = self.mean(X=self.dX_, start=order + 1, end=np.inf)
                 shift, red_diag, red = self._condition(X, self.dX_, np.asarray(self.dy_, dtype=float) - m_old_trunc,
                                                        order + 1, np.inf, return_cov)
                 m_pred = m_pred + m_new_trunc + shift
                 if want_var:
-                    K_pred = K_pred + (K_nn_trunc - red if return_cov else np.diag(K_nn_trunc) - red_diag)
+                    K_pred = K_pred + (K_nn_trunc - red if return_cov else d_nn_trunc - red_diag)
             else:
                 m_pred = m_pred + m_new_trunc
                 if want_var:
-                    K_pred = K_pred + (K_nn_trunc if return_cov else np.diag(K_nn_trunc))
+                    K_pred = K_pred + (K_nn_trunc if return_cov else d_nn_trunc)
         if return_cov:
             return m_pred, K_pred
         if return_std:

@@ -292,3 +292,75 @@ def test_notebook_grid_with_a_tree_kernel_stays_on_the_fast_path():
                 assert abs(grid[i, j] - want) <= 1e-10 * abs(want)
     record_parity("notebook_grid_tree_vs_flat_ms", flat_ms=times["flat"] * 1e3, tree_ms=times["tree"] * 1e3, bound=1.5)
     assert times["tree"] <= 1.5 * times["flat"], times
+
+
+# ---- O(m) variance, the predictive sweep on k_panel256 ------------------------------------------------------
+def test_truncation_std_moves_no_square_matrix(monkeypatch):
+    """``TruncationGP.predict(return_std=True)`` and ``underlying_properties(return_std=True)`` used to build the m x m ``K_nn`` on the
+    device, copy it over PCIe and take ``np.diag`` (2 GiB at m = 16384 for an O(m) answer; models.py:1443-1482 does the same on the
+    host).  Now the diagonal is host arithmetic: every array that crosses the binding during the call is counted here, and the values
+    equal ``np.diag`` of the full matrices."""
+    gp, X, y = _fitted(400)
+    m = 1500
+    Xs = np.linspace(0.0, 40.0, m)[:, None]
+    ctx = gp.coeffs_process._context()
+    moved = []
+    for name in ("kernel_matrix", "predict_terms", "forward_gram", "forward_solve", "cho_solve"):
+        orig = getattr(ctx, name)
+
+        def counted(*a, _orig=orig, **kw):
+            out = _orig(*a, **kw)
+            for arr in (out if isinstance(out, tuple) else (out,)):
+                if isinstance(arr, np.ndarray):
+                    moved.append(arr.nbytes)
+            return out
+        monkeypatch.setattr(ctx, name, counted)
+    for kind in ("both", "interp", "trunc"):
+        moved.clear()
+        mean, std = gp.predict(Xs, order=2, return_std=True, kind=kind)
+        assert sum(moved) < 1 << 20, (kind, sum(moved))                     # < 1 MB (the m x m matrix alone would be 18 MB here)
+        mean_c, cov = gp.predict(Xs, order=2, return_cov=True, kind=kind)
+        var = np.diag(cov)                      # (the variance is a difference that cancels near the conditioning points: absolute bound)
+        np.testing.assert_allclose(std ** 2, var, rtol=1e-9, atol=1e-12 * float(np.abs(var).max()))
+        np.testing.assert_array_equal(mean, mean_c)
+    moved.clear()
+    mu, sd = gp.underlying_properties(Xs, order=1, return_std=True)
+    assert sum(moved) == 0
+    np.testing.assert_allclose(sd, np.sqrt(np.diag(gp.underlying_properties(Xs, order=1, return_cov=True)[1])), rtol=1e-13)
+    cg = gp.coeffs_process
+    moved.clear()
+    mu, sd = cg.underlying_properties(Xs, return_std=True)
+    assert sum(moved) == 0
+    np.testing.assert_allclose(sd, np.sqrt(np.diag(cg.cov(Xs))), rtol=1e-13)
+
+
+@pytest.mark.parametrize("n,m", [(700, 300), (2304, 1100)])
+def test_predict_sweep_on_panel256_equals_the_three_launch_sweep(n, m):
+    """The predictive sweep V^T = K* L^-T with every pair of block columns solved by ONE k_panel256 launch (sibling images rebuilt from
+    the factor: k_make_lsib) against the k_panel / K = 128 GEMM / k_panel sweep of rounds 1-4: same arithmetic, same bits --
+    column sums of squares, V^T W and the full V^T V (models.py:822-836)."""
+    lab = gsum_amd.lab_context(0)
+    rng = np.random.RandomState(n)
+    X = rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    Xs = rng.rand(m, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    rhs = np.concatenate([rng.randn(n, 5), np.ones((n, 1))], axis=1)
+    desc = gsum_amd.describe_kernel(Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2)
+    for persist in (0, 1):                     # a factor of the unfused host-enqueued schedule (no sibling images) and of the chain schedule
+        lab.set_option("chain_persist", persist)
+        L, info = lab.factorize(desc, X, diag_add=1e-10)
+        assert info == 0
+        try:
+            lab.set_option("predict_panel256", 0)
+            lab.set_option("predict_split", 0)
+            want = lab.predict_terms(L, desc, X, Xs, rhs=rhs, want_cov=True)
+            for p256, split in ((1, 0), (0, 1), (1, 1)):      # ... and the two half-sweeps on two streams (rows of the new points never meet)
+                lab.set_option("predict_panel256", p256)
+                lab.set_option("predict_split", split)
+                got = lab.predict_terms(L, desc, X, Xs, rhs=rhs, want_cov=True)
+                for a, b in zip(got, want):
+                    np.testing.assert_array_equal(a, b)
+        finally:
+            lab.set_option("predict_panel256", 1)
+            lab.set_option("predict_split", 1)
+            lab.set_option("chain_persist", -1)
+            L.free()
