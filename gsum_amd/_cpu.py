@@ -243,6 +243,14 @@ class CpuContext:
     def set_inputs(self, X, rhs):
         self._X, self._Z = np.array(X, dtype=float), np.array(rhs, dtype=float)
 
+    def set_inputs_sets(self, X, rhs_sets):
+        self._X, self._Zsets = np.array(X, dtype=float), np.array(rhs_sets, dtype=float)
+        self._Z = self._Zsets[0]
+
+    def lml_resident_sets(self, descs, set_of, nugget):
+        out = [self._evaluate(d, self._X, self._Zsets[int(s)], nugget)[:3] for d, s in zip(descs, set_of)]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out], dtype=np.int64)
+
     def resident_shape(self):
         if self._X is None:
             return 0, 0, 0

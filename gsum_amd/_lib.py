@@ -187,6 +187,8 @@ PROTOTYPES = {
     "gsum_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_resident_shape": (C.c_int, [_p, _ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsum_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip]),
+    "gsum_set_inputs_sets": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_int32]),
+    "gsum_lml_resident_sets": (C.c_int, [_p, _kp, C.POINTER(C.c_int32), C.c_int32, C.c_double, _dp, _dp, _ip]),
     "gsum_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _ip, _ip]),
     "gsum_lml_resident_shard": (C.c_int, [_p, _kp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _ip, _ip, _ip]),
     "gsum_timers": (C.c_int, [_p, _dp, C.c_int32]),
@@ -588,6 +590,28 @@ class HipContext:
     def set_inputs(self, X, rhs):
         X, rhs = _f64(X), _f64(rhs)
         self._check(self._lib.gsum_set_inputs(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(rhs), rhs.shape[1]))
+
+    def set_inputs_sets(self, X, rhs_sets):
+        """Several right-hand-side sets resident at once (``rhs_sets``: (n_sets, n, k)); see :meth:`lml_resident_sets`."""
+        X, Z = _f64(X), _f64(rhs_sets)
+        if Z.ndim != 3 or Z.shape[1] != X.shape[0]:
+            raise ValueError("rhs_sets must have shape (n_sets, n, k)")
+        self._check(self._lib.gsum_set_inputs_sets(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Z), Z.shape[0], Z.shape[2]))
+
+    def lml_resident_sets(self, descs, set_of, nugget: float):
+        """``lml_resident`` with evaluation i reading right-hand-side set ``set_of[i]`` (gsum_lml_resident_sets): a whole
+        (ratio, theta) surface in one call."""
+        n, _, k = self.resident_shape()
+        if n == 0:
+            raise ValueError("gsum_set_inputs has not been called")
+        nk = len(descs)
+        sets = np.ascontiguousarray(set_of, dtype=np.int32)
+        if sets.shape != (nk,):
+            raise ValueError("one set index per descriptor")
+        G, sld, info = np.empty((nk, k, k)), np.empty(nk), np.zeros(nk, dtype=np.int64)
+        self._check(self._lib.gsum_lml_resident_sets(self._h, self._desc_array(descs), sets.ctypes.data_as(C.POINTER(C.c_int32)), nk,
+                                                     float(nugget), _ptr(G), _ptr(sld), info.ctypes.data_as(_ip)))
+        return G, sld, info
 
     def resident_shape(self):
         """(n, d, k) of the inputs gsum_set_inputs left on the device ((0, 0, 0) before the first call)."""

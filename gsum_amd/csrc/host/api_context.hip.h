@@ -246,6 +246,8 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
+    else if (!strcmp(name, "wave_tail_rows")) ctx->wave_tail_rows = (int)value;
+    else if (!strcmp(name, "wave_long_rounds")) ctx->wave_long_rounds = (int)std::max<int64_t>(2, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "grad_batch_wave")) ctx->grad_batch_wave = value != 0;
     else if (!strcmp(name, "wave_head")) ctx->wave_head = (int)std::max<int64_t>(0, value);

@@ -1,15 +1,24 @@
 // C ABI, fused path: resident inputs, one evaluation on a slot, whole evaluations in one workgroup (small / medium)
 // (part of gsum_capi.hip: included from there, in order -- one translation unit)
 #pragma once
-int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k) {
+int gsum_set_inputs_sets(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS_sets, int32_t n_sets, int32_t k) {
     if (!ctx) return -2;
     GS_CHECK(hipSetDevice(ctx->device));
     ctx->cur = &ctx->slots[0];
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
     if (gs_upload_X(ctx, &ctx->res, X, n, d)) return -1;
-    if (gs_upload_Z(ctx, &ctx->res, RHS, n, k)) return -1;
+    if (gs_upload_Z(ctx, &ctx->res, RHS_sets, n, k, n_sets)) return -1;
     GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
     return 0;
+}
+
+int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k) {
+    return gsum_set_inputs_sets(ctx, X, n, d, RHS, 1, k);
+}
+
+// right-hand sides of evaluation i of the current call (device pointer)
+static const double* gs_z_of(const gsum_ctx* ctx, int i) {
+    return ctx->in->Z + (ctx->set_of ? (size_t)ctx->set_of[i] * (size_t)ctx->in->n * (size_t)ctx->in->k : 0);
 }
 
 int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k) {
@@ -32,7 +41,7 @@ static int gs_upload_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d
 }
 
 // enqueue one evaluation on the current slot (asynchronous: nothing waits on the host)
-static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double nugget) {
+static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double nugget, int eval_index = 0) {
     gs_slot* sl = ctx->cur;
     const auto h0 = std::chrono::steady_clock::now();
     struct HostTimer {
@@ -51,7 +60,8 @@ static int gs_eval_enqueue(gsum_ctx* ctx, const gsum_kernel_desc* desc, double n
     if (ctx->profile_gemm > 0) ctx->prof_this_eval = (ctx->prof_eval_count++ % ctx->profile_gemm) == 0;
     GS_CHECK(hipEventRecord(sl->tev[0], sl->sm));
     if (gs_build_into(ctx, sl->sm, m, desc, ctx->in->X, ctx->in->d, nugget, ctx->build_lower_only)) return -1;
-    if (gs_set_border(ctx, sl->sm, m, ctx->in->Z, ctx->in->k)) return -1;
+    sl->last_index = eval_index;
+    if (gs_set_border(ctx, sl->sm, m, gs_z_of(ctx, eval_index), ctx->in->k)) return -1;
     GS_CHECK(hipEventRecord(sl->tev[1], sl->sm));
     if (gs_potrf(ctx, m)) return -1;
     GS_CHECK(hipEventRecord(sl->tev[2], sl->sm));
@@ -73,7 +83,7 @@ static int gs_eval_harvest(gsum_ctx* ctx, gs_slot* sl, double* G_out, double* sl
         gs_slot* keep = ctx->cur;
         ctx->cur = sl;
         const gsum_kernel_desc d = sl->last_desc;
-        const int rc = gs_eval_enqueue(ctx, &d, sl->last_nugget);
+        const int rc = gs_eval_enqueue(ctx, &d, sl->last_nugget, sl->last_index);
         ctx->cur = keep;
         if (rc) return rc;
         GS_CHECK(hipStreamSynchronize(sl->sm));
@@ -112,19 +122,22 @@ static int gs_lml_small(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ke
     const int k = ctx->in->k, CH = std::min(4096, (n_kernels + 511) / 512 * 512);
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
+    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_set = o_res + up((size_t)CH * 258 * 8),
+                 o_scr = o_set + up((size_t)CH * sizeof(int32_t));
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * GS_SMALL_SCRATCH * 8)) return -1;
     char* base = (char*)ctx->scratch;
     if (gs_reserve_pinned(ctx, (size_t)CH * 258 * 8)) return -1;
     double* hres = ctx->hbatch;
+    const int32_t* dset = ctx->set_of ? (const int32_t*)(base + o_set) : nullptr;
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
+        if (dset) GS_CHECK(hipMemcpyAsync(base + o_set, ctx->set_of + lo, (size_t)cnt * sizeof(int32_t), hipMemcpyHostToDevice, s));
         bool tree = false;                        // a tree among this launch's descriptors: the instantiation that can walk one
         for (int e = 0; e < cnt; ++e) tree = tree || kernels[lo + e].n_ops > 0;
         hipLaunchKernelGGL(tree ? k_lml_small<true> : k_lml_small<false>, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n,
                            ctx->in->d, ctx->in->Z, k, (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr),
-                           (double*)(base + o_res));
+                           (double*)(base + o_res), dset);
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));
@@ -156,7 +169,8 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
     const int64_t fit = (int64_t)(budget / (double)(stride * 8));
     const int cap = fit >= 512 ? 512 : (fit >= 256 ? 256 : (int)std::max<int64_t>(1, fit));
     const int CH = std::min(n_kernels, cap);
-    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_scr = o_res + up((size_t)CH * 258 * 8);
+    const size_t o_desc = 0, o_res = up((size_t)CH * sizeof(gsum_kernel_desc)), o_set = o_res + up((size_t)CH * 258 * 8),
+                 o_scr = o_set + up((size_t)CH * sizeof(int32_t));
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * stride * 8)) return -1;
     char* base = (char*)ctx->scratch;
     const size_t shmem = (size_t)std::max<int>(GS_TILE_LD_DOUBLES, GS_DIAG_WS) * sizeof(double);
@@ -167,14 +181,16 @@ static int gs_lml_medium(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_k
         }
     if (gs_reserve_pinned(ctx, (size_t)CH * 258 * 8)) return -1;
     double* hres = ctx->hbatch;
+    const int32_t* dset = ctx->set_of ? (const int32_t*)(base + o_set) : nullptr;
     for (int lo = 0; lo < n_kernels; lo += CH) {
         const int cnt = std::min(CH, n_kernels - lo);
         GS_CHECK(hipMemcpyAsync(base + o_desc, kernels + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
+        if (dset) GS_CHECK(hipMemcpyAsync(base + o_set, ctx->set_of + lo, (size_t)cnt * sizeof(int32_t), hipMemcpyHostToDevice, s));
         bool tree = false;
         for (int e = 0; e < cnt; ++e) tree = tree || kernels[lo + e].n_ops > 0;
         hipLaunchKernelGGL(tree ? k_lml_medium<true> : k_lml_medium<false>, dim3(cnt), dim3(256), shmem, s, ctx->in->X, (int)n, ctx->in->d, ctx->in->Z, k,
                            (const gsum_kernel_desc*)(base + o_desc), nugget, (double*)(base + o_scr), stride, (double*)(base + o_res),
-                           ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr);
+                           ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr, dset);
         GS_CHECK(hipGetLastError());
         GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));

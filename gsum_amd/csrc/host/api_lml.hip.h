@@ -1,9 +1,24 @@
 // C ABI: gsum_lml_resident[_shard], gsum_lml_batch, gsum_shard_range
 // (part of gsum_capi.hip: included from there, in order -- one translation unit)
 #pragma once
+static int gs_lml_on_sets(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                          double* G_out, double* sld_out, int64_t* info_out);
+
+// set_of (or NULL): the right-hand-side set of every evaluation (gsum_set_inputs_sets)
 static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
-                     double* G_out, double* sld_out, int64_t* info_out) {
+                     double* G_out, double* sld_out, int64_t* info_out, const int32_t* set_of = nullptr) {
     if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
+    if (set_of)
+        for (int i = 0; i < n_kernels; ++i)
+            if (set_of[i] < 0 || set_of[i] >= I->n_sets) GS_FAIL("set_of: no such right-hand-side set (gsum_set_inputs_sets)");
+    ctx->set_of = set_of;
+    const int rc = gs_lml_on_sets(ctx, I, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+    ctx->set_of = nullptr;
+    return rc;
+}
+
+static int gs_lml_on_sets(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
+                          double* G_out, double* sld_out, int64_t* info_out) {
     GS_CHECK(hipSetDevice(ctx->device));
     ctx->in = I;
     if (!ctx->in->X) GS_FAIL("gsum_set_inputs has not been called");
@@ -36,7 +51,7 @@ static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernel
     ctx->batch_active = 1;
     int rc = 0;
     for (int i = 0; i < n_kernels && !rc; ++i) {
-        rc = gs_eval_enqueue(ctx, &kernels[i], nugget);
+        rc = gs_eval_enqueue(ctx, &kernels[i], nugget, i);
         if (!rc) sl->pending = i;
         if (!rc) rc = gs_eval_harvest(ctx, sl, G_out, sld_out, info_out);
     }
@@ -47,6 +62,12 @@ int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_
                       double* G_out, double* sld_out, int64_t* info_out) {
     if (!ctx) return -2;
     return gs_lml_on(ctx, &ctx->res, kernels, n_kernels, nugget, G_out, sld_out, info_out);
+}
+
+int gsum_lml_resident_sets(gsum_ctx* ctx, const gsum_kernel_desc* kernels, const int32_t* set_of, int32_t n_kernels, double nugget,
+                           double* G_out, double* sld_out, int64_t* info_out) {
+    if (!ctx) return -2;
+    return gs_lml_on(ctx, &ctx->res, kernels, n_kernels, nugget, G_out, sld_out, info_out, set_of);
 }
 
 int gsum_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {

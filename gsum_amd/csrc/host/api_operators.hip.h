@@ -10,12 +10,15 @@ static int gs_upload_X(gsum_ctx* ctx, gs_inputs* I, const double* X, int64_t n, 
     return 0;
 }
 
-static int gs_upload_Z(gsum_ctx* ctx, gs_inputs* I, const double* Z, int64_t n, int k) {
+static int gs_upload_Z(gsum_ctx* ctx, gs_inputs* I, const double* Z, int64_t n, int k, int n_sets = 1) {
     if (k < 0 || k > GSUM_MAX_RHS) GS_FAIL("k must be 0..GSUM_MAX_RHS");
     if (k > 0 && !Z) GS_FAIL("RHS is NULL");
-    if (gs_reserve(ctx, &I->Z, &I->Z_cap, std::max<size_t>(8, (size_t)n * k * sizeof(double)))) return -1;
-    if (k > 0) GS_CHECK(hipMemcpyAsync(I->Z, Z, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->cur->sm));
+    if (n_sets < 1 || n_sets > (1 << 20)) GS_FAIL("the number of right-hand-side sets must be 1..2^20");
+    const size_t bytes = (size_t)n_sets * n * k * sizeof(double);
+    if (gs_reserve(ctx, &I->Z, &I->Z_cap, std::max<size_t>(8, bytes))) return -1;
+    if (k > 0) GS_CHECK(hipMemcpyAsync(I->Z, Z, bytes, hipMemcpyHostToDevice, ctx->cur->sm));
     I->k = k;
+    I->n_sets = n_sets;
     return 0;
 }
 

@@ -57,6 +57,7 @@ struct gs_slot {
     double* hgrad = nullptr;                     // ... and its pinned read-back buffer (GSUM_MAX_GRAD x 257)
     gsum_kernel_desc last_desc;      // ... and what it was (a chain-schedule timeout re-runs it on the host-enqueued schedule)
     double last_nugget = 0.0;
+    int last_index = 0;              // ... and its index in the call (its right-hand-side set)
 };
 
 #define GS_MAX_SLOTS 24
@@ -82,7 +83,8 @@ struct gs_wave {
 
 struct gs_inputs {
     double* X = nullptr; int64_t n = 0; int d = 0; size_t X_cap = 0;     // n x d points
-    double* Z = nullptr; int k = 0; size_t Z_cap = 0;                    // n x k right-hand sides
+    double* Z = nullptr; int k = 0; size_t Z_cap = 0;                    // n x k right-hand sides; n_sets of them back to back
+    int n_sets = 1;                                                      // (gsum_set_inputs_sets: evaluation i of a call reads set set_of[i])
 };
 
 struct gsum_ctx {
@@ -159,6 +161,7 @@ struct gsum_ctx {
     // point (operator level, gsum_lml_batch, gsum_lml_grad) uploads into `op`.  `in` is the set the fused path reads.
     gs_inputs op, res;
     gs_inputs* in = &res;
+    const int32_t* set_of = nullptr;   // the current call's right-hand-side set per evaluation (host array; NULL: set 0 throughout)
     double* scratch = nullptr; size_t scratch_cap = 0;
     double* hbatch = nullptr; size_t hbatch_cap = 0;   // pinned host buffer for the fused paths' result blocks (258 doubles each)
     double* gws = nullptr; size_t gws_cap = 0;     // gradient path: U = L^-T, R^-1, V^T, per-parameter partials
@@ -184,6 +187,9 @@ struct gsum_ctx {
     int wave_groups = 3;             // groups = chain streams; their bulk launches alternate on ONE bulk stream (4 streams: the HIP runtime's
                                      // default number of hardware queues)
     int wave_size = 8;               // evaluations per group at most
+    int wave_long_rounds = 6;        // a call of at least this many rounds is "long": groups out of phase (wave_shift = -1) and own-stream tails
+    int wave_tail_rows = 0;          // far updates of at most this many rows go out on the group's chain stream in long calls (< 0: in every call of
+                                     // several rounds; 0: never)
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
     int wave_panel_rows_lds = 1;     // ... their rows go global <-> registers as whole 128-B lines and change layout in LDS
     int wave_head = 124;               // first macro-step lengths of the groups in a call (decimal digits; 0: all `wave_depth`)

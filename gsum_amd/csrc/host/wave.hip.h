@@ -201,7 +201,15 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
     // the groups' big updates alternate on one stream, so all groups advance at the same macro-step rate, and a group in its
     // latency-bound last steps is paced by the other's 5-ms updates; 80 evaluations on 2 x 10: 315 evals/s in phase, 305 / 300
     // with the second group 4 / 8 macro-steps behind (the chains of the first and last macro-steps then run with nothing beside them).
-    const int shift = !several_rounds ? 0 : (ctx->wave_shift > 0 ? std::min(ctx->wave_shift, S) : 0);
+    const int rounds_of_call = (n_kernels + G * B - 1) / (G * B);
+    const bool long_call = rounds_of_call >= ctx->wave_long_rounds;
+    // calls of many rounds (a whole likelihood surface in one call, gsum_lml_resident_sets): the groups run out of phase by a third (1 / G)
+    // of a round's macro-steps and the far updates of a group's last macro-steps stay on its own stream (wave_shift = -1: automatic)
+    int ticks_per_round = 0;
+    for (int st_ = 0; st_ < S; ++st_) ticks_per_round += plans[0][(size_t)st_].near ? 0 : 1;
+    const int auto_shift = long_call ? std::max(1, ticks_per_round / G) : 0;
+    const int shift = !several_rounds ? 0 : (ctx->wave_shift > 0 ? std::min(ctx->wave_shift, S) : (ctx->wave_shift < 0 ? auto_shift : 0));
+    const int64_t tail_rows = (several_rounds && (long_call || ctx->wave_tail_rows < 0)) ? std::abs(ctx->wave_tail_rows) : 0;
     for (int i = 0; i < GS_WV_GROUPS; ++i) {           // (all groups: after the call cnt / first_eval say which members a group's workspaces hold)
         gs_wave_group* g = &wv->g[i];
         g->active = false;
@@ -239,8 +247,10 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 next += g->cnt;
                 gs_wave_fill_chain(g, &ca, false);
                 const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_OTHER, 0.0);
+                gs_wv_zsets zs;
+                for (int e = 0; e < g->cnt; ++e) zs.off[e] = (int64_t)(gs_z_of(ctx, g->first_eval + e) - ctx->in->Z);
                 hipLaunchKernelGGL(k_set_border_g, dim3((unsigned)((naug + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca, (int)n,
-                                   (const double*)ctx->in->Z, k);
+                                   (const double*)ctx->in->Z, k, zs);
                 hipLaunchKernelGGL(k_wave_begin, dim3((unsigned)((np + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca);
                 gs_prof_end(ctx, g->sc, rec);
                 GS_CHECK(hipGetLastError());
@@ -252,6 +262,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
             // critical path -- chain(s) -> near(s) -> chain(s + 1) -- and goes out on the CHAIN stream, followed at once by the next
             // step's chain; only the big updates (whole lower triangle, K = 512 or 256) go to the bulk stream.  So between two of its
             // big updates a group needs diag + panel + near + diag + panel (~0.8 ms) and the other groups' big updates cover it.
+            bool last_on_chain = false;
             for (;;) {
                 {
                     const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_DIAG, (double)g->cnt * 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
@@ -277,7 +288,12 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 }
                 GS_CHECK(hipGetLastError());
                 const gs_wave_step st = plans[i][(size_t)g->step];
-                const bool near = st.near && ctx->wave_near_on_chain && !serial;
+                // own: the update goes out on the group's CHAIN stream -- the near updates, and (option wave_tail_rows, calls of many rounds)
+                // the far updates of a group's last, small macro-steps: on the shared bulk stream a group in its latency-bound last steps is
+                // paced by the other groups' 5-ms updates queued in front of its own, which is why groups out of phase lost in round 4
+                const bool own_far = !st.near && !serial && tail_rows > 0 && mrest <= tail_rows;
+                const bool near = (st.near && ctx->wave_near_on_chain && !serial) || own_far;
+                last_on_chain = own_far;
                 hipStream_t su = near ? g->sc : wv->sb;
                 if (!near && !serial) {
                     GS_CHECK(hipEventRecord(g->evChain, g->sc));
@@ -315,9 +331,9 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 gs_prof_end(ctx, su, rec);
                 GS_CHECK(hipGetLastError());
                 ++g->step;
-                if (!near) break;
+                if (!near || own_far) break;
             }
-            GS_CHECK(hipEventRecord(g->evBulk, wv->sb));
+            GS_CHECK(hipEventRecord(g->evBulk, last_on_chain ? g->sc : wv->sb));
             if (g->step < S) continue;
             // ---- the round is complete: read-out on the chain stream (the bulk stream goes on with the other groups)
             GS_CHECK(hipStreamWaitEvent(g->sc, g->evBulk, 0));

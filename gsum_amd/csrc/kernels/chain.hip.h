@@ -302,8 +302,10 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_panel256gw(const gs_
                      TR ? tiles + (threadIdx.x >> 6) * GS_PT_TILE : (double*)nullptr);
 }
 // entering evaluations: border rows <- RHS^T (k_set_border), grid ((np + 16) / 256 rounded up, entries)
-__global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k) {
+struct gs_wv_zsets { int64_t off[GS_WVC_MAX]; };         // per entry: offset (doubles) of its right-hand-side set in Z
+__global__ __launch_bounds__(256) void k_set_border_g(const gs_wv_chain_args a, int n, const double* Z, int k, const gs_wv_zsets zs) {
     const int64_t q = a.q[blockIdx.y];
+    Z += zs.off[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.p.np + GS_BORDER) return;
     double* A = a.p.A + q * a.p.strideA;

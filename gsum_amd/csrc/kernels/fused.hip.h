@@ -16,7 +16,7 @@
 template <bool TREE>
 __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, int d, const double* Z, int k,
                                                     const gsum_kernel_desc* __restrict__ descs, double nugget, double* scratch,
-                                                    double* res) {
+                                                    double* res, const int32_t* zset) {
 #pragma clang fp contract(off)
     __shared__ double dg0[128];
     __shared__ double ldet;
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
     double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
     double* out = res + (int64_t)blockIdx.x * 258;
+    if (zset) Z += (int64_t)zset[blockIdx.x] * n * k;                  // this evaluation's right-hand-side set (gsum_lml_resident_sets)
     // ---- kernel matrix (full symmetric 128x128 tile, identity padding beyond n)
     double* etab = us + 128 * GSUM_MAX_D;                               // exp tables th[16] | tl[16]
     if (t < 16) etab[t] = gs_exp_th[t];
@@ -198,7 +199,7 @@ __device__ __forceinline__ void gs_tile128(double* C, int64_t ldc, const double*
 template <bool TREE>
 __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, int d, const double* Z, int k,
                                                      const gsum_kernel_desc* __restrict__ descs, double nugget, double* scratch,
-                                                     int64_t scratch_stride, double* res, unsigned long long* stamps = nullptr) {
+                                                     int64_t scratch_stride, double* res, unsigned long long* stamps, const int32_t* zset) {
     extern __shared__ double lds[];                 // max(GS_DIAG_WS, GS_TILE_LD_DOUBLES) doubles, lent in turn to the kernel
                                                     // build, the diagonal-block routine and the tile routine: 77.6 KB in
                                                     // all, so TWO evaluations share a CU
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
                                                                        // while the right-hand sides had a sweep of their own)
     double* Wt = diag0 + np;                        // 16 x np, row-major
     double* out = res + (int64_t)blockIdx.x * 258;
+    if (zset) Z += (int64_t)zset[blockIdx.x] * n * k;                  // this evaluation's right-hand-side set (gsum_lml_resident_sets)
     // diagnostics (option "diag_stamps"): shader cycles of workgroup 0 per phase -> stamps[40..47] =
     // {build, diagonal blocks, panel solves, sibling tiles, trailing tiles, W step, Gram + rest, total}
     unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0, tstart = 0;

@@ -326,14 +326,28 @@ class TruncationGP:
             for flat in mine:
                 i, rest = divmod(int(flat), nj * ns)
                 rows.setdefault(i, []).append(divmod(rest, ns))
-            for i, pts in rows.items():
-                Zi, det = rhs_for(i)
-                ctx.set_inputs(Xd, Zi)
-                G, sld, info = ctx.lml_resident([desc_for(j) for j, _ in pts], gp.nugget)
-                svals = None if scale_vals is None else scale_vals[[s for _, s in pts]]
-                vals = np.where(info != 0, -np.inf, lml_values(G, sld, svals) - det)
-                for (j, s), v in zip(pts, vals):
-                    out[i, j, s] = v
+            # ... and the rows go to the device TOGETHER: every row's right-hand sides resident as a set of their own, every point naming
+            # its set (gsum_lml_resident_sets) -- the whole surface is one call whose rounds follow one another on the device, instead of
+            # one call per ratio row with an upload, a drained pipeline and the host algebra in between (in chunks of rows whose sets
+            # stay under 1 GiB)
+            row_ids = list(rows)
+            k_rhs = rhs_for(row_ids[0])[0].shape[1]
+            max_rows = max(1, int((1 << 30) // max(1, n_pts * k_rhs * 8)))
+            for lo in range(0, len(row_ids), max_rows):
+                chunk = row_ids[lo:lo + max_rows]
+                ctx.set_inputs_sets(Xd, np.stack([rhs_for(i)[0] for i in chunk]))
+                descs, set_of, where, dets = [], [], [], []
+                for si, i in enumerate(chunk):
+                    for j, sc_ in rows[i]:
+                        descs.append(desc_for(j))
+                        set_of.append(si)
+                        where.append((i, j, sc_))
+                        dets.append(rhs_for(i)[1])
+                G, sld, info = ctx.lml_resident_sets(descs, set_of, gp.nugget)
+                svals = None if scale_vals is None else scale_vals[[w[2] for w in where]]
+                vals = np.where(info != 0, -np.inf, lml_values(G, sld, svals) - np.asarray(dets))
+                idx = np.asarray(where)
+                out[idx[:, 0], idx[:, 1], idx[:, 2]] = vals
         elif mode == "reuse":
             by_theta = {}
             for flat in mine:

@@ -167,6 +167,12 @@ int gsum_set_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const 
 int gsum_resident_shape(gsum_ctx* ctx, int64_t* n, int32_t* d, int32_t* k);      /* zeros before the first gsum_set_inputs */
 int gsum_lml_resident(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                       double* G_out, double* sld_out, int64_t* info_out);
+/* Several right-hand-side sets resident at once (RHS_sets: n_sets x n x k, C order), evaluation i reading set set_of[i]: a whole
+ * (ratio, theta) likelihood surface -- one set of coefficient curves per ratio row, docs/notebooks/correlated_EFT_publication.ipynb:
+ * 1444-1459 -- is then ONE call, its rounds back to back on the device instead of one call per row with the host in between. */
+int gsum_set_inputs_sets(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, const double* RHS_sets, int32_t n_sets, int32_t k);
+int gsum_lml_resident_sets(gsum_ctx* ctx, const gsum_kernel_desc* kernels, const int32_t* set_of, int32_t n_kernels, double nugget,
+                           double* G_out, double* sld_out, int64_t* info_out);
 /* Value AND gradient pieces of one evaluation (log_marginal_likelihood(theta, eval_gradient=True)).  Replaces
  * kernel(X, eval_gradient=True) (the n x n x p array at models.py:958, 1204), cho_solve(L, eye(N)) (:1044, 1266) and the einsum
  * contractions at :229, 276, 453-454, 1049.  With R = kernel(X) + nugget I, V = R^-1 RHS: G, sld, info as above;

@@ -364,3 +364,41 @@ def test_predict_sweep_on_panel256_equals_the_three_launch_sweep(n, m):
             lab.set_option("predict_split", 1)
             lab.set_option("chain_persist", -1)
             L.free()
+
+
+# ---- several right-hand-side sets in one call -------------------------------------------------------------
+@pytest.mark.parametrize("n,n_thetas", [(60, 9), (300, 40), (1100, 7), (2300, 30)])
+def test_resident_sets_equal_one_call_per_set(ctx, n, n_thetas):
+    """gsum_set_inputs_sets + gsum_lml_resident_sets: evaluation i reads right-hand-side set set_of[i] -- on every path (one
+    workgroup per evaluation for n <= 128 and for many evaluations of a medium order, the grouped schedule, one or two evaluations
+    alone) the results equal, bit for bit, one gsum_set_inputs + gsum_lml_resident call per set."""
+    rng = np.random.RandomState(n)
+    X = 0.1 * np.arange(n)[:, None]
+    n_sets, k = 4, 5
+    Zs = np.concatenate([rng.randn(n_sets, n, k - 1), np.ones((n_sets, n, 1))], axis=2)
+    descs = [gsum_amd.describe_kernel(RBF(0.15 + 0.1 * j / n_thetas), 1) for j in range(n_thetas)]
+    set_of = rng.randint(0, n_sets, size=n_thetas)
+    want = [np.empty((n_thetas, k, k)), np.empty(n_thetas), np.empty(n_thetas, dtype=np.int64)]
+    for s_ in range(n_sets):
+        pick = np.flatnonzero(set_of == s_)
+        if not len(pick):
+            continue
+        ctx.set_inputs(X, Zs[s_])
+        got = ctx.lml_resident([descs[j] for j in pick], 1e-10)
+        for w, g in zip(want, got):
+            w[pick] = g
+    ctx.set_inputs_sets(X, Zs)
+    got = ctx.lml_resident_sets(descs, set_of, 1e-10)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    # one or two evaluations: the single-factorisation schedule reads its set too
+    got2 = ctx.lml_resident_sets(descs[:2], set_of[:2], 1e-10)
+    for a, b in zip(got2, want):
+        np.testing.assert_array_equal(a, b[:2])
+    with pytest.raises(ValueError, match="set"):
+        ctx.lml_resident_sets(descs[:3], [0, n_sets, 1], 1e-10)
+    # the plain call after a sets call reads set 0
+    got3 = ctx.lml_resident(descs[:5], 1e-10)
+    ctx.set_inputs(X, Zs[0])
+    for a, b in zip(got3, ctx.lml_resident(descs[:5], 1e-10)):
+        np.testing.assert_array_equal(a, b)
