@@ -246,6 +246,8 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "chain_stamps")) ctx->chain_stamps = value != 0;
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
+    else if (!strcmp(name, "wave_cohorts")) ctx->wave_cohorts = value >= 2 ? 2 : 1;
+    else if (!strcmp(name, "wave_cohort_min")) ctx->wave_cohort_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_tail_rows")) ctx->wave_tail_rows = (int)value;
     else if (!strcmp(name, "wave_long_rounds")) ctx->wave_long_rounds = (int)std::max<int64_t>(2, value);
     else if (!strcmp(name, "wave_min")) ctx->wave_min = (int)std::max<int64_t>(1, value);
@@ -297,7 +299,7 @@ int gsum_set_option(gsum_ctx* ctx, const char* name, int64_t value) {
         GS_CHECK(hipDeviceSynchronize());
         GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_pivot_guard), &g, sizeof g));
     }
-    else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_GROUPS, value));
+    else if (!strcmp(name, "wave_groups")) ctx->wave_groups = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WV_STREAM_GROUPS, value));
     else if (!strcmp(name, "wave_size")) ctx->wave_size = (int)std::max<int64_t>(1, std::min<int64_t>(GS_WVC_MAX, value));
     else {
 #ifdef GSUM_LAB

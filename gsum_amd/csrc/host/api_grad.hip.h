@@ -211,7 +211,7 @@ static int gs_grad_batch_wave(gsum_ctx* ctx, const gsum_kernel_desc* descs, int 
     const int64_t npw = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB);
     const int fit = gs_wave_fit(ctx, n, npw);
     if (fit < 1) GS_FAIL("not enough device memory for one workspace matrix");
-    const int Gq = std::max(1, std::min(std::min(GS_WV_GROUPS, ctx->wave_groups), fit));
+    const int Gq = std::max(1, std::min(std::min(GS_WV_STREAM_GROUPS, ctx->wave_groups), fit));
     const int cap = Gq * std::max(1, std::min(std::min(GS_WVC_MAX, ctx->wave_size), fit / Gq));       // a multiple of the groups: ONE round per chunk
     auto harvest = [&](gs_slot* sl) -> int {                 // wait for the gradient stage pending on a slot, copy its pieces out
         const int i = sl->pending;

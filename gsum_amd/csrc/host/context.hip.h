@@ -63,9 +63,11 @@ struct gs_slot {
 #define GS_MAX_SLOTS 24
 
 // ---- grouped batch schedule ---------------------------------------------------------------------------------------------------------
-#define GS_WV_GROUPS 4
+#define GS_WV_STREAM_GROUPS 4        // groups with a chain stream of their own (option wave_groups)
+#define GS_WV_GROUPS 8               // ... times two COHORTS in calls of many rounds: group i + G runs on group i's stream, half a round behind
 struct gs_wave_group {
     hipStream_t sc = nullptr;            // this group's chain stream (high priority): kernel builds, diagonal blocks, panels, read-out
+    hipStream_t run = nullptr;           // ... the stream it runs on in the current call: sc, or -- a second cohort -- the stream of the group it shadows
     bool own_sc = false;                 // groups 0 and 1 borrow slot 0's panel and auxiliary streams (see gs_wave_prepare)
     hipEvent_t evChain = nullptr, evBulk = nullptr;
     gs_wv_pool pool;                     // `cap` workspaces at fixed strides
@@ -187,9 +189,14 @@ struct gsum_ctx {
     int wave_groups = 3;             // groups = chain streams; their bulk launches alternate on ONE bulk stream (4 streams: the HIP runtime's
                                      // default number of hardware queues)
     int wave_size = 8;               // evaluations per group at most
+    int wave_cohorts = 2;            // calls of at least wave_cohort_min x (groups x size) evaluations: every group runs TWO cohorts of evaluations half a
+    int wave_cohort_min = 4;         // round apart on its one chain stream, so that the latency-bound last steps of one cohort run under the far updates
+                                     // of the other (gs_lml_wave); 1: one cohort (rounds in phase, each ending with ~2.5 ms of latency-bound steps)
     int wave_long_rounds = 6;        // a call of at least this many rounds is "long": groups out of phase (wave_shift = -1) and own-stream tails
-    int wave_tail_rows = 0;          // far updates of at most this many rows go out on the group's chain stream in long calls (< 0: in every call of
-                                     // several rounds; 0: never)
+    int wave_tail_rows = 2048;       // with two cohorts: far updates of at most this many rows go out on the group's chain stream, not on the shared bulk
+                                     // stream, where a cohort in its latency-bound last steps would queue behind the other groups' 5-ms updates
+                                     // (< 0: in every call of several rounds; 0: never).  n = 8192, 1536 evaluations per call
+                                     // (profiles/r05_long_call.log): one cohort 337.0 evals/s, two 339.1, two + own-stream tails 343.8 (345.9 with 12 per cohort)
     int wave_shift = 0;              // macro-steps by which consecutive groups are out of phase in calls of several rounds (0: in phase)
     int wave_panel_rows_lds = 1;     // ... their rows go global <-> registers as whole 128-B lines and change layout in LDS
     int wave_head = 124;               // first macro-step lengths of the groups in a call (decimal digits; 0: all `wave_depth`)

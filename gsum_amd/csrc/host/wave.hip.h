@@ -45,14 +45,16 @@ static double gs_wave_ws_bytes(int64_t np) {
            (T + (double)np + 258.0) * 8.0 + 4.0;
 }
 
-static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
+// G groups in all, the first Gs of them with a chain stream of their own; group i >= Gs (a second cohort) runs on group (i - Gs)'s
+static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np, int Gs) {
     gs_wave* wv = &ctx->wave;
     if (!wv->sb) wv->sb = ctx->slots[0].sm;
     const int T = (int)(np / GS_NB);
     const int64_t ld = GS_LD(np);
     for (int i = 0; i < G; ++i) {
         gs_wave_group* g = &wv->g[i];
-        if (!g->sc) {
+        if (i >= Gs) g->run = wv->g[i - Gs].sc;            // a second cohort: on the stream of the group it shadows (ensured above: i - Gs < i)
+        if (i < Gs && !g->sc) {
             // A batch call and a single factorisation never run at the same time: the first two groups run on slot 0's two
             // high-priority streams, the third on the stream gsum_init created next to them (see there: four streams on four pipes)
             gs_slot* s0 = &ctx->slots[0];
@@ -69,6 +71,7 @@ static int gs_wave_prepare(gsum_ctx* ctx, int G, int B, int64_t n, int64_t np) {
                 if (gs_pipe_probe(ctx, all, cnt, nullptr)) return -1;
             }
         }
+        if (i < Gs) g->run = g->sc;
         if (!g->evChain) {
             GS_CHECK(hipEventCreateWithFlags(&g->evChain, hipEventDisableTiming));
             GS_CHECK(hipEventCreateWithFlags(&g->evBulk, hipEventDisableTiming));
@@ -153,18 +156,30 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                        int64_t* info_out) {
     const int64_t n = ctx->in->n, np = (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB), ld = GS_LD(np), naug = np + GS_BORDER;
     const int k = ctx->in->k, d = ctx->in->d, S = (int)(np / (2 * GS_NB));
-    int G = std::max(1, std::min(GS_WV_GROUPS, ctx->wave_groups));
+    int G = std::max(1, std::min(GS_WV_STREAM_GROUPS, ctx->wave_groups));
     int B = std::max(1, std::min(GS_WVC_MAX, ctx->wave_size));
     if (n_kernels < G * B) {                      // a short call: every evaluation in flight at once, the groups equally full
         G = std::min(G, n_kernels);
         B = (n_kernels + G - 1) / G;
     }
+    const int Gs = G;                             // groups with a stream of their own
+    // TWO COHORTS per group in calls of many rounds (round 5): rounds in phase end with ~2.5 ms of latency-bound last steps in which
+    // no group has a far update worth the chip (4 % of a 71-ms round at n = 8192), and groups out of phase on streams of their own lose
+    // more than that (a group's chain is then covered by ONE other group's update instead of two: measured, tools/gpu_long_call.py).  So
+    // every group gets a second set of workspaces and runs a second cohort of evaluations half a round behind the first ON THE SAME
+    // chain stream: per sweep of the loop below the stream carries cohort one's macro-step, then cohort two's, and the bulk stream
+    // both far updates -- the last steps of one cohort run under the far updates of the other, with no stream added.
+    const bool cohorts = ctx->wave_cohorts >= 2 && n_kernels >= ctx->wave_cohort_min * Gs * B && 2 * Gs <= GS_WV_GROUPS;
+    if (cohorts) G = 2 * Gs;
     {
         const int fit = gs_wave_fit(ctx, n, np);
         if (fit < 1) GS_FAIL("not enough device memory for one workspace matrix");
         if (G * B > fit) {
-            G = std::max(1, std::min(G, fit));
-            B = std::max(1, fit / G);
+            if (cohorts && Gs * B <= fit) B = std::max(1, fit / G);          // (both cohorts, smaller)
+            else {
+                G = std::max(1, std::min(G, fit));
+                B = std::max(1, fit / G);
+            }
         }
     }
     // A call of several rounds hands out EQUAL shares: R = ceil(n / (G B)) rounds, G R group-rounds of floor or ceil(n / (G R))
@@ -177,8 +192,8 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
         B = std::min(B, shares[0]);
     }
     size_t next_share = 0;
-    if (gs_wave_prepare(ctx, G, B, n, np)) return -1;
-    ctx->wave_last_streams = G + 1;
+    if (gs_wave_prepare(ctx, G, B, n, np, std::min(Gs, G))) return -1;
+    ctx->wave_last_streams = std::min(Gs, G) + 1;
     if (gs_reserve_pinned(ctx, (size_t)n_kernels * 258 * sizeof(double))) return -1;
     gs_wave* wv = &ctx->wave;
     // One plan per group: in a call's first round the groups' first macro-steps differ in length (option wave_head, decimal digits,
@@ -209,12 +224,13 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
     for (int st_ = 0; st_ < S; ++st_) ticks_per_round += plans[0][(size_t)st_].near ? 0 : 1;
     const int auto_shift = long_call ? std::max(1, ticks_per_round / G) : 0;
     const int shift = !several_rounds ? 0 : (ctx->wave_shift > 0 ? std::min(ctx->wave_shift, S) : (ctx->wave_shift < 0 ? auto_shift : 0));
-    const int64_t tail_rows = (several_rounds && (long_call || ctx->wave_tail_rows < 0)) ? std::abs(ctx->wave_tail_rows) : 0;
+    const int64_t tail_rows = (several_rounds && (cohorts || ctx->wave_tail_rows < 0)) ? std::abs(ctx->wave_tail_rows) : 0;
     for (int i = 0; i < GS_WV_GROUPS; ++i) {           // (all groups: after the call cnt / first_eval say which members a group's workspaces hold)
         gs_wave_group* g = &wv->g[i];
         g->active = false;
         g->cnt = g->step = 0;
         g->start_tick = i * shift;
+        if (cohorts && i >= Gs && i < G) g->start_tick = std::max(1, ticks_per_round / 2);      // the second cohorts: half a round behind
     }
     const bool prof = ctx->profile_gemm > 0;
     if (prof) ctx->prof_this_eval = true;
@@ -222,7 +238,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
     hipStream_t s0 = ctx->slots[0].sm;
     GS_CHECK(hipEventRecord(ctx->slots[0].evFork, s0));
     GS_CHECK(hipStreamWaitEvent(wv->sb, ctx->slots[0].evFork, 0));
-    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamWaitEvent(wv->g[i].sc, ctx->slots[0].evFork, 0));
+    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamWaitEvent(wv->g[i].run, ctx->slots[0].evFork, 0));
     int next = 0, live = 0;
     for (int tick = 0; next < n_kernels || live > 0; ++tick) {
         for (int i = 0; i < G; ++i) {
@@ -238,24 +254,24 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 g->active = true;
                 ++live;
                 for (int e = 0; e < g->cnt; ++e) {
-                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_BUILD, 0.0);
-                    const int rc = gs_launch_build<false>(ctx, g->sc, g->pool.A + (int64_t)e * g->pool.strideA, ld, ctx->in->X, nullptr, n, n,
+                    const int rec = gs_prof_begin(ctx, g->run, GS_PROF_BUILD, 0.0);
+                    const int rc = gs_launch_build<false>(ctx, g->run, g->pool.A + (int64_t)e * g->pool.strideA, ld, ctx->in->X, nullptr, n, n,
                                                           np, np, d, &kernels[next + e], nugget, ctx->build_lower_only);
-                    gs_prof_end(ctx, g->sc, rec);
+                    gs_prof_end(ctx, g->run, rec);
                     if (rc) return rc;
                 }
                 next += g->cnt;
                 gs_wave_fill_chain(g, &ca, false);
-                const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_OTHER, 0.0);
+                const int rec = gs_prof_begin(ctx, g->run, GS_PROF_OTHER, 0.0);
                 gs_wv_zsets zs;
                 for (int e = 0; e < g->cnt; ++e) zs.off[e] = (int64_t)(gs_z_of(ctx, g->first_eval + e) - ctx->in->Z);
-                hipLaunchKernelGGL(k_set_border_g, dim3((unsigned)((naug + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca, (int)n,
+                hipLaunchKernelGGL(k_set_border_g, dim3((unsigned)((naug + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->run, ca, (int)n,
                                    (const double*)ctx->in->Z, k, zs);
-                hipLaunchKernelGGL(k_wave_begin, dim3((unsigned)((np + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->sc, ca);
-                gs_prof_end(ctx, g->sc, rec);
+                hipLaunchKernelGGL(k_wave_begin, dim3((unsigned)((np + 255) / 256), (unsigned)g->cnt), dim3(256), 0, g->run, ca);
+                gs_prof_end(ctx, g->run, rec);
                 GS_CHECK(hipGetLastError());
             } else {
-                GS_CHECK(hipStreamWaitEvent(g->sc, g->evBulk, 0));            // the trailing update of the previous step
+                GS_CHECK(hipStreamWaitEvent(g->run, g->evBulk, 0));            // the trailing update of the previous step
             }
             // ---- one macro-step: the chain of outer step g->step (diagonal super-blocks, then both panels of all rows below them) and
             // its trailing update.  A "near" update (the next panel's 256 columns only, K = 256: ~1 GF per member) sits on the chain's
@@ -265,19 +281,19 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
             bool last_on_chain = false;
             for (;;) {
                 {
-                    const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_DIAG, (double)g->cnt * 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
+                    const int rec = gs_prof_begin(ctx, g->run, GS_PROF_DIAG, (double)g->cnt * 8.0 * GS_NB * GS_NB * GS_NB / 3.0);
                     gs_wave_fill_chain(g, &ca, false);
-                    hipLaunchKernelGGL(k_potrf_diag256g, dim3((unsigned)g->cnt), dim3(256), 0, g->sc, ca);
-                    gs_prof_end(ctx, g->sc, rec);
+                    hipLaunchKernelGGL(k_potrf_diag256g, dim3((unsigned)g->cnt), dim3(256), 0, g->run, ca);
+                    gs_prof_end(ctx, g->run, rec);
                 }
                 const int64_t c0 = 2 * GS_NB * (int64_t)g->step, r2 = c0 + 2 * GS_NB, mrest = naug - r2;
                 const bool serial = ctx->wave_serial != 0;
                 if (serial) {                  // only the diagonal blocks run beside the bulk stream's kernels (see wave_serial)
-                    GS_CHECK(hipEventRecord(g->evChain, g->sc));
+                    GS_CHECK(hipEventRecord(g->evChain, g->run));
                     GS_CHECK(hipStreamWaitEvent(wv->sb, g->evChain, 0));
                 }
                 {
-                    hipStream_t spn = serial ? wv->sb : g->sc;
+                    hipStream_t spn = serial ? wv->sb : g->run;
                     const int groups = gs_wave_fill_chain(g, &ca, true);
                     const int rec = gs_prof_begin(ctx, spn, GS_PROF_PANEL, (double)g->cnt * 4.0 * (double)mrest * GS_NB * GS_NB);
                     if (ctx->wave_panel_wg4 == 8) hipLaunchKernelGGL(k_panel256gw<8>, dim3((unsigned)((groups + 7) / 8)), dim3(512), 0, spn, ca);
@@ -294,9 +310,9 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 const bool own_far = !st.near && !serial && tail_rows > 0 && mrest <= tail_rows;
                 const bool near = (st.near && ctx->wave_near_on_chain && !serial) || own_far;
                 last_on_chain = own_far;
-                hipStream_t su = near ? g->sc : wv->sb;
+                hipStream_t su = near ? g->run : wv->sb;
                 if (!near && !serial) {
-                    GS_CHECK(hipEventRecord(g->evChain, g->sc));
+                    GS_CHECK(hipEventRecord(g->evChain, g->run));
                     GS_CHECK(hipStreamWaitEvent(wv->sb, g->evChain, 0));
                 }
                 gs_wv_gemm_args ga;
@@ -333,22 +349,22 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 ++g->step;
                 if (!near || own_far) break;
             }
-            GS_CHECK(hipEventRecord(g->evBulk, last_on_chain ? g->sc : wv->sb));
+            GS_CHECK(hipEventRecord(g->evBulk, last_on_chain ? g->run : wv->sb));
             if (g->step < S) continue;
             // ---- the round is complete: read-out on the chain stream (the bulk stream goes on with the other groups)
-            GS_CHECK(hipStreamWaitEvent(g->sc, g->evBulk, 0));
+            GS_CHECK(hipStreamWaitEvent(g->run, g->evBulk, 0));
             gs_wave_fill_chain(g, &ca, false);
-            const int rec = gs_prof_begin(ctx, g->sc, GS_PROF_OTHER, 0.0);
-            hipLaunchKernelGGL(k_finalize_g, dim3((unsigned)g->cnt), dim3(256), 0, g->sc, ca);
-            gs_prof_end(ctx, g->sc, rec);
+            const int rec = gs_prof_begin(ctx, g->run, GS_PROF_OTHER, 0.0);
+            hipLaunchKernelGGL(k_finalize_g, dim3((unsigned)g->cnt), dim3(256), 0, g->run, ca);
+            gs_prof_end(ctx, g->run, rec);
             GS_CHECK(hipGetLastError());
             GS_CHECK(hipMemcpyAsync(ctx->hbatch + (size_t)g->first_eval * 258, g->pool.res, (size_t)g->cnt * 258 * sizeof(double),
-                                    hipMemcpyDeviceToHost, g->sc));
+                                    hipMemcpyDeviceToHost, g->run));
             g->active = false;
             --live;
         }
     }
-    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamSynchronize(wv->g[i].sc));
+    for (int i = 0; i < G; ++i) GS_CHECK(hipStreamSynchronize(wv->g[i].run));
     GS_CHECK(hipStreamSynchronize(wv->sb));
     for (int i = 0; i < n_kernels; ++i) {
         const double* r = ctx->hbatch + (size_t)i * 258;

@@ -402,3 +402,42 @@ def test_resident_sets_equal_one_call_per_set(ctx, n, n_thetas):
     ctx.set_inputs(X, Zs[0])
     for a, b in zip(got3, ctx.lml_resident(descs[:5], 1e-10)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_two_cohorts_per_group_equal_single_evaluations():
+    """Calls of many rounds run two cohorts of evaluations per group, half a round apart on the group's one chain stream (option
+    wave_cohorts; the last small far updates on that stream too): every evaluation equals, bit for bit, the same evaluation of a call
+    with one cohort and of a call of its own -- several orders, ragged call sizes, right-hand-side sets, a failing evaluation inside."""
+    lab = gsum_amd.lab_context(0)
+    rng = np.random.RandomState(11)
+    try:
+        for n, N, size in ((1100, 61, 3), (2304, 50, 2), (4096, 40, 2)):
+            X = 0.1 * np.arange(n)[:, None]
+            Zs = np.concatenate([rng.randn(3, n, 4), np.ones((3, n, 1))], axis=2)
+            descs = [gsum_amd.describe_kernel(RBF(0.15 + 0.1 * j / N), 1) for j in range(N)]
+            descs[N // 2] = gsum_amd.describe_kernel(RBF(40.0), 1)            # not positive definite with a zero nugget ... (info > 0 below)
+            set_of = rng.randint(0, 3, size=N)
+            lab.set_option("medium_path", 0)
+            lab.set_option("wave_size", size)
+            lab.set_option("wave_cohort_min", 2)
+            lab.set_inputs_sets(X, Zs)
+            lab.set_option("wave_cohorts", 1)
+            want = lab.lml_resident_sets(descs, set_of, 0.0 if n == 1100 else 1e-10)
+            lab.set_option("wave_cohorts", 2)
+            got = lab.lml_resident_sets(descs, set_of, 0.0 if n == 1100 else 1e-10)
+            assert lab.get_option("wave_streams") == 4
+            ok = want[2] == 0                                                  # (G and sld are undefined where info > 0)
+            np.testing.assert_array_equal(got[2], want[2])
+            np.testing.assert_array_equal(got[0][ok], want[0][ok])
+            np.testing.assert_array_equal(got[1][ok], want[1][ok])
+            if n == 1100:
+                assert want[2][N // 2] > 0 and np.count_nonzero(want[2]) >= 1
+            one = lab.lml_resident_sets(descs[5:6], set_of[5:6], 0.0 if n == 1100 else 1e-10)
+            for a, b in zip(one, want):
+                np.testing.assert_array_equal(a[0], b[5])
+    finally:
+        lab.set_option("medium_path", 1)
+        lab.set_option("wave_size", 8)
+        lab.set_option("wave_cohort_min", 4)
+        lab.set_option("wave_cohorts", 2)
+        lab.set_option("release_scratch", 1)
