@@ -699,7 +699,7 @@ def main():
 
     pmc_traffic = pmc_file = pmc_alg = None
     pmc_what = ""
-    for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
+    for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):          # the newest committed counter passes
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)

@@ -85,6 +85,9 @@ static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kern
     hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, su, U, ldg, (int)np);
     GS_CHECK(hipGetLastError());
     // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
+    const bool have_sib = m->Lsib != nullptr && (on_chain || (!solo && m->have_lsib));      // (the chain publishes the images pair by pair, ahead of RP[s])
+    const bool lazy_ok = ctx->predict_lazy && np >= ctx->lazy_min_np && !trail && !on_chain;      // (a trailing sweep keeps the per-pair rhythm of the factorisation)
+    bool deferred = false;
     for (int c = 0; c < m->T; c += 2) {
         const bool two = c + 1 < m->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
@@ -99,13 +102,32 @@ static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kern
                 GS_CHECK(hipStreamWaitEvent(su, sl->evC, 0));                  // the last outer step has no flag of this kind: the chain kernel's end
             }
         }
-        if (gs_trsm_rows(ctx, su, m, c, U + c0, ldg, c1)) return -1;
-        if (two) {
-            // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
-            if (gs_gemm(ctx, su, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-            if (gs_trsm_rows(ctx, su, m, c + 1, U + c1, ldg, r2)) return -1;
+        // The pair's two panel solves and the sibling update between them: ONE k_panel256 launch where the factor's sibling images exist
+        // as the sweep reaches the pair (the persistent chain publishes them step by step, the grouped batch leaves them in the pool) --
+        // rows [c1, r2) of block column c are still zero and come out zero; otherwise k_panel / K = 128 GEMM / k_panel as in rounds 1-4.
+        if (two && have_sib && ctx->predict_panel256) {
+            if (gs_panel256(ctx, su, m, c, U + c0, ldg, r2)) return -1;
+        } else {
+            if (gs_trsm_rows(ctx, su, m, c, U + c0, ldg, c1)) return -1;
+            if (two) {
+                // rows below c1 are still zero in block column c: only rows < c1 feed the sibling column
+                if (gs_gemm(ctx, su, 1, U + c1, ldg, U + c0, ldg, m->A + c1 * ld + c0, ld, c1, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                if (gs_trsm_rows(ctx, su, m, c + 1, U + c1, ldg, r2)) return -1;
+            }
         }
-        if (r2 < np && gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
+        if (r2 >= np) continue;
+        // the trailing update, paired like the predictive sweep's (predict_lazy): after an even pair only the next pair's 256 columns take
+        // this pair's update (K = 256), the pair after it applies both to everything right of it in one K = 512 launch -- rows [r2 - 256, r2)
+        // of the older pair's columns are structural zeros.  Same products in the same ascending order per element.
+        const bool pair = lazy_ok && two && c + 3 < m->T && r2 + 2 * GS_NB <= np;
+        if (!deferred && pair) {
+            if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
+            deferred = true;
+        } else if (deferred) {
+            const int64_t cp = c0 - 2 * GS_NB;
+            if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + cp, ldg, m->A + r2 * ld + cp, ld, r2, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
+            deferred = false;
+        } else if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
     hipStream_t sv = s;
@@ -262,6 +284,8 @@ static int gs_grad_batch_wave(gsum_ctx* ctx, const gsum_kernel_desc* descs, int 
                 view.A = g->pool.A + (int64_t)q * g->pool.strideA;
                 view.Ltab = g->pool.Ltab + (size_t)q * g->pool.T * GS_LTAB;
                 view.have_ltab = true;
+                view.Lsib = g->pool.Lsib + (size_t)q * (g->pool.T / 2 + 1) * GS_LSIB;      // (left by k_potrf_diag256g: the grouped factorisation)
+                view.have_lsib = true;
                 rc = gs_grad_post(ctx, sl, &view, &descs[i], params + (size_t)i * P, P, false, false);
                 if (!rc) sl->pending = i;
             }

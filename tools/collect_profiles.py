@@ -99,7 +99,7 @@ for name in ("wave_trace_1x20.txt", "wave_trace_3x7.txt", "parity_achieved.json"
     copy(os.path.join(SRC, name), name)
 json_line("bench_predict.log", "bench_predict.jsonl")
 copy(os.path.join(SRC, "single_eval_chain_timeline.txt"), "single_eval_timeline.txt")       # round 3: the chain kernel's own stamps
-for log in ("wave_profile.log", "wave_sweep.log", "chain_abort_repro.log", "chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages.log", "rocprof_single.log", "rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
+for log in ("rocprof_medium.log", "wave_profile.log", "wave_sweep.log", "chain_abort_repro.log", "chain_check.log", "grad_batch.log", "bulk_cphase.log", "bulk_stages.log", "rocprof_single.log", "rccl_world1.log", "two_ranks_one_gpu_gloo.log", "two_ranks_one_gpu_nccl.log", "medium_rates.log", "r2_kernels.log",
             "single_sweep.log", "slots_sweep.log", "clock_power.log", "medium_phases.log"):
     path = os.path.join(SRC, log)
     if os.path.exists(path):
@@ -182,3 +182,45 @@ if b:
                        "note": "WRITE_SIZE x 1 KiB equals the bytes the kernel stores (lower 128-column tiles); nothing is read back"}}
     json.dump(rec, open(os.path.join(OUT, f"{TAG}_build_pmc.json"), "w"), indent=1)
     print("wrote", f"{TAG}_build_pmc.json")
+
+# ---- round 5: k_lml_medium (BASELINE configs[1]: n = 2048, 512 evaluations per launch, one workgroup each) under PMC
+def any_values(sub, needle, counter):
+    f = newest(sub, "*counter_collection.csv")
+    if not f or stale(f):
+        return []
+    return [(float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
+
+
+med = {c: any_values(sub, "k_lml_medium", c) for sub, cs in (("pmc_med1", ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVES")),
+                                                                ("pmc_med2", ("FETCH_SIZE",)), ("pmc_med3", ("WRITE_SIZE",)),
+                                                                ("pmc_med4", ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                                                              "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F64"))) for c in cs}
+if med.get("FETCH_SIZE") and med.get("WRITE_SIZE"):
+    n_, evals = 2048, 512
+    last_of = lambda c: med[c][-1] if med.get(c) else (None, None)      # noqa: E731  (the last dispatch: warmed-up buffers)
+    fetch, dur_f = last_of("FETCH_SIZE")
+    write, _ = last_of("WRITE_SIZE")
+    gui, dur_g = last_of("GRBM_GUI_ACTIVE")
+    busy, _ = last_of("SQ_VALU_MFMA_BUSY_CYCLES")
+    rd, wr = fetch * 2048, write * 1024
+    flops = evals * n_ ** 3 / 3.0
+    dur = (dur_g or dur_f) / 1e9
+    rec = {"kernel": "k_lml_medium<false>", "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 tools/prof_medium.py 2048 512 2",
+           "what": "one launch = 512 full evaluations at n = 2048 (K build + Cholesky + solve + Gram), one workgroup each, two per CU; counters of the "
+                   "last dispatch of each pass (FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB as the guide prescribes for gfx950)",
+           "counters": {c: (v[-1][0] if v else None) for c, v in med.items()},
+           "derived": {"duration_ms_profiled": dur * 1e3, "evals_per_s_profiled": evals / dur, "cholesky_tflops": flops / dur / 1e12,
+                       "frac_of_fp64_mfma_peak": flops / dur / 1e12 / 78.6,
+                       "hbm_read_bytes_per_eval": rd / evals, "hbm_write_bytes_per_eval": wr / evals,
+                       "fabric_side_GBps": (rd + wr) / dur / 1e9, "frac_of_hbm_peak_8TBps": (rd + wr) / dur / 8e12,
+                       "matrix_bytes_per_eval": n_ * (n_ + 16) * 8,
+                       "flops_per_fabric_byte": flops / (rd + wr),
+                       "mfma_busy_frac": (busy / (gui / 8 * 1024)) if busy and gui else None,
+                       "note": "memory-busy = fabric-side bytes / time against the 8 TB/s spec (an in-order sweep measures 6.0-6.3 TB/s on this part); "
+                               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"}}
+    json.dump(rec, open(os.path.join(OUT, f"{TAG}_medium_pmc.json"), "w"), indent=1)
+    print("wrote", f"{TAG}_medium_pmc.json")
+copy(newest("prof_medium", "*kernel_stats.csv"), "medium_n2048_kernel_stats.csv")
+json_line("inproc1.log", "inproc1.jsonl")
+json_line("inproc2_one_gpu.log", "inproc2_two_contexts_one_gpu.jsonl")
