@@ -275,7 +275,7 @@ def test_lml_resident_shard_fills_exactly_its_slice(ctx):
 
 def test_batches_run_on_three_streams_whatever_the_hardware_queue_count(ctx):
     """Round 4: a batch advances in groups with ONE launch per kernel class and outer step (gs_lml_wave); it owns a chain
-    stream per group and one bulk stream -- 3 with the default two groups, inside the HIP runtime's default of 4 hardware
+    stream per group and one bulk stream -- 4 with the default three groups, the HIP runtime's default number of hardware
     queues -- and this process never asked for more (tests/conftest.py no longer sets GPU_MAX_HW_QUEUES).  Group layout is
     scheduling only: 1 x 24, 2 x 10, 3 x 5 and 4 x 2 give the same bits, the non-positive-definite member included."""
     assert "GPU_MAX_HW_QUEUES" not in os.environ
