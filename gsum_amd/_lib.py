@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -259,6 +260,8 @@ def _ptr(a):
 
 
 _pipes_warned = False
+_live_contexts = weakref.WeakSet()        # every HipContext / HipGroup alive: closed at exit, groups first (see _close_default_contexts)
+_live_groups = weakref.WeakSet()
 
 
 def _warn_pipes(ctx):
@@ -326,6 +329,7 @@ class HipContext:
             raise RuntimeError(f"gsum_init(device={device}) failed: {msg.decode() if msg else rc}")
         self._h = h
         self.device = int(device)
+        _live_contexts.add(self)
         _warn_pipes(self)
 
     # -- plumbing ------------------------------------------------------------
@@ -774,6 +778,7 @@ class HipGroup:
                 raise RuntimeError(f"gsum_group_adopt failed: {msg.decode() if msg else rc}")
             self._h = h
         self.devices = [c.device for c in self.contexts]
+        _live_groups.add(self)
 
     def __len__(self):
         return len(self.contexts)
@@ -917,13 +922,13 @@ def _close_default_contexts():
     # Streams with a CU mask must be gone before the C++ finalisers of the HIP runtime / a profiler run (rocprofv3
     # segfaults in __cxa_finalize on a process that exits with one alive): destroy the contexts first.  DeviceMatrix
     # objects still alive only lose their handle (their frees become no-ops).
-    for grp in list(_groups.values()):               # groups first: they borrow the contexts below
+    for grp in list(_groups.values()) + list(_live_groups):        # groups first: they borrow the contexts below
         try:
             grp.close()
         except Exception:
             pass
     _groups.clear()
-    for ctx in list(_default_ctx.values()) + list(_lab_ctx.values()):
+    for ctx in list(_default_ctx.values()) + list(_lab_ctx.values()) + list(_live_contexts):
         try:
             ctx.close()
         except Exception:
