@@ -216,6 +216,8 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "lazy_far")) ctx->lazy_far = (int)value;
     else if (!strcmp(name, "predict_lazy")) ctx->predict_lazy = value != 0;
     else if (!strcmp(name, "predict_panel256")) ctx->predict_panel256 = value != 0;
+    else if (!strcmp(name, "predict_lookahead")) ctx->predict_lookahead = value != 0;
+    else if (!strcmp(name, "predict_depth")) ctx->predict_depth = (int)std::max<int64_t>(1, std::min<int64_t>(8, value));
     else if (!strcmp(name, "predict_split")) ctx->predict_split = value != 0;
     else if (!strcmp(name, "medium_lazy")) {            // (process-wide: a __device__ variable of the code object)
         const int v = (int)std::max<int64_t>(1, std::min<int64_t>(64, value));      // grouping depth: 1 none, 2 pairs, ..., >= 16: left-looking at n <= 4096

@@ -345,6 +345,54 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                            (int)n, d_ref_s, d_rat_s, d_ref_x, d_rat_x, *sc);
         GS_CHECK(hipGetLastError());
     }
+    // LOOK-AHEAD SWEEP (round 5; m >= 1024 rows, large orders): pairs of block columns are steps, two steps a macro-step.  The context's chain
+    // stream carries what the next step needs -- P(a) (both panels of pair a, k_panel256), N(a) (pair b's 256 columns, K = 256), P(b), then NB:
+    // the next macro-step's 512 columns with both pairs at once (K = 512) --, the main stream ONE far launch per macro-step for everything right
+    // of those (K = 512), which the chain stream only meets again a macro-step later: the 64 latency-bound panel launches of n = 16384 (17 % of
+    // the one-stream sweep: the chip idles while 128 waves solve) run beside a far launch instead of between two.  Column block q receives the
+    // far launches of all earlier macro-steps, then NB of the macro-step before its own, then N: ascending k per element, bit-identical.
+    if (m >= 1024 && ctx->predict_lookahead && ctx->predict_lazy && ctx->predict_panel256 && np >= ctx->lazy_min_np && ctx->cur->sa && L->T >= 8) {
+        const int T = L->T, S2 = (T + 1) / 2;
+        hipStream_t sc = ctx->cur->sa, sf = ctx->cur->sm;
+        auto col = [&](int st) { return std::min<int64_t>(2 * GS_NB * (int64_t)st, np); };
+        if (gs_need_lsib(ctx, sf, L)) return -1;
+        if (gs_potrf_events(ctx, ctx->cur, 2)) return -1;
+        hipEvent_t evP = ctx->cur->evP[0], evF = ctx->cur->evP[1];
+        GS_CHECK(hipEventRecord(ctx->cur->evFork, sf));
+        GS_CHECK(hipStreamWaitEvent(sc, ctx->cur->evFork, 0));
+        bool far_pending = false;
+        // macro-steps of D pairs (option predict_depth; 2: K = 512 far launches, 4: K = 1024): inside one, pair a + i's near update N applies
+        // all pairs of the macro-step so far to pair a + i + 1's 256 columns (K = 256 (i + 1)); NB and Far apply all D pairs
+        const int D = std::max(2, std::min(8, ctx->predict_depth));
+        for (int a = 0; a < S2; a += D) {
+            const int64_t ca = col(a);
+            int last = a;
+            for (int q = 0; q < D && a + q < S2; ++q) {
+                const int st = a + q;
+                const int64_t cq = col(st);
+                last = st;
+                if (2 * st + 1 < T) { if (gs_panel256(ctx, sc, L, 2 * st, Bt + cq, ldb, m)) return -1; }
+                else if (gs_trsm_rows(ctx, sc, L, 2 * st, Bt + cq, ldb, m)) return -1;
+                if (q + 1 < D && st + 1 < S2) {            // N: the next pair's columns take every pair of the macro-step so far
+                    const int64_t c1 = col(st + 1), c2 = col(st + 2);
+                    if (gs_gemm(ctx, sc, 7, Bt + c1, ldb, Bt + ca, ldb, L->A + c1 * ld + ca, ld, m, c2 - c1, (int)(c1 - ca), 0, 1, -1.0)) return -1;
+                }
+            }
+            const int64_t cn = col(last + 1), cf = col(last + 1 + D);      // the next macro-step's columns [cn, cf); far: [cf, np)
+            if (cn >= np) break;
+            GS_CHECK(hipEventRecord(evP, sc));                               // every pair of the macro-step is solved
+            if (far_pending) GS_CHECK(hipStreamWaitEvent(sc, evF, 0));      // the previous far launch covered the columns NB is about to update
+            if (gs_gemm(ctx, sc, 7, Bt + cn, ldb, Bt + ca, ldb, L->A + cn * ld + ca, ld, m, cf - cn, (int)(cn - ca), 0, 1, -1.0)) return -1;
+            if (cf < np) {
+                GS_CHECK(hipStreamWaitEvent(sf, evP, 0));
+                if (gs_gemm(ctx, sf, GS_BULK, Bt + cf, ldb, Bt + ca, ldb, L->A + cf * ld + ca, ld, m, np - cf, (int)(cn - ca), 0, 1, -1.0)) return -1;
+                GS_CHECK(hipEventRecord(evF, sf));
+                far_pending = true;
+            }
+        }
+        GS_CHECK(hipEventRecord(ctx->cur->evS, sc));
+        GS_CHECK(hipStreamWaitEvent(sf, ctx->cur->evS, 0));
+    } else {
     // V^T = kernel(Xs, X) L^-T by a right-looking sweep, two block columns per trailing update (K = 256) like the
     // factorisation: the trailing part of Bt is read and written once per 256 eliminated columns instead of once per 128
     // (at m = 2048, n = 16384 a K = 128 sweep moved 0.5 GB per step against 190 us of MFMA work).
@@ -360,17 +408,31 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
         GS_CHECK(hipStreamWaitEvent(hs[1], ctx->cur->evFork, 0));
     }
     const int64_t m_lo = n_half == 2 ? (m / 2 + 127) / 128 * 128 : m;       // rows of the first half: whole 128-row tiles
-    bool deferred = false;                               // the columns right of the next panel still owe the previous panel's update
-    for (int c = 0; c < L->T; c += 2) {
-        const bool two = c + 1 < L->T;
+    // The batch factorisation's grouping of trailing updates (gs_wave_bulk_plan) applied to this sweep: steps are pairs of block columns;
+    // inside a macro-step of up to `predict_depth` pairs a step updates only the NEXT pair's 256 columns, with all pairs of the macro-step so
+    // far at once (K = 256 (i + 1)); its last step applies all of them to everything to its right in ONE launch (K up to 1024) -- the
+    // trailing part of Bt is read and written once per macro-step and the tile runs at its K = 1024 rate (65 TF/s alone against 58 at
+    // K = 512, 47 at 256).  Round 3 paired (depth 2); round 5: depth 4.  Same products in the same ascending-k order per element.
+    const int T = L->T, S2 = (T + 1) / 2;
+    struct Step { bool near; int first; };
+    std::vector<Step> plan((size_t)S2, Step{false, 0});
+    {
+        const int depth = (ctx->predict_lazy && m >= 1024 && np >= ctx->lazy_min_np) ? std::max(1, ctx->predict_depth) : 1;
+        for (int a = 0; a < S2;) {
+            int Lm = 1;
+            while (Lm < depth && 2 * (a + Lm) + 1 < T && 2 * GS_NB * (int64_t)(a + Lm + 1) <= np) ++Lm;      // step a + Lm is a full pair
+            if (Lm > 2 && np - 2 * GS_NB * (int64_t)(a + 1) < ctx->wave_deep_rows) Lm = 2;
+            for (int q = 0; q < Lm; ++q) plan[(size_t)(a + q)] = Step{q < Lm - 1, a};
+            a += Lm;
+        }
+    }
+    for (int c = 0; c < T; c += 2) {
+        const bool two = c + 1 < T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
-        // The batch factorisation's lazy far updates (lazy_far = 2) applied to this sweep: after an even step only the next panel's 256 columns take
-        // this panel's update (K = 256); the step after it applies both panels to everything to its right in ONE K = 512 launch -- half as many passes
-        // over the trailing part of Bt, each at the tile kernel's better K = 512 rate.  Same products in the same ascending-k order per element.
-        const bool pair = ctx->predict_lazy && two && m >= 1024 && np >= ctx->lazy_min_np && c + 3 < L->T && r2 + 2 * GS_NB <= np;
-        const bool was_deferred = deferred;
+        const Step st = plan[(size_t)(c / 2)];
+        const int64_t cp = 2 * GS_NB * (int64_t)st.first;          // the macro-step's first column: [cp, r2) are its panels so far
         for (int h = 0; h < n_half; ++h) {
-            hipStream_t st = hs[h];
+            hipStream_t sth = hs[h];
             const int64_t row0 = h == 0 ? 0 : m_lo, mh = n_half == 1 ? m : (h == 0 ? m_lo : m - m_lo);
             double* Bh = Bt + row0 * ldb;
             if (mh <= 0) continue;
@@ -378,29 +440,24 @@ static int gs_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* 
                 // both panels of the pair and the sibling update between them in ONE launch, 16 rows per wave (k_panel256: the factorisation's
                 // own panel step; rounds 1-4 ran k_panel, a K = 128 GEMM and k_panel again here: 3 dependent launches per pair, 896 launches
                 // of ~12 us on the sweep's critical path at n = 16384)
-                if (gs_need_lsib(ctx, st, L)) return -1;
-                if (gs_panel256(ctx, st, L, c, Bh + c0, ldb, mh)) return -1;
+                if (gs_need_lsib(ctx, sth, L)) return -1;
+                if (gs_panel256(ctx, sth, L, c, Bh + c0, ldb, mh)) return -1;
             } else {
-                if (gs_trsm_rows(ctx, st, L, c, Bh + c0, ldb, mh)) return -1;
+                if (gs_trsm_rows(ctx, sth, L, c, Bh + c0, ldb, mh)) return -1;
                 if (two) {
-                    if (gs_gemm(ctx, st, sib_cfg, Bh + c1, ldb, Bh + c0, ldb, L->A + c1 * ld + c0, ld, mh, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
-                    if (gs_trsm_rows(ctx, st, L, c + 1, Bh + c1, ldb, mh)) return -1;
+                    if (gs_gemm(ctx, sth, sib_cfg, Bh + c1, ldb, Bh + c0, ldb, L->A + c1 * ld + c0, ld, mh, GS_NB, GS_NB, 0, 1, -1.0)) return -1;
+                    if (gs_trsm_rows(ctx, sth, L, c + 1, Bh + c1, ldb, mh)) return -1;
                 }
             }
             if (r2 >= np) continue;
-            if (!was_deferred && pair) {
-                if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + c0, ldb, L->A + r2 * ld + c0, ld, mh, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
-            } else if (was_deferred) {
-                const int64_t cp = c0 - 2 * GS_NB;            // the previous panel's first column: [cp, r2) is 512 columns wide
-                if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + cp, ldb, L->A + r2 * ld + cp, ld, mh, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
-            } else if (gs_gemm(ctx, st, GS_BULK, Bh + r2, ldb, Bh + c0, ldb, L->A + r2 * ld + c0, ld, mh, np - r2, (int)(r2 - c0), 0, 1, -1.0))
-                return -1;
+            const int64_t ncols = st.near ? 2 * GS_NB : np - r2;
+            if (gs_gemm(ctx, sth, GS_BULK, Bh + r2, ldb, Bh + cp, ldb, L->A + r2 * ld + cp, ld, mh, ncols, (int)(r2 - cp), 0, 1, -1.0)) return -1;
         }
-        if (r2 < np) deferred = (!was_deferred && pair);
     }
     if (n_half == 2) {
         GS_CHECK(hipEventRecord(ctx->cur->evS, hs[1]));
         GS_CHECK(hipStreamWaitEvent(ctx->cur->sm, ctx->cur->evS, 0));
+    }
     }
     std::vector<double> vw;
     if (k > 0) {

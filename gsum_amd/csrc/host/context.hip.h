@@ -103,7 +103,9 @@ struct gsum_ctx {
     std::string err;
     int lookahead = 1;
     double next_algo_flops = -1.0;   // profile only: algorithmic flops of the next cfg-5 launch when not M(M+1)K / 2MNK
-    int predict_split = 1;           // ... in two independent half-sweeps (rows of the new points) on two streams from 1024 rows up
+    int predict_lookahead = 1;       // the predictive sweep with its panels and near updates on the chain stream, one far launch per macro-step beside them
+    int predict_depth = 2;           // pairs of block columns per macro-step of the predictive sweep (2: the pairing of round 3)
+    int predict_split = 0;           // ... in two independent half-sweeps (rows of the new points) on two streams from 1024 rows up
     int predict_panel256 = 1;        // the predictive sweep's panel pairs as ONE k_panel256 launch (0: k_panel, K = 128 GEMM, k_panel)
     int predict_lazy = 1;            // the predictive sweep V^T = K* L^-T with the same pairing of trailing updates (K = 512 every other step)
     int lazy_min_np = 4352;          // smallest padded order the lazy far updates are used at (profiles/r03_lazy_threshold.log, 20 in flight: +3 % at 4352,

@@ -334,7 +334,7 @@ def test_truncation_std_moves_no_square_matrix(monkeypatch):
     np.testing.assert_allclose(sd, np.sqrt(np.diag(cg.cov(Xs))), rtol=1e-13)
 
 
-@pytest.mark.parametrize("n,m", [(700, 300), (2304, 1100)])
+@pytest.mark.parametrize("n,m", [(700, 300), (2304, 1100), (2200, 1300)])
 def test_predict_sweep_on_panel256_equals_the_three_launch_sweep(n, m):
     """The predictive sweep V^T = K* L^-T with every pair of block columns solved by ONE k_panel256 launch (sibling images rebuilt from
     the factor: k_make_lsib) against the k_panel / K = 128 GEMM / k_panel sweep of rounds 1-4: same arithmetic, same bits --
@@ -352,16 +352,39 @@ def test_predict_sweep_on_panel256_equals_the_three_launch_sweep(n, m):
         try:
             lab.set_option("predict_panel256", 0)
             lab.set_option("predict_split", 0)
+            lab.set_option("predict_depth", 1)
+            lab.set_option("predict_lookahead", 0)
             want = lab.predict_terms(L, desc, X, Xs, rhs=rhs, want_cov=True)
-            for p256, split in ((1, 0), (0, 1), (1, 1)):      # ... and the two half-sweeps on two streams (rows of the new points never meet)
+            lab.set_option("lazy_min_np", 1024)                # (so that the grouping of trailing updates is on at these orders)
+            for p256, split, depth in ((1, 0, 1), (0, 1, 2), (1, 1, 2), (1, 1, 3), (1, 1, 4), (1, 0, 4)):
+                # ... the two half-sweeps on two streams (rows of the new points never meet), trailing updates grouped 2 / 3 / 4 pairs deep
                 lab.set_option("predict_panel256", p256)
                 lab.set_option("predict_split", split)
+                lab.set_option("predict_depth", depth)
                 got = lab.predict_terms(L, desc, X, Xs, rhs=rhs, want_cov=True)
                 for a, b in zip(got, want):
                     np.testing.assert_array_equal(a, b)
+            # ... and the look-ahead sweep (panels and near updates on the chain stream, one far launch per macro-step beside them)
+            lab.set_option("predict_lookahead", 1)
+            lab.set_option("predict_panel256", 1)
+            lab.set_option("predict_split", 0)
+            lab.set_option("predict_depth", 2)
+            for rows, depth in ((m, 2), (max(1024, m - 37), 2), (m, 3), (m, 4)):
+                lab.set_option("predict_depth", depth)
+                got = lab.predict_terms(L, desc, X, Xs[:rows], rhs=rhs, want_cov=True)
+                lab.set_option("predict_lookahead", 0)
+                lab.set_option("predict_depth", 1)
+                base = lab.predict_terms(L, desc, X, Xs[:rows], rhs=rhs, want_cov=True) if rows >= 1024 and rows != m else want
+                lab.set_option("predict_lookahead", 1)
+                if rows == m or rows >= 1024:
+                    for a, b in zip(got, base):
+                        np.testing.assert_array_equal(a, b)
         finally:
             lab.set_option("predict_panel256", 1)
-            lab.set_option("predict_split", 1)
+            lab.set_option("predict_split", 0)
+            lab.set_option("predict_depth", 2)
+            lab.set_option("predict_lookahead", 1)
+            lab.set_option("lazy_min_np", 4352)
             lab.set_option("chain_persist", -1)
             L.free()
 
