@@ -537,7 +537,7 @@ def main():
     n, r, K, W = args.n, args.orders, args.steps, args.warmup
     ctx = gsum_amd.default_context(dev)
     if args.config == "predict":
-        out = predict_leg(ctx, 16384, 2048, reps=5)
+        out = predict_leg(ctx, 16384, 2048, reps=8)
         if rank == 0:
             print(json.dumps({"metric": "predict_points_per_sec", "value": out["points_per_s"], "unit": "points/s",
                               "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
@@ -694,7 +694,7 @@ def main():
                     "seconds": dt, "evals_per_s": g2.size / dt, "n_neg_inf": int(np.isneginf(g2).sum()),
                     "argmax": [int(v) for v in np.unravel_index(np.argmax(g2), g2.shape)], "mode": "full-recompute"}
         ctx.set_option("release_scratch", 1)
-        pred = predict_leg(ctx, 16384, 2048)
+        pred = predict_leg(ctx, 16384, 2048, reps=5)
         ctx.set_option("release_scratch", 1)
 
     pmc_traffic = pmc_file = pmc_alg = None
