@@ -795,6 +795,9 @@ def main():
                                    "profiled_region_ms_per_step": prof_elapsed / K * 1e3,
                                    "sum_of_shares": float(sum(v["share_of_region_time"] for v in shares.values()))},
             "rank_check": rank_check,
+            "streams": {"pipes_ok": ctx.get_option("pipes_ok"), "pipe_overlap_permille": ctx.get_option("pipe_overlap_permille"),
+                        "streams_replaced_at_init": ctx.get_option("pipe_heals"),
+                        "what": "gsum_init's pairwise probe of the context's four streams (100-us kernels): 1 = every pair ran side by side"},
             "factor_reuse": reuse,
             "ell_ratio_grid": ell_grid,
             "predict": pred,
