@@ -321,11 +321,13 @@ def predict_leg(ctx, n, m, reps=3):
     y = np.random.RandomState(2).randn(n, r)
     kern = Matern(length_scale=[0.7, 1.3], nu=2.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
     gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, optimizer=None)
-    fit_all = []
-    for _ in range(2):                       # (the first fit of a process also allocates the 2.2-GB workspace: both are reported)
+    fit_all, fit_diag = [], []
+    for _ in range(3):                       # (the first fit of a process also allocates the 2.2-GB workspace: all are reported)
         t0 = time.perf_counter()
         gp.fit(X, y)
         fit_all.append(time.perf_counter() - t0)
+        fit_diag.append({"chain_aborts": ctx.get_option("chain_aborts"), "chain_persist": ctx.get_option("chain_persist"),
+                         "potrf_ms": ctx.timers()["potrf_ms"]})
     fit_s = min(fit_all)
     ts = []
     for _ in range(reps):
@@ -358,7 +360,7 @@ def predict_leg(ctx, n, m, reps=3):
     flops = float(n) * n * m            # TRSM on the new points' columns: n^2 m
     return {"workload": f"n={n} 2-D Matern-5/2(ell=[0.7,1.3]) + White(1e-6), {r} curves, m={m} new points "
                         f"(BASELINE configs[4], S5; m = one GPU's share of 16384)",
-            "fit_ms": fit_s * 1e3, "fit_ms_all": [v * 1e3 for v in fit_all], "predict_ms": best * 1e3, "predict_ms_all": [v * 1e3 for v in ts],
+            "fit_ms": fit_s * 1e3, "fit_ms_all": [v * 1e3 for v in fit_all], "fit_schedule": fit_diag, "predict_ms": best * 1e3, "predict_ms_all": [v * 1e3 for v in ts],
             "points_per_s": m / best,
             "roofline": {"kernel": "triangular solve of the new points' columns on the bulk MFMA tile", "bound": "mfma",
                          "achieved": flops / best / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -688,6 +690,9 @@ def main():
                          "GP-drawn data is tests/test_gpu_config4.py"}
         # the reference-faithful scan (notebook :1444-1459): 64 length scales x 64 ratios, every point recomputed
         ell_axis = np.linspace(0.05, 0.5, 64)
+        # set-up, not part of the scan: a call of 96 evaluations or more runs two cohorts per group and allocates the second cohort's
+        # workspaces (13 GB) on first use
+        gp.log_marginal_likelihood_grid([np.log([e]) for e in ell_axis], list(ratios[:2]), mode="full")
         t1 = time.perf_counter()
         g2 = gp.log_marginal_likelihood_grid([np.log([e]) for e in ell_axis], list(ratios), mode="full")
         dt = time.perf_counter() - t1
