@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Mixed soak on ONE context (the streams are shared between the schedules since round 4): batch calls, single evaluations (persistent chain),
 value + gradient evaluations alone and in batches, operator-level factorisations, in random order for a given time; every result must
-equal the first result of its kind bit for bit, no chain time-out may occur.     python tools/gpu_mixed_soak.py [seconds] [n]"""
+equal the first result of its kind bit for bit, no chain time-out may occur.  Round 5 adds: long calls (two cohorts per group), calls with
+right-hand-side sets, predictive sweeps (look-ahead) on a kept factor, the device group over [this GPU] with the RCCL gather, and -- with
+n >= 10240 -- the deep-grouped single factorisation.     python tools/gpu_mixed_soak.py [seconds] [n]"""
 import json
 import os
 import sys
@@ -26,6 +28,18 @@ descs = [describe_kernel(RBF(0.19 + 1e-3 * i), 1) for i in range(24)]
 gk = [C(1.0) * RBF(0.2 + 0.01 * i) + WhiteKernel(1e-8) for i in range(5)]
 gd, gp = [describe_kernel(k, 1) for k in gk], [describe_gradient(k, 1) for k in gk]
 ref, counts = {}, {}
+Zs = np.concatenate([np.random.RandomState(5).randn(3, n, 6), np.ones((3, n, 1))], axis=2)
+Zs[0] = Z
+set_of = np.arange(24) % 3
+Xs = 0.1 * n * np.random.RandomState(7).rand(1100, 1)
+grp = gsum_amd.HipGroup([0], own=False) if False else None          # (the group adopts the default context: this soak owns its own -> gsum_group_adopt below)
+from gsum_amd import _lib as _l  # noqa: E402
+import ctypes as _C  # noqa: E402
+_h = _l._p()
+_arr = (_l._p * 1)(ctx._h)
+assert ctx._lib.gsum_group_adopt(1, _arr, _C.byref(_h)) == 0
+many = ctx.desc_array([describe_kernel(RBF(0.19 + 2e-4 * i), 1) for i in range(100)])
+kept = {}
 
 
 def check(kind, key, out):
@@ -40,7 +54,7 @@ def check(kind, key, out):
 
 t_end = time.time() + seconds
 while time.time() < t_end:
-    what = rng.integers(0, 6)
+    what = rng.integers(0, 10)
     if what == 0:
         k = int(rng.choice([3, 7, 20, 24]))
         check("batch", k, ctx.lml_resident(descs[:k], 1e-10))
@@ -57,8 +71,28 @@ while time.time() < t_end:
         G, sld = ctx.forward_gram(K, Z)
         K.free()
         check("factorize", 0, (G, [sld, info]))
-    else:
+    elif what == 5:
         check("two", 0, ctx.lml_resident(descs[:2], 1e-10))
+    elif what == 6:                                   # a long call: two cohorts per group (n_kernels >= 96)
+        check("long", 100, ctx.lml_resident(many, 1e-10))
+    elif what == 7:                                   # right-hand-side sets (then the plain inputs again: set 0 is Z)
+        ctx.set_inputs_sets(X, Zs)
+        k = int(rng.choice([2, 9, 24]))
+        check("sets", k, ctx.lml_resident_sets(descs[:k], set_of[:k], 1e-10))
+    elif what == 8:                                   # predictive sweep on a kept factor (look-ahead sweep from 1024 new points up)
+        if "L" not in kept:
+            kept["L"], info = ctx.factorize(descs[0], X, diag_add=1e-10)
+            assert info == 0
+        check("predict", 0, ctx.predict_terms(kept["L"], descs[0], X, Xs, rhs=Z)[:2])
+    else:                                             # the device group over this context, RCCL gather
+        nk, k_ = 9, Z.shape[1]
+        G, sld, info = np.empty((nk, k_, k_)), np.empty(nk), np.zeros(nk, dtype=np.int64)
+        rc = ctx._lib.gsum_group_lml_resident(_h, ctx.desc_array(descs[:nk]), nk, 1e-10, _l._ptr(G), _l._ptr(sld), info.ctypes.data_as(_l._ip), 1)
+        assert rc == 0, ctx._lib.gsum_group_last_error(_h)
+        check("group", nk, (G, sld, info))
+if "L" in kept:
+    kept["L"].free()
+ctx._lib.gsum_group_destroy(_h)
 print(json.dumps({"n": n, "seconds": seconds, "calls": counts, "chain_aborts": ctx.get_option("chain_aborts"), "chain_probe": ctx.get_option("chain_probe"),
                   "chain_persist": ctx.get_option("chain_persist")}), flush=True)
 assert ctx.get_option("chain_aborts") == 0
