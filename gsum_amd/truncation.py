@@ -120,7 +120,7 @@ class TruncationGP:
         return self
 
     # -- predict (models.py:1389-1483) ----------------------------------------------------------------
-    def _condition(self, X, Xc, resid, start, end, want_cov):
+    def _condition(self, X, Xc, resid, start, end, want_cov, ctx=None):
         """The conditioning algebra of models.py:1443-1452 / 1464-1473 for K = cov(., ., start, end):
         returns (K_no K_oo^-1 resid, diag(K_no K_oo^-1 K_on), K_no K_oo^-1 K_on or None).
 
@@ -131,7 +131,7 @@ class TruncationGP:
         jitter (RuntimeWarning), or raises LinAlgError when ``strict_conditioning`` is set."""
         from ._lib import SeriesScale
         gp = self.coeffs_process
-        ctx = gp._context()
+        ctx = gp._context() if ctx is None else ctx
         X = np.asarray(X, dtype=float)
         Xc = np.asarray(Xc, dtype=float)
         factor, desc = gp._cov_terms(Xc.shape[1])      # coefficient covariance = factor * kernel_desc(X, Xp)
@@ -166,7 +166,29 @@ class TruncationGP:
                           'LinAlgError instead)' % jitter, RuntimeWarning, stacklevel=3)
         return shift[:, 0], colsumsq, red
 
-    def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both'):
+    def predict(self, X, order, return_std=False, return_cov=False, Xc=None, y=None, pred_noise=False, kind='both', devices=None):
+        """``devices`` (additive; "all" or a list of GPU indices): the new points in one block per device, every device conditioning
+        on its own copy of ``cov(Xc, Xc)``; mean and standard deviation equal the one-device call (``return_cov`` is refused)."""
+        if devices is not None and self._fit:
+            if return_cov:
+                raise ValueError("return_cov needs every new point on one device: call predict without devices=")
+            from .grid import shard_range
+            grp = self.coeffs_process._group(devices)
+            world = len(grp)
+            Xa = np.asarray(X)
+
+            def block(r, ctx):
+                lo, hi = shard_range(Xa.shape[0], r, world)
+                if hi == lo:
+                    return None
+                return self._predict_on(Xa[lo:hi], order, return_std, False, Xc, y, pred_noise, kind, ctx)
+            parts = [p for p in grp.map(block) if p is not None]
+            if return_std:
+                return np.concatenate([np.atleast_1d(p[0]) for p in parts]), np.concatenate([np.atleast_1d(p[1]) for p in parts])
+            return np.concatenate([np.atleast_1d(p) for p in parts])
+        return self._predict_on(X, order, return_std, return_cov, Xc, y, pred_noise, kind, None)
+
+    def _predict_on(self, X, order, return_std, return_cov, Xc, y, pred_noise, kind, ctx):
         if not self._fit:
             return self.underlying_properties(X, order, return_cov=return_cov, return_std=return_std)
         if Xc is None:
@@ -186,7 +208,7 @@ class TruncationGP:
             # interpolating prediction of y_order, conditioned on (Xc, y)             models.py:1434-1453
             m_old = self.mean(X=Xc, start=0, end=order)
             m_new = self.mean(X=X, start=0, end=order)
-            shift, red_diag, red = self._condition(X, Xc, np.asarray(y, dtype=float) - m_old, 0, order, return_cov)
+            shift, red_diag, red = self._condition(X, Xc, np.asarray(y, dtype=float) - m_old, 0, order, return_cov, ctx)
             m_pred = m_pred + m_new + shift
             if return_cov:
                 K_pred = K_pred + (self.cov(start=0, end=order, X=X, Xp=X) - red)
@@ -200,7 +222,7 @@ class TruncationGP:
             if self.dX_ is not None:                                                   # constrained
                 m_old_trunc = self.mean(X=self.dX_, start=order + 1, end=np.inf)
                 shift, red_diag, red = self._condition(X, self.dX_, np.asarray(self.dy_, dtype=float) - m_old_trunc,
-                                                       order + 1, np.inf, return_cov)
+                                                       order + 1, np.inf, return_cov, ctx)
                 m_pred = m_pred + m_new_trunc + shift
                 if want_var:
                     K_pred = K_pred + (K_nn_trunc - red if return_cov else d_nn_trunc - red_diag)

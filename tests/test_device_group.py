@@ -180,3 +180,18 @@ def test_ratio_and_ref_accept_the_override_positionally():
     with pytest.raises(TypeError):
         gp.ratio(X, 0.4, ratio=0.3)
     assert gp.ratio_kws is kws                          # the caller's dict, like models.py:1326
+
+
+def test_truncation_predict_over_a_group_of_cpu_contexts():
+    """``TruncationGP.predict(devices=...)``: new points in blocks, every member conditioning on its own copy of cov(Xc, Xc)."""
+    gp, X, y = _fitted()
+    Xs = np.linspace(0.05, 5.9, 41)[:, None]
+    for kind in ("both", "interp", "trunc"):
+        mean, std = gp.predict(Xs, order=2, return_std=True, kind=kind)
+        for devices in ([0], [0, 1, 2]):
+            m2, s2 = gp.predict(Xs, order=2, return_std=True, kind=kind, devices=devices)
+            np.testing.assert_allclose(m2, mean, rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(s2, std, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(gp.predict(Xs, order=2, kind=kind, devices=[0, 1]), mean, rtol=1e-11, atol=1e-11)
+    with pytest.raises(ValueError, match="return_cov"):
+        gp.predict(Xs, order=2, return_cov=True, devices=[0, 1])

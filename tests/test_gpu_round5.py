@@ -141,6 +141,17 @@ def test_predict_over_devices_equals_the_plain_predict():
         gp.predict(Xs, return_cov=True, devices=[0])
 
 
+def test_truncation_predict_over_devices_equals_the_plain_predict():
+    """``TruncationGP.predict(devices=...)`` (every kind): blocks of new points, each device conditioning on its own cov(Xc, Xc)."""
+    gp, X, y = _fitted(300)
+    Xs = np.linspace(0.03, 29.9, 257)[:, None]
+    for kind in ("both", "interp", "trunc"):
+        mean, std = gp.predict(Xs, order=2, return_std=True, kind=kind)
+        for devices in ([0], "all"):
+            m2, s2 = gp.predict(Xs, order=2, return_std=True, kind=kind, devices=devices)
+            assert np.array_equal(m2, mean) and np.array_equal(s2, std, equal_nan=True)
+
+
 def test_streams_of_a_context_run_side_by_side(ctx):
     """gsum_init's pairwise stream probe (option "pipes_ok"): the context's four streams overlap pairwise -- also in the second, third,
     ... context of a process, where the runtime's hand-out of hardware queues put two of the four on one queue until gsum_init
