@@ -750,8 +750,12 @@ class HipGroup:
         self.lab = bool(lab)
         self._h = None
         h = _p()
-        if own or devices == "all" or devices is None:
-            ids = None if (devices == "all" or devices is None) else [int(d) for d in devices]
+        if devices is None:
+            devices = "all"
+        if own:
+            ids = None if isinstance(devices, str) else [int(d) for d in devices]
+            if isinstance(devices, str) and devices != "all":
+                raise ValueError('devices must be "all" or a sequence of device indices')
             arr = (C.c_int * len(ids))(*ids) if ids else None
             rc = self._lib.gsum_init_multi(len(ids) if ids else 0, arr, C.byref(h))
             if rc != 0:
@@ -767,7 +771,7 @@ class HipGroup:
                 self.contexts.append(c)
                 _warn_pipes(c)
         else:
-            ids = [int(d) for d in devices]
+            ids = resolve_devices(devices)
             if len(set(ids)) != len(ids):
                 raise ValueError("a device may appear once in a group (own=True opens separate contexts on one device)")
             self.contexts = [(lab_context if lab else default_context)(d) for d in ids]
@@ -879,7 +883,6 @@ _groups = {}
 
 def device_count() -> int:
     """GPUs the HIP runtime shows this process (0 without one); does not create a context."""
-    import ctypes.util
     for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
         try:
             hip = C.CDLL(name)
