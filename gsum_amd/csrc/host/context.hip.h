@@ -191,6 +191,10 @@ struct gsum_ctx {
     int wave_groups = 3;             // groups = chain streams; their bulk launches alternate on ONE bulk stream (4 streams: the HIP runtime's
                                      // default number of hardware queues)
     int wave_size = 8;               // evaluations per group at most
+    int wave_tile128_rows = 0;       // far updates of at least this many rows on the 128 x 128 workgroup tile (k_gemm_ld3g2); 0 (default): never.  Alone the
+                                     // tile is +2.7 % at M = 15120 and +1.5 % at 11280; inside a batch it LOSES (profiles/r05_tile128.log: n = 16384 45.4
+                                     // against 45.6 evals/s, n = 12288 104.6 / 105.3, n = 8192 from 6144 rows 327.8 / 333.7): two 66-KB workgroups of
+                                     // 380-us tiles per CU leave the chain kernels less room than three 48-KB ones of 190 us
     int wave_cohorts = 2;            // calls of at least wave_cohort_min x (groups x size) evaluations: every group runs TWO cohorts of evaluations half a
     int wave_cohort_min = 4;         // round apart on its one chain stream, so that the latency-bound last steps of one cohort run under the far updates
                                      // of the other (gs_lml_wave); 1: one cohort (rounds in phase, each ending with ~2.5 ms of latency-bound steps)

@@ -40,6 +40,31 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
     // every matrix this library allocates); anything else takes the register-staged tile, which gives the same bits
     if (cfg == 7 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
     if (ctx->first_tiles && cfg != 7) GS_FAIL("internal: only the cfg-7 bulk tile counts first-column tiles");
+    if (cfg == 8 && (((uintptr_t)A | (uintptr_t)B) & 15 || (lda & 1) || (ldb & 1))) cfg = 5;
+    if (cfg == 8) {                                   // 128 x 128 tiles, 64 x 32 wave tiles, two workgroups per CU (round 5: large trailing matrices)
+        if (M <= 0 || N <= 0) return 0;
+        if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");
+        if (tri == 2) GS_FAIL("gemm: the 128 x 128 tile has no tri = 2 form");
+        const size_t shmem = 2 * (size_t)((128 + 128) * GS_KC + 4) * sizeof(double);
+        const void* kfn = (const void*)k_gemm_ld3b;
+        if (!ctx->lds_attr_done.count(kfn)) {
+            GS_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            ctx->lds_attr_done.insert(kfn);
+        }
+        int64_t blocks;
+        if (tri) {
+            if (M != N) GS_FAIL("gemm: tri mode needs a square C");
+            const int64_t Tt = (M + 127) / 128;
+            blocks = Tt * (Tt + 1) / 2;
+        } else {
+            blocks = ((M + 127) / 128) * ((N + 127) / 128);
+        }
+        hipLaunchKernelGGL(k_gemm_ld3b, dim3((unsigned)blocks), dim3(512), shmem, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, K, tri, beta, sign,
+                           ctx->kst_ptr);
+        ctx->kst_ptr = nullptr;
+        GS_CHECK(hipGetLastError());
+        return 0;
+    }
     if (cfg == 7) {                                   // 128 x 64 tiles, 32 x 32 wave tiles, 3 workgroups per CU: the bulk default
         if (M <= 0 || N <= 0) return 0;
         if (K % GS_KC != 0) GS_FAIL("gemm: K must be a multiple of 16");

@@ -330,7 +330,10 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 en.tri = st.near ? 0 : 1;
                 en.pad = 0;
                 const int64_t tm = (mrest + 127) / 128;
-                const int tiles = (int)(en.tri ? tm * (tm + 1) : tm * ((en.N + 63) / 64));
+                // large lower triangles on the 128 x 128 tile (round 5; alone +2.7 % at M = 15120, +1.5 % at 11280, -7 % on ONE matrix at 7184:
+                // profiles/r05_tile128.log), far updates on the bulk stream only
+                const bool big_tile = en.tri && !near && ctx->wave_tile128_rows > 0 && mrest >= ctx->wave_tile128_rows;
+                const int tiles = (int)(big_tile ? tm * (tm + 1) / 2 : (en.tri ? tm * (tm + 1) : tm * ((en.N + 63) / 64)));
                 const double fl = en.tri ? (double)mrest * (double)(mrest + 1) * en.K
                                          : (double)en.K * (2.0 * (double)mrest * en.N - (double)en.N * (en.N - 1));
                 int run = 0;
@@ -341,8 +344,13 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                     ga.end[e] = run;
                 }
                 const int rec = gs_prof_begin(ctx, su, near ? GS_PROF_PANEL : GS_PROF_BULK, fl * g->cnt);     // (near updates on the bulk stream: the same kernel, the same class)
-                const size_t shm = 2 * (size_t)((128 + 64) * GS_KC + 4) * sizeof(double);
+                const size_t shm = 2 * (size_t)((128 + (big_tile ? 128 : 64)) * GS_KC + 4) * sizeof(double);
+                if (big_tile && !ctx->lds_attr_done.count((const void*)k_gemm_ld3g2)) {
+                    GS_CHECK(hipFuncSetAttribute((const void*)k_gemm_ld3g2, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                    ctx->lds_attr_done.insert((const void*)k_gemm_ld3g2);
+                }
                 if (near) hipLaunchKernelGGL(k_gemm_ld3n, dim3((unsigned)run), dim3(512), shm, su, ga);
+                else if (big_tile) hipLaunchKernelGGL(k_gemm_ld3g2, dim3((unsigned)run), dim3(512), shm, su, ga);
                 else hipLaunchKernelGGL(k_gemm_ld3g, dim3((unsigned)run), dim3(512), shm, su, ga);
                 gs_prof_end(ctx, su, rec);
                 GS_CHECK(hipGetLastError());

@@ -19,12 +19,17 @@ __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
 
 // (body of k_gemm_ld3 / k_gemm_ld3g: `bid_in` is the tile's index within ITS product -- the workgroup id of a plain launch, the
 // offset into its entry's tile range for a grouped one)
-template <int NST>
+// BNT = 1: the 128 x 64 workgroup tile (8 waves of 32 x 32, 63 registers, three workgroups per CU) -- every launch of rounds 2-4.
+// BNT = 2 (round 5): 128 x 128 (8 waves of 64 x 32: WM = 4, 2 waves down x 4 across; ~100 registers, 66 KB of LDS, two workgroups per CU): 0.75
+// LDS reads and 0.125 LDS-direct loads per MFMA instead of 1 and 0.1875, a third fewer operand bytes per flop.  Same k order per accumulator:
+// bit-identical.  Chosen per launch for large trailing matrices (gs_gemm / gs_lml_wave); the counted-tile orders exist for BNT = 1 only.
+template <int NST, int BNT = 1>
 __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                                  int64_t ldb, int M, int N, int K, int tri, int beta, double sign,
                                                  unsigned long long* kst, int nfirst, unsigned* first_done, const int bid_in,
                                                  const int c2 = 0, unsigned* second_done = nullptr) {
-    constexpr int WM = 2, WN = 2, WAVES_M = 4, BM = 128, BN = 64;
+    constexpr int WM = BNT == 2 ? 4 : 2, WN = 2, WAVES_M = BNT == 2 ? 2 : 4, BM = 128, BN = 64 * BNT;
+    static_assert(BNT == 1 || (BNT == 2 && NST == 2), "the 128 x 128 tile exists with two LDS stages only");
     constexpr int OPA = BM * GS_KC + 2, OPB = BN * GS_KC + 2, STAGE = OPA + OPB;
     constexpr int HALFA = BM / 2 * GS_KC + 1, HALFB = BN / 2 * GS_KC + 1;
     extern __shared__ double lds[];
@@ -38,7 +43,14 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
     bool first_cols = false, second_cols = false;
-    if (tri && nfirst > 0) {
+    if (BNT == 2 && tri) {
+        // square tiles: row bm of the lower triangle holds column tiles 0 .. bm
+        const int bid = bid_in;
+        bm = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
+        while ((int64_t)bm * (bm + 1) / 2 > bid) --bm;
+        bn = bid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else if (tri && nfirst > 0) {
         // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
         // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
         const int bid = bid_in;
@@ -161,19 +173,37 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     }
     const int hb = w & 1, gb = w >> 1;
     const double* srcB;
-    {
+    const double* srcB2[2];                 // (BNT == 2: B has 16 eight-row slices too, two per wave, staged exactly like A)
+    if (BNT == 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 16 * w + 2 * lrow + h;
+            const int kp = lg ^ ((r >> 1) & 7);
+            int rb = n0 + r;
+            rb = rb < N ? rb : N - 1;
+            srcB2[h] = B + (int64_t)rb * ldb + 2 * kp;
+        }
+        srcB = srcB2[0];
+    } else {
         const int r = 16 * gb + 2 * lrow + hb;
         const int kp = lg ^ ((r >> 1) & 7);
         int rb = n0 + r;
         rb = rb < N ? rb : N - 1;
         srcB = B + (int64_t)rb * ldb + 2 * kp;
+        srcB2[0] = srcB2[1] = srcB;
     }
     auto stage_load = [&](int kc, int stage) {
         double* base = lds + stage * STAGE;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             __builtin_amdgcn_global_load_lds(srcA[h] + kc * GS_KC, base + h * HALFA + 8 * w * GS_KC, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(srcB + kc * GS_KC, base + OPA + hb * HALFB + 8 * gb * GS_KC, 16, 0, 0);
+        if (BNT == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds(srcB2[h] + kc * GS_KC, base + OPA + h * HALFB + 8 * w * GS_KC, 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds(srcB + kc * GS_KC, base + OPA + hb * HALFB + 8 * gb * GS_KC, 16, 0, 0);
+        }
     };
     const int swz = (fr >> 1) & 7;
     const int rselA = (fr & 1) * HALFA + (fr >> 1) * GS_KC, rselB = (fr & 1) * HALFB + (fr >> 1) * GS_KC;
@@ -232,8 +262,9 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
         // `arrived` is an empty statement that reads a fragment set: the compiler's wait for that set lands THERE, i.e. before the next set's reads are
         // issued -- placed in front of the MFMAs (its own choice) the wait came out as lgkmcnt(0) and covered the reads just issued as well.
         auto arrived = [&](const double (&af)[WM], const double (&bf)[WN]) {
-            static_assert(WM == 2 && WN == 2, "two row and two column fragments per wave");
-            asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(bf[0]), "v"(bf[1]));
+            static_assert((WM == 2 || WM == 4) && WN == 2, "two or four row and two column fragments per wave");
+            if constexpr (WM == 4) asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(bf[0]), "v"(bf[1]));
+            else asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(bf[0]), "v"(bf[1]));
         };
         for (int c = 0; c < nk; ++c) {
             __builtin_amdgcn_sched_barrier(0);
@@ -348,6 +379,12 @@ __global__ __launch_bounds__(512, NST == 2 ? 7 : 4) void k_gemm_ld3(double* C, i
     gs_gemm_ld3_body<NST>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, nfirst, first_done, (int)blockIdx.x, c2, second_done);
 }
 
+// the 128 x 128 tile (BNT = 2) as a plain launch: lower triangles / rectangles without counted tiles
+__global__ __launch_bounds__(512, 4) void k_gemm_ld3b(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int M, int N,
+                                                      int K, int tri, int beta, double sign, unsigned long long* kst) {
+    gs_gemm_ld3_body<2, 2>(C, ldc, A, lda, B, ldb, M, N, K, tri, beta, sign, kst, 0, (unsigned*)nullptr, (int)blockIdx.x);
+}
+
 // ---- grouped launches: the same outer step of SEVERAL evaluations in one launch -------------------------------------------------
 // A batch of evaluations (a likelihood grid) used to run as up to 20 independent HIP streams, one evaluation each, and counted on
 // the runtime giving every stream a hardware queue of its own (GPU_MAX_HW_QUEUES) -- 24 live streams collapsed it, a process with an
@@ -381,6 +418,19 @@ __device__ __forceinline__ void gs_gemm_ld3g_body(const gs_wv_gemm_args& a) {
 // k_gemm_ld3g: the big ("far") trailing updates, one after the other on the batch schedule's bulk stream.  k_gemm_ld3n: the same
 // code under a name of its own for the small "near" updates that run on the groups' chain streams BESIDE them -- so that a
 // per-kernel profile (rocprofv3 --stats) keeps the two roles apart and the far updates' launch times add up to the step time.
+template <int BNT>
+__device__ __forceinline__ void gs_gemm_ld3g_body_t(const gs_wv_gemm_args& a) {
+    const int bid = (int)blockIdx.x;
+    int e = 0;
+    while (e + 1 < a.n && bid >= a.end[e]) ++e;
+    const int first = e ? a.end[e - 1] : 0;
+    const gs_wv_gemm_entry& en = a.e[e];
+    double* W = a.base + (int64_t)en.q * a.strideA;
+    gs_gemm_ld3_body<2, BNT>(W + en.offC, a.ld, W + en.offA, a.ld, W + en.offB, a.ld, en.M, en.N, en.K, en.tri, 1, -1.0,
+                             (unsigned long long*)nullptr, 0, (unsigned*)nullptr, bid - first);
+}
+// the far updates of large trailing matrices on the 128 x 128 tile (option wave_tile128_rows)
+__global__ __launch_bounds__(512, 4) void k_gemm_ld3g2(const gs_wv_gemm_args a) { gs_gemm_ld3g_body_t<2>(a); }
 __global__ __launch_bounds__(512, 7) void k_gemm_ld3g(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
 __global__ __launch_bounds__(512, 7) void k_gemm_ld3n(const gs_wv_gemm_args a) { gs_gemm_ld3g_body(a); }
 

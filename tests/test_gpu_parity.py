@@ -46,7 +46,9 @@ def lml_tol(R):
                                        (2, 16, 256, 128), (2, 16, 1000, 128), (2, 16, 128, 128), (2, 9, 40, 32),
                                        (5, 128, 128, 128), (5, 300, 300, 256), (5, 130, 70, 64),
                                        (7, 128, 128, 128), (7, 300, 300, 256), (7, 130, 70, 64), (7, 1000, 257, 512),
-                                       (7, 128, 128, 16), (7, 200, 100, 32), (7, 128, 64, 48), (7, 257, 129, 16)])     # one, two, three chunks: the pipelined K loop's edges
+                                       (7, 128, 128, 16), (7, 200, 100, 32), (7, 128, 64, 48), (7, 257, 129, 16),      # one, two, three chunks: the pipelined K loop's edges
+                                       (8, 128, 128, 128), (8, 300, 300, 256), (8, 130, 70, 64), (8, 1000, 257, 512), (8, 128, 128, 16),
+                                       (8, 200, 100, 32), (8, 257, 129, 48), (8, 640, 384, 1024)])                      # round 5: the 128 x 128 tile
 def test_mfma_gemm_tiles(lab, cfg, M, N, K):
     """C -= A B^T through each MFMA tile configuration, ragged edges included; asymmetric operands so a
     swapped accumulator map cannot hide (cdna_hip_programming.md §3)."""
@@ -56,14 +58,14 @@ def test_mfma_gemm_tiles(lab, cfg, M, N, K):
     np.testing.assert_allclose(got, C - A @ B.T, rtol=1e-12, atol=1e-12 * K)
     got = lab.debug_gemm_nt(cfg, C, A, B, tri=False, beta=0, sign=1.0)
     np.testing.assert_allclose(got, A @ B.T, rtol=1e-12, atol=1e-12 * K)
-    if cfg == 7:   # LDS-direct staging: bit-identical to the register-staged 8-wave tile
+    if cfg in (7, 8):   # LDS-direct staging (128 x 64 and 128 x 128 workgroup tiles): bit-identical to the register-staged 8-wave tile
         for beta, sign in ((1, -1.0), (0, 1.0), (1, 1.0)):
             np.testing.assert_array_equal(lab.debug_gemm_nt(cfg, C, A, B, tri=False, beta=beta, sign=sign),
                                           lab.debug_gemm_nt(5, C, A, B, tri=False, beta=beta, sign=sign))
 
 
 @pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552])
-@pytest.mark.parametrize("cfg,BM", [(5, 128), (7, 128)])
+@pytest.mark.parametrize("cfg,BM", [(5, 128), (7, 128), (8, 128)])
 def test_mfma_gemm_lower_tiles(lab, M, cfg, BM):
     """SYRK mode: every element of the lower triangle is updated exactly once (also through the XCD-aware
     tile map, M >= 1024), and tiles that lie wholly above the diagonal are never touched."""
