@@ -333,7 +333,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 // large lower triangles on the 128 x 128 tile (round 5; alone +2.7 % at M = 15120, +1.5 % at 11280, -7 % on ONE matrix at 7184:
                 // profiles/r05_tile128.log), far updates on the bulk stream only
                 const bool big_tile = en.tri && !near && ctx->wave_tile128_rows > 0 && mrest >= ctx->wave_tile128_rows;
-                const int tiles = (int)(big_tile ? tm * (tm + 1) / 2 : (en.tri ? tm * (tm + 1) : tm * ((en.N + 63) / 64)));
+                const int tiles = (int)(big_tile ? tm * (tm + 1) / 2 : (en.tri ? gs_tri_tiles64(mrest) : tm * ((en.N + 63) / 64)));
                 const double fl = en.tri ? (double)mrest * (double)(mrest + 1) * en.K
                                          : (double)en.K * (2.0 * (double)mrest * en.N - (double)en.N * (en.N - 1));
                 int run = 0;

@@ -19,6 +19,19 @@ __global__ __launch_bounds__(512) void k_mfma_peak(double* out, int iters) {
 
 // (body of k_gemm_ld3 / k_gemm_ld3g: `bid_in` is the tile's index within ITS product -- the workgroup id of a plain launch, the
 // offset into its entry's tile range for a grouped one)
+// Lower-triangle launches of the 128 x 64 tile without counted tiles (the batch's far updates, plain SYRKs): number of tiles of an M x M triangle.
+// M a multiple of 128: row bm holds column tiles 0 .. 2 bm + 1.  Otherwise (round 5) the PARTIAL row tile comes FIRST: the trailing matrices of
+// the bordered factorisation have 128 k + 16 rows (the right-hand-side rows), and with the partial tile row last, 2 tm + 2 tiles -- the longest
+// row of the triangle: 114 of 3306 at M = 7184 -- multiply for 16 valid rows each.  Rows [0, off) (off = M mod 128) form tile row 0 (c0 column
+// tiles), row bm >= 1 covers [off + 128 (bm - 1), off + 128 bm) and holds 2 bm + c0 column tiles: 3249 tiles at M = 7184.
+__host__ __device__ inline bool gs_tri_shifted(int M) { return (M & 127) != 0 && M > 128; }
+__host__ __device__ inline int64_t gs_tri_tiles64(int64_t M) {
+    const int64_t tm = (M + 127) / 128;
+    if (!gs_tri_shifted((int)M)) return tm * (tm + 1);
+    const int64_t off = M & 127, c0 = (off - 1) / 64 + 1, R = 1 + M / 128;
+    return c0 + (R - 1) * (R + c0);
+}
+
 // BNT = 1: the 128 x 64 workgroup tile (8 waves of 32 x 32, 63 registers, three workgroups per CU) -- every launch of rounds 2-4.
 // BNT = 2 (round 5): 128 x 128 (8 waves of 64 x 32: WM = 4, 2 waves down x 4 across; ~100 registers, 66 KB of LDS, two workgroups per CU): 0.75
 // LDS reads and 0.125 LDS-direct loads per MFMA instead of 1 and 0.1875, a third fewer operand bytes per flop.  Same k order per accumulator:
@@ -42,7 +55,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     // runs at 66 TF/s, the clock-limited rate under this kernel: profiles/r03_bulk_cphase.log.)
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     int bm, bn;
-    bool first_cols = false, second_cols = false;
+    bool first_cols = false, second_cols = false, shifted = false;
     if (BNT == 2 && tri) {
         // square tiles: row bm of the lower triangle holds column tiles 0 .. bm
         const int bid = bid_in;
@@ -92,6 +105,22 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
             while ((int64_t)bm * (bm - 1) <= f) ++bm;
             bn = 4 + f - (bm - 1) * (bm - 2);
         }
+    } else if (tri == 1 && BNT == 1 && gs_tri_shifted(M)) {
+        // the partial row tile first (gs_tri_tiles64): tile row 0 = rows [0, off), c0 column tiles; row bm >= 1 holds 2 bm + c0
+        const int off = M & 127, c0 = (off - 1) / 64 + 1;
+        const int bid = bid_in;
+        if (bid < c0) {
+            bm = 0;
+            bn = bid;
+        } else {
+            const int g = bid - c0;
+            bm = (int)((-(double)(c0 - 1) + sqrt((double)(c0 - 1) * (c0 - 1) + 4.0 * (double)(c0 + g))) * 0.5);
+            if (bm < 1) bm = 1;
+            while ((int64_t)(bm - 1) * (bm + c0) > g) --bm;
+            while ((int64_t)bm * (bm + 1 + c0) <= g) ++bm;
+            bn = g - (bm - 1) * (bm + c0);
+        }
+        shifted = true;
     } else if (tri) {
         // lower tiles of a square C with 128 x 64 tiles: row bm holds column tiles 0 .. 2 bm + 1.
         // (An XCD-aware order -- rows padded to multiples of 8 slots so that workgroup id and column tile agree modulo 8
@@ -110,7 +139,9 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
         bn = bid_in / tm;
         first_cols = bid_in < nfirst;        // column-major tile order: the first 4 tm ids are the first 256 columns
     }
-    const int m0 = bm * BM, n0 = bn * BN;
+    // (shifted grid: tile row 0 ends at row off -- the rows behind it belong to tile row 1 -- and the full tile rows start there)
+    const int m0 = shifted ? (bm == 0 ? 0 : (M & 127) + (bm - 1) * BM) : bm * BM, n0 = bn * BN;
+    const int Mr = (shifted && bm == 0) ? (M & 127) : M;          // row bound of THIS tile
     if (n0 >= N) {                            // tri: the last row of a ragged matrix may have one column tile too many
         if (first_cols && t == 0) gs_flag_add(first_done);
         if (second_cols && t == 0) gs_flag_add(second_done);
@@ -132,7 +163,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     // interior tiles (all but the last row / column of a ragged matrix): the 16 C loads -- and the 16 stores at the end -- go out back to back, without a
     // compare and a branch each (same-process A/B, profiles/r03_bulk_interior_tiles_ab.log: batch +0.8 %, K = 256 / 512 steady state at M = 7936 +2 / +1.5 %,
     // M = 4096 -1.1 %, one factorisation unchanged; bit-identical)
-    const bool full = m0 + BM <= M && n0 + BN <= N;
+    const bool full = m0 + BM <= Mr && n0 + BN <= N;
     if (idle) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -155,7 +186,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int row = m0 + (wm * WM + i) * 16 + fq + 4 * x;
-                acc[i][j][x] = (beta && row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;      // sign applied below, behind the wait
+                acc[i][j][x] = (beta && row < Mr && col < N) ? C[(int64_t)row * ldc + col] : 0.0;      // sign applied below, behind the wait
             }
         }
     }
@@ -168,7 +199,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
         const int r = 16 * w + 2 * lrow + h;
         const int kp = lg ^ ((r >> 1) & 7);
         int ra = m0 + r;
-        ra = ra < M ? ra : M - 1;
+        ra = ra < Mr ? ra : Mr - 1;
         srcA[h] = A + (int64_t)ra * lda + 2 * kp;
     }
     const int hb = w & 1, gb = w >> 1;
@@ -330,7 +361,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
     const int fr2 = lane2 & 15, fq2 = lane2 >> 4, wm2 = w2 % WAVES_M, wn2 = w2 / WAVES_M;
     if (idle) {
         // (nothing to store)
-    } else if (!(first_cols || second_cols) && m0 + BM <= M && n0 + BN <= N) {
+    } else if (!(first_cols || second_cols) && m0 + BM <= Mr && n0 + BN <= N) {
         double* c0 = C + (int64_t)(m0 + wm2 * WM * 16 + fq2) * ldc + n0 + wn2 * WN * 16 + fr2;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -347,7 +378,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
-                    if (row < M && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
+                    if (row < Mr && col < N) C[(int64_t)row * ldc + col] = neg ? -acc[i][j][x] : acc[i][j][x];
                 }
             }
     } else {
@@ -359,7 +390,7 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int row = m0 + (wm2 * WM + i) * 16 + fq2 + 4 * x;
-                    if (row < M && col < N) gs_st_wt(C + (int64_t)row * ldc + col, neg ? -acc[i][j][x] : acc[i][j][x]);
+                    if (row < Mr && col < N) gs_st_wt(C + (int64_t)row * ldc + col, neg ? -acc[i][j][x] : acc[i][j][x]);
                 }
             }
     }

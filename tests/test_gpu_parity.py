@@ -64,7 +64,7 @@ def test_mfma_gemm_tiles(lab, cfg, M, N, K):
                                           lab.debug_gemm_nt(5, C, A, B, tri=False, beta=beta, sign=sign))
 
 
-@pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552])
+@pytest.mark.parametrize("M", [128, 272, 400, 1100, 1552, 1424, 2000, 2064])
 @pytest.mark.parametrize("cfg,BM", [(5, 128), (7, 128), (8, 128)])
 def test_mfma_gemm_lower_tiles(lab, M, cfg, BM):
     """SYRK mode: every element of the lower triangle is updated exactly once (also through the XCD-aware
@@ -75,9 +75,13 @@ def test_mfma_gemm_lower_tiles(lab, M, cfg, BM):
     want = C - A @ A.T
     low = np.tril(np.ones((M, M), dtype=bool))
     np.testing.assert_allclose(got[low], want[low], rtol=1e-12, atol=1e-10)
+    # (round 5: on a ragged matrix the 128 x 64 tile puts its PARTIAL tile row first -- gs_tri_tiles64 -- so a full tile row starts at
+    # M mod 128 and its last column tiles reach up to 128 columns past the 128-aligned block diagonal: still strictly above the diagonal,
+    # which nothing reads; one block further right nothing is touched)
+    slack = 1 if (cfg == 7 and M % 128) else 0
     for bi in range(-(-M // BM)):
         for bj in range(-(-M // 128)):
-            if bj * 128 > bi * BM + BM - 1:          # tile entirely above the diagonal
+            if bj * 128 > bi * BM + BM - 1 + 128 * slack:          # tile entirely above the diagonal
                 sl = (slice(bi * BM, min(M, (bi + 1) * BM)), slice(bj * 128, min(M, (bj + 1) * 128)))
                 np.testing.assert_array_equal(got[sl], C[sl])
 
