@@ -80,8 +80,8 @@ static int gs_dispatch(gsum_ctx* ctx, hipStream_t s, int cfg, double* C, int64_t
         if (tri) {
             if (M != N) GS_FAIL("gemm: tri mode needs a square C");
             const int64_t Tt = (M + 127) / 128;
-            // (tri == 1 without counted tiles: the partial row tile first, see gs_tri_tiles64 -- the kernel makes the same choice from the same values)
-            blocks = (tri == 1 && ctx->first_tiles == 0) ? gs_tri_tiles64(M) : Tt * (Tt + 1);
+            // (tri == 1: the partial row tile first, see gs_tri_tiles64 -- the kernel makes the same choice from the same values)
+            blocks = tri == 1 ? gs_tri_tiles64(M) : Tt * (Tt + 1);
         } else {
             blocks = ((M + 127) / 128) * ((N + 63) / 64);
         }

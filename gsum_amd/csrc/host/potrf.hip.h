@@ -231,7 +231,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             const int64_t lo = std::max(bound[p], r3), hi = bound[p + 1];
             if (lo >= hi) continue;
             if (lo > r3) cnt += 4u * (unsigned)((hi - lo + 127) / 128);               // rectangle: all its first four column tiles
-            else cnt += 4u * (unsigned)((hi - lo + 127) / 128) - 2u;                   // the triangle that starts at r3
+            else cnt += gs_tri_first4(hi - lo);                                        // the triangle that starts at r3
         }
         return cnt;
     };
@@ -247,10 +247,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // what the chain waits for: inside a macro-step only the small near launches -- the far launches (K = 1024: 65 TF/s alone against 47 at
     // K = 256) follow one another on the main stream and no chain step queues behind a whole one.
     std::vector<int> macro_a((size_t)S, -1), macro_L((size_t)S, 0);          // per step: first panel and length of its macro-step (deep steps only)
-    auto second_count = [](int64_t mrows, int c2) {                          // mirrors gs_gemm_ld3_body: tiles in column tiles 4 .. c2 - 1
-        const int64_t tm = (mrows + 127) / 128, bm0 = c2 / 2 - 1, cum0 = (bm0 - 1) * (bm0 - 2);
-        return (unsigned)(tm <= bm0 ? (tm >= 2 ? (tm - 1) * (tm - 2) : 0) : cum0 + (tm - bm0) * (c2 - 4));
-    };
+    auto second_count = [](int64_t mrows, int c2) { return gs_tri_second(mrows, c2); };       // (tile.hip.h: the kernel counts with the same function)
     const bool deep_on = ctx->chain_events_needed == 0 && ctx->wave.g[2].sc != nullptr &&
                          (ctx->chain_deep > 0 || (ctx->chain_deep < 0 && m->np >= 10240));
     const int depth = std::max(2, std::min(8, ctx->chain_depth));
@@ -264,7 +261,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
                 macro_a[s] = a;
                 macro_L[s] = depth;
                 if (i + 1 < depth) plan[s] = Plan{3, 4u * (unsigned)((naug - 256 * (int64_t)(s + 2) + 127) / 128)};
-                else plan[s] = Plan{4, 4u * (unsigned)((mF + 127) / 128) - 2u};
+                else plan[s] = Plan{4, gs_tri_first4(mF)};
             }
             s_plain = a + depth;
         }
@@ -275,7 +272,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             if (m3 <= 0) continue;
             const unsigned tm = (unsigned)((m3 + 127) / 128);
             if (deferred) {
-                plan[s] = Plan{2, near256 ? 4u * tm - 2u : 4u * tm};
+                plan[s] = Plan{2, near256 ? gs_tri_first4(m3) : 4u * tm};
                 deferred = false;
             } else if (lazy && m3 >= 1024 + GS_BORDER && s + 2 < S) {
                 plan[s] = Plan{1, 4u * tm};
@@ -426,7 +423,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
                     if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;
                 } else {
                     // the band the trailing matrix starts in: a triangle from r3, first-256-column tiles first
-                    ctx->first_tiles = (int)(4 * ((hi - lo + 127) / 128) - 2);
+                    ctx->first_tiles = (int)gs_tri_first4(hi - lo);
                     ctx->first_done = fbp;
                     if (p == NB - 1) kstamp(s, 3); else kstamp(s, 2);
                     if (gs_gemm(ctx, sb, GS_BULK, A + lo * ld + lo, ld, Plo, ld, Plo, ld, hi - lo, hi - lo, 256, 1, 1, -1.0)) return -1;

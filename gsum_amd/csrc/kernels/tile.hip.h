@@ -32,6 +32,40 @@ __host__ __device__ inline int64_t gs_tri_tiles64(int64_t M) {
     return c0 + (R - 1) * (R + c0);
 }
 
+// ... with COUNTED tiles (the single-factorisation schedules: the tiles of the first 256 columns first, counted for the chain kernel; then,
+// in the deep schedule, column tiles 4 .. c2 - 1): how many tiles each group holds, for the host's wait counts and the kernel's id -> tile map.
+// Row bm holds nt(bm) column tiles: 2 bm + 2 unshifted; shifted c0 for row 0 and 2 bm + c0 for bm >= 1 (c0 = 1 or 2).
+__host__ __device__ inline int gs_tri_row_tiles(int M, int bm) {
+    if (!gs_tri_shifted(M)) return 2 * bm + 2;
+    const int c0 = ((M & 127) - 1) / 64 + 1;
+    return bm == 0 ? c0 : 2 * bm + c0;
+}
+__host__ __device__ inline int gs_tri_rows(int M) { return gs_tri_shifted(M) ? 1 + M / 128 : (M + 127) / 128; }
+// largest q >= 0 with q (q + e - 1) <= f  (e = 1 or 2: tiles before row q of a run of rows holding e, e + 2, e + 4, ... tiles)
+__device__ __forceinline__ int gs_tri_q(int f, int e) {
+    int q = (int)((-(double)(e - 1) + sqrt((double)(e - 1) * (e - 1) + 4.0 * (double)f)) * 0.5);
+    if (q < 0) q = 0;
+    while ((int64_t)q * (q + e - 1) > f) --q;
+    while ((int64_t)(q + 1) * (q + e) <= f) ++q;
+    return q;
+}
+__host__ __device__ inline unsigned gs_tri_first4(int64_t M) {               // tiles with column tile < 4
+    const int R = gs_tri_rows((int)M);
+    unsigned cnt = 0;
+    for (int bm = 0; bm < R && bm < 2; ++bm) cnt += (unsigned)(gs_tri_row_tiles((int)M, bm) < 4 ? gs_tri_row_tiles((int)M, bm) : 4);
+    return cnt + (R > 2 ? 4u * (unsigned)(R - 2) : 0u);
+}
+__host__ __device__ inline unsigned gs_tri_second(int64_t M, int c2) {       // tiles with 4 <= column tile < c2
+    const int R = gs_tri_rows((int)M);
+    unsigned cnt = 0;
+    for (int bm = 2; bm < R; ++bm) {
+        const int nt = gs_tri_row_tiles((int)M, bm), hi = nt < c2 ? nt : c2;
+        if (hi > 4) cnt += (unsigned)(hi - 4);
+        if (nt >= c2) { cnt += (unsigned)(R - 1 - bm) * (unsigned)(c2 - 4); break; }      // every later row holds all c2 - 4
+    }
+    return cnt;
+}
+
 // BNT = 1: the 128 x 64 workgroup tile (8 waves of 32 x 32, 63 registers, three workgroups per CU) -- every launch of rounds 2-4.
 // BNT = 2 (round 5): 128 x 128 (8 waves of 64 x 32: WM = 4, 2 waves down x 4 across; ~100 registers, 66 KB of LDS, two workgroups per CU): 0.75
 // LDS reads and 0.125 LDS-direct loads per MFMA instead of 1 and 0.1875, a third fewer operand bytes per flop.  Same k order per accumulator:
@@ -63,6 +97,46 @@ __device__ __forceinline__ void gs_gemm_ld3_body(double* C, int64_t ldc, const d
         while ((int64_t)(bm + 1) * (bm + 2) / 2 <= bid) ++bm;
         while ((int64_t)bm * (bm + 1) / 2 > bid) --bm;
         bn = bid - (int)((int64_t)bm * (bm + 1) / 2);
+    } else if (tri == 1 && nfirst > 0 && BNT == 1 && gs_tri_shifted(M)) {
+        // counted tiles on the shifted grid (partial row tile first; row 0 holds c0 column tiles, row bm >= 1 holds 2 bm + c0, c0 = 1 or 2):
+        // group 1 = column tiles < 4 of every row, group 2 (c2 > 4) = column tiles 4 .. c2 - 1, then the rest.  Closed forms: a run of rows
+        // whose counts grow by two per row, e + 2 q in row q of the run, has q (q + e - 1) tiles before row q (gs_tri_q inverts that);
+        // the host counts the groups with gs_tri_first4 / gs_tri_second, which walk the same per-row counts.
+        const int R = gs_tri_rows(M), c0 = ((M & 127) - 1) / 64 + 1;
+        int f = bid_in;
+        shifted = true;
+        if (f < nfirst) {
+            const int n0r = c0 < 4 ? c0 : 4, n1r = 2 + c0 < 4 ? 2 + c0 : 4;          // rows 0 and 1 hold fewer than four
+            if (f < n0r) { bm = 0; bn = f; }
+            else if (f < n0r + n1r) { bm = 1; bn = f - n0r; }
+            else { bm = 2 + (f - n0r - n1r) / 4; bn = (f - n0r - n1r) % 4; }
+            first_cols = true;
+        } else {
+            f -= nfirst;
+            const int lo = c2 > 4 ? c2 : 4;
+            const int nsec = c2 > 4 ? (int)gs_tri_second(M, c2) : 0;
+            if (f < nsec) {
+                // rows 2 .. bmF - 1 hold c0 + 2 (bm - 2) tiles of the group, rows from bmF = ceil((c2 - c0) / 2) on all c2 - 4
+                const int bmF = (c2 - c0 + 1) / 2, qF = bmF - 2, cumF = qF > 0 ? qF * (qF + c0 - 1) : 0;
+                if (f < cumF) {
+                    const int q = gs_tri_q(f, c0);
+                    bm = 2 + q;
+                    bn = 4 + f - q * (q + c0 - 1);
+                } else {
+                    bm = bmF + (f - cumF) / (c2 - 4);
+                    bn = 4 + (f - cumF) % (c2 - 4);
+                }
+                second_cols = true;
+            } else {
+                f -= nsec;
+                // the rest: rows from bmS = floor((lo - c0) / 2) + 1 on hold 2 bm + c0 - lo = e + 2 (bm - bmS) tiles from column tile lo on
+                const int bmS = (lo - c0) / 2 + 1, e = 2 * bmS + c0 - lo;
+                const int q = gs_tri_q(f, e);
+                bm = bmS + q;
+                bn = lo + f - q * (q + e - 1);
+            }
+        }
+        if (bm >= R) return;                     // (cannot happen: the grid is gs_tri_tiles64(M))
     } else if (tri && nfirst > 0) {
         // row bm of the lower triangle holds column tiles 0 .. 2 bm + 1 (64 wide); the first four of every row come first
         // (row 0 has two), then rows 2.. with their tiles 4 .. 2 bm + 1
