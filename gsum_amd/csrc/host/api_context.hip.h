@@ -249,6 +249,7 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "batch_slots")) ctx->batch_slots = (int)std::max<int64_t>(1, std::min<int64_t>(GS_MAX_SLOTS, value));
     else if (!strcmp(name, "wave_shift")) ctx->wave_shift = (int)std::max<int64_t>(-1, value);
     else if (!strcmp(name, "wave_tile128_rows")) ctx->wave_tile128_rows = (int)std::max<int64_t>(0, value);
+    else if (!strcmp(name, "wave_far_own")) ctx->wave_far_own = value != 0;
     else if (!strcmp(name, "wave_cohorts")) ctx->wave_cohorts = value >= 2 ? 2 : 1;
     else if (!strcmp(name, "wave_cohort_min")) ctx->wave_cohort_min = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "wave_tail_rows")) ctx->wave_tail_rows = (int)value;

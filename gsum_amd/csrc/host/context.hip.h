@@ -195,6 +195,9 @@ struct gsum_ctx {
                                      // tile is +2.7 % at M = 15120 and +1.5 % at 11280; inside a batch it LOSES (profiles/r05_tile128.log: n = 16384 45.4
                                      // against 45.6 evals/s, n = 12288 104.6 / 105.3, n = 8192 from 6144 rows 327.8 / 333.7): two 66-KB workgroups of
                                      // 380-us tiles per CU leave the chain kernels less room than three 48-KB ones of 190 us
+    int wave_far_own = 0;            // (lab) every far update on its group's chain stream: the groups' far launches then overlap one another's ramp and
+                                     // drain, and the chain kernels lose their priority over them: 336.6 against 339.3 evals/s (20 per call), 345.8 / 350.4
+                                     // (96 per call); profiles/r05_far_own.log -- the one low-priority bulk stream stays
     int wave_cohorts = 2;            // calls of at least wave_cohort_min x (groups x size) evaluations: every group runs TWO cohorts of evaluations half a
     int wave_cohort_min = 4;         // round apart on its one chain stream, so that the latency-bound last steps of one cohort run under the far updates
                                      // of the other (gs_lml_wave); 1: one cohort (rounds in phase, each ending with ~2.5 ms of latency-bound steps)

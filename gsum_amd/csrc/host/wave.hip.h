@@ -307,7 +307,7 @@ static int gs_lml_wave(gsum_ctx* ctx, const gsum_kernel_desc* kernels, int n_ker
                 // own: the update goes out on the group's CHAIN stream -- the near updates, and (option wave_tail_rows, calls of many rounds)
                 // the far updates of a group's last, small macro-steps: on the shared bulk stream a group in its latency-bound last steps is
                 // paced by the other groups' 5-ms updates queued in front of its own, which is why groups out of phase lost in round 4
-                const bool own_far = !st.near && !serial && tail_rows > 0 && mrest <= tail_rows;
+                const bool own_far = !st.near && !serial && ((tail_rows > 0 && mrest <= tail_rows) || ctx->wave_far_own);
                 const bool near = (st.near && ctx->wave_near_on_chain && !serial) || own_far;
                 last_on_chain = own_far;
                 hipStream_t su = near ? g->run : wv->sb;
