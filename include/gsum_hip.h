@@ -94,7 +94,8 @@ const char* gsum_last_error(gsum_ctx* ctx);             /* NULL ctx: error of a 
  *   "small_path", "medium_path" 0 | 1, "medium_min_batch"   n <= 128 / 128 < n <= 4096: whole evaluations in one workgroup when a
  *                                  call carries enough of them (<= 0: the measured break-even)
  *   "wave_groups" 1..4, "wave_size" 1..24   layout of a batch: groups x evaluations per group in flight (default 3 x 8; each
- *                                  evaluation in flight owns a workspace matrix, 0.55 GB at n = 8192)
+ *                                  evaluation in flight owns a workspace matrix, 0.55 GB at n = 8192; a call of at least
+ *                                  4 x groups x size evaluations runs two cohorts per group: twice as many in flight)
  *   "chain_persist"   -1 | 0 | 1   schedule of ONE factorisation: persistent chain kernel from order 768 up / never / whenever
  *                                  the order allows;  "lookahead" 0 | 1  look-ahead in the host-enqueued schedule
  *   "pivot_guard_ulps" 0..1024     a pivot p <= guard * eps * A_jj counts as not positive (default 2; process-wide)
