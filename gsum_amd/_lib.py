@@ -203,6 +203,8 @@ PROTOTYPES = {
     "gsum_group_get": (C.c_int64, [_p, C.c_char_p]),
     "gsum_group_set_inputs": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32]),
     "gsum_group_lml_resident": (C.c_int, [_p, _kp, C.c_int32, C.c_double, _dp, _dp, _ip, C.c_int32]),
+    "gsum_group_set_inputs_sets": (C.c_int, [_p, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_int32]),
+    "gsum_group_lml_resident_sets": (C.c_int, [_p, _kp, C.POINTER(C.c_int32), C.c_int32, C.c_double, _dp, _dp, _ip, C.c_int32]),
     "gsum_lml_batch_multi": (C.c_int, [_p, _kp, C.c_int32, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_double,
                                        _dp, _dp, _ip, C.c_int32]),
     "gsum_group_allgather": (C.c_int, [_p, _dp, C.c_int64, C.c_int64]),
@@ -827,6 +829,26 @@ class HipGroup:
         G, sld, info = np.empty((nk, k, k)), np.empty(nk), np.zeros(nk, dtype=np.int64)
         self._check(self._lib.gsum_group_lml_resident(self._h, HipContext._desc_array(descs), nk, float(nugget), _ptr(G), _ptr(sld),
                                                       info.ctypes.data_as(_ip), GATHER_FLAGS[gather]))
+        return G, sld, info
+
+    def set_inputs_sets(self, X, rhs_sets):
+        X, Z = _f64(X), _f64(rhs_sets)
+        if Z.ndim != 3 or Z.shape[1] != X.shape[0]:
+            raise ValueError("rhs_sets must have shape (n_sets, n, k)")
+        self._check(self._lib.gsum_group_set_inputs_sets(self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(Z), Z.shape[0], Z.shape[2]))
+
+    def lml_resident_sets(self, descs, set_of, nugget: float, gather: str = "host"):
+        """``HipContext.lml_resident_sets`` with the descriptors block-partitioned over the devices (every device holds all sets)."""
+        n, _, k = self.contexts[0].resident_shape()
+        if n == 0:
+            raise ValueError("gsum_group_set_inputs_sets has not been called")
+        nk = len(descs)
+        sets = np.ascontiguousarray(set_of, dtype=np.int32)
+        if sets.shape != (nk,):
+            raise ValueError("one set index per descriptor")
+        G, sld, info = np.empty((nk, k, k)), np.empty(nk), np.zeros(nk, dtype=np.int64)
+        self._check(self._lib.gsum_group_lml_resident_sets(self._h, HipContext._desc_array(descs), sets.ctypes.data_as(C.POINTER(C.c_int32)), nk,
+                                                           float(nugget), _ptr(G), _ptr(sld), info.ctypes.data_as(_ip), GATHER_FLAGS[gather]))
         return G, sld, info
 
     def lml_batch(self, descs, X, rhs, nugget: float, gather: str = "host"):

@@ -150,6 +150,12 @@ int gsum_group_set_inputs(gsum_group* g, const double* X, int64_t n, int32_t d, 
     return gs_group_run(g, [&](int r) { return gsum_set_inputs(g->ctx[r], X, n, d, RHS, k); });
 }
 
+// every device keeps ALL right-hand-side sets (a surface's 64 sets at n = 8192, k = 7: 29 MB): the descriptors, not the sets, are partitioned
+int gsum_group_set_inputs_sets(gsum_group* g, const double* X, int64_t n, int32_t d, const double* RHS_sets, int32_t n_sets, int32_t k) {
+    if (!g) return -2;
+    return gs_group_run(g, [&](int r) { return gsum_set_inputs_sets(g->ctx[r], X, n, d, RHS_sets, n_sets, k); });
+}
+
 // ---- RCCL (optional): communicators over the group's devices, opened on first use ---------------------------------------------------
 static int gs_group_rccl_open(gsum_group* g) {
     if (g->rccl_state == 1) return 0;
@@ -259,7 +265,7 @@ int gsum_group_allgather(gsum_group* g, double* buf, int64_t rows, int64_t width
 
 // ---- the sharded scan ------------------------------------------------------------------------------------------------------------------
 static int gs_group_lml(gsum_group* g, bool resident, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget, double* G_out,
-                        double* sld_out, int64_t* info_out, int32_t flags) {
+                        double* sld_out, int64_t* info_out, int32_t flags, const int32_t* set_of = nullptr) {
     if (!kernels || !G_out || !sld_out || !info_out || n_kernels < 0) {
         g->err = "gsum_lml_batch_multi: null argument";
         return -2;
@@ -284,7 +290,7 @@ static int gs_group_lml(gsum_group* g, bool resident, const gsum_kernel_desc* ke
         if (hi == lo) return 0;
         gs_inputs* I = resident ? &c->res : &c->op;
         const int64_t kk = (int64_t)I->k * I->k;
-        return gs_lml_on(c, I, kernels + lo, (int32_t)(hi - lo), nugget, G_out + lo * kk, sld_out + lo, info_out + lo);
+        return gs_lml_on(c, I, kernels + lo, (int32_t)(hi - lo), nugget, G_out + lo * kk, sld_out + lo, info_out + lo, set_of ? set_of + lo : nullptr);
     });
     if (rc || !(flags & GSUM_GATHER_RCCL) || n_kernels == 0) return rc;
     // the grid's exchange step on the devices: sld, G and info (exact as fp64: LAPACK's info <= n < 2^53) as ONE packed array
@@ -311,6 +317,12 @@ int gsum_group_lml_resident(gsum_group* g, const gsum_kernel_desc* kernels, int3
                             double* sld_out, int64_t* info_out, int32_t flags) {
     if (!g) return -2;
     return gs_group_lml(g, true, kernels, n_kernels, nugget, G_out, sld_out, info_out, flags);
+}
+
+int gsum_group_lml_resident_sets(gsum_group* g, const gsum_kernel_desc* kernels, const int32_t* set_of, int32_t n_kernels, double nugget,
+                                 double* G_out, double* sld_out, int64_t* info_out, int32_t flags) {
+    if (!g) return -2;
+    return gs_group_lml(g, true, kernels, n_kernels, nugget, G_out, sld_out, info_out, flags, set_of);
 }
 
 int gsum_lml_batch_multi(gsum_group* g, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n, int32_t d,

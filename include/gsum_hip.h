@@ -223,6 +223,10 @@ int64_t gsum_group_get(gsum_group* group, const char* name);
 int gsum_group_set_inputs(gsum_group* group, const double* X, int64_t n, int32_t d, const double* RHS, int32_t k);   /* every device */
 int gsum_group_lml_resident(gsum_group* group, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                             double* G_out, double* sld_out, int64_t* info_out, int32_t flags);
+/* ... with several right-hand-side sets (gsum_set_inputs_sets): every device keeps all sets, the descriptors are partitioned */
+int gsum_group_set_inputs_sets(gsum_group* group, const double* X, int64_t n, int32_t d, const double* RHS_sets, int32_t n_sets, int32_t k);
+int gsum_group_lml_resident_sets(gsum_group* group, const gsum_kernel_desc* kernels, const int32_t* set_of, int32_t n_kernels, double nugget,
+                                 double* G_out, double* sld_out, int64_t* info_out, int32_t flags);
 /* gsum_lml_batch over the group's devices: X and RHS uploaded to every device (0.5 MB at n = 8192), descriptors block-partitioned */
 int gsum_lml_batch_multi(gsum_group* group, const gsum_kernel_desc* kernels, int32_t n_kernels, const double* X, int64_t n, int32_t d,
                          const double* RHS, int32_t k, double nugget, double* G_out, double* sld_out, int64_t* info_out, int32_t flags);

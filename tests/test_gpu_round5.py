@@ -425,6 +425,13 @@ def test_resident_sets_equal_one_call_per_set(ctx, n, n_thetas):
     got = ctx.lml_resident_sets(descs, set_of, 1e-10)
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
+    # the device group: every device holds all sets, the descriptors are partitioned (gsum_group_lml_resident_sets)
+    for devices in ([0], "all"):
+        grp = gsum_amd.default_group(devices)
+        grp.set_inputs_sets(X, Zs)
+        for gather in ("host", "rccl"):
+            for a, b in zip(grp.lml_resident_sets(descs, set_of, 1e-10, gather=gather), want):
+                np.testing.assert_array_equal(a, b)
     # one or two evaluations: the single-factorisation schedule reads its set too
     got2 = ctx.lml_resident_sets(descs[:2], set_of[:2], 1e-10)
     for a, b in zip(got2, want):
