@@ -361,6 +361,23 @@ class CpuGroup:
         self.map(block)
         return G, sld, info
 
+    def set_inputs_sets(self, X, rhs_sets):
+        for c in self.contexts:
+            c.set_inputs_sets(X, rhs_sets)
+
+    def lml_resident_sets(self, descs, set_of, nugget, gather="host"):
+        from .grid import shard_range
+        k = self.contexts[0].resident_shape()[2]
+        nk, world = len(descs), len(self.contexts)
+        G, sld, info = np.full((nk, k, k), np.nan), np.full(nk, np.nan), np.full(nk, -1, dtype=np.int64)
+
+        def block(r, ctx):
+            lo, hi = shard_range(nk, r, world)
+            if hi > lo:
+                G[lo:hi], sld[lo:hi], info[lo:hi] = ctx.lml_resident_sets(list(descs[lo:hi]), list(set_of[lo:hi]), nugget)
+        self.map(block)
+        return self._gathered((G, sld, info), gather)
+
     def lml_resident(self, descs, nugget, gather="host"):
         k = self.contexts[0].resident_shape()[2]
         out = self._sharded(lambda ctx, part: ctx.lml_resident(part, nugget), descs, k)

@@ -286,7 +286,13 @@ class TruncationGP:
         if devices is not None:
             if shard is not None:
                 raise ValueError("shard= (one process per GPU) and devices= (one process, several GPUs) exclude each other")
-            return self._grid_over_devices(thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather)
+            if gather not in ("host", "rccl"):
+                raise ValueError('gather must be "host" or "rccl"')
+            if mode != "full":
+                return self._grid_over_devices(thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather)
+            # mode "full": the surface is ONE call of the library's device group (gsum_group_lml_resident_sets: the flattened points
+            # block-partitioned over the devices, one host thread per device inside the library, the optional RCCL gather there too)
+            _ctx = _GroupEngine(self.coeffs_process._group(devices), gather)
         X = self.X_train_ if X is None else X
         y = self.y_train_ if y is None else y
         orders = self.orders_ if orders is None else orders
@@ -453,6 +459,19 @@ class TruncationGP:
         from .grid import lml_grid_distributed
         fn = functools.partial(self.log_marginal_likelihood_grid, thetas, ratio_kws_list, scales=scales, mode=mode, **kwargs)
         return lml_grid_distributed(fn, len(ratio_kws_list), len(thetas), group=group, partition="theta" if mode == "reuse" else "flat")
+
+
+class _GroupEngine:
+    """The two calls ``log_marginal_likelihood_grid(mode="full")`` makes, on a device group instead of one context."""
+
+    def __init__(self, group, gather):
+        self.group, self.gather = group, gather
+
+    def set_inputs_sets(self, X, rhs_sets):
+        self.group.set_inputs_sets(X, rhs_sets)
+
+    def lml_resident_sets(self, descs, set_of, nugget):
+        return self.group.lml_resident_sets(descs, set_of, nugget, gather=self.gather)
 
 
 class TruncationTP(TruncationGP):
