@@ -172,6 +172,7 @@ PROTOTYPES = {
     "gsum_cho_solve": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_predict_terms": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
                                      _dp, _dp, _dp]),
+    "gsum_predict_var": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, _dp]),
     "gsum_tri_multiply": (C.c_int, [_p, _p, _dp, C.c_int64, C.c_int32, _dp]),
     "gsum_mat_scale_series": (C.c_int, [_p, _p, C.POINTER(SeriesScale), _dp, _dp]),
     "gsum_predict_terms_series": (C.c_int, [_p, _p, _kp, _dp, C.c_int64, C.c_int32, _dp, C.c_int64, _dp, C.c_int32,
@@ -523,6 +524,18 @@ class HipContext:
                 self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m, _ptr(rhs), k, C.byref(sc), _ptr(ref_x),
                 _ptr(ratio_x), _ptr(ref_s), _ptr(ratio_s), _ptr(colsumsq), _ptr(VtW), _ptr(cov)))
         return colsumsq, VtW, cov
+
+    def predict_var(self, L: DeviceMatrix, desc: KernelDesc, X, Xs, want_vtw: bool = False):
+        """gsum_predict_var (SURVEY.md 8b's name): the column sums of squares of V = L^-1 kernel(X, Xs) and, with ``want_vtw``, V^T W as
+        m x GSUM_MAX_RHS (columns beyond the k right-hand sides zero) for the right-hand sides whose forward solve the factor already
+        holds (the last forward_gram / forward_solve / predict_terms on it): models.py:822-836 after fit, nothing handed over again."""
+        X, Xs = _f64(X), _f64(Xs)
+        n, d = X.shape
+        m = Xs.shape[0]
+        css = np.empty(m)
+        vtw = np.empty((m, GSUM_MAX_RHS)) if want_vtw else None
+        self._check(self._lib.gsum_predict_var(self._h, L._h, C.byref(desc), _ptr(X), n, d, _ptr(Xs), m, _ptr(css), _ptr(vtw)))
+        return css, vtw
 
     # -- fused hot path ------------------------------------------------------
     @staticmethod

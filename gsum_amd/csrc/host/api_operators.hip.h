@@ -299,6 +299,24 @@ int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc,
                             VtW, cov_out);
 }
 
+// SURVEY.md section 8b's name and signature for the predictive pieces: the right-hand sides are the ones the factor's border rows already hold
+// (the last gsum_forward_gram / gsum_forward_solve / gsum_predict_terms on this factor).  The signature carries no k, so VtW is
+// m x GSUM_MAX_RHS (row-major, columns >= k zero); VtW == NULL: the column sums of squares only
+int gsum_predict_var(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d, const double* Xs,
+                     int64_t m, double* colsumsq, double* VtW) {
+    if (!ctx || !L) return -2;
+    if (VtW && L->solved_k <= 0) GS_FAIL("gsum_predict_var: V^T W needs right-hand sides solved against this factor first (gsum_forward_gram)");
+    const int k = VtW ? L->solved_k : 0;
+    const std::vector<double> rhs = VtW ? L->solved_rhs : std::vector<double>();       // (a copy: gs_border_prepare compares against the original)
+    std::vector<double> vw(VtW ? (size_t)m * k : 0);
+    const int rc = gs_predict_terms(ctx, L, desc, X, n, d, Xs, m, k ? rhs.data() : nullptr, k, nullptr, nullptr, nullptr, nullptr, nullptr, colsumsq,
+                                    k ? vw.data() : nullptr, nullptr);
+    if (rc || !VtW) return rc;
+    for (int64_t j = 0; j < m; ++j)
+        for (int c = 0; c < GSUM_MAX_RHS; ++c) VtW[j * GSUM_MAX_RHS + c] = c < k ? vw[(size_t)j * k + c] : 0.0;
+    return 0;
+}
+
 int gsum_predict_terms_series(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n,
                               int32_t d, const double* Xs, int64_t m, const double* RHS, int32_t k,
                               const gsum_series_scale* sc, const double* ref_x, const double* ratio_x,

@@ -142,6 +142,11 @@ int gsum_tri_multiply(gsum_ctx* ctx, gsum_mat* L, const double* Z, int64_t n, in
  * colsumsq[j] = sum_i V_ij^2;  VtW = V^T (L^-1 RHS) (m x k; NULL / k = 0 to skip);  cov_out (or NULL) = V^T V (m x m). */
 int gsum_predict_terms(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
                        const double* Xs, int64_t m, const double* RHS, int32_t k, double* colsumsq, double* VtW, double* cov_out);
+/* the same under SURVEY.md section 8b's name: colsumsq (m) and, optionally, VtW (m x GSUM_MAX_RHS, columns >= k zero) for the k right-hand
+ * sides whose forward solve the factor already holds (the last gsum_forward_gram / gsum_forward_solve on it): predict after fit without
+ * handing the residuals over again (models.py:822-836) */
+int gsum_predict_var(gsum_ctx* ctx, gsum_mat* L, const gsum_kernel_desc* desc, const double* X, int64_t n, int32_t d,
+                     const double* Xs, int64_t m, double* colsumsq, double* VtW);
 /* in-place series scaling of an unfactored device matrix (ref, ratio: n host values): K_oo of models.py:1443, 1466 */
 int gsum_mat_scale_series(gsum_ctx* ctx, gsum_mat* A, const gsum_series_scale* sc, const double* ref, const double* ratio);
 /* gsum_predict_terms with kernel(X, Xs) scaled like cov(X, Xs, start, end) first: the pieces of models.py:1449-1452, 1470-1473 */

@@ -482,3 +482,36 @@ def test_two_cohorts_per_group_equal_single_evaluations():
         lab.set_option("wave_cohort_min", 4)
         lab.set_option("wave_cohorts", 2)
         lab.set_option("release_scratch", 1)
+
+
+@pytest.mark.parametrize("n,m,k", [(300, 77, 3), (1500, 640, 16)])
+def test_predict_var_is_predict_terms_on_the_held_right_hand_sides(ctx, n, m, k):
+    """gsum_predict_var (the name and signature SURVEY.md 8b gives the predictive pieces of models.py:822-836): after forward_gram on
+    a factor, the column sums of squares and V^T W for the right-hand sides the factor holds -- bit for bit gsum_predict_terms' with the
+    same right-hand sides handed over again; without a solved right-hand side V^T W is refused, the sums of squares are not."""
+    rng = np.random.RandomState(n + k)
+    X = rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    Xs = rng.rand(m, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    rhs = rng.randn(n, k)
+    desc = gsum_amd.describe_kernel(Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2)
+    L, info = ctx.factorize(desc, X, diag_add=1e-10)
+    assert info == 0
+    try:
+        css0, none = ctx.predict_var(L, desc, X, Xs)
+        assert none is None
+        with pytest.raises(ValueError, match="solved"):
+            ctx.predict_var(L, desc, X, Xs, want_vtw=True)
+        ctx.forward_gram(L, rhs)
+        css, vtw = ctx.predict_var(L, desc, X, Xs, want_vtw=True)
+        want_css, want_vtw, _ = ctx.predict_terms(L, desc, X, Xs, rhs=rhs)
+        assert np.array_equal(css, want_css) and np.array_equal(css0, want_css)
+        assert vtw.shape == (m, _lib.GSUM_MAX_RHS)
+        assert np.array_equal(vtw[:, :k], want_vtw) and not vtw[:, k:].any()
+        # against scipy on the host copy of the factor (the oracle's own formulation, models.py:822-836)
+        from scipy.linalg import solve_triangular
+        Lh = np.tril(L.to_host())
+        V = solve_triangular(Lh, ctx.kernel_matrix(desc, X, Xs), lower=True)
+        np.testing.assert_allclose(css, np.einsum("ij,ij->j", V, V), rtol=1e-10)
+        np.testing.assert_allclose(vtw[:, :k], V.T @ solve_triangular(Lh, rhs, lower=True), rtol=1e-9, atol=1e-10)
+    finally:
+        L.free()
