@@ -28,71 +28,98 @@ static int gs_grad_check(gsum_ctx* ctx, const gsum_grad_param* params, int32_t n
 //   solo: the single-evaluation schedule -- the U = L^-T sweep trails the look-ahead factorisation panel by panel on a stream
 //         of its own, V^T runs beside the SYRK on the panel stream;
 //  !solo: everything in order on the slot's main stream (a batch hides latencies with its other evaluations: gs_lml_on's rule).
-static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, bool solo,
-                        bool on_chain);
+// The stage is cut in three so that the sweep's launches can be ENQUEUED between the factorisation's (round 5, gs_potrf_chain's step hook):
+// with the whole factorisation enqueued first -- ~280 launches, 3-4 ms of host time at n = 8192 -- the sweep's first launch reached its stream
+// when the factorisation was almost over and "trailing" trailed nothing (kernel trace: k_set_identity at 5.1 ms of a 5.4-ms factorisation).
+//   gs_grad_reserve   buffers, streams, events: everything that may allocate (a hipFree inside the hook would wait for a chain kernel that
+//                     waits for launches the host has not enqueued yet);
+//   gs_grad_prepare   the identity and the sweep stream's first waits;
+//   gs_grad_sweep     block-column pairs [run->next_c, c_end) of U = L^-T;
+//   gs_grad_post      whatever of the sweep is left, V^T, R^-1 = U U^T, the contractions, the read-back.
 
-static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, double nugget,
-                           bool solo) {
-    ctx->cur = sl;
-    // the sweep below trails the factorisation: by the evP events of the host-enqueued schedule, or -- round 4 -- by the persistent
-    // chain's own flags (RP[s]: the panel of outer step s is complete in every row), so that a gradient evaluation's factorisation
-    // runs on the schedule a value-only evaluation gets (5.3 instead of 6.6 ms at n = 8192)
-    ctx->chain_events_needed = 2;
-    const int rc_eval = gs_eval_enqueue(ctx, desc, nugget);
-    ctx->chain_events_needed = 0;
-    if (rc_eval) return -1;
-    return gs_grad_post(ctx, sl, sl->ws, desc, params, P, solo, solo && ctx->last_potrf_chain);
+struct gs_grad_layout { size_t o_u, o_r, o_v, o_q, o_t, o_o, o_p, o_d, total; int chunks, rows_per; };
+// split: room for the P stored lower triangles of dR (one evaluation alone: gs_grad_post)
+static gs_grad_layout gs_grad_offsets(int64_t n, int64_t np, int P, bool split) {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const int64_t ldg = np + GS_BORDER;
+    gs_grad_layout L;
+    L.chunks = (int)std::min<int64_t>(128, (n + 63) / 64);
+    L.rows_per = (int)((n + L.chunks - 1) / L.chunks);
+    L.o_u = 0;
+    L.o_r = up((size_t)np * ldg * 8);
+    L.o_v = L.o_r + up((size_t)np * ldg * 8);
+    L.o_q = L.o_v + up((size_t)16 * ldg * 8);
+    L.o_t = L.o_q + up((size_t)P * n * 16 * 8);
+    L.o_o = L.o_t + up((size_t)P * n * 8);
+    L.o_p = L.o_o + up((size_t)P * 257 * 8);
+    L.o_d = L.o_p + up((size_t)P * L.chunks * 257 * 8);
+    L.total = L.o_d + (split ? (size_t)P * up((size_t)np * ldg * 8) : 0);
+    return L;
 }
 
-// everything behind the factorisation of m (L in m->A, the tables of its diagonal blocks, W^T in the border rows), on the slot's streams
-static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, bool solo,
-                        bool on_chain) {
-    const int64_t n = ctx->in->n;
-    const int d = ctx->in->d;
-    ctx->cur = sl;
-    const int64_t np = m->np, ld = m->ld, ldg = np + GS_BORDER;
-    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const int chunks = (int)std::min<int64_t>(128, (n + 63) / 64), rows_per = (int)((n + chunks - 1) / chunks);
-    const size_t o_u = 0, o_r = up((size_t)np * ldg * 8), o_v = o_r + up((size_t)np * ldg * 8), o_q = o_v + up((size_t)16 * ldg * 8),
-                 o_t = o_q + up((size_t)P * n * 16 * 8), o_o = o_t + up((size_t)P * n * 8), o_p = o_o + up((size_t)P * 257 * 8),
-                 total = o_p + up((size_t)P * chunks * 257 * 8);
-    if (gs_reserve(ctx, &sl->gws, &sl->gws_cap, total)) return -1;
+static int gs_grad_reserve(gsum_ctx* ctx, gs_slot* sl, int64_t n, int64_t np, int P, bool solo) {
+    if (gs_reserve(ctx, &sl->gws, &sl->gws_cap, gs_grad_offsets(n, np, P, solo && ctx->grad_split).total)) return -1;
     if (!sl->hgrad) GS_CHECK(hipHostMalloc((void**)&sl->hgrad, (size_t)GSUM_MAX_GRAD * 257 * sizeof(double), hipHostMallocDefault));
+    if (solo && !sl->su) {
+        // the sweep runs beside the factorisation's main and panel streams: it takes the context's fourth stream (the third group's chain
+        // stream of a batch, idle here) -- a stream created now would share a command-processor pipe with one of those two
+        // (round 4 found the single gradient evaluation at 19.7 ms instead of 14.2 that way)
+        if (sl == &ctx->slots[0] && ctx->wave.g[2].sc) { sl->su = ctx->wave.g[2].sc; sl->own_su = false; }
+        else GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
+        GS_CHECK(hipEventCreateWithFlags(&sl->evU, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static int gs_grad_prepare(gsum_ctx* ctx, gs_grad_run* r, gs_slot* sl, gsum_mat* m, int P, bool solo, bool on_chain) {
+    *r = gs_grad_run();
+    r->sl = sl; r->m = m; r->P = P; r->solo = solo; r->on_chain = on_chain;
+    r->n = ctx->in->n; r->d = ctx->in->d;
+    r->np = m->np; r->ld = m->ld; r->ldg = m->np + GS_BORDER;
+    r->split = solo && ctx->grad_split;
+    const gs_grad_layout L = gs_grad_offsets(r->n, r->np, P, r->split);
+    if (sl->gws_cap < L.total || !sl->hgrad || (solo && !sl->su)) GS_FAIL("internal: gradient buffers were not reserved for this order");
+    r->chunks = L.chunks; r->rows_per = L.rows_per;
     char* base = (char*)sl->gws;
-    double *U = (double*)(base + o_u), *Ri = (double*)(base + o_r), *Vt = (double*)(base + o_v), *Q = (double*)(base + o_q),
-           *trow = (double*)(base + o_t), *dout = (double*)(base + o_o), *part = (double*)(base + o_p);
-    hipStream_t s = sl->sm;
+    r->U = (double*)(base + L.o_u); r->Ri = (double*)(base + L.o_r); r->Vt = (double*)(base + L.o_v); r->Q = (double*)(base + L.o_q);
+    r->trow = (double*)(base + L.o_t); r->dout = (double*)(base + L.o_o); r->part = (double*)(base + L.o_p);
+    r->dR = (double*)(base + L.o_d);
+    r->dr_stride = (int64_t)((((size_t)r->np * r->ldg * 8 + 255) / 256 * 256) / 8);
+    r->s = sl->sm;
     // U = L^-T.  Solo: on a stream of its own, trailing the factorisation: block columns c, c + 1 of the sweep need the factor's
     // columns c0 .. c0 + 255 and their tables, which are final once the panel chain of that outer step has run (event
-    // evP[c] of the look-ahead schedule).  One factorisation alone is bound by its panel chain, with most of the chip idle
-    // behind it -- the sweep's GEMMs (n^3 / 3 flops) fill that time instead of following it (5.5 ms at n = 8192).
-    const bool trail = !on_chain && solo && ctx->lookahead != 0 && ctx->batch_active < 3;       // the condition under which gs_potrf records evP
-    hipStream_t su = s;
+    // evP[c] of the look-ahead schedule, flag RP[s] of the persistent chain).  One factorisation alone is bound by its panel chain, with most
+    // of the chip idle behind it -- the sweep's GEMMs (n^3 / 3 flops) fill that time instead of following it.
+    r->trail = !on_chain && solo && ctx->lookahead != 0 && ctx->batch_active < 3;       // the condition under which gs_potrf records evP
+    r->su = r->s;
     if (solo) {
-        if (!sl->su) {
-            // the sweep runs beside the factorisation's main and panel streams: it takes the context's fourth stream (the third group's chain
-            // stream of a batch, idle here) -- a stream created now would share a command-processor pipe with one of those two
-            // (round 4 found the single gradient evaluation at 19.7 ms instead of 14.2 that way)
-            if (sl == &ctx->slots[0] && ctx->wave.g[2].sc) { sl->su = ctx->wave.g[2].sc; sl->own_su = false; }
-            else GS_CHECK(hipStreamCreateWithPriority(&sl->su, hipStreamNonBlocking, ctx->prio_lo));
-            GS_CHECK(hipEventCreateWithFlags(&sl->evU, hipEventDisableTiming));
-        }
-        su = sl->su;
-        GS_CHECK(hipEventRecord(sl->evU, s));                                  // everything enqueued so far (nothing of U is in use)
-        if (!trail && !on_chain) GS_CHECK(hipStreamWaitEvent(su, sl->evU, 0));  // no per-panel events: the sweep follows the factorisation
-        if (on_chain) GS_CHECK(hipStreamWaitEvent(su, sl->evFork, 0));         // (the chain's flags are zeroed on the main stream in front of that event)
+        r->su = sl->su;
+        GS_CHECK(hipEventRecord(sl->evU, r->s));                                  // everything enqueued so far (nothing of U is in use)
+        if (!r->trail && !on_chain) GS_CHECK(hipStreamWaitEvent(r->su, sl->evU, 0));  // no per-panel events: the sweep follows the factorisation
+        if (on_chain) GS_CHECK(hipStreamWaitEvent(r->su, sl->evFork, 0));         // (the chain's flags are zeroed on the main stream in front of that event)
     }
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, su, U, ldg, (int)np);
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((r->np + 255) / 256), (unsigned)r->np), dim3(256), 0, r->su, r->U, r->ldg, (int)r->np);
     GS_CHECK(hipGetLastError());
     // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
-    const bool have_sib = m->Lsib != nullptr && (on_chain || (!solo && m->have_lsib));      // (the chain publishes the images pair by pair, ahead of RP[s])
-    const bool lazy_ok = ctx->predict_lazy && np >= ctx->lazy_min_np && !trail && !on_chain;      // (a trailing sweep keeps the per-pair rhythm of the factorisation)
-    bool deferred = false;
-    for (int c = 0; c < m->T; c += 2) {
+    r->have_sib = m->Lsib != nullptr && (on_chain || (!solo && m->have_lsib));      // (the chain publishes the images pair by pair, ahead of RP[s])
+    r->lazy_ok = ctx->predict_lazy && r->np >= ctx->lazy_min_np && !r->trail && !on_chain;      // (a trailing sweep keeps the per-pair rhythm of the factorisation)
+    r->prepared = true;
+    return 0;
+}
+
+// block-column pairs [r->next_c, c_end) of the sweep; on_chain: a pair whose outer step is the factorisation's last waits for the chain
+// kernel's end (evC), so it can only be enqueued behind gs_potrf_chain's last line
+static int gs_grad_sweep(gsum_ctx* ctx, gs_grad_run* r, int c_end) {
+    gsum_mat* m = r->m;
+    gs_slot* sl = r->sl;
+    const int64_t np = r->np, ld = r->ld, ldg = r->ldg;
+    double* U = r->U;
+    hipStream_t su = r->su;
+    for (int c = r->next_c; c < c_end && c < m->T; c += 2) {
         const bool two = c + 1 < m->T;
         const int64_t c0 = (int64_t)c * GS_NB, c1 = c0 + GS_NB, r2 = two ? c1 + GS_NB : c1;
-        if (trail) GS_CHECK(hipStreamWaitEvent(su, sl->evP[c], 0));
-        if (on_chain) {
+        if (r->trail) GS_CHECK(hipStreamWaitEvent(su, sl->evP[c], 0));
+        if (r->on_chain) {
             const int S = m->T / 2, so = c / 2;
             if (so + 1 < S) {                 // a one-wave kernel that polls the flag in stream order (k_wait_flag), like the chain's own launches
                 hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, su, (const unsigned*)(m->cflags + gs_fl(GS_FL_RP, S, so)), 1u,
@@ -105,7 +132,7 @@ static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kern
         // The pair's two panel solves and the sibling update between them: ONE k_panel256 launch where the factor's sibling images exist
         // as the sweep reaches the pair (the persistent chain publishes them step by step, the grouped batch leaves them in the pool) --
         // rows [c1, r2) of block column c are still zero and come out zero; otherwise k_panel / K = 128 GEMM / k_panel as in rounds 1-4.
-        if (two && have_sib && ctx->predict_panel256) {
+        if (two && r->have_sib && ctx->predict_panel256) {
             if (gs_panel256(ctx, su, m, c, U + c0, ldg, r2)) return -1;
         } else {
             if (gs_trsm_rows(ctx, su, m, c, U + c0, ldg, c1)) return -1;
@@ -115,21 +142,82 @@ static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kern
                 if (gs_trsm_rows(ctx, su, m, c + 1, U + c1, ldg, r2)) return -1;
             }
         }
+        r->next_c = c + 2;
         if (r2 >= np) continue;
         // the trailing update, paired like the predictive sweep's (predict_lazy): after an even pair only the next pair's 256 columns take
         // this pair's update (K = 256), the pair after it applies both to everything right of it in one K = 512 launch -- rows [r2 - 256, r2)
         // of the older pair's columns are structural zeros.  Same products in the same ascending order per element.
-        const bool pair = lazy_ok && two && c + 3 < m->T && r2 + 2 * GS_NB <= np;
-        if (!deferred && pair) {
+        const bool pair = r->lazy_ok && two && c + 3 < m->T && r2 + 2 * GS_NB <= np;
+        if (!r->deferred && pair) {
             if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, 2 * GS_NB, (int)(r2 - c0), 0, 1, -1.0)) return -1;
-            deferred = true;
-        } else if (deferred) {
+            r->deferred = true;
+        } else if (r->deferred) {
             const int64_t cp = c0 - 2 * GS_NB;
             if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + cp, ldg, m->A + r2 * ld + cp, ld, r2, np - r2, (int)(r2 - cp), 0, 1, -1.0)) return -1;
-            deferred = false;
+            r->deferred = false;
         } else if (gs_gemm(ctx, su, GS_BULK, U + r2, ldg, U + c0, ldg, m->A + r2 * ld + c0, ld, r2, np - r2, (int)(r2 - c0), 0, 1, -1.0))
             return -1;
     }
+    return 0;
+}
+
+static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, bool solo,
+                        bool on_chain, gs_grad_run* started);
+
+// gs_potrf_chain's step hook (ctx->chain_step_hook): outer step s of the factorisation is enqueued -- enqueue the sweep's pair of that step behind
+// its RP[s] wait, so that it sits in its stream's queue when the flag comes
+static int gs_grad_chain_hook(gsum_ctx* ctx, gsum_mat* m, int s) {
+    gs_grad_run* r = &ctx->grad_run;
+    gs_slot* sl = ctx->cur;
+    if (!r->prepared && gs_grad_prepare(ctx, r, sl, m, ctx->chain_hook_P, true, true)) return -1;
+    if (s + 1 >= m->T / 2) return 0;                    // (the last outer step's pair waits for evC: gs_grad_post)
+    return gs_grad_sweep(ctx, r, 2 * (s + 1));
+}
+
+static int gs_grad_enqueue(gsum_ctx* ctx, gs_slot* sl, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, double nugget,
+                           bool solo) {
+    ctx->cur = sl;
+    // everything the stage may allocate, before anything of the evaluation is enqueued (np: the larger of the two paddings a factorisation may take)
+    {
+        const int64_t n = ctx->in->n;
+        const int64_t npg = std::max<int64_t>(gs_padded_order(ctx, n), (n + 2 * GS_NB - 1) / (2 * GS_NB) * (2 * GS_NB));
+        if (gs_grad_reserve(ctx, sl, n, npg, P, solo)) return -1;
+    }
+    // the sweep below trails the factorisation: by the evP events of the host-enqueued schedule, or -- round 4 -- by the persistent
+    // chain's own flags (RP[s]: the panel of outer step s is complete in every row), so that a gradient evaluation's factorisation
+    // runs on the schedule a value-only evaluation gets (5.3 instead of 6.6 ms at n = 8192)
+    ctx->chain_events_needed = 2;
+    ctx->grad_run = gs_grad_run();
+    if (solo && ctx->grad_interleave) {
+        ctx->chain_hook_P = P;
+        ctx->chain_step_hook = gs_grad_chain_hook;
+    }
+    const int rc_eval = gs_eval_enqueue(ctx, desc, nugget);
+    ctx->chain_step_hook = nullptr;
+    ctx->chain_events_needed = 0;
+    if (rc_eval) return -1;
+    return gs_grad_post(ctx, sl, sl->ws, desc, params, P, solo, solo && ctx->last_potrf_chain,
+                        ctx->grad_run.prepared ? &ctx->grad_run : nullptr);
+}
+
+// everything behind the factorisation of m (L in m->A, the tables of its diagonal blocks, W^T in the border rows), on the slot's streams
+static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kernel_desc* desc, const gsum_grad_param* params, int P, bool solo,
+                        bool on_chain, gs_grad_run* started) {
+    ctx->cur = sl;
+    gs_grad_run local;
+    gs_grad_run* r = started;
+    if (!r) {
+        r = &local;
+        if (gs_grad_reserve(ctx, sl, ctx->in->n, m->np, P, solo)) return -1;
+        if (gs_grad_prepare(ctx, r, sl, m, P, solo, on_chain)) return -1;
+    } else if (r->m != m || !on_chain) {
+        GS_FAIL("internal: the sweep was started for another factorisation");
+    }
+    if (gs_grad_sweep(ctx, r, m->T)) return -1;
+    const int64_t n = r->n, np = r->np, ld = r->ld, ldg = r->ldg;
+    const int d = r->d, chunks = r->chunks, rows_per = r->rows_per;
+    double *U = r->U, *Ri = r->Ri, *Vt = r->Vt, *Q = r->Q, *trow = r->trow, *dout = r->dout, *part = r->part;
+    hipStream_t s = r->s, su = r->su;
     hipStream_t sv = s;
     if (solo) {
         GS_CHECK(hipEventRecord(sl->evU, su));
@@ -142,16 +230,32 @@ static int gs_grad_post(gsum_ctx* ctx, gs_slot* sl, gsum_mat* m, const gsum_kern
     }
     hipLaunchKernelGGL(k_upper_times_rows, dim3((unsigned)((np + 15) / 16)), dim3(256), 0, sv, U, ldg, (int)np, m->A + np * ld, ld, Vt, ldg);
     GS_CHECK(hipGetLastError());
+    gs_grad_params prm;
+    memset(&prm, 0, sizeof prm);
+    for (int p = 0; p < P; ++p) prm.p[p] = params[p];
+    // One evaluation alone (round 5): Q_p = dR_p V -- every kernel-gradient evaluation of the stage, vector-pipe work that needs V^T only -- runs
+    // behind V^T on the panel stream BESIDE the product R^-1 = U U^T (matrix pipes), leaves the lower triangles of dR_p in memory, and the traces
+    // are a streaming pass over R^-1 and those triangles afterwards: 1.1 ms of contractions behind the product become ~0.1.
+    const bool split = r->split;
+    if (split) {
+        if (desc->n_ops > 0) {
+            hipLaunchKernelGGL((k_grad_contract<true, 1, true>), dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, sv, ctx->in->X, (int)n, (int)d,
+                               *desc, prm, Ri, ldg, Vt, ldg, Q, trow, r->dR, r->dr_stride);
+        } else {
+            hipLaunchKernelGGL((k_grad_contract<false, 2, true>), dim3((unsigned)((n + 7) / 8), (unsigned)P), dim3(256), 0, sv, ctx->in->X, (int)n, (int)d,
+                               *desc, prm, Ri, ldg, Vt, ldg, Q, trow, r->dR, r->dr_stride);
+        }
+        GS_CHECK(hipGetLastError());
+    }
     if (solo) {
         if (gs_potrf_events(ctx, sl, 1)) return -1;
         GS_CHECK(hipEventRecord(sl->evP[0], sl->sp));
     }
     if (gs_gemm(ctx, s, GS_BULK, Ri, ldg, U, ldg, U, ldg, np, np, (int)np, 2, 0, 1.0)) return -1;
     if (solo) GS_CHECK(hipStreamWaitEvent(s, sl->evP[0], 0));
-    gs_grad_params prm;
-    memset(&prm, 0, sizeof prm);
-    for (int p = 0; p < P; ++p) prm.p[p] = params[p];
-    if (desc->n_ops > 0) {
+    if (split) {
+        hipLaunchKernelGGL(k_grad_trace, dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, Ri, ldg, r->dR, r->dr_stride, (int)n, trow);
+    } else if (desc->n_ops > 0) {
         hipLaunchKernelGGL((k_grad_contract<true, 1>), dim3((unsigned)((n + 3) / 4), (unsigned)P), dim3(256), 0, s, ctx->in->X, (int)n, (int)d, *desc,
                        prm, Ri, ldg, Vt, ldg, Q, trow);
     } else {
@@ -286,7 +390,7 @@ static int gs_grad_batch_wave(gsum_ctx* ctx, const gsum_kernel_desc* descs, int 
                 view.have_ltab = true;
                 view.Lsib = g->pool.Lsib + (size_t)q * (g->pool.T / 2 + 1) * GS_LSIB;      // (left by k_potrf_diag256g: the grouped factorisation)
                 view.have_lsib = true;
-                rc = gs_grad_post(ctx, sl, &view, &descs[i], params + (size_t)i * P, P, false, false);
+                rc = gs_grad_post(ctx, sl, &view, &descs[i], params + (size_t)i * P, P, false, false, nullptr);
                 if (!rc) sl->pending = i;
             }
         }

@@ -89,12 +89,34 @@ struct gs_inputs {
     int n_sets = 1;                                                      // (gsum_set_inputs_sets: evaluation i of a call reads set set_of[i])
 };
 
+// state of a gradient evaluation's stage behind the factorisation (api_grad.hip.h), kept in the context so that gs_potrf_chain's step hook can
+// enqueue the sweep's launches between the factorisation's
+struct gs_grad_run {
+    bool prepared = false;
+    int next_c = 0;                      // first block column of the sweep not yet enqueued
+    gs_slot* sl = nullptr;
+    gsum_mat* m = nullptr;
+    int P = 0, d = 0, chunks = 0, rows_per = 0;
+    bool solo = false, on_chain = false, trail = false, have_sib = false, lazy_ok = false, deferred = false;
+    int64_t n = 0, np = 0, ld = 0, ldg = 0;
+    double *U = nullptr, *Ri = nullptr, *Vt = nullptr, *Q = nullptr, *trow = nullptr, *dout = nullptr, *part = nullptr;
+    bool split = false;                  // Q_p beside the R^-1 product, traces from stored triangles of dR_p (gs_grad_post)
+    double* dR = nullptr;
+    int64_t dr_stride = 0;
+    hipStream_t s = nullptr, su = nullptr;
+};
+
 struct gsum_ctx {
     int device = 0;
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
     int grad_batch_wave = 1;         // gradient batches: the factorisations on the grouped schedule (gs_grad_batch_wave)
+    int grad_interleave = 1;         // one gradient evaluation alone: the U = L^-T sweep's launches enqueued step by step between the factorisation's
+    int grad_split = 1;              // ... and its kernel-gradient contractions split: Q_p beside the R^-1 product, the traces from stored triangles of dR_p
+    int (*chain_step_hook)(gsum_ctx*, gsum_mat*, int) = nullptr;      // gs_potrf_chain calls it when outer step s is enqueued (the gradient path's sweep)
+    int chain_hook_P = 0;
+    gs_grad_run grad_run;
     int batch_slots = 4;             // gradient evaluations kept in flight by gsum_lml_grad_batch, one stream each: the context's four
                                      // streams on four pipes (n = 8192: 14.3 / 13.3 / 12.4 / 12.2 / 12.4 ms each with 2 / 3 / 4 / 5 / 8;
                                      // value-only batches do not use slots: gs_lml_wave)

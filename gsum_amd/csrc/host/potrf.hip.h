@@ -353,6 +353,9 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     // against 42-44 for one factorisation's exclusive launches).  A band = a rectangle (columns left of its own rows) + a triangle.
     hipStream_t sbd[1] = {sm};
     for (int s = 0; s + 1 < S; ++s) {             // the last outer step has nothing below its window: the chain does all of it
+        // a caller's launches that follow the factorisation step by step (the gradient path's U = L^-T sweep, gated by RP[s - 1] on its own stream)
+        // enter their queue HERE, not behind the ~9 S launches of this loop
+        if (s > 0 && ctx->chain_step_hook && ctx->chain_step_hook(ctx, m, s - 1)) return -1;
         const int k = 2 * s;
         const int64_t c0 = 256 * (int64_t)s, r2 = c0 + 256, wend = std::min<int64_t>(r2 + W, naug), mr = naug - wend;
         const int Gs = (int)((wend - r2) / 16);
@@ -459,6 +462,7 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
             }
         }
     }
+    if (S >= 2 && ctx->chain_step_hook && ctx->chain_step_hook(ctx, m, S - 2)) return -1;
     GS_CHECK(hipEventRecord(sl->evC, sp));
     GS_CHECK(hipEventRecord(sl->evS, sa));
     GS_CHECK(hipStreamWaitEvent(sm, sl->evC, 0));

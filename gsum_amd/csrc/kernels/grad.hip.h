@@ -46,10 +46,13 @@ __device__ __forceinline__ double gs_kernel_grad(const gsum_kernel_desc& desc, c
 // whole gradient evaluation 5 % slower.
 // R rows of dR_p per wave (round 4): the 16 loads of V^T (and X_j) per column j then feed R x 16 FMAs -- with one row per wave those
 // L1-served loads bound the kernel (1.3 ms per parameter at n = 8192).  Per row the same terms in the same order as before.
-template <bool TREE, int R>
+// SPLIT (round 5, one evaluation alone): Q_p only, and dR_p,ij for j <= i goes to dR (P lower triangles, leading dimension ldr) -- this half needs
+// V^T alone and runs on the vector pipes BESIDE the R^-1 = U U^T product on the matrix pipes; k_grad_trace then takes the traces from R^-1 and the
+// stored triangle with the same terms in the same order per lane (bit-identical to the fused form, which a batch keeps: its other members fill the chip).
+template <bool TREE, int R, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, int d, gsum_kernel_desc desc, gs_grad_params prm,
                                                         const double* Rinv, int64_t ldr, const double* Vt, int64_t ldv,
-                                                        double* Q, double* trow) {
+                                                        double* Q, double* trow, double* dR = nullptr, int64_t dr_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     const int p = blockIdx.y;
@@ -90,7 +93,11 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, i
             const double dm = pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel;
             if constexpr (TREE) (void)gs_tree_eval(desc, xi[r], xj, d, i == j, &pr, &g[r]);      // a general tree: the kernel build's walk, with dual numbers
             else g[r] = gs_kernel_grad(desc, pr, s, dm, i == j);
-            if (i < n && j <= i) tr[r] = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g[r], tr[r]);
+            if constexpr (SPLIT) {
+                if (i < n && j <= i) dR[(int64_t)p * dr_stride + (int64_t)i * ldr + j] = g[r];
+            } else {
+                if (i < n && j <= i) tr[r] = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[(int64_t)i * ldr + j], g[r], tr[r]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -118,8 +125,24 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* X, int n, i
             for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[r][c] : v;
             Q[((int64_t)p * n + i0 + r) * 16 + lane] = v;
         }
-        if (lane == 0) trow[(int64_t)p * n + i0 + r] = t;
+        if (!SPLIT && lane == 0) trow[(int64_t)p * n + i0 + r] = t;
     }
+}
+
+// the other half of the split form: trow_p[i] = sum_{j <= i} (2 - [i == j]) Rinv_ij dR_p,ij from the stored triangle, one wave per row, lane l
+// taking j = l, l + 64, ... in ascending order and the same xor tree over the lanes as k_grad_contract: the same bits
+__global__ __launch_bounds__(256) void k_grad_trace(const double* Rinv, int64_t ldr, const double* dR, int64_t dr_stride, int n, double* trow) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = blockIdx.y;
+    if (i >= n) return;
+    const double* rr = Rinv + (int64_t)i * ldr;
+    const double* dd = dR + (int64_t)p * dr_stride + (int64_t)i * ldr;
+    double t = 0.0;
+    for (int j = lane; j <= i; j += 64) t = __builtin_fma((j < i ? 2.0 : 1.0) * rr[j], dd[j], t);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) trow[(int64_t)p * n + i] = t;
 }
 
 // H_p = V^T Q_p (16 x 16) and sum_i trow_p[i], in two deterministic stages.  Stage 1 (grid: chunks x P): chunk c
