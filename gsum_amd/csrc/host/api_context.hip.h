@@ -258,6 +258,7 @@ static int gs_set_option_lab(gsum_ctx* ctx, const char* name, int64_t value) {
     else if (!strcmp(name, "grad_batch_wave")) ctx->grad_batch_wave = value != 0;
     else if (!strcmp(name, "grad_interleave")) ctx->grad_interleave = value != 0;
     else if (!strcmp(name, "grad_split")) ctx->grad_split = value != 0;
+    else if (!strcmp(name, "grad_lazy_chain")) ctx->grad_lazy_chain = value != 0;
     else if (!strcmp(name, "wave_head")) ctx->wave_head = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "wave_panel_rows_lds")) ctx->wave_panel_rows_lds = value != 0;
     else if (!strcmp(name, "wave_near_on_chain")) ctx->wave_near_on_chain = value != 0;

@@ -102,7 +102,7 @@ static int gs_grad_prepare(gsum_ctx* ctx, gs_grad_run* r, gs_slot* sl, gsum_mat*
     GS_CHECK(hipGetLastError());
     // two block columns per trailing update (K = 256), like the factorisation: halves the traffic of U's trailing part
     r->have_sib = m->Lsib != nullptr && (on_chain || (!solo && m->have_lsib));      // (the chain publishes the images pair by pair, ahead of RP[s])
-    r->lazy_ok = ctx->predict_lazy && r->np >= ctx->lazy_min_np && !r->trail && !on_chain;      // (a trailing sweep keeps the per-pair rhythm of the factorisation)
+    r->lazy_ok = ctx->predict_lazy && r->np >= ctx->lazy_min_np && !r->trail && (!on_chain || (ctx->grad_lazy_chain && r->np >= 10240));      // (a sweep that trails by EVENTS keeps the per-pair rhythm of the factorisation)
     r->prepared = true;
     return 0;
 }

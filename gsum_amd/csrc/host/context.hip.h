@@ -114,6 +114,7 @@ struct gsum_ctx {
     int grad_batch_wave = 1;         // gradient batches: the factorisations on the grouped schedule (gs_grad_batch_wave)
     int grad_interleave = 1;         // one gradient evaluation alone: the U = L^-T sweep's launches enqueued step by step between the factorisation's
     int grad_split = 1;              // ... and its kernel-gradient contractions split: Q_p beside the R^-1 product, the traces from stored triangles of dR_p
+    int grad_lazy_chain = 1;         // ... its trailing updates paired (K = 512 every other pair) also when it trails the persistent chain by flags
     int (*chain_step_hook)(gsum_ctx*, gsum_mat*, int) = nullptr;      // gs_potrf_chain calls it when outer step s is enqueued (the gradient path's sweep)
     int chain_hook_P = 0;
     gs_grad_run grad_run;

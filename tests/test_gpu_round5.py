@@ -515,3 +515,39 @@ def test_predict_var_is_predict_terms_on_the_held_right_hand_sides(ctx, n, m, k)
         np.testing.assert_allclose(vtw[:, :k], V.T @ solve_triangular(Lh, rhs, lower=True), rtol=1e-9, atol=1e-10)
     finally:
         L.free()
+
+
+@pytest.mark.parametrize("n,kind", [(700, "flat"), (1500, "tree"), (2300, "flat"), (4400, "flat")])
+def test_single_gradient_evaluation_forms_are_bit_identical(n, kind):
+    """One value + gradient evaluation alone (gsum_lml_grad; models.py:957-958, 1041-1056), round-5 form against round-4 form: the U = L^-T sweep's
+    launches enqueued between the factorisation's outer steps (gs_potrf_chain's step hook) instead of behind all of them, the kernel-gradient
+    contractions split (Q_p beside the R^-1 product, the traces from stored triangles of dR_p) instead of fused, the sweep's trailing updates
+    paired.  Same kernels, same terms in the same order: G, sum log diag, traces and H equal bit for bit -- also against the batch path, which
+    keeps the fused contraction."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C
+    lab = gsum_amd.lab_context(0)
+    rng = np.random.RandomState(n)
+    d = 2 if kind == "tree" else 1
+    X = 0.1 * np.arange(n)[:, None] if d == 1 else rng.rand(n, 2) * np.array([0.35, 0.65]) * np.sqrt(n)
+    Z = np.concatenate([rng.randn(n, 5), np.ones((n, 1))], axis=1)
+    kern = (C(1.3) * RBF(0.2) + WhiteKernel(1e-8)) if kind == "flat" else (C(0.8) * RBF([0.6, 1.1]) + C(0.3) * Matern(1.4, nu=1.5) + WhiteKernel(1e-7))
+    desc, prm = gsum_amd.describe_kernel(kern, d), gsum_amd.kernels.describe_gradient(kern, d)
+    names = ("grad_interleave", "grad_split", "grad_lazy_chain")
+    try:
+        for name in names:
+            lab.set_option(name, 0)
+        want = lab.lml_grad(desc, prm, X, Z, 1e-10)
+        assert want[2] == 0
+        for combo in ((1, 0, 0), (0, 1, 0), (1, 1, 1)):
+            for name, v in zip(names, combo):
+                lab.set_option(name, v)
+            got = lab.lml_grad(desc, prm, X, Z, 1e-10)
+            for a, b in zip(got, want):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), combo
+        batch = lab.lml_grad_batch([desc, desc], [prm, prm], X, Z, 1e-10)
+        for a, b in zip(batch, want):
+            assert np.array_equal(np.asarray(a)[1], np.asarray(b))
+        assert lab.get_option("chain_aborts") == 0
+    finally:
+        for name in names:
+            lab.set_option(name, 1)

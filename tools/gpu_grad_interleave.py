@@ -27,6 +27,7 @@ for n in sizes:
         # 0: the round-4 form; 1: sweep launches interleaved + contractions split (Q beside the R^-1 product, traces from stored dR triangles)
         ctx.set_option("grad_interleave", mode)
         ctx.set_option("grad_split", mode)
+        ctx.set_option("grad_lazy_chain", mode)
         out = ctx.lml_grad(desc, prm, X, Z, 1e-10)
         reps = 6 if n <= 8192 else 3
         ts = []
@@ -42,3 +43,4 @@ for n in sizes:
     ctx.set_option("release_scratch", 1)
 ctx.set_option("grad_interleave", 1)
 ctx.set_option("grad_split", 1)
+ctx.set_option("grad_lazy_chain", 1)
