@@ -20,12 +20,12 @@ import numpy as np
 from scipy.linalg import cho_solve as _cho_solve
 from scipy.linalg import solve_triangular
 from scipy.linalg.lapack import dpotrf
-from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, RationalQuadratic
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, ExpSineSquared, Matern, RationalQuadratic
 
-from ._lib import FAMILY, GSUM_MAX_RHS, OP_ADD, OP_CONST, OP_LEAF, OP_WHITE, GradParam, KernelDesc
+from ._lib import FAMILY, GSUM_MAX_RHS, OP_ADD, OP_CONST, OP_LEAF, OP_POW, OP_WHITE, GradParam, KernelDesc
 from .series import geometric_sum
 
-_NU = {FAMILY["rbf"]: None, FAMILY["matern52"]: 2.5, FAMILY["matern32"]: 1.5, FAMILY["matern12"]: 0.5}
+_NU = {FAMILY["rbf"]: None, FAMILY["matern52"]: 2.5, FAMILY["matern32"]: 1.5, FAMILY["matern12"]: 0.5, FAMILY["matern_inf"]: np.inf}
 
 
 def _leaf(desc, d: int, free=False):
@@ -34,6 +34,8 @@ def _leaf(desc, d: int, free=False):
     bounds = (1e-300, 1e300) if free else "fixed"
     if int(desc.family) == FAMILY["rq"]:
         return RationalQuadratic(length_scale=ls, alpha=float(desc.alpha), length_scale_bounds=bounds, alpha_bounds=bounds)
+    if int(desc.family) == FAMILY["expsine"]:
+        return ExpSineSquared(length_scale=ls, periodicity=float(desc.alpha), length_scale_bounds=bounds, periodicity_bounds=bounds)
     nu = _NU[int(desc.family)]
     return RBF(ls, length_scale_bounds=bounds) if nu is None else Matern(ls, length_scale_bounds=bounds, nu=nu)
 
@@ -49,7 +51,11 @@ def _tree_matrix(desc, X, Y, param=None):
     stack = []
     for k in range(desc.n_ops):
         op = desc.op[k]
-        if op >= OP_WHITE:
+        if op >= OP_POW:                       # Exponentiation (kernels.py: K ** exponent, K_gradient *= exponent K ** (exponent - 1))
+            e = desc.cval[op - OP_POW]
+            a, da = stack.pop()
+            stack.append((a ** e, da * (e * a ** (e - 1))))
+        elif op >= OP_WHITE:
             c = op - OP_WHITE
             hit = param is not None and param.code == GradParam.TREE_WHITE and param.dim == c
             stack.append((desc.cval[c] * eye, desc.cval[c] * eye if hit else zero))
@@ -65,6 +71,8 @@ def _tree_matrix(desc, X, Y, param=None):
                 # scikit-learn's theta order within a leaf: alphabetical -- RationalQuadratic: alpha, length_scale; else length_scale[s]
                 if int(desc.leaf[l].family) == FAMILY["rq"]:
                     dv = dK[:, :, 0] if param.code == GradParam.TREE_ALPHA else dK[:, :, 1]
+                elif int(desc.leaf[l].family) == FAMILY["expsine"]:         # length_scale, periodicity
+                    dv = dK[:, :, 1] if param.code == GradParam.TREE_ALPHA else dK[:, :, 0]
                 else:
                     dv = dK[:, :, param.dim & 15] if param.code == GradParam.TREE_LENGTH_DIM else dK[:, :, 0]
                 stack.append((V, dv))

@@ -23,8 +23,8 @@ GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
 GSUM_MAX_LEAVES = 4
 GSUM_MAX_OPS = 16
-FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4}
-OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE = 1, 2, 16, 32, 64
+FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4, "expsine": 5, "matern_inf": 6}
+OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE, OP_POW = 1, 2, 16, 32, 64, 128
 
 
 class KernelLeaf(C.Structure):
@@ -65,7 +65,9 @@ class KernelDesc(C.Structure):
         stack = []
         for k in range(self.n_ops):
             op = self.op[k]
-            if op >= OP_CONST:
+            if op >= OP_POW:
+                stack.append(stack.pop() ** self.cval[op - OP_POW])          # Exponentiation.diag: kernel.diag(X) ** exponent
+            elif op >= OP_CONST:
                 stack.append(self.cval[op - (OP_WHITE if op >= OP_WHITE else OP_CONST)])
             elif op >= OP_LEAF:
                 stack.append(1.0)
@@ -80,7 +82,7 @@ class KernelDesc(C.Structure):
         out = copy.copy(self)
         out.white_noise = 0.0
         for k in range(self.n_ops):
-            if self.op[k] >= OP_WHITE:
+            if OP_WHITE <= self.op[k] < OP_POW:
                 out.cval[self.op[k] - OP_WHITE] = 0.0
         return out
 
@@ -91,7 +93,8 @@ class KernelDesc(C.Structure):
         if not self.is_tree:
             out.additive_const += float(c)
             return out
-        used = {self.op[k] - (OP_WHITE if self.op[k] >= OP_WHITE else OP_CONST) for k in range(self.n_ops) if self.op[k] >= OP_CONST}
+        used = {self.op[k] - (OP_POW if self.op[k] >= OP_POW else OP_WHITE if self.op[k] >= OP_WHITE else OP_CONST)
+                for k in range(self.n_ops) if self.op[k] >= OP_CONST}
         slot = next(i for i in range(GSUM_MAX_OPS) if i not in used)
         if self.n_ops + 2 > GSUM_MAX_OPS:
             raise NotImplementedError("kernel tree too large for the device descriptor")

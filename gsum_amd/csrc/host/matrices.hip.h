@@ -80,6 +80,8 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
         if (op == GSUM_OP_ADD || op == GSUM_OP_MUL) {
             if (depth < 2) GS_FAIL("kernel tree: operator without two operands");
             --depth;
+        } else if (op >= GSUM_OP_POW) {
+            if (depth < 1 || op - GSUM_OP_POW >= GSUM_MAX_OPS) GS_FAIL("kernel tree: exponentiation without an operand or with a bad exponent slot");
         } else {
             const int idx = op >= GSUM_OP_WHITE ? op - GSUM_OP_WHITE : (op >= GSUM_OP_CONST ? op - GSUM_OP_CONST : op - GSUM_OP_LEAF);
             if (op < GSUM_OP_LEAF || idx < 0 || idx >= (op >= GSUM_OP_CONST ? GSUM_MAX_OPS : desc->n_leaves)) GS_FAIL("kernel tree: bad operand");
@@ -89,7 +91,8 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
     if (depth != 1) GS_FAIL("kernel tree: the program does not reduce to one value");
     for (int l = 0; l < desc->n_leaves; ++l) {
         const gsum_kernel_leaf& lf = desc->leaf[l];
-        if (lf.family < GSUM_RBF || lf.family > GSUM_RQ) GS_FAIL("kernel tree: unknown leaf family");
+        if (lf.family < GSUM_RBF || lf.family > GSUM_MATERN_INF) GS_FAIL("kernel tree: unknown leaf family");
+        if (lf.family == GSUM_EXPSINE && (lf.anisotropic || !(lf.alpha > 0.0))) GS_FAIL("kernel tree: ExpSineSquared needs periodicity > 0 and an isotropic length scale");
         if (lf.family == GSUM_RQ && (lf.anisotropic || !(lf.alpha > 0.0))) GS_FAIL("kernel tree: RationalQuadratic needs alpha > 0 and an isotropic length scale");
         for (int i = 0; i < (lf.anisotropic ? d : 1); ++i)
             if (!(lf.length_scale[i] > 0.0)) GS_FAIL("length_scale must be positive");

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_build2(double* out, int64_t ldo, const 
 // ---- general kernel trees (gsum_kernel_desc with n_ops > 0) ----------------------------------------------------------------------
 // The reference hands ANY scikit-learn kernel to its three call sites (gsum/models.py:708, 822-824, 958-960).  The flattened
 // descriptor covers the family its own tests and notebooks use and runs the templated kernels above; everything else that is a
-// Sum / Product tree over stationary leaves (RBF, Matern 1/2 3/2 5/2, RationalQuadratic), ConstantKernel and WhiteKernel is
+// Sum / Product / Exponentiation tree over stationary leaves (RBF, Matern 1/2 3/2 5/2 inf, RationalQuadratic, ExpSineSquared), ConstantKernel and WhiteKernel is
 // evaluated entry by entry as a postfix program in scikit-learn's own evaluation order (Sum: k1 + k2, kernels.py:858-866;
 // Product: k1 * k2, :956-966), so that `RBF + RBF` or `C * RBF + C * Matern` come out bit-identical to sklearn's matrix like
 // the flattened family does; RationalQuadratic goes through pow() and is within an ulp or two of numpy's.
@@ -463,8 +463,10 @@ __global__ __launch_bounds__(256) void k_build2(double* out, int64_t ldo, const 
 #define GS_TREE_STACK 8
 
 // want: 0 value only, 1 d / d log length_scale (isotropic), 2 d / d log length_scale[dim], 3 d / d log alpha
+// cross: the TWO-argument form kernel(X, Y) (it differs from the one-argument form off the diagonal only where scikit-learn orders the arithmetic
+// differently: ExpSineSquared)
 __device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const double* xi, const double* xj, int d, bool diag, int want,
-                                             int dim, double& v, double& dv) {
+                                             int dim, double& v, double& dv, bool cross = false) {
 #pragma clang fp contract(off)
     dv = 0.0;
     if (diag) {                                  // np.fill_diagonal(K, 1) of the one-argument form; every leaf gradient is 0 there
@@ -484,6 +486,23 @@ __device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const d
         else if (want == 3) dv = v * (-lf.alpha * log(base) + s / ((2.0 * ls2) * base));
         return;
     }
+    if (lf.family == GSUM_EXPSINE) {             // kernels.py ExpSineSquared.__call__: exp(-2 (sin(pi dists / p) / ls)^2), dists = euclidean(X)
+        double s = 0.0;
+        for (int m = 0; m < d; ++m) {
+            const double e = xi[m] - xj[m];
+            s = s + e * e;
+        }
+        const double ls = lf.length_scale[0];
+        // (alpha holds the periodicity)  one argument: arg = pi * dists / p; two arguments: sin(pi / p * dists) -- at arguments of tens of radians
+        // one ulp of the argument is tens of ulps of the value
+        const double arg = cross ? (3.141592653589793 / lf.alpha) * sqrt(s) : 3.141592653589793 * sqrt(s) / lf.alpha;
+        const double sn = sin(arg);
+        const double q = sn / ls;
+        v = gs_exp_np(-2.0 * (q * q));
+        if (want == 1) dv = 4.0 / (ls * ls) * (sn * sn) * v;                 // d / d log length_scale
+        else if (want == 3) dv = 4.0 * arg / (ls * ls) * cos(arg) * sn * v;  // d / d log periodicity
+        return;
+    }
     double s = 0.0, dsel = 0.0;                  // sqeuclidean(X / length_scale): divide first, like pdist on the scaled points
     for (int m = 0; m < d; ++m) {
         const double ls = lf.anisotropic ? lf.length_scale[m] : lf.length_scale[0];
@@ -491,6 +510,12 @@ __device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const d
         const double dmm = u * u;
         s = s + dmm;
         if (m == dim) dsel = dmm;
+    }
+    if (lf.family == GSUM_MATERN_INF) {          // Matern(nu = inf): exp(-dists^2 / 2) with dists = euclidean(X / length_scale) -- the root is taken and squared again
+        const double dist = sqrt(s);
+        v = gs_exp_np(-(dist * dist) / 2.0);
+        if (want == 1 || want == 2) dv = (want == 1 ? s : dsel) * v;
+        return;
     }
     v = gs_base_value(lf.family, s);
     if (want == 1 || want == 2) {
@@ -512,14 +537,18 @@ __device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const d
 // value of the tree at (xi, xj); diag: the entry is on the diagonal of the ONE-argument form (leaves exactly 1, WhiteKernel on).
 // pr != NULL: *dout = d value / d log(parameter pr) as well.
 __device__ __forceinline__ double gs_tree_eval(const gsum_kernel_desc& t, const double* xi, const double* xj, int d, bool diag,
-                                               const gsum_grad_param* pr, double* dout) {
+                                               const gsum_grad_param* pr, double* dout, bool cross = false) {
 #pragma clang fp contract(off)
     double sv[GS_TREE_STACK], sd[GS_TREE_STACK];
     int sp = 0;
     const int code = pr ? pr->code : -1, pdim = pr ? pr->dim : 0;
     for (int k = 0; k < t.n_ops; ++k) {
         const int op = t.op[k];
-        if (op >= GSUM_OP_WHITE) {
+        if (op >= GSUM_OP_POW) {                  // Exponentiation: K ** exponent, K_gradient *= exponent K ** (exponent - 1)
+            const double e = t.cval[op - GSUM_OP_POW], a = sv[sp - 1];
+            sv[sp - 1] = pow(a, e);
+            sd[sp - 1] = sd[sp - 1] * (e * pow(a, e - 1.0));
+        } else if (op >= GSUM_OP_WHITE) {
             const int c = op - GSUM_OP_WHITE;
             const double w = diag ? t.cval[c] : 0.0;
             sv[sp] = w;
@@ -536,7 +565,7 @@ __device__ __forceinline__ double gs_tree_eval(const gsum_kernel_desc& t, const 
             if (code >= GSUM_GRAD_TREE_LENGTH_ISO && (pdim >> 4) == l)
                 want = code == GSUM_GRAD_TREE_LENGTH_ISO ? 1 : (code == GSUM_GRAD_TREE_LENGTH_DIM ? 2 : 3);
             double v, dv;
-            gs_leaf_eval(t.leaf[l], xi, xj, d, diag, want, pdim & 15, v, dv);
+            gs_leaf_eval(t.leaf[l], xi, xj, d, diag, want, pdim & 15, v, dv, cross);
             sv[sp] = v;
             sd[sp] = dv;
             ++sp;
@@ -634,7 +663,7 @@ __global__ __launch_bounds__(256) void k_build_tree(double* out, int64_t ldo, co
         for (int c = 0; c < 2; ++c) {
             const int gj = gj0 + c;
             if (CROSS) {
-                v[c] = (gi < n && gj < m) ? gs_tree_eval(desc, xi, xj[c], d, false, nullptr, nullptr) : 0.0;
+                v[c] = (gi < n && gj < m) ? gs_tree_eval(desc, xi, xj[c], d, false, nullptr, nullptr, true) : 0.0;
             } else if (gi >= n || gj >= n) {
                 v[c] = gi == gj ? 1.0 : 0.0;                       // identity padding
             } else {

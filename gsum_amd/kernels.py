@@ -5,21 +5,22 @@ The reference calls ``kernel(X)`` / ``kernel(X, Y)`` on arbitrary scikit-learn k
 
 * flattened -- ``[ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5})) [+ WhiteKernel] [+ ConstantKernel]``, the family the
   reference's own tests, notebooks and defaults use; it runs the templated fast kernels and the one-workgroup-per-evaluation paths;
-* tree (round 4) -- any ``Sum`` / ``Product`` tree over RBF, Matern(0.5, 1.5, 2.5), RationalQuadratic, ConstantKernel and
-  WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``RationalQuadratic`` ...): a postfix program in scikit-learn's own
-  evaluation order, at most 4 stationary leaves and 16 operations.
+* tree (round 4) -- any ``Sum`` / ``Product`` / ``Exponentiation`` tree over RBF, Matern(0.5, 1.5, 2.5, inf), RationalQuadratic,
+  ExpSineSquared, ConstantKernel and WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``ExpSineSquared * RBF``,
+  ``RBF ** 2`` ...): a postfix program in scikit-learn's own evaluation order, at most 4 stationary leaves and 16 operations.
 
-Other leaves (DotProduct, ExpSineSquared, Exponentiation ...) raise ``NotImplementedError`` -- on the 'hip' backend there is
-deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's: leaves left to right, a leaf's
+Other leaves (DotProduct, PairwiseKernel, Matern with another nu: not stationary with a unit diagonal, or Bessel functions) raise
+``NotImplementedError`` -- on the 'hip' backend there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's: leaves left to right, a leaf's
 hyperparameters in alphabetical order.  :func:`describe_thetas` / :func:`describe_gradients` reproduce the
 setter's values without a clone per theta.
 """
 from __future__ import annotations
 
 import numpy as np
-from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Matern, Product, RationalQuadratic, Sum, WhiteKernel)
+from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Exponentiation, ExpSineSquared, Matern, Product, RationalQuadratic, Sum,
+                                              WhiteKernel)
 
-from ._lib import (FAMILY, GSUM_MAX_D, GSUM_MAX_LEAVES, GSUM_MAX_OPS, OP_ADD, OP_CONST, OP_LEAF, OP_MUL, OP_WHITE, GradParam,
+from ._lib import (FAMILY, GSUM_MAX_D, GSUM_MAX_LEAVES, GSUM_MAX_OPS, OP_ADD, OP_CONST, OP_LEAF, OP_MUL, OP_POW, OP_WHITE, GradParam,
                    KernelDesc)
 
 __all__ = ["describe_kernel", "describe_thetas", "describe_gradient", "describe_gradients", "default_kernel"]
@@ -153,6 +154,11 @@ def _compile_tree(kernel):
             walk(k.k2)
             prog.append("add" if isinstance(k, Sum) else "mul")
             return
+        if isinstance(k, Exponentiation):            # theta is the inner kernel's (kernels.py Exponentiation.theta); the exponent is a plain parameter
+            walk(k.kernel)
+            prog.append(_TreeNode("pow", k, counts["cval"], {}))
+            counts["cval"] += 1
+            return
         if isinstance(k, WhiteKernel):
             h = k.hyperparameter_noise_level
             node = _TreeNode("white", k, counts["cval"], {"value": free(h, offset[0])})
@@ -171,21 +177,29 @@ def _compile_tree(kernel):
             offset[0] += 0 if hl.fixed else 1
             node = _TreeNode("leaf", k, counts["leaf"], offs)
             counts["leaf"] += 1
+        elif isinstance(k, ExpSineSquared):
+            hl, hp = k.hyperparameter_length_scale, k.hyperparameter_periodicity    # alphabetical: length_scale, periodicity
+            offs = {"length_scale": free(hl, offset[0])}
+            offset[0] += 0 if hl.fixed else 1
+            offs["periodicity"] = free(hp, offset[0])
+            offset[0] += 0 if hp.fixed else 1
+            node = _TreeNode("leaf", k, counts["leaf"], offs)
+            counts["leaf"] += 1
         elif isinstance(k, (RBF, Matern)):
-            if isinstance(k, Matern) and float(k.nu) not in (0.5, 1.5, 2.5):
-                raise NotImplementedError(f"Matern nu={k.nu} is not supported on the device (0.5, 1.5, 2.5 are)")
+            if isinstance(k, Matern) and float(k.nu) not in (0.5, 1.5, 2.5, np.inf):
+                raise NotImplementedError(f"Matern nu={k.nu} is not supported on the device (0.5, 1.5, 2.5 and inf are)")
             h = k.hyperparameter_length_scale
             node = _TreeNode("leaf", k, counts["leaf"], {"length_scale": free(h, offset[0]), "n": h.n_elements})
             counts["leaf"] += 1
             offset[0] += 0 if h.fixed else h.n_elements
         else:
-            raise NotImplementedError(f"kernel {k!r} is not supported on the device (Sum / Product trees over RBF, Matern, "
-                                      "RationalQuadratic, ConstantKernel and WhiteKernel are)")
+            raise NotImplementedError(f"kernel {k!r} is not supported on the device (Sum / Product / Exponentiation trees over RBF, Matern, "
+                                      "RationalQuadratic, ExpSineSquared, ConstantKernel and WhiteKernel are)")
         prog.append(node)
 
     walk(kernel)
     if counts["leaf"] < 1:
-        raise NotImplementedError(f"kernel {kernel} has no stationary (RBF / Matern / RationalQuadratic) part")
+        raise NotImplementedError(f"kernel {kernel} has no stationary (RBF / Matern / RationalQuadratic / ExpSineSquared) part")
     if counts["leaf"] > GSUM_MAX_LEAVES or len(prog) > GSUM_MAX_OPS:
         raise NotImplementedError(f"kernel {kernel} is too large for the device descriptor ({GSUM_MAX_LEAVES} stationary leaves, "
                                   f"{GSUM_MAX_OPS} operations)")
@@ -207,8 +221,12 @@ def _tree_values(node, theta):
         return val("value", k.noise_level)
     if node.kind == "const":
         return val("value", k.constant_value)
+    if node.kind == "pow":
+        return float(k.exponent)
     if isinstance(k, RationalQuadratic):
         return val("length_scale", k.length_scale), val("alpha", k.alpha)
+    if isinstance(k, ExpSineSquared):
+        return val("length_scale", k.length_scale), val("periodicity", k.periodicity)
     return val("length_scale", k.length_scale), None
 
 
@@ -223,6 +241,9 @@ def _describe_tree(prog, theta, n_features, shown) -> KernelDesc:
             desc.op[i] = OP_ADD
         elif item == "mul":
             desc.op[i] = OP_MUL
+        elif item.kind == "pow":
+            desc.cval[item.slot] = float(_tree_values(item, theta))
+            desc.op[i] = OP_POW + item.slot
         elif item.kind in ("white", "const"):
             desc.cval[item.slot] = float(_tree_values(item, theta))
             desc.op[i] = (OP_WHITE if item.kind == "white" else OP_CONST) + item.slot
@@ -232,8 +253,10 @@ def _describe_tree(prog, theta, n_features, shown) -> KernelDesc:
             k = item.kernel
             if isinstance(k, RationalQuadratic):
                 lf.family, lf.alpha = FAMILY["rq"], float(alpha)
+            elif isinstance(k, ExpSineSquared):
+                lf.family, lf.alpha = FAMILY["expsine"], float(alpha)          # (the leaf's second parameter: the periodicity)
             elif isinstance(k, Matern):
-                lf.family = FAMILY[{0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(k.nu)]]
+                lf.family = FAMILY[{0.5: "matern12", 1.5: "matern32", 2.5: "matern52", np.inf: "matern_inf"}[float(k.nu)]]
             else:
                 lf.family = FAMILY["rbf"]
             ls = np.atleast_1d(np.asarray(ls, dtype=float))
@@ -264,6 +287,8 @@ def _tree_gradient_params(prog, theta, n_features):
     for item in prog:
         if isinstance(item, str):
             continue
+        if item.kind == "pow":
+            continue
         if item.kind in ("white", "const"):
             off = item.offsets["value"]
             if off is not None:
@@ -273,6 +298,11 @@ def _tree_gradient_params(prog, theta, n_features):
                 slots[item.offsets["alpha"]] = [gp(GradParam.TREE_ALPHA, item.slot * 16)]
             if item.offsets["length_scale"] is not None:
                 slots[item.offsets["length_scale"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
+        elif isinstance(item.kernel, ExpSineSquared):
+            if item.offsets["length_scale"] is not None:
+                slots[item.offsets["length_scale"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
+            if item.offsets["periodicity"] is not None:
+                slots[item.offsets["periodicity"]] = [gp(GradParam.TREE_ALPHA, item.slot * 16)]       # the leaf's second parameter
         else:
             off = item.offsets["length_scale"]
             if off is not None:

@@ -165,5 +165,8 @@ def record_parity(name, **values):
 
 def tree_kernel(expr):
     """Kernel of a tests/golden/tree_kernels.json case (see make_golden.py): the expression evaluated over the scikit-learn kernel classes."""
-    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, RationalQuadratic, ConstantKernel as C
-    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic))
+    import numpy as np
+    from sklearn.gaussian_process.kernels import (RBF, Exponentiation, ExpSineSquared, Matern, WhiteKernel, RationalQuadratic,
+                                                  ConstantKernel as C)
+    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic,
+                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, np=np))

@@ -743,12 +743,19 @@ TREE_KERNELS = [          # (expression, input dimension): scikit-learn kernels 
     ("(RBF(0.7) + C(0.1)) * Matern([1.0, 2.0], nu=1.5) + WhiteKernel(1e-4, noise_level_bounds='fixed')", 2),
     ("RationalQuadratic(length_scale=1.1, alpha=0.7) * RBF([0.9, 1.7]) + C(0.3, constant_value_bounds='fixed')", 2),
     ("C(1.5) * Matern(0.8, nu=0.5) + RBF(1.9)", 1),
+    # round 5: the remaining stationary scikit-learn kernels with a unit diagonal, and the Exponentiation operator
+    ("C(1.2) * ExpSineSquared(length_scale=1.1, periodicity=3.0) * RBF(4.0) + WhiteKernel(1e-3)", 1),
+    ("Exponentiation(RBF(0.8), 2.0) + C(0.2) + WhiteKernel(1e-4)", 1),
+    ("Matern([1.2, 2.1], nu=np.inf) * C(1.5) + WhiteKernel(1e-3)", 2),
+    ("Exponentiation(C(1.1) * RationalQuadratic(length_scale=1.2, alpha=0.7) + C(0.5), 2) + WhiteKernel(1e-3)", 2),
+    ("ExpSineSquared(length_scale=0.9, periodicity=6.0) * C(0.8) + WhiteKernel(1e-2)", 1),
 ]
 
 
 def tree_kernel(expr):
-    from sklearn.gaussian_process.kernels import RationalQuadratic
-    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic))
+    from sklearn.gaussian_process.kernels import Exponentiation, ExpSineSquared, RationalQuadratic
+    return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic,
+                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, np=np))
 
 
 def gen_tree_kernels():

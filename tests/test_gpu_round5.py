@@ -290,7 +290,7 @@ def test_notebook_grid_with_a_tree_kernel_stays_on_the_fast_path():
         thetas = [[t] for t in np.log(g["ls_vals"])]
         gp.log_marginal_likelihood_grid(thetas, g["ratio_vals"], mode="full")
         best = np.inf
-        for _ in range(3):
+        for _ in range(12):                # (most of a call is host algebra: the minimum of many, host noise only ever adds)
             t0 = time.perf_counter()
             grid = gp.log_marginal_likelihood_grid(thetas, g["ratio_vals"], mode="full")
             best = min(best, time.perf_counter() - t0)

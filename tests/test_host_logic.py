@@ -129,7 +129,19 @@ def test_describe_kernel_flattening():
     from gsum_amd._lib import GradParam
     assert [(g.code, g.dim) for g in describe_gradient(k, 2)] == [(GradParam.TREE_ALPHA, 0), (GradParam.TREE_LENGTH_ISO, 0),
                                                                  (GradParam.TREE_LENGTH_DIM, 16), (GradParam.TREE_LENGTH_DIM, 17), (GradParam.TREE_CONST, 0)]
-    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), DotProduct() + RBF(1.0), ExpSineSquared(), RBF(1.0) ** 2,
+    # round 5: ExpSineSquared (second parameter = periodicity, theta order length_scale, periodicity), Matern(nu = inf), Exponentiation
+    es = gsum_amd.describe_kernel(C(2.0) * ExpSineSquared(length_scale=1.1, periodicity=3.0) ** 2 + WhiteKernel(0.5), 1)
+    assert es.is_tree and (es.leaf[0].family, es.leaf[0].alpha, es.leaf[0].length_scale[0]) == (5, 3.0, 1.1)
+    assert [es.op[i] for i in range(es.n_ops)] == [32 + 0, 16 + 0, 128 + 1, 2, 64 + 2, 1] and es.cval[1] == 2.0
+    assert es.one_arg_diagonal() == 2.0 * 1.0 ** 2 + 0.5 and es.without_white().one_arg_diagonal() == 2.0
+    assert es.plus_constant(0.25).one_arg_diagonal() == 2.75 and es.plus_constant(0.25).cval[3] == 0.25       # (a slot no operand uses)
+    k2 = ExpSineSquared(length_scale=1.1, periodicity=3.0) * Matern([1.0, 2.0], nu=np.inf)
+    assert gsum_amd.describe_kernel(k2, 2).leaf[1].family == 6
+    assert [(g.code, g.dim) for g in describe_gradient(k2, 2)] == [(GradParam.TREE_LENGTH_ISO, 0), (GradParam.TREE_ALPHA, 0),
+                                                                  (GradParam.TREE_LENGTH_DIM, 16), (GradParam.TREE_LENGTH_DIM, 17)]
+    th2 = k2.theta - 0.2
+    assert bytes(gsum_amd.describe_thetas(k2, [th2], 2)[0]) == bytes(gsum_amd.describe_kernel(k2.clone_with_theta(th2), 2))
+    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), DotProduct() + RBF(1.0), C(2.0) ** 2,
                 RBF(1.0) + RBF(2.0) + RBF(3.0) + RBF(4.0) + RBF(5.0)):
         with pytest.raises(NotImplementedError):
             gsum_amd.describe_kernel(bad, 1)
