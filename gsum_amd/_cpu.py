@@ -20,7 +20,7 @@ import numpy as np
 from scipy.linalg import cho_solve as _cho_solve
 from scipy.linalg import solve_triangular
 from scipy.linalg.lapack import dpotrf
-from sklearn.gaussian_process.kernels import RBF, ConstantKernel, ExpSineSquared, Matern, RationalQuadratic
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, DotProduct, ExpSineSquared, Matern, RationalQuadratic
 
 from ._lib import FAMILY, GSUM_MAX_RHS, OP_ADD, OP_CONST, OP_LEAF, OP_POW, OP_WHITE, GradParam, KernelDesc
 from .series import geometric_sum
@@ -34,6 +34,8 @@ def _leaf(desc, d: int, free=False):
     bounds = (1e-300, 1e300) if free else "fixed"
     if int(desc.family) == FAMILY["rq"]:
         return RationalQuadratic(length_scale=ls, alpha=float(desc.alpha), length_scale_bounds=bounds, alpha_bounds=bounds)
+    if int(desc.family) == FAMILY["dot"]:
+        return DotProduct(sigma_0=float(desc.length_scale[0]), sigma_0_bounds=bounds)
     if int(desc.family) == FAMILY["expsine"]:
         return ExpSineSquared(length_scale=ls, periodicity=float(desc.alpha), length_scale_bounds=bounds, periodicity_bounds=bounds)
     nu = _NU[int(desc.family)]

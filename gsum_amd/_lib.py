@@ -23,7 +23,7 @@ GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
 GSUM_MAX_LEAVES = 4
 GSUM_MAX_OPS = 16
-FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4, "expsine": 5, "matern_inf": 6}
+FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4, "expsine": 5, "matern_inf": 6, "dot": 7}
 OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE, OP_POW = 1, 2, 16, 32, 64, 128
 
 
@@ -57,9 +57,10 @@ class KernelDesc(C.Structure):
     def is_tree(self):
         return self.n_ops > 0
 
-    def one_arg_diagonal(self):
+    def one_arg_diagonal(self, X=None):
         """k(x, x) of the ONE-argument form (every stationary leaf exactly 1, WhiteKernel noise in): the diagonal of R_nn at
-        gsum/models.py:824."""
+        gsum/models.py:824.  One number -- unless the tree holds a DotProduct leaf (x . x + sigma_0^2: kernels.py DotProduct.diag), then
+        one value per row of ``X``."""
         if not self.is_tree:
             return self.amplitude * 1.0 + self.white_noise + self.additive_const
         stack = []
@@ -70,7 +71,14 @@ class KernelDesc(C.Structure):
             elif op >= OP_CONST:
                 stack.append(self.cval[op - (OP_WHITE if op >= OP_WHITE else OP_CONST)])
             elif op >= OP_LEAF:
-                stack.append(1.0)
+                lf = self.leaf[op - OP_LEAF]
+                if lf.family == FAMILY["dot"]:
+                    if X is None:
+                        raise ValueError("the diagonal of a kernel with a DotProduct leaf depends on the points: pass X")
+                    Xa = np.asarray(X, dtype=float)
+                    stack.append(np.einsum("ij,ij->i", Xa, Xa) + lf.length_scale[0] ** 2)
+                else:
+                    stack.append(1.0)
             else:
                 b, a = stack.pop(), stack.pop()
                 stack.append(a + b if op == OP_ADD else a * b)

@@ -755,7 +755,7 @@ class ConjugateGaussianProcess:
         if return_std:                               # diag of the one-argument kernel: one number (leaves exactly 1, WhiteKernel noise in)
             X = np.asarray(X, dtype=float)
             factor, desc = self._cov_parts(X.shape[1])
-            return y_mean, np.sqrt(np.full(X.shape[0], factor * desc.one_arg_diagonal()))
+            return y_mean, np.sqrt(np.full(X.shape[0], factor * desc.one_arg_diagonal(X)))      # (a DotProduct leaf: one value per point)
         return y_mean
 
     # -- predict (models.py:753-845) ------------------------------------------------
@@ -876,7 +876,7 @@ class ConjugateGaussianProcess:
             var = cov_factor(self.scale_ ** 2, self.df_)                           # models.py:840
             if return_std:
                 # diag of the one-argument kernel: unit base value, WhiteKernel noise included (:824)
-                diag_nn = desc.one_arg_diagonal()
+                diag_nn = desc.one_arg_diagonal(X)
                 r_diag = diag_nn - colsumsq                                        # models.py:836
                 if pred_noise:
                     r_diag = r_diag + self.nugget                                  # models.py:837-838

@@ -91,7 +91,11 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
     if (depth != 1) GS_FAIL("kernel tree: the program does not reduce to one value");
     for (int l = 0; l < desc->n_leaves; ++l) {
         const gsum_kernel_leaf& lf = desc->leaf[l];
-        if (lf.family < GSUM_RBF || lf.family > GSUM_MATERN_INF) GS_FAIL("kernel tree: unknown leaf family");
+        if (lf.family < GSUM_RBF || lf.family > GSUM_DOT) GS_FAIL("kernel tree: unknown leaf family");
+        if (lf.family == GSUM_DOT) {
+            if (lf.anisotropic || !(lf.length_scale[0] >= 0.0)) GS_FAIL("kernel tree: DotProduct needs sigma_0 >= 0");
+            continue;
+        }
         if (lf.family == GSUM_EXPSINE && (lf.anisotropic || !(lf.alpha > 0.0))) GS_FAIL("kernel tree: ExpSineSquared needs periodicity > 0 and an isotropic length scale");
         if (lf.family == GSUM_RQ && (lf.anisotropic || !(lf.alpha > 0.0))) GS_FAIL("kernel tree: RationalQuadratic needs alpha > 0 and an isotropic length scale");
         for (int i = 0; i < (lf.anisotropic ? d : 1); ++i)

@@ -469,6 +469,14 @@ __device__ __forceinline__ void gs_leaf_eval(const gsum_kernel_leaf& lf, const d
                                              int dim, double& v, double& dv, bool cross = false) {
 #pragma clang fp contract(off)
     dv = 0.0;
+    if (lf.family == GSUM_DOT) {                 // kernels.py DotProduct.__call__: np.inner(X, Y) + sigma_0 ** 2, on and off the diagonal; K_gradient = 2 sigma_0 ** 2
+        double s = 0.0;
+        for (int m = 0; m < d; ++m) s = s + xi[m] * xj[m];
+        const double s0 = lf.length_scale[0] * lf.length_scale[0];
+        v = s + s0;
+        if (want == 1) dv = 2.0 * s0;
+        return;
+    }
     if (diag) {                                  // np.fill_diagonal(K, 1) of the one-argument form; every leaf gradient is 0 there
         v = 1.0;
         return;

@@ -6,10 +6,10 @@ The reference calls ``kernel(X)`` / ``kernel(X, Y)`` on arbitrary scikit-learn k
 * flattened -- ``[ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5})) [+ WhiteKernel] [+ ConstantKernel]``, the family the
   reference's own tests, notebooks and defaults use; it runs the templated fast kernels and the one-workgroup-per-evaluation paths;
 * tree (round 4) -- any ``Sum`` / ``Product`` / ``Exponentiation`` tree over RBF, Matern(0.5, 1.5, 2.5, inf), RationalQuadratic,
-  ExpSineSquared, ConstantKernel and WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``ExpSineSquared * RBF``,
+  ExpSineSquared, DotProduct, ConstantKernel and WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``ExpSineSquared * RBF``,
   ``RBF ** 2`` ...): a postfix program in scikit-learn's own evaluation order, at most 4 stationary leaves and 16 operations.
 
-Other leaves (DotProduct, PairwiseKernel, Matern with another nu: not stationary with a unit diagonal, or Bessel functions) raise
+Other leaves (PairwiseKernel, Matern with another nu: Bessel functions) raise
 ``NotImplementedError`` -- on the 'hip' backend there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's: leaves left to right, a leaf's
 hyperparameters in alphabetical order.  :func:`describe_thetas` / :func:`describe_gradients` reproduce the
 setter's values without a clone per theta.
@@ -17,8 +17,8 @@ setter's values without a clone per theta.
 from __future__ import annotations
 
 import numpy as np
-from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, Exponentiation, ExpSineSquared, Matern, Product, RationalQuadratic, Sum,
-                                              WhiteKernel)
+from sklearn.gaussian_process.kernels import (RBF, ConstantKernel, DotProduct, Exponentiation, ExpSineSquared, Matern, Product,
+                                              RationalQuadratic, Sum, WhiteKernel)
 
 from ._lib import (FAMILY, GSUM_MAX_D, GSUM_MAX_LEAVES, GSUM_MAX_OPS, OP_ADD, OP_CONST, OP_LEAF, OP_MUL, OP_POW, OP_WHITE, GradParam,
                    KernelDesc)
@@ -177,6 +177,11 @@ def _compile_tree(kernel):
             offset[0] += 0 if hl.fixed else 1
             node = _TreeNode("leaf", k, counts["leaf"], offs)
             counts["leaf"] += 1
+        elif isinstance(k, DotProduct):
+            h = k.hyperparameter_sigma_0
+            node = _TreeNode("leaf", k, counts["leaf"], {"sigma_0": free(h, offset[0])})
+            counts["leaf"] += 1
+            offset[0] += 0 if h.fixed else 1
         elif isinstance(k, ExpSineSquared):
             hl, hp = k.hyperparameter_length_scale, k.hyperparameter_periodicity    # alphabetical: length_scale, periodicity
             offs = {"length_scale": free(hl, offset[0])}
@@ -194,12 +199,12 @@ def _compile_tree(kernel):
             offset[0] += 0 if h.fixed else h.n_elements
         else:
             raise NotImplementedError(f"kernel {k!r} is not supported on the device (Sum / Product / Exponentiation trees over RBF, Matern, "
-                                      "RationalQuadratic, ExpSineSquared, ConstantKernel and WhiteKernel are)")
+                                      "RationalQuadratic, ExpSineSquared, DotProduct, ConstantKernel and WhiteKernel are)")
         prog.append(node)
 
     walk(kernel)
     if counts["leaf"] < 1:
-        raise NotImplementedError(f"kernel {kernel} has no stationary (RBF / Matern / RationalQuadratic / ExpSineSquared) part")
+        raise NotImplementedError(f"kernel {kernel} has no RBF / Matern / RationalQuadratic / ExpSineSquared / DotProduct part")
     if counts["leaf"] > GSUM_MAX_LEAVES or len(prog) > GSUM_MAX_OPS:
         raise NotImplementedError(f"kernel {kernel} is too large for the device descriptor ({GSUM_MAX_LEAVES} stationary leaves, "
                                   f"{GSUM_MAX_OPS} operations)")
@@ -227,6 +232,8 @@ def _tree_values(node, theta):
         return val("length_scale", k.length_scale), val("alpha", k.alpha)
     if isinstance(k, ExpSineSquared):
         return val("length_scale", k.length_scale), val("periodicity", k.periodicity)
+    if isinstance(k, DotProduct):
+        return val("sigma_0", k.sigma_0), None
     return val("length_scale", k.length_scale), None
 
 
@@ -255,6 +262,8 @@ def _describe_tree(prog, theta, n_features, shown) -> KernelDesc:
                 lf.family, lf.alpha = FAMILY["rq"], float(alpha)
             elif isinstance(k, ExpSineSquared):
                 lf.family, lf.alpha = FAMILY["expsine"], float(alpha)          # (the leaf's second parameter: the periodicity)
+            elif isinstance(k, DotProduct):
+                lf.family = FAMILY["dot"]                                      # (sigma_0 travels in length_scale[0])
             elif isinstance(k, Matern):
                 lf.family = FAMILY[{0.5: "matern12", 1.5: "matern32", 2.5: "matern52", np.inf: "matern_inf"}[float(k.nu)]]
             else:
@@ -298,6 +307,9 @@ def _tree_gradient_params(prog, theta, n_features):
                 slots[item.offsets["alpha"]] = [gp(GradParam.TREE_ALPHA, item.slot * 16)]
             if item.offsets["length_scale"] is not None:
                 slots[item.offsets["length_scale"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
+        elif isinstance(item.kernel, DotProduct):
+            if item.offsets["sigma_0"] is not None:
+                slots[item.offsets["sigma_0"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]
         elif isinstance(item.kernel, ExpSineSquared):
             if item.offsets["length_scale"] is not None:
                 slots[item.offsets["length_scale"]] = [gp(GradParam.TREE_LENGTH_ISO, item.slot * 16)]

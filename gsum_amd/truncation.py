@@ -95,7 +95,7 @@ class TruncationGP:
         gp = self.coeffs_process
         X = np.asarray(X, dtype=float)
         factor, desc = gp._cov_parts(X.shape[1])
-        kd = (desc.without_white() if two_arg else desc).one_arg_diagonal()
+        kd = (desc.without_white() if two_arg else desc).one_arg_diagonal(X)
         ref, ratio = self.ref(X), self.ratio(X, **self.ratio_kws)
         return (ref * ref) * geometric_sum(x=ratio * ratio, start=start, end=end, excluded=self.excluded) * (factor * kd)
 
@@ -143,7 +143,7 @@ class TruncationGP:
         # matrix fails; rather than regress those workflows the conditioning is retried with a relative jitter on the
         # diagonal of the correlation matrix, smallest first, and says so.
         # (relative to the kernel's own diagonal: amplitude + additive constant of the descriptor)
-        kdiag = float(desc.one_arg_diagonal())      # (desc carries no white noise here: see _cov_terms)
+        kdiag = float(np.mean(desc.one_arg_diagonal(Xc)))      # (desc carries no white noise here: see _cov_terms; a DotProduct leaf: the mean over the points)
         for jitter in (0.0, 1e-14, 1e-12, 1e-10, 1e-8, 1e-6):
             K, info = ctx.factorize(desc, Xc, diag_add=jitter * kdiag, series=(sc, ref_c, ratio_c))
             try:

@@ -30,19 +30,20 @@ extern "C" {
 typedef struct gsum_ctx gsum_ctx;
 typedef struct gsum_mat gsum_mat;   /* device square matrix / Cholesky factor */
 enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3,
-       GSUM_RQ = 4, GSUM_EXPSINE = 5, GSUM_MATERN_INF = 6 /* RationalQuadratic, ExpSineSquared, Matern(nu = inf): tree leaves only */ };
+       GSUM_RQ = 4, GSUM_EXPSINE = 5, GSUM_MATERN_INF = 6, /* RationalQuadratic, ExpSineSquared, Matern(nu = inf): tree leaves only */
+       GSUM_DOT = 7 /* DotProduct (tree leaf; sigma_0 in length_scale[0]): x . y + sigma_0^2, the one leaf whose diagonal is not 1 */ };
 /* A scikit-learn kernel (the reference accepts any: models.py:146-147, 686-688, 958-960).  Arithmetic follows
  * sklearn/gaussian_process/kernels.py: RBF 1556-1565, Matern 1711-1738, RationalQuadratic 1874-1903, WhiteKernel 1401-1414, Sum 858-866,
- * Product 956-966, ExpSineSquared 2032-2064, Exponentiation 1126-1150.  n_ops == 0: the flattened form amplitude * base(X / length_scale) + additive_const (+ white_noise on the
+ * Product 956-966, ExpSineSquared 2032-2064, Exponentiation 1126-1150, DotProduct 2166-2186.  n_ops == 0: the flattened form amplitude * base(X / length_scale) + additive_const (+ white_noise on the
  * one-argument diagonal) -- the reference's own kernels, the templated fast kernels.  n_ops > 0: a Sum / Product tree as a postfix
- * program in scikit-learn's evaluation order: GSUM_OP_LEAF + l pushes leaf[l](x, y) (exactly 1 on the one-argument diagonal),
+ * program in scikit-learn's evaluation order: GSUM_OP_LEAF + l pushes leaf[l](x, y) (exactly 1 on the one-argument diagonal; DotProduct: x . x + sigma_0^2),
  * GSUM_OP_CONST + c pushes cval[c], GSUM_OP_WHITE + c pushes cval[c] on that diagonal and 0 elsewhere, ADD / MUL combine two values,
  * GSUM_OP_POW + c raises the top value to the power cval[c] (Exponentiation: the exponent is no hyperparameter). */
 #define GSUM_MAX_LEAVES 4
 #define GSUM_MAX_OPS 16
 enum { GSUM_OP_ADD = 1, GSUM_OP_MUL = 2, GSUM_OP_LEAF = 16, GSUM_OP_CONST = 32, GSUM_OP_WHITE = 64, GSUM_OP_POW = 128 };
 typedef struct {
-    int32_t family;                    /* GSUM_RBF ... GSUM_MATERN_INF */
+    int32_t family;                    /* GSUM_RBF ... GSUM_DOT */
     int32_t anisotropic;               /* 0: length_scale[0] for every dimension */
     double length_scale[GSUM_MAX_D];
     double alpha;                      /* RationalQuadratic: scale mixture alpha; ExpSineSquared: periodicity (unused otherwise) */

@@ -166,7 +166,7 @@ def record_parity(name, **values):
 def tree_kernel(expr):
     """Kernel of a tests/golden/tree_kernels.json case (see make_golden.py): the expression evaluated over the scikit-learn kernel classes."""
     import numpy as np
-    from sklearn.gaussian_process.kernels import (RBF, Exponentiation, ExpSineSquared, Matern, WhiteKernel, RationalQuadratic,
+    from sklearn.gaussian_process.kernels import (RBF, DotProduct, Exponentiation, ExpSineSquared, Matern, WhiteKernel, RationalQuadratic,
                                                   ConstantKernel as C)
     return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic,
-                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, np=np))
+                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, DotProduct=DotProduct, np=np))

@@ -749,13 +749,16 @@ TREE_KERNELS = [          # (expression, input dimension): scikit-learn kernels 
     ("Matern([1.2, 2.1], nu=np.inf) * C(1.5) + WhiteKernel(1e-3)", 2),
     ("Exponentiation(C(1.1) * RationalQuadratic(length_scale=1.2, alpha=0.7) + C(0.5), 2) + WhiteKernel(1e-3)", 2),
     ("ExpSineSquared(length_scale=0.9, periodicity=6.0) * C(0.8) + WhiteKernel(1e-2)", 1),
+    # ... and the one scikit-learn leaf that is not stationary (its diagonal depends on the points)
+    ("C(0.001) * DotProduct(sigma_0=2.0) ** 2 + RBF(1.1) + WhiteKernel(1e-3)", 1),
+    ("C(0.05) * DotProduct(sigma_0=1.3) * RBF([2.5, 4.0]) + WhiteKernel(1e-2)", 2),
 ]
 
 
 def tree_kernel(expr):
-    from sklearn.gaussian_process.kernels import Exponentiation, ExpSineSquared, RationalQuadratic
+    from sklearn.gaussian_process.kernels import DotProduct, Exponentiation, ExpSineSquared, RationalQuadratic
     return eval(expr, {"__builtins__": {}}, dict(RBF=RBF, Matern=Matern, WhiteKernel=WhiteKernel, C=C, RationalQuadratic=RationalQuadratic,
-                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, np=np))
+                                                 ExpSineSquared=ExpSineSquared, Exponentiation=Exponentiation, DotProduct=DotProduct, np=np))
 
 
 def gen_tree_kernels():

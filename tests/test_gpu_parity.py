@@ -1164,7 +1164,7 @@ def test_tree_kernels_golden():
         ctx = gp._context()
         K = ctx.kernel_matrix(desc, X)
         Kx = ctx.kernel_matrix(desc, X, Xs)
-        libm = any(name in case["expr"] for name in ("RationalQuadratic", "ExpSineSquared", "Exponentiation"))     # pow() / sin(): within ulps of numpy's
+        libm = any(name in case["expr"] for name in ("RationalQuadratic", "ExpSineSquared", "Exponentiation", "**", "DotProduct"))     # pow() / sin() / BLAS dot products: within ulps of numpy's
         assert ulp_close(K[3], np.array(case["K_row3"]), 16 if libm else 4) and ulp_close(Kx[3], np.array(case["K_cross_row3"]), 16 if libm else 4)
         if not libm and SVML_HOST:
             np.testing.assert_array_equal(K, kern(X))                       # same exp restatement, same evaluation order: bit for bit

@@ -533,6 +533,7 @@ def test_single_gradient_evaluation_forms_are_bit_identical(n, kind):
     kern = (C(1.3) * RBF(0.2) + WhiteKernel(1e-8)) if kind == "flat" else (C(0.8) * RBF([0.6, 1.1]) + C(0.3) * Matern(1.4, nu=1.5) + WhiteKernel(1e-7))
     desc, prm = gsum_amd.describe_kernel(kern, d), gsum_amd.kernels.describe_gradient(kern, d)
     names = ("grad_interleave", "grad_split", "grad_lazy_chain")
+    aborts = lab.get_option("chain_aborts")            # (earlier tests provoke give-ups on this context on purpose)
     try:
         for name in names:
             lab.set_option(name, 0)
@@ -547,7 +548,7 @@ def test_single_gradient_evaluation_forms_are_bit_identical(n, kind):
         batch = lab.lml_grad_batch([desc, desc], [prm, prm], X, Z, 1e-10)
         for a, b in zip(batch, want):
             assert np.array_equal(np.asarray(a)[1], np.asarray(b))
-        assert lab.get_option("chain_aborts") == 0
+        assert lab.get_option("chain_aborts") == aborts
     finally:
         for name in names:
             lab.set_option(name, 1)

@@ -141,7 +141,13 @@ def test_describe_kernel_flattening():
                                                                   (GradParam.TREE_LENGTH_DIM, 16), (GradParam.TREE_LENGTH_DIM, 17)]
     th2 = k2.theta - 0.2
     assert bytes(gsum_amd.describe_thetas(k2, [th2], 2)[0]) == bytes(gsum_amd.describe_kernel(k2.clone_with_theta(th2), 2))
-    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), DotProduct() + RBF(1.0), C(2.0) ** 2,
+    dp = gsum_amd.describe_kernel(C(0.5) * DotProduct(sigma_0=0.7) ** 2 + RBF(1.0), 2)           # the one leaf whose diagonal is not 1
+    assert dp.leaf[0].family == 7 and dp.leaf[0].length_scale[0] == 0.7
+    Xd = np.array([[1.0, 2.0], [0.5, -1.0]])
+    np.testing.assert_array_equal(dp.one_arg_diagonal(Xd), (C(0.5) * DotProduct(sigma_0=0.7) ** 2 + RBF(1.0)).diag(Xd))
+    with pytest.raises(ValueError):
+        dp.one_arg_diagonal()
+    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), C(2.0) ** 2,
                 RBF(1.0) + RBF(2.0) + RBF(3.0) + RBF(4.0) + RBF(5.0)):
         with pytest.raises(NotImplementedError):
             gsum_amd.describe_kernel(bad, 1)
@@ -248,9 +254,10 @@ def test_gradient_parameter_map_follows_sklearn_theta_order():
     assert [(g.code, g.weight) for g in describe_gradient(k, 1)] == [(P.WHITE, 0.1), (P.LENGTH_ISO, 0.0)]
     assert describe_gradient(C(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed"), 1) == []
     assert [(g.code, g.dim) for g in describe_gradient(RBF(1.0) + RBF(2.0), 1)] == [(P.TREE_LENGTH_ISO, 0), (P.TREE_LENGTH_ISO, 16)]     # a tree
+    from sklearn.gaussian_process.kernels import DotProduct, PairwiseKernel
+    assert [(g.code, g.dim) for g in describe_gradient(DotProduct() + RBF(2.0), 1)] == [(P.TREE_LENGTH_ISO, 0), (P.TREE_LENGTH_ISO, 16)]   # (sigma_0 rides in length_scale[0])
     with pytest.raises(NotImplementedError):
-        from sklearn.gaussian_process.kernels import DotProduct
-        describe_gradient(DotProduct() + RBF(2.0), 1)
+        describe_gradient(PairwiseKernel() + RBF(2.0), 1)
 
 
 def test_series_scale_struct_and_student_host_algebra():
@@ -513,10 +520,10 @@ def test_describe_thetas_equals_describing_the_clones():
         assert all(bytes(a) == bytes(b) for a, b in zip(got, want)), kern
     with pytest.raises(ValueError, match="correct number of entries"):
         describe_thetas(RBF(0.2), [[0.1, 0.2]], 1)
-    from sklearn.gaussian_process.kernels import DotProduct
+    from sklearn.gaussian_process.kernels import PairwiseKernel
     assert describe_thetas(RBF(0.1) * RBF(0.2), [[0.1, 0.2]], 1)[0].is_tree              # (a tree since round 4)
     with pytest.raises(NotImplementedError, match="not supported on the device"):       # the family check comes before the theta-size check
-        describe_thetas(C(1.0) * (DotProduct() + WhiteKernel(0.1)), [[0.1, 0.2, 0.3, 0.4, 0.5]], 1)
+        describe_thetas(C(1.0) * (PairwiseKernel() + WhiteKernel(0.1)), [[0.1, 0.2, 0.3, 0.4, 0.5]], 1)
 
 
 def test_describe_gradients_equals_describing_the_clones():
