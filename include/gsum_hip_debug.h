@@ -16,7 +16,8 @@ extern "C" {
 /* ---- options accepted by gsum_set_option only in the lab build ---------------------------------------------------------------
  * batch schedule: "wave_min" (calls with fewer evaluations run them one after the other), "wave_depth" (panels per far update,
  *   default 4), "wave_deep_rows", "wave_near_on_chain", "wave_serial", "wave_shift", "wave_panel_wg4" (0 | 4 | 8 waves per panel workgroup), "lazy_far" (0: no grouping of trailing
- *   updates), "lazy_min_np";  gradient batches: "batch_slots"
+ *   updates), "lazy_min_np";  gradient batches: "batch_slots", "grad_batch_wave";  one gradient evaluation alone: "grad_interleave" (the sweep's launches
+ *   enqueued between the factorisation's outer steps), "grad_split" (Q_p beside the R^-1 product, traces from stored dR triangles), "grad_lazy_chain"
  * single factorisation: "chain_rows" 256 | 512, "chain_lazy", "chain_min_np", "chain_fused", "chain_prefetch", "la_depth2",
  *   "bulk_lds_pad", "chain_test_abort" (one-shot give-up of the persistent chain at that outer step), "chain_stamps"
  * other sweeps: "predict_lazy", "medium_lazy", "build_lower_only", "diag_stamps", "panel_stats", "bench_fill" */
