@@ -127,3 +127,80 @@ def test_fuzz_truncation_predict_vs_oracle(seed):
         mg, cg = gp.predict(Xs, order=order, return_cov=True, kind=kind)
         np.testing.assert_allclose(mg, mo, rtol=tol, atol=tol * np.abs(mo).max())
         np.testing.assert_allclose(cg, co, rtol=1e-6, atol=tol * max(np.abs(co).max(), 1e-300))
+
+
+def random_tree(rng, d):
+    """A random Sum / Product / Exponentiation tree over every leaf class the device evaluates (round 5: ExpSineSquared, Matern(nu = inf),
+    DotProduct; round 4: RationalQuadratic), positive definite by construction (products and integer powers of positive definite kernels,
+    a white-noise floor)."""
+    from sklearn.gaussian_process.kernels import DotProduct, Exponentiation, ExpSineSquared, RationalQuadratic
+
+    def leaf():
+        kind = rng.choice(["rbf", "m52", "m32", "m12", "minf", "rq", "ess", "dot"] if d == 1 else ["rbf", "m52", "m32", "m12", "minf", "rq", "dot"])
+        ls = rng.uniform(0.5, 1.6, size=d) if (d > 1 and rng.rand() < 0.5 and kind not in ("rq", "ess", "dot")) else float(rng.uniform(0.5, 1.6))
+        if kind == "rbf":
+            return RBF(ls)
+        if kind == "rq":
+            return RationalQuadratic(length_scale=ls, alpha=float(rng.uniform(0.5, 2.0)))
+        if kind == "ess":                     # (a periodic kernel of the Euclidean distance is positive definite in one dimension only)
+            return ExpSineSquared(length_scale=ls, periodicity=float(rng.uniform(2.0, 5.0)))
+        if kind == "dot":
+            return C(0.05) * DotProduct(sigma_0=float(rng.uniform(0.5, 2.0)))
+        return Matern(ls, nu={"m52": 2.5, "m32": 1.5, "m12": 0.5, "minf": np.inf}[kind])
+
+    n_leaves = int(rng.randint(1, 4))
+    kern = None
+    for _ in range(n_leaves):
+        term = leaf()
+        if rng.rand() < 0.4:
+            term = C(float(rng.uniform(0.5, 2.0))) * term
+        if rng.rand() < 0.25:
+            term = Exponentiation(term, 2)
+        kern = term if kern is None else (kern * term if rng.rand() < 0.4 else kern + term)
+    w = float(10 ** rng.uniform(-4, -2))
+    return kern + (WhiteKernel(w) if rng.rand() < 0.5 else WhiteKernel(w, noise_level_bounds="fixed"))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_kernel_trees_vs_oracle(seed):
+    """Random kernel trees (models.py:146-147, 958-960 accept any scikit-learn kernel): the matrix against scikit-learn's, likelihood and
+    gradient of both process classes and the predictive mean / standard deviation against the oracle; tolerances scaled by conditioning."""
+    rng = np.random.RandomState(7000 + seed)
+    d = int(rng.randint(1, 3))
+    n = int(rng.choice([17, 60, 128, 150, 300]))
+    while True:
+        kern = random_tree(rng, d)
+        try:
+            desc = gsum_amd.describe_kernel(kern, d)
+            break
+        except NotImplementedError as exc:                # (a draw beyond the descriptor's 16 operations: the next one)
+            assert "too large" in str(exc)
+    X = rng.rand(n, d) * (3.0 + 0.02 * n)
+    Xs = rng.rand(11, d) * (3.0 + 0.02 * n)
+    ctx = gsum_amd.default_context(0)
+    K, Kx = ctx.kernel_matrix(desc, X), ctx.kernel_matrix(desc, X, Xs)
+    scale = np.abs(kern(X)).max()
+    np.testing.assert_allclose(K, kern(X), rtol=1e-13, atol=1e-14 * scale)
+    np.testing.assert_allclose(Kx, kern(X, Xs), rtol=1e-13, atol=1e-14 * scale)
+    y = drawn(rng, kern, X, int(rng.randint(1, 4)))
+    pri = random_priors(rng)
+    theta = kern.theta + rng.uniform(-0.15, 0.15, size=len(kern.theta))
+    cond = np.linalg.cond(kern.clone_with_theta(theta)(X) + 1e-10 * np.eye(n))
+    for cls, ofn in ((gsum_amd.ConjugateGaussianProcess, orc.cgp_lml_grad), (gsum_amd.ConjugateStudentProcess, orc.csp_lml_grad)):
+        if cls is gsum_amd.ConjugateStudentProcess and "sd" in pri:
+            continue
+        gp = cls(kernel=kern, optimizer=None, **pri)
+        val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+        vo, go = ofn(kern, theta, X, y, **pri)
+        assert val == pytest.approx(vo, rel=max(1e-10, 1e-15 * cond)), kern
+        tol = 1e-14 * cond + 1e-9
+        np.testing.assert_allclose(grad, go, rtol=tol, atol=tol * np.abs(go).max(), err_msg=str(kern))
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri)
+    gp.fit(X, y)
+    mean, std = gp.predict(Xs, return_std=True)
+    fit = orc.cgp_fit(kern, X, y, **pri)
+    condf = np.linalg.cond(fit["corr"] + 1e-10 * np.eye(n))
+    ptol = 1e-14 * condf + 1e-10
+    mo, so = orc.cgp_predict(fit, Xs, return_std=True)
+    np.testing.assert_allclose(mean, mo, rtol=ptol, atol=ptol * max(1.0, np.abs(mo).max()), err_msg=str(kern))
+    np.testing.assert_allclose(std ** 2, so ** 2, rtol=1e-6, atol=ptol * fit["cov_factor"] * max(1.0, scale), err_msg=str(kern))
