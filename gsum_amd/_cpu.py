@@ -207,7 +207,22 @@ class CpuContext:
         if rhs.ndim == 1:
             rhs = rhs[:, None]
         W = solve_triangular(L.A, rhs, lower=True)
+        L.solved_W = W                              # (what the device factor's border rows hold: gsum_predict_var reads it)
         return W.T @ W, float(np.log(np.diag(L.A)).sum())
+
+    def predict_var(self, L: CpuMatrix, desc, X, Xs, want_vtw=False):
+        """gsum_predict_var's contract: column sums of squares of V = L^-1 kernel(X, Xs) and, with ``want_vtw``, V^T W as m x GSUM_MAX_RHS
+        (columns beyond the k held right-hand sides zero) for the right-hand sides of the last forward_gram on this factor."""
+        W = getattr(L, "solved_W", None)
+        if want_vtw and W is None:
+            raise ValueError("gsum_predict_var: V^T W needs right-hand sides solved against this factor first (gsum_forward_gram)")
+        V = solve_triangular(L.A, kernel_matrix(desc, np.asarray(X, dtype=float), np.asarray(Xs, dtype=float)), lower=True)
+        css = np.einsum("ij,ij->j", V, V)
+        if not want_vtw:
+            return css, None
+        out = np.zeros((V.shape[1], GSUM_MAX_RHS))
+        out[:, :W.shape[1]] = V.T @ W
+        return css, out
 
     def cho_solve(self, L: CpuMatrix, B):
         return _cho_solve((L.A, True), np.asarray(B, dtype=float))

@@ -100,3 +100,28 @@ def test_large_known_answer_n512(cpu_backend, large_lml):
 
 def test_tree_kernels_golden(cpu_backend):
     T.test_tree_kernels_golden()
+
+
+def test_predict_var_contract_on_the_cpu_backend():
+    """gsum_predict_var (SURVEY.md 8b's name for the predictive pieces, models.py:822-836) on the cpu backend's operator interface: the same
+    contract as the HIP entry point -- sums of squares always, V^T W only for right-hand sides a forward_gram left on the factor."""
+    import numpy as np
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel
+    from gsum_amd._cpu import CpuContext
+    from gsum_amd._lib import GSUM_MAX_RHS
+    rng = np.random.RandomState(3)
+    X, Xs, rhs = rng.rand(40, 2) * 4, rng.rand(9, 2) * 4, rng.randn(40, 3)
+    desc = gsum_amd.describe_kernel(Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-6), 2)
+    ctx = CpuContext()
+    L, info = ctx.factorize(desc, X, diag_add=1e-10)
+    assert info == 0
+    css0, none = ctx.predict_var(L, desc, X, Xs)
+    assert none is None
+    with pytest.raises(ValueError, match="solved"):
+        ctx.predict_var(L, desc, X, Xs, want_vtw=True)
+    ctx.forward_gram(L, rhs)
+    css, vtw = ctx.predict_var(L, desc, X, Xs, want_vtw=True)
+    want = ctx.predict_terms(L, desc, X, Xs, rhs=rhs)
+    np.testing.assert_allclose(css, want[0], rtol=1e-13)
+    assert np.array_equal(css, css0) and vtw.shape == (9, GSUM_MAX_RHS) and not vtw[:, 3:].any()
+    np.testing.assert_allclose(vtw[:, :3], want[1], rtol=1e-12, atol=1e-13)
