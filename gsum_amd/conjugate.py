@@ -479,21 +479,20 @@ class ConjugateGaussianProcess:
         X = self.X_train_ if X is None else X
         y = self.y_train_ if y is None else y
         X = np.asarray(X, dtype=float)
-        if theta is not None and not eval_gradient:
-            # models.py:953 without scikit-learn's clone (0.1-0.3 ms of get_params / set_params): same descriptor, byte for byte
+        if theta is not None:
+            # models.py:953 without scikit-learn's clone (0.1-0.4 ms of get_params / set_params per call -- more than the device takes at the
+            # reference's own sizes): same descriptor and gradient parameters, byte for byte (tests/test_host_logic.py)
             desc = describe_thetas(kernel, [theta], X.shape[1])[0]
         else:
-            if theta is not None:
-                kernel = kernel.clone_with_theta(np.asarray(theta, dtype=float))     # models.py:953
             desc = describe_kernel(kernel, X.shape[1])
         Z = self._rhs(X, y)
         if eval_gradient:                                                            # models.py:957-958, 1041-1056
-            params = describe_gradient(kernel, X.shape[1])
+            params = describe_gradients(kernel, [theta], X.shape[1])[0] if theta is not None else describe_gradient(kernel, X.shape[1])
             if not params:
                 return self.log_marginal_likelihood(theta, X=X, y=y), np.zeros(0)
             G, sld, info, trace, H = self._context().lml_grad(desc, params, X, Z, self.nugget)
             if info != 0:
-                return -np.inf, np.zeros_like(kernel.theta)                          # models.py:970-972
+                return -np.inf, np.zeros(len(params))                                # models.py:970-972
             return self._lml_grad_gram(G, sld, trace, H, X.shape[0])
         G, sld, info = self._context().lml_batch([desc], X, Z, self.nugget)
         if info[0] != 0:

@@ -338,13 +338,60 @@ def _is_flat(kernel, n_features):
         return False
 
 
+# ---- the walk over a kernel, once per kernel ---------------------------------------------------------------------------------------
+# An objective evaluation of ``fit`` describes the SAME kernel object at another theta, tens of times; the walk over scikit-learn's
+# objects (every ``hyperparameter_*`` property builds a namedtuple) costs 30-150 us, at the reference's own sizes as much as the device
+# call.  The result of the walk is kept per (fingerprint of the kernel, n_features): the fingerprint is every node's class and every
+# leaf's parameters and bounds read from its ``__dict__`` (plain attributes: a few us), so an edited kernel is another key, and a hit is
+# used only while the kernel it was compiled from still has that fingerprint (its nodes are what the cached walk reads values from).
+_COMPILED = {}
+_COMPILED_MAX = 128
+
+
+def _fingerprint(k):
+    if isinstance(k, (Sum, Product)):
+        return (type(k), _fingerprint(k.k1), _fingerprint(k.k2))
+    if isinstance(k, Exponentiation):
+        return (type(k), float(k.exponent), _fingerprint(k.kernel))
+    items = []
+    for name, v in k.__dict__.items():
+        if isinstance(v, np.ndarray):
+            v = (v.shape, v.tobytes())
+        elif isinstance(v, (list, tuple)):
+            v = tuple((x.shape, x.tobytes()) if isinstance(x, np.ndarray) else x for x in v)
+        items.append((name, v))
+    return (type(k), tuple(items))
+
+
+def _compiled(kernel, n_features):
+    """(is_flat, terms | prog, n_dims) of a kernel: ``_flatten`` where the flattened descriptor covers it, else ``_compile_tree``
+    (which raises NotImplementedError for what the device cannot evaluate)."""
+    try:
+        key = (_fingerprint(kernel), n_features)
+        hit = _COMPILED.get(key)
+    except TypeError:                              # (an unhashable parameter: no cache)
+        key = hit = None
+    if hit is not None and _fingerprint(hit[0]) == key[0]:
+        return hit[1]
+    if _is_flat(kernel, n_features):
+        terms, n_dims = _flatten(kernel)
+        out = (True, terms, n_dims)
+    else:
+        prog, n_dims = _compile_tree(kernel)
+        out = (False, prog, n_dims)
+    if key is not None:
+        if len(_COMPILED) >= _COMPILED_MAX:
+            _COMPILED.clear()
+        _COMPILED[key] = (kernel, out)
+    return out
+
+
 def describe_kernel(kernel, n_features: int) -> KernelDesc:
     """``kernel`` as a :class:`KernelDesc` for inputs with ``n_features`` columns: the flattened form where it applies, else a tree."""
-    if _is_flat(kernel, n_features):
-        terms, _ = _flatten(kernel)
-        return _describe(terms, lambda leaf: leaf.value, n_features, kernel)
-    prog, _ = _compile_tree(kernel)
-    return _describe_tree(prog, None, n_features, kernel)
+    flat, walk, _ = _compiled(kernel, n_features)
+    if flat:
+        return _describe(walk, lambda leaf: leaf.value, n_features, kernel)
+    return _describe_tree(walk, None, n_features, kernel)
 
 
 def describe_thetas(kernel, thetas, n_features: int):
@@ -352,9 +399,9 @@ def describe_thetas(kernel, thetas, n_features: int):
     costs 70-320 us per call (get_params / set_params over the tree), more than a batched n = 2048 evaluation takes on the device.
     The values are formed exactly as the setter forms them (kernels.py Kernel.theta: ``np.exp(theta[i])`` for a scalar hyperparameter,
     ``np.exp(theta[i:i+n])`` for a vector one), so the descriptors are equal byte for byte (tests/test_host_logic.py)."""
-    describe_kernel(kernel, n_features)          # the family check first: an unsupported tree says so, not "wrong theta size"
-    if not _is_flat(kernel, n_features):
-        prog, n_dims = _compile_tree(kernel)
+    flat, walk, n_dims = _compiled(kernel, n_features)     # the family check first: an unsupported tree says so, not "wrong theta size"
+    if not flat:
+        prog = walk
         out = []
         for theta in thetas:
             theta = np.atleast_1d(np.asarray(theta, dtype=float))
@@ -362,7 +409,7 @@ def describe_thetas(kernel, thetas, n_features: int):
                 raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
             out.append(_describe_tree(prog, theta, n_features, kernel))
         return out
-    terms, n_dims = _flatten(kernel)
+    terms = walk
     out = []
     for theta in thetas:
         theta = np.atleast_1d(np.asarray(theta, dtype=float))
@@ -421,13 +468,13 @@ def describe_gradient(kernel, n_features: int):
     a leaf's free hyperparameters in alphabetical order): what ``kernel(X, eval_gradient=True)``
     would put in ``K_gradient[:, :, p]``.  Same kernel family as :func:`describe_kernel`."""
     describe_kernel(kernel, n_features)                       # same validation, same error messages
-    if not _is_flat(kernel, n_features):
-        prog, n_dims = _compile_tree(kernel)
-        out = _tree_gradient_params(prog, None, n_features)
+    flat, walk, n_dims = _compiled(kernel, n_features)
+    if not flat:
+        out = _tree_gradient_params(walk, None, n_features)
         if len(out) != n_dims or n_dims != len(kernel.theta):
             raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
         return out
-    terms, n_dims = _flatten(kernel)
+    terms = walk
     out = _gradient_params(terms, lambda leaf: leaf.value, n_features)
     if len(out) != n_dims or n_dims != len(kernel.theta):
         raise NotImplementedError(f"could not map theta of {kernel} onto device gradient parameters")
@@ -438,9 +485,9 @@ def describe_gradients(kernel, thetas, n_features: int):
     """``[describe_gradient(kernel.clone_with_theta(t), n_features) for t in thetas]`` without the clones (see
     :func:`describe_thetas`): the weights of the additive / white parameters are the hyperparameter VALUES, so there is one list
     per theta."""
-    describe_kernel(kernel, n_features)
-    if not _is_flat(kernel, n_features):
-        prog, n_dims = _compile_tree(kernel)
+    flat, walk, n_dims = _compiled(kernel, n_features)
+    if not flat:
+        prog = walk
         out = []
         for theta in thetas:
             theta = np.atleast_1d(np.asarray(theta, dtype=float))
@@ -448,7 +495,7 @@ def describe_gradients(kernel, thetas, n_features: int):
                 raise ValueError("theta has not the correct number of entries. Should be %d; given are %d" % (n_dims, theta.size))
             out.append(_tree_gradient_params(prog, theta, n_features))
         return out
-    terms, n_dims = _flatten(kernel)
+    terms = walk
     out = []
     for theta in thetas:
         theta = np.atleast_1d(np.asarray(theta, dtype=float))

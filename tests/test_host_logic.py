@@ -556,3 +556,33 @@ def test_product_library_reads_no_environment_variable():
     text = subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True).stdout
     for name in ("GSUM_LOOKAHEAD", "GSUM_CHAIN_PERSIST", "GSUM_PIVOT_GUARD_ULPS", "GPU_MAX_HW_QUEUES"):
         assert name not in text, name
+
+
+def test_kernel_walk_cache_never_serves_an_edited_kernel():
+    """kernels._compiled keeps the walk over a scikit-learn kernel per fingerprint (class of every node, parameters and bounds of every leaf):
+    an objective evaluation of fit describes the same kernel at another theta tens of times (models.py:634-640).  A kernel edited in place is
+    another key; an entry whose kernel was edited afterwards is not used for an equal, fresh kernel."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    from gsum_amd import kernels as K
+    from gsum_amd.kernels import describe_gradient
+
+    def make(flat):
+        return (C(1.0) * RBF(0.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")) if flat else \
+            (C(1.0) * RBF(0.5) + C(0.5) * RBF([2.0, 3.0]) + WhiteKernel(1e-6, noise_level_bounds="fixed"))
+
+    for flat in (True, False):
+        K._COMPILED.clear()
+        k = make(flat)
+        d0 = bytes(gsum_amd.describe_kernel(k, 2))
+        assert len(K._COMPILED) == 1 and bytes(gsum_amd.describe_kernel(k, 2)) == d0 and len(K._COMPILED) == 1
+        th = k.theta + 0.2
+        assert bytes(gsum_amd.describe_thetas(k, [th], 2)[0]) == bytes(gsum_amd.describe_kernel(k.clone_with_theta(th), 2))
+        node = k
+        while not isinstance(node, C):
+            node = node.k1
+        node.constant_value = 2.5                                         # edited in place: the cached walk's object now holds 2.5
+        d1 = gsum_amd.describe_kernel(k, 2)
+        assert (d1.amplitude if flat else d1.cval[0]) == 2.5
+        assert bytes(gsum_amd.describe_kernel(make(flat), 2)) == d0       # a fresh kernel equal to the ORIGINAL: not the edited values
+        node.constant_value_bounds = "fixed"                              # ... and a changed bound changes theta's layout
+        assert len(describe_gradient(k, 2)) == len(k.theta) == (1 if flat else 4)
