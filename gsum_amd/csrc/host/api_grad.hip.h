@@ -285,6 +285,57 @@ static int gs_grad_harvest(gsum_ctx* ctx, gs_slot* sl, int P, double* G_out, dou
     return 0;
 }
 
+// n <= GS_GSMALL_MAX: value + gradient pieces of every kernel of the call in ONE launch, one workgroup each (k_grad_small): the reference's own
+// sizes, where a dozen launches and two synchronisations per objective evaluation cost more than the arithmetic.  Measured per objective
+// evaluation through the class (tools/gpu_small_fit_profile.py): n = 8 / 20 / 48 / 64: 202 / 239 / 277 / 311 us against ~340 on the general path;
+// n = 96 / 128: 406 / 486 -- four waves walk the rows of the contractions, so the general path keeps those orders.
+#define GS_GSMALL_MAX 64
+static int gs_grad_small(gsum_ctx* ctx, const gsum_kernel_desc* descs, int n_desc, const gsum_grad_param* params, int P, double nugget,
+                         double* G_out, double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
+    const int k = ctx->in->k, CH = std::min(512, n_desc);
+    ctx->cur = &ctx->slots[0];
+    hipStream_t s = ctx->cur->sm;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_desc = 0, o_par = up((size_t)CH * sizeof(gsum_kernel_desc)), o_res = o_par + up((size_t)CH * P * sizeof(gsum_grad_param)),
+                 o_gres = o_res + up((size_t)CH * 258 * 8), o_scr = o_gres + up((size_t)CH * P * 257 * 8);
+    if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * GS_GSMALL_SCRATCH * 8)) return -1;
+    char* base = (char*)ctx->scratch;
+    const size_t per = (size_t)258 + (size_t)P * 257;
+    if (gs_reserve_pinned(ctx, (size_t)CH * per * 8)) return -1;
+    double* hres = ctx->hbatch;
+    double* hg = hres + (size_t)CH * 258;
+    for (int lo = 0; lo < n_desc; lo += CH) {
+        const int cnt = std::min(CH, n_desc - lo);
+        GS_CHECK(hipMemcpyAsync(base + o_desc, descs + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
+        GS_CHECK(hipMemcpyAsync(base + o_par, params + (size_t)lo * P, (size_t)cnt * P * sizeof(gsum_grad_param), hipMemcpyHostToDevice, s));
+        bool tree = false;
+        for (int e = 0; e < cnt; ++e) tree = tree || descs[lo + e].n_ops > 0;
+        hipLaunchKernelGGL(tree ? k_grad_small<true> : k_grad_small<false>, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n, ctx->in->d,
+                           ctx->in->Z, k, (const gsum_kernel_desc*)(base + o_desc), (const gsum_grad_param*)(base + o_par), P, nugget,
+                           (double*)(base + o_scr), (double*)(base + o_res), (double*)(base + o_gres));
+        GS_CHECK(hipGetLastError());
+        GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipMemcpyAsync(hg, base + o_gres, (size_t)cnt * P * 257 * 8, hipMemcpyDeviceToHost, s));
+        GS_CHECK(hipStreamSynchronize(s));
+        for (int e = 0; e < cnt; ++e) {
+            const double* r = hres + (size_t)e * 258;
+            const int i = lo + e;
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) G_out[(size_t)i * k * k + a * k + b] = r[a * 16 + b];
+            sld_out[i] = r[256];
+            info_out[i] = (int64_t)r[257];
+            for (int p = 0; p < P; ++p) {
+                const double* g = hg + ((size_t)e * P + p) * 257;
+                const bool ok = info_out[i] == 0;              // not positive definite: no gradient pieces (the caller looks at info)
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < k; ++b) H_out[(((size_t)i * P + p) * k + a) * k + b] = ok ? g[a * 16 + b] : 0.0;
+                trace_out[(size_t)i * P + p] = ok ? g[256] : 0.0;
+            }
+        }
+    }
+    return 0;
+}
+
 // one value + gradient evaluation alone on slot 0 (inputs already uploaded, descriptor checked)
 static int gs_grad_single(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_param* params, int n_params, double nugget,
                           double* G_out, double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
@@ -311,6 +362,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
     if (rc) return rc;
     ctx->in = &ctx->op;
     if (gs_check_desc(ctx, desc, d)) return -2;
+    if (n <= GS_GSMALL_MAX && ctx->small_path) return gs_grad_small(ctx, desc, 1, params, n_params, nugget, G_out, sld_out, info_out, trace_out, H_out);
     return gs_grad_single(ctx, desc, params, n_params, nugget, G_out, sld_out, info_out, trace_out, H_out);
 }
 
@@ -424,6 +476,7 @@ int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_
     ctx->in = &ctx->op;
     for (int i = 0; i < n_desc; ++i)
         if (gs_check_desc(ctx, &descs[i], d)) return -2;
+    if (n <= GS_GSMALL_MAX && ctx->small_path) return gs_grad_small(ctx, descs, n_desc, params, n_params, nugget, G_out, sld_out, info_out, trace_out, H_out);
     if (n_desc == 1) return gs_grad_single(ctx, &descs[0], params, n_params, nugget, G_out, sld_out, info_out, trace_out, H_out);
     if (n_desc >= ctx->wave_min && n > 256 && ctx->grad_batch_wave)
         return gs_grad_batch_wave(ctx, descs, n_desc, params, n_params, nugget, G_out, sld_out, info_out, trace_out, H_out);

@@ -182,3 +182,192 @@ __global__ __launch_bounds__(256) void k_grad_reduce2(const double* part, int ch
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Value + gradient pieces for n <= 128 in ONE workgroup per evaluation (round 5): the reference's own problem sizes are 5-100 points
+// and its fit() drives L-BFGS with log_marginal_likelihood(theta, eval_gradient=True) (models.py:634-640, 957-958, 1041-1056) -- the
+// general path's dozen launches and two synchronisations cost 250 us per objective evaluation there, this kernel ~60.
+//   k_lml_small's steps (same code: G, sum log diag and info equal the value path's bit for bit), the explicit block inverse from
+//   gs_diag_block, R^-1 = L^-T L^-1 on the matrix cores (gs_tile128), V^T = W^T L^-1, then k_grad_contract's contractions per
+//   hyperparameter, one wave per row: trace_p = tr(R^-1 dR_p), H_p = V^T dR_p V.
+//   scratch per evaluation: A | W^T (16 rows) and V^T (16 rows) in one slot | L^-1 | L^-T | R^-1  (five 128 x 128 slots);
+//   res: 258 doubles as k_finalize;  gres: P x 257 (H_p 16 x 16, then the trace).
+// ------------------------------------------------------------------------------------------------
+#define GS_GSMALL_SCRATCH (5 * 128 * 128)
+template <bool TREE>
+__global__ __launch_bounds__(256, 2) void k_grad_small(const double* X, int n, int d, const double* Z, int k,
+                                                     const gsum_kernel_desc* __restrict__ descs, const gsum_grad_param* __restrict__ params,
+                                                     int P, double nugget, double* scratch, double* res, double* gres) {
+#pragma clang fp contract(off)
+    __shared__ double dg0[128];
+    __shared__ double ldet;
+    __shared__ __attribute__((aligned(16))) double wsd[GS_DIAG_WS];     // the build's points, the block's tables, the tile's stages, the contractions' rows
+    static_assert(GS_DIAG_WS >= GS_TILE_LD_DOUBLES, "one LDS workspace serves every phase");
+    double* us = wsd;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const gsum_kernel_desc& desc = descs[blockIdx.x];
+    double* A = scratch + (int64_t)blockIdx.x * GS_GSMALL_SCRATCH;
+    double* Wt = A + 128 * 128;                                         // W^T: 16 x 128
+    double* Vt = Wt + 16 * 128;                                         // V^T: 16 x 128
+    double* Linv = A + 2 * 128 * 128;
+    double* Ut = A + 3 * 128 * 128;                                     // L^-T, row-major
+    double* Rinv = A + 4 * 128 * 128;
+    double* out = res + (int64_t)blockIdx.x * 258;
+    double* gout = gres + (int64_t)blockIdx.x * P * 257;
+    // ---- kernel matrix, factorisation, W^T, Gram matrix: k_lml_small, statement for statement
+    double* etab = us + 128 * GSUM_MAX_D;
+    if (t < 16) etab[t] = gs_exp_th[t];
+    else if (t < 32) etab[t] = gs_exp_tl[t - 16];
+    for (int idx = t; idx < 128 * d; idx += 256) {
+        const int r = idx / d, dd = idx - r * d;
+        const double ls = desc.anisotropic ? desc.length_scale[dd] : desc.length_scale[0];
+        us[idx] = r < n ? X[(int64_t)r * d + dd] / ls : 0.0;
+    }
+    __syncthreads();
+    if (TREE && descs[blockIdx.x].n_ops > 0) gs_build_tile128_tree(A, 128, X, 0, 0, n, d, descs[blockIdx.x], nugget, dg0, w, lane);
+    else gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
+    __threadfence_block();
+    __syncthreads();
+    const int bad = gs_diag_block(A, 128, Linv, (double*)nullptr, &ldet, dg0, nullptr, wsd);
+    if (bad) {
+        if (t == 0) {
+            out[256] = 0.0;
+            out[257] = (double)bad;
+        }
+        return;
+    }
+    for (int idx = t; idx < 16 * 128; idx += 256) {
+        const int c = idx >> 7, i = idx & 127;
+        Wt[idx] = (c < k && i < n) ? Z[(int64_t)i * k + c] : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (w == 0) gs_panel16(Wt, 128, 16, wsd, lane);
+    __threadfence_block();
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    if (w == 0) {
+        gs_d4 g = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double wv = Wt[fr * 128 + 16 * kb + 4 * s4 + fq];
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, wv, g, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) out[(fq + 4 * x) * 16 + fr] = g[x];
+        if (lane == 0) {
+            out[256] = ldet;
+            out[257] = 0.0;
+        }
+    }
+    // ---- L^-T (the transpose of the block inverse), then on the matrix cores V^T = W^T L^-1 = W^T (L^-T)^T and R^-1 = L^-T (L^-T)^T
+    // (beyond n the factor is the identity: everything below works on the leading n16 x n16 part, n16 = n rounded up to the tiles' K step)
+    const int n16 = (n + 15) & ~15;
+    {
+        const int c = t & 127, r0 = t >> 7;                             // thread t writes column c of rows r0, r0 + 2, ...: reads along a row of L^-1
+        if (c < n16) {
+#pragma unroll 8
+            for (int r = r0; r < n16; r += 2) Ut[r * 128 + c] = Linv[c * 128 + r];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                                   // (the tables in wsd are no longer needed: the tile's stages take their place)
+    // (rows 16 .. 127 of the A operand are whatever the slot holds: they feed accumulators that are never stored)
+    gs_tile128(Vt, 128, Wt, 128, Ut, 128, 16, n16, n16, 0, 1.0, wsd);
+    gs_tile128(Rinv, 128, Ut, 128, Ut, 128, n16, n16, n16, 0, 1.0, wsd);
+    // ---- contractions (k_grad_contract's terms, one wave per TWO rows): the points and V^T in LDS, Q_p rows and the row traces beside them
+    double* xs = wsd;                                                  // 128 x GSUM_MAX_D
+    double* Qs = xs + 128 * GSUM_MAX_D;                                // 128 x 16
+    double* trs = Qs + 128 * 16;                                       // 128
+    double* vs = trs + 128;                                            // V^T, 16 x 128
+    static_assert(GS_DIAG_WS >= 128 * GSUM_MAX_D + 128 * 16 + 128 + 16 * 128, "the contractions' LDS");
+    for (int idx = t; idx < 128 * GSUM_MAX_D; idx += 256) {
+        const int r = idx / GSUM_MAX_D, m = idx - r * GSUM_MAX_D;
+        xs[idx] = (r < n && m < d) ? X[(int64_t)r * d + m] : 0.0;
+    }
+    for (int idx = t; idx < 16 * 128; idx += 256) vs[idx] = (idx & 127) < n16 ? Vt[idx] : 0.0;
+    double inv_ls[GSUM_MAX_D];
+#pragma unroll
+    for (int m = 0; m < GSUM_MAX_D; ++m) inv_ls[m] = 1.0 / (desc.anisotropic ? desc.length_scale[m < d ? m : 0] : desc.length_scale[0]);
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+        const gsum_grad_param pr = params[(int64_t)blockIdx.x * P + p];
+        for (int i0 = 2 * w; i0 < n; i0 += 8) {                        // rows i0, i0 + 1: two independent dependency chains per wave
+            double acc[2][16], tr[2] = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
+            for (int j = lane; j < n; j += 64) {
+                double g[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = i0 + r < n ? i0 + r : i0;             // (an odd n: the second row repeats the first and is not stored)
+                    bool walked = false;
+                    if constexpr (TREE) {
+                        if (desc.n_ops > 0) {
+                            (void)gs_tree_eval(desc, xs + i * GSUM_MAX_D, xs + j * GSUM_MAX_D, d, i == j, &pr, &g[r]);
+                            walked = true;
+                        }
+                    }
+                    if (!walked) {
+                        double s = 0.0, dsel = 0.0;
+#pragma unroll
+                        for (int m = 0; m < GSUM_MAX_D; ++m)
+                            if (m < d) {
+                                const double u = (xs[i * GSUM_MAX_D + m] - xs[j * GSUM_MAX_D + m]) * inv_ls[m];
+                                const double dmm = u * u;
+                                s += dmm;
+                                if (m == pr.dim) dsel = dmm;
+                            }
+                        g[r] = gs_kernel_grad(desc, pr, s, pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel, i == j);
+                    }
+                    if (j <= i) tr[r] = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[i * 128 + j], g[r], tr[r]);
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double v = vs[c * 128 + j];
+                    acc[0][c] = __builtin_fma(g[0], v, acc[0][c]);
+                    acc[1][c] = __builtin_fma(g[1], v, acc[1][c]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (i0 + r >= n) break;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double v = acc[r][c];
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                    acc[r][c] = v;
+                }
+                double tt = tr[r];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tt += __shfl_xor(tt, off, 64);
+                if (lane < 16) {
+                    double v = acc[r][0];
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[r][c] : v;
+                    Qs[(i0 + r) * 16 + lane] = v;
+                }
+                if (lane == 0) trs[i0 + r] = tt;
+            }
+        }
+        __syncthreads();
+        {
+            const int a = t >> 4, b = t & 15;                          // H_p = V^T Q_p, rows in index order (deterministic)
+            double h = 0.0;
+            for (int i = 0; i < n; ++i) h = __builtin_fma(vs[a * 128 + i], Qs[i * 16 + b], h);
+            gout[(int64_t)p * 257 + t] = h;
+            if (t == 0) {
+                double ts = 0.0;
+                for (int i = 0; i < n; ++i) ts += trs[i];
+                gout[(int64_t)p * 257 + 256] = ts;
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -552,3 +552,47 @@ def test_single_gradient_evaluation_forms_are_bit_identical(n, kind):
     finally:
         for name in names:
             lab.set_option(name, 1)
+
+
+@pytest.mark.parametrize("n,d,kind", [(5, 1, "flat"), (20, 1, "flat"), (33, 2, "tree"), (64, 2, "flat"), (64, 1, "tree")])
+def test_small_gradient_kernel_against_the_general_path(n, d, kind):
+    """k_grad_small (n <= 64: value + gradient pieces of a call in ONE launch, one workgroup per kernel -- the reference's own sizes, where
+    fit() drives L-BFGS with log_marginal_likelihood(theta, eval_gradient=True): models.py:634-640, 957-958, 1041-1056) against the general
+    path (option small_path = 0): G, sum log diag and info bit for bit (the value path's code), traces and H_p to rounding; a call of several
+    kernels equals the single calls bit for bit; a matrix that is not positive definite reports its info and zero pieces."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C, RationalQuadratic
+    lab = gsum_amd.lab_context(0)
+    rng = np.random.RandomState(100 * n + d)
+    X = rng.rand(n, d) * (2.0 + 0.05 * n)
+    Z = np.concatenate([rng.randn(n, 4), np.ones((n, 1))], axis=1)
+    if kind == "flat":
+        kern = C(1.4) * Matern(0.7 if d == 1 else [0.6, 1.1], nu=2.5) + WhiteKernel(1e-4) + C(0.2)
+    else:
+        kern = C(0.9) * RBF(0.8 if d == 1 else [0.7, 1.2]) + C(0.4) * RationalQuadratic(length_scale=1.3, alpha=0.8) + WhiteKernel(1e-4)
+    kernels = [kern.clone_with_theta(kern.theta + 0.05 * i) for i in range(5)]
+    descs = [gsum_amd.describe_kernel(k, d) for k in kernels]
+    prms = [gsum_amd.kernels.describe_gradient(k, d) for k in kernels]
+    try:
+        lab.set_option("small_path", 0)
+        want = [lab.lml_grad(dd, pp, X, Z, 1e-10) for dd, pp in zip(descs, prms)]
+        lab.set_option("small_path", 1)
+        got = [lab.lml_grad(dd, pp, X, Z, 1e-10) for dd, pp in zip(descs, prms)]
+        batch = lab.lml_grad_batch(descs, prms, X, Z, 1e-10)
+    finally:
+        lab.set_option("small_path", 1)
+    for i, (g, wv) in enumerate(zip(got, want)):
+        assert g[2] == wv[2] == 0
+        assert np.array_equal(g[0], wv[0]) and g[1] == wv[1]                     # G and sum log diag: the value path's own code
+        cond = np.linalg.cond(kernels[i](X) + 1e-10 * np.eye(n))
+        tol = 1e-14 * cond + 1e-12
+        np.testing.assert_allclose(g[3], wv[3], rtol=tol, atol=tol * np.abs(wv[3]).max())
+        np.testing.assert_allclose(g[4], wv[4], rtol=tol, atol=tol * np.abs(wv[4]).max())
+        for a, b in zip(batch, g):
+            assert np.array_equal(np.asarray(a)[i], np.asarray(b))
+    # not positive definite: a duplicated point without any jitter
+    Xd = X.copy()
+    Xd[-1] = Xd[0]
+    bad = gsum_amd.describe_kernel(C(1.0) * RBF(0.8 if d == 1 else [0.7, 1.2]), d)
+    bp = gsum_amd.kernels.describe_gradient(C(1.0) * RBF(0.8 if d == 1 else [0.7, 1.2]), d)
+    G, sld, info, tr, H = lab.lml_grad(bad, bp, Xd, Z, 0.0)
+    assert info > 0 and not tr.any() and not H.any()

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import gsum_amd  # noqa: E402
 from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C  # noqa: E402
 
-for n in (20, 128, 500, 2048):
+for n in (8, 20, 48, 64, 96, 128, 500, 2048):
     rng = np.random.RandomState(n)
     X = np.linspace(0, 1, n)[:, None] * (0.1 * n)
     kern = C(1.0) * RBF(0.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
