@@ -304,6 +304,34 @@ def notebook_leg():
             rec["max_rel_vs_reference_grid"] = float(np.max(np.abs(grid - np.array(g["grid"])) / np.abs(np.array(g["grid"]))))
         out[name] = rec
     out["tree_over_flat"] = out["tree_rbf_rbf_white"]["ms"] / out["flat_rbf_white"]["ms"]
+    # fit() with the default optimiser at the notebook's own training-set sizes (models.py:630-669): L-BFGS over objective evaluations with
+    # gradient, each ONE launch of k_grad_small; the same class on the cpu backend (numpy / scipy / scikit-learn) beside it
+    from sklearn.gaussian_process.kernels import ConstantKernel as C
+    fits = {}
+    for nn in (5, 20, 64):
+        Xf = np.linspace(0, 1, nn)[:, None] * (0.1 * nn + 1.0)
+        kern = C(1.0) * RBF(0.5) + WhiteKernel(1e-6, noise_level_bounds="fixed")
+        yf = gsum_amd.sample_mvn_cholesky(kern, Xf, 4, nugget=1e-8, random_state=1)
+        rec = {}
+        for backend in ("hip", "cpu"):
+            gpf = gsum_amd.ConjugateGaussianProcess(kernel=kern, center=0, disp=0, df=1, scale=1, backend=backend)
+            gpf.fit(Xf, yf)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                gpf.fit(Xf, yf)
+                ts.append(time.perf_counter() - t0)
+            th = gpf.kernel_.theta + 0.05
+            gpf.log_marginal_likelihood(th, eval_gradient=True)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                gpf.log_marginal_likelihood(th, eval_gradient=True)
+            rec[backend] = {"fit_ms": min(ts) * 1e3, "objective_with_gradient_us": (time.perf_counter() - t0) / 50 * 1e6,
+                            "length_scale": float(gpf.kernel_.k1.k2.length_scale)}
+        fits[f"n{nn}"] = rec
+    out["small_fit"] = {"what": "ConjugateGaussianProcess(C * RBF + fixed White).fit with fmin_l_bfgs_b, 4 curves: wall time of fit() and of one "
+                                "log_marginal_likelihood(theta, eval_gradient=True); 'cpu' = the same class on numpy / scipy / scikit-learn",
+                        **fits}
     return out
 
 

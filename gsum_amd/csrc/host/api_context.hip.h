@@ -177,6 +177,7 @@ int64_t gsum_get_option(gsum_ctx* ctx, const char* name) {
     if (!strcmp(name, "chain_persist")) return ctx->chain_persist;
     if (!strcmp(name, "chain_probe")) return ctx->chain_probe;          // 0 not run, 1 streams concurrent, -1 serialised
     if (!strcmp(name, "chain_aborts")) return ctx->chain_aborts;
+    if (!strcmp(name, "uploads_skipped")) return ctx->uploads_skipped;
     if (!strcmp(name, "pipes_ok")) return ctx->pipes_ok;
     if (!strcmp(name, "pipe_overlap_permille")) return ctx->pipe_overlap_permille;
     if (!strcmp(name, "pipe_heals")) return ctx->pipe_heals;

@@ -8,7 +8,8 @@ int gsum_set_inputs_sets(gsum_ctx* ctx, const double* X, int64_t n, int32_t d, c
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
     if (gs_upload_X(ctx, &ctx->res, X, n, d)) return -1;
     if (gs_upload_Z(ctx, &ctx->res, RHS_sets, n, k, n_sets)) return -1;
-    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    if (ctx->upload_pending) GS_CHECK(hipStreamSynchronize(ctx->cur->sm));        // (nothing was copied: the bytes were already there)
+    ctx->upload_pending = false;
     return 0;
 }
 
@@ -36,7 +37,8 @@ static int gs_upload_inputs(gsum_ctx* ctx, const double* X, int64_t n, int32_t d
     if (d < 1 || d > GSUM_MAX_D) GS_FAIL("input dimension must be 1..GSUM_MAX_D");
     if (gs_upload_X(ctx, &ctx->op, X, n, d)) return -1;
     if (gs_upload_Z(ctx, &ctx->op, RHS, n, k)) return -1;
-    GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    if (ctx->upload_pending) GS_CHECK(hipStreamSynchronize(ctx->cur->sm));
+    ctx->upload_pending = false;
     return 0;
 }
 

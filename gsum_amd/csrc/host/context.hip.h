@@ -87,6 +87,8 @@ struct gs_inputs {
     double* X = nullptr; int64_t n = 0; int d = 0; size_t X_cap = 0;     // n x d points
     double* Z = nullptr; int k = 0; size_t Z_cap = 0;                    // n x k right-hand sides; n_sets of them back to back
     int n_sets = 1;                                                      // (gsum_set_inputs_sets: evaluation i of a call reads set set_of[i])
+    std::vector<double> x_host, z_host;                                  // host copies of SMALL inputs (gs_upload_X / gs_upload_Z skip an equal upload)
+    int64_t z_rows = 0;
 };
 
 // state of a gradient evaluation's stage behind the factorisation (api_grad.hip.h), kept in the context so that gs_potrf_chain's step hook can
@@ -111,6 +113,8 @@ struct gsum_ctx {
     gs_slot slots[GS_MAX_SLOTS];
     int n_slots_ready = 0;
     gs_slot* cur = nullptr;          // slot the helpers below enqueue on
+    bool upload_pending = false;     // a host -> device copy of inputs was enqueued since the last synchronisation of the main stream
+    int64_t uploads_skipped = 0;     // uploads of small inputs whose bytes were already on the device
     int grad_batch_wave = 1;         // gradient batches: the factorisations on the grouped schedule (gs_grad_batch_wave)
     int grad_interleave = 1;         // one gradient evaluation alone: the U = L^-T sweep's launches enqueued step by step between the factorisation's
     int grad_split = 1;              // ... and its kernel-gradient contractions split: Q_p beside the R^-1 product, the traces from stored triangles of dR_p

@@ -596,3 +596,36 @@ def test_small_gradient_kernel_against_the_general_path(n, d, kind):
     bp = gsum_amd.kernels.describe_gradient(C(1.0) * RBF(0.8 if d == 1 else [0.7, 1.2]), d)
     G, sld, info, tr, H = lab.lml_grad(bad, bp, Xd, Z, 0.0)
     assert info > 0 and not tr.any() and not H.any()
+
+
+def test_equal_small_inputs_are_not_uploaded_again(ctx):
+    """Objective evaluations of fit() hand the same points and right-hand sides over every time (models.py:634-640): inputs of up to 256 KB
+    are remembered on the host and an equal upload is skipped (read-back "uploads_skipped"); a changed byte, another shape or a large input is
+    copied, and results never depend on it."""
+    rng = np.random.RandomState(11)
+    n = 40
+    X = rng.rand(n, 2) * 4
+    Z = np.concatenate([rng.randn(n, 3), np.ones((n, 1))], axis=1)
+    desc = gsum_amd.describe_kernel(Matern([0.7, 1.3], nu=2.5) + WhiteKernel(1e-4), 2)
+    first = ctx.lml_batch([desc], X, Z, 1e-10)
+    s0 = ctx.get_option("uploads_skipped")
+    again = ctx.lml_batch([desc], X, Z, 1e-10)
+    assert ctx.get_option("uploads_skipped") == s0 + 2                    # X and Z
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    Z2 = Z.copy()
+    Z2[7, 1] += 1.0
+    changed = ctx.lml_batch([desc], X, Z2, 1e-10)
+    assert ctx.get_option("uploads_skipped") == s0 + 3 and not np.array_equal(changed[0], first[0])      # X skipped, Z copied
+    back = ctx.lml_batch([desc], X, Z, 1e-10)
+    assert np.array_equal(back[0], first[0]) and ctx.get_option("uploads_skipped") == s0 + 4
+    # another entry point writes the same operator-level set: the memory follows it
+    K = ctx.kernel_matrix(desc, X[:10])
+    assert K.shape == (10, 10)
+    after = ctx.lml_batch([desc], X, Z, 1e-10)
+    assert np.array_equal(after[0], first[0])
+    big = rng.rand(20000, 2)                                              # 320 KB: not remembered
+    s1 = ctx.get_option("uploads_skipped")
+    ctx.kernel_matrix(desc, big[:3], big)
+    ctx.kernel_matrix(desc, big[:3], big)
+    assert ctx.get_option("uploads_skipped") <= s1 + 2
