@@ -358,6 +358,7 @@ int gsum_lml_grad(gsum_ctx* ctx, const gsum_kernel_desc* desc, const gsum_grad_p
                   double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
     if (!ctx || !desc || !params || !G_out || !sld_out || !info_out || !trace_out || !H_out) return -2;
     if (gs_grad_check(ctx, params, n_params, d, k)) return -2;
+    if (gs_check_order(ctx, n)) return -2;
     int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
     if (rc) return rc;
     ctx->in = &ctx->op;
@@ -471,6 +472,7 @@ int gsum_lml_grad_batch(gsum_ctx* ctx, const gsum_kernel_desc* descs, int32_t n_
             if (params[(size_t)i * n_params + p].code != params[p].code || params[(size_t)i * n_params + p].dim != params[p].dim)
                 GS_FAIL("gsum_lml_grad_batch: every kernel must have the same hyperparameter structure");
     }
+    if (gs_check_order(ctx, n)) return -2;
     int rc = gs_upload_inputs(ctx, X, n, d, RHS, k);
     if (rc) return rc;
     ctx->in = &ctx->op;

@@ -22,6 +22,7 @@ static int gs_lml_on_sets(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* k
     GS_CHECK(hipSetDevice(ctx->device));
     ctx->in = I;
     if (!ctx->in->X) GS_FAIL("gsum_set_inputs has not been called");
+    if (gs_check_order(ctx, ctx->in->n)) return -2;
     for (int i = 0; i < n_kernels; ++i)
         if (gs_check_desc(ctx, &kernels[i], ctx->in->d)) return -2;
     // (kernel trees take the one-workgroup-per-evaluation paths too since round 5: k_lml_small<true> / k_lml_medium<true> walk the

@@ -22,8 +22,16 @@ static int64_t gs_padded_order(const gsum_ctx* ctx, int64_t n) {
     return p128;
 }
 
+// orders the factorisation paths accept (see gs_mat_alloc)
+static int gs_check_order(gsum_ctx* ctx, int64_t n) {
+    if (n <= 0 || (n + 2 * GS_NB) * (n + 2 * GS_NB + GS_BORDER) >= (int64_t)1 << 31) GS_FAIL("matrix order out of range (1 .. 46000)");
+    return 0;
+}
+
 static int gs_mat_alloc(gsum_ctx* ctx, int64_t n, gsum_mat** out) {
-    if (n <= 0 || n > (1 << 20)) GS_FAIL("matrix order out of range");
+    // validated up to n = 40960 (tools/gpu_large_order.py: build + factorisation + solve reproduce K[cols, cols] to 2e-15 at 24576 / 32768 / 40960,
+    // 57-60 TF/s); above 46 000 the padded matrix has 2^31 elements or more, which no test has exercised: refused rather than trusted
+    if (gs_check_order(ctx, n)) return -2;
     gsum_mat* m = new gsum_mat();
     m->n = n;
     m->np = gs_padded_order(ctx, n);

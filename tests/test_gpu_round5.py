@@ -629,3 +629,26 @@ def test_equal_small_inputs_are_not_uploaded_again(ctx):
     ctx.kernel_matrix(desc, big[:3], big)
     ctx.kernel_matrix(desc, big[:3], big)
     assert ctx.get_option("uploads_skipped") <= s1 + 2
+
+
+def test_order_32768_property_and_the_refused_orders(ctx):
+    """Twice BASELINE's largest configuration (an 8.6-GB augmented matrix, 128 outer steps on the deep-grouped single-factorisation schedule):
+    with right-hand sides taken from K itself, G = Z^T K^-1 Z must return K[cols][:, cols] (tools/gpu_large_order.py shows the same at 40960).
+    Orders whose padded matrix would have 2^31 elements or more were never exercised and are refused with a message, not attempted."""
+    rng = np.random.RandomState(8)
+    n = 32768
+    X = rng.rand(n, 2) * 58.0
+    kern = Matern(length_scale=1.0, nu=2.5) + WhiteKernel(1e-2, noise_level_bounds="fixed")
+    cols = np.array([0, 1, 127, 128, 16383, 32767])
+    Z = kern(X, X[cols])
+    Z[cols, np.arange(len(cols))] += 1e-2
+    desc = gsum_amd.describe_kernel(kern, 2)
+    G, sld, info = ctx.lml_batch([desc], X, Z, 0.0)
+    assert info[0] == 0 and np.isfinite(sld[0])
+    np.testing.assert_allclose(G[0], Z[cols], rtol=0, atol=1e-11)
+    ctx.set_option("release_scratch", 1)
+    big = np.zeros((47000, 1))
+    with pytest.raises(ValueError, match="out of range"):
+        ctx.lml_batch([gsum_amd.describe_kernel(RBF(1.0), 1)], big, np.ones((47000, 1)), 1e-10)
+    with pytest.raises((ValueError, RuntimeError), match="out of range"):
+        ctx.kernel_matrix_dev(gsum_amd.describe_kernel(RBF(1.0), 1), big)
