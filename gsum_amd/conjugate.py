@@ -233,8 +233,12 @@ class ConjugateGaussianProcess:
 
     Parameters are those of gsum/models.py:107-109.  Additive: ``device`` (GPU index; default
     ``$LOCAL_RANK`` or 0) and ``backend`` ('hip', the default, or 'cpu': the same operator interface on
-    numpy / scipy; also ``GSUM_BACKEND``).  ``basis`` other than ``None`` and
-    ``decomposition='eig'`` are not available on the device and raise ``NotImplementedError``.
+    numpy / scipy; also ``GSUM_BACKEND``).  ``basis`` other than ``None`` raises ``NotImplementedError`` (the reference
+    does not support it either, models.py:149-150).  ``decomposition='eig'`` (models.py:713-717, 810-811, 973-974) is accepted: every quantity
+    the reference computes through ``(eig, Q) = eigh(R)`` -- R^-1 y, log det R, the predictive pieces -- is the same quantity the factorisation
+    on the device gives (the reference's own two modes agree to 1e-14), so likelihood, fit and predict run the one device path; the
+    eigen-decomposition itself exists only as the attributes ``_eigh_tuple_`` / ``corr_sqrt_`` / ``corr_L_`` (= Q sqrt(eig), models.py:715-717),
+    computed from ``corr_`` on the host when one of them is read.
     """
 
     def __init__(self, kernel=None, center=0, disp=0, df=1, scale=1, sd=None, basis=None, nugget=1e-10,
@@ -430,9 +434,7 @@ class ConjugateGaussianProcess:
         return self._ctx
 
     def _check_decomposition(self):
-        if self.decomposition == 'eig':
-            raise NotImplementedError("decomposition='eig' is not built for the device path")
-        if self.decomposition != 'cholesky':
+        if self.decomposition not in ('cholesky', 'eig'):
             raise ValueError('decomposition must be "cholesky" or "eig"')     # models.py:719, 976
 
     @staticmethod
@@ -461,7 +463,21 @@ class ConjugateGaussianProcess:
         return self._corr
 
     @property
+    def _eigh_tuple_(self):
+        """(eig, Q) of corr_ + nugget I (models.py:714-715) -- an attribute of the 'eig' mode only, computed on the host when it is read."""
+        if self.decomposition != 'eig' or not self._fit:
+            return None
+        if getattr(self, '_eigh_cache', None) is None:
+            from scipy.linalg import eigh
+            C = np.array(self.corr_, dtype=float)
+            self._eigh_cache = eigh(C + self.nugget * np.eye(C.shape[0]))
+        return self._eigh_cache
+
+    @property
     def corr_L_(self):
+        if self.decomposition == 'eig':                      # models.py:717: Q @ diag(sqrt(eig)), not triangular
+            tup = self._eigh_tuple_
+            return None if tup is None else tup[1] @ np.diag(np.sqrt(tup[0]))
         if self._corr_L is None and self._L_dev is not None:
             self._corr_L = self._L_dev.to_host()
         return self._corr_L
@@ -675,7 +691,7 @@ class ConjugateGaussianProcess:
             self.X_train_, self.y_train_ = X, y
         self.basis_train_ = self.basis(self.X_train_)
         self._fit = False
-        self._corr = self._corr_L = None
+        self._corr = self._corr_L = self._eigh_cache = None
         Xd = np.asarray(self.X_train_, dtype=float)
         Z = self._rhs(Xd, self.y_train_)
 

@@ -795,11 +795,45 @@ def gen_tree_kernels():
     return cases
 
 
+def gen_eig_mode():
+    """decomposition='eig' through the reference (models.py:713-717, 810-811, 973-974, 1016-1019): likelihood value + gradient, fit,
+    predict (mean, std, cov) and the square-root attributes' defining property, for a conjugate GP, a Student process and a truncation GP."""
+    cases = []
+    for idx, (expr, dim) in enumerate([("C(1.2) * RBF(0.8) + WhiteKernel(1e-3)", 1), ("Matern([0.9, 1.6], nu=2.5) + WhiteKernel(1e-2)", 2)]):
+        rng = np.random.RandomState(900 + idx)
+        n, r = 40, 3
+        X = (np.sort(rng.rand(n))[:, None] * 8.0) if dim == 1 else rng.rand(n, 2) * np.array([5.0, 7.0])
+        Xs = (np.linspace(0.3, 7.5, 7)[:, None]) if dim == 1 else rng.rand(7, 2) * np.array([5.0, 7.0])
+        y = rng.randn(n, r)
+        kern = tree_kernel(expr)
+        pri = dict(center=0.2, disp=0.5, df=3, scale=1.3)
+        gp = gsum.ConjugateGaussianProcess(kernel=kern, optimizer=None, nugget=1e-8, decomposition='eig', **pri)
+        theta = kern.theta + 0.1 * np.cos(np.arange(len(kern.theta)))
+        val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+        gp.fit(X, y)
+        mean, std = gp.predict(Xs, return_std=True)
+        _, cov = gp.predict(Xs, return_cov=True)
+        S = gp.corr_sqrt_
+        sp = gsum.ConjugateStudentProcess(kernel=kern, optimizer=None, nugget=1e-8, decomposition='eig', **pri)
+        sval = sp.log_marginal_likelihood(theta, X=X, y=y)
+        tg = gsum.TruncationGP(kernel=kern, ratio=0.6, ref=2.0, optimizer=None, nugget=1e-8, decomposition='eig', **pri)
+        orders = np.arange(r)
+        tg.fit(X, gsum.partials(y, ratio=0.6, ref=2.0, orders=orders), orders=orders)
+        cases.append(dict(expr=expr, dim=dim, X=L(X), y=L(y), Xs=L(Xs), priors=pri, nugget=1e-8, theta=L(theta), lml=float(val), grad=L(grad),
+                          fit=dict(lml=float(gp.log_marginal_likelihood_value_), center=L(gp.center_), disp=L(gp.disp_), df=float(gp.df_),
+                                   scale=float(gp.scale_), cov_factor=float(gp.cov_factor_)),
+                          predict=dict(mean=L(mean), std=L(std), cov=L(cov)),
+                          sqrt_residual=float(np.abs(S @ S.T - (gp.corr_ + 1e-8 * np.eye(n))).max()),
+                          student_lml=float(sval), trunc_lml=float(tg.log_marginal_likelihood(theta=kern.theta, ratio=0.55))))
+    return cases
+
+
 def main():
     only = set(sys.argv[1:])           # e.g. `make_golden.py classmethods cbar_ratio_grid` regenerates just those files
     if only:
         gens = dict(classmethods=gen_classmethods, cbar_ratio_grid=gen_cbar_ratio_grid, s5_predict=gen_s5_predict,
-                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying, sample_y=gen_sample_y, tree_kernels=gen_tree_kernels)
+                    s1_plumbing=gen_s1_plumbing, underlying=gen_underlying, sample_y=gen_sample_y, tree_kernels=gen_tree_kernels,
+                    eig_mode=gen_eig_mode)
         for name in only:
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(gens[name](), f, indent=1)
@@ -839,6 +873,8 @@ def main():
         json.dump(gen_sample_y(), f, indent=1)
     with open(os.path.join(HERE, "tree_kernels.json"), "w") as f:
         json.dump(gen_tree_kernels(), f, indent=1)
+    with open(os.path.join(HERE, "eig_mode.json"), "w") as f:
+        json.dump(gen_eig_mode(), f, indent=1)
     with open(os.path.join(HERE, "s5_predict.json"), "w") as f:      # ~10 minutes on 8 cores, ~15 GB
         json.dump(gen_s5_predict(), f, indent=1)
     import sklearn, scipy

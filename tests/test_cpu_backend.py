@@ -125,3 +125,7 @@ def test_predict_var_contract_on_the_cpu_backend():
     np.testing.assert_allclose(css, want[0], rtol=1e-13)
     assert np.array_equal(css, css0) and vtw.shape == (9, GSUM_MAX_RHS) and not vtw[:, 3:].any()
     np.testing.assert_allclose(vtw[:, :3], want[1], rtol=1e-12, atol=1e-13)
+
+
+def test_eig_mode_golden(cpu_backend):
+    T.test_eig_mode_golden()

@@ -1202,3 +1202,41 @@ def test_tree_kernels_golden():
                                    grid, rtol=max(1e-10, 100 * vtol))
         achieved[case["expr"]] = dict(lml_rel=worst_v, grad_rel_to_max=worst_g, cond=case["cond"])
     record_parity("tree_kernels_golden_" + gp.backend, **achieved)
+
+
+def test_eig_mode_golden():
+    """decomposition='eig' (models.py:713-717, 810-811, 973-974, 1016-1019) against the reference's own outputs in that mode
+    (tests/golden/eig_mode.json): likelihood value and gradient, fit, predict (mean, std, cov), the Student process and the truncation
+    likelihood -- the same quantities the factorisation on the device gives (the reference's two modes agree to 1e-14) -- and the mode's
+    attributes, materialised when read: corr_sqrt_ = Q sqrt(eig) with S S^T = corr_ + nugget I, _eigh_tuple_."""
+    from conftest import load_golden, tree_kernel
+    for case in load_golden("eig_mode.json"):
+        kern = tree_kernel(case["expr"])
+        X, y, Xs = np.array(case["X"]), np.array(case["y"]), np.array(case["Xs"])
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, nugget=case["nugget"], decomposition="eig", **case["priors"])
+        theta = np.array(case["theta"])
+        val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+        assert val == pytest.approx(case["lml"], rel=1e-10)
+        np.testing.assert_allclose(grad, case["grad"], rtol=1e-8, atol=1e-8 * np.abs(case["grad"]).max())
+        gp.fit(X, y)
+        f = case["fit"]
+        assert gp.log_marginal_likelihood_value_ == pytest.approx(f["lml"], rel=1e-10)
+        np.testing.assert_allclose(gp.center_, f["center"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gp.disp_, f["disp"], rtol=1e-9)
+        assert gp.df_ == f["df"] and gp.scale_ == pytest.approx(f["scale"], rel=1e-9) and gp.cov_factor_ == pytest.approx(f["cov_factor"], rel=1e-9)
+        mean, std = gp.predict(Xs, return_std=True)
+        np.testing.assert_allclose(mean, case["predict"]["mean"], rtol=1e-8, atol=1e-8 * np.abs(case["predict"]["mean"]).max())
+        np.testing.assert_allclose(std ** 2, np.array(case["predict"]["std"]) ** 2, rtol=1e-7, atol=1e-9 * gp.cov_factor_)
+        cov = gp.predict(Xs, return_cov=True)[1]
+        np.testing.assert_allclose(cov, case["predict"]["cov"], rtol=1e-6, atol=1e-9 * gp.cov_factor_)
+        S = gp.corr_sqrt_
+        w, Q = gp._eigh_tuple_
+        n = len(X)
+        assert S.shape == (n, n) and np.abs(S @ S.T - (gp.corr_ + case["nugget"] * np.eye(n))).max() < 1e-12
+        np.testing.assert_allclose(Q @ np.diag(np.sqrt(w)), S)
+        sp = gsum_amd.ConjugateStudentProcess(kernel=kern, optimizer=None, nugget=case["nugget"], decomposition="eig", **case["priors"])
+        assert sp.log_marginal_likelihood(theta, X=X, y=y) == pytest.approx(case["student_lml"], rel=1e-10)
+        r = y.shape[1]
+        tg = gsum_amd.TruncationGP(kernel=kern, ratio=0.6, ref=2.0, optimizer=None, nugget=case["nugget"], decomposition="eig", **case["priors"])
+        tg.fit(X, gsum_amd.partials(y, ratio=0.6, ref=2.0, orders=np.arange(r)), orders=np.arange(r))
+        assert tg.log_marginal_likelihood(theta=kern.theta, ratio=0.55) == pytest.approx(case["trunc_lml"], rel=1e-10)

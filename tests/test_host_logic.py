@@ -229,8 +229,7 @@ def test_constructor_and_argument_errors():
     gp._fit = False
     with pytest.raises(ValueError):
         gsum_amd.ConjugateGaussianProcess(decomposition="lu").log_marginal_likelihood(np.array([0.0]), X=np.zeros((2, 1)), y=np.zeros(2))
-    with pytest.raises(NotImplementedError):
-        gsum_amd.ConjugateGaussianProcess(decomposition="eig").log_marginal_likelihood(np.array([0.0]), X=np.zeros((2, 1)), y=np.zeros(2))
+    assert gsum_amd.ConjugateGaussianProcess(decomposition="eig")._check_decomposition() is None          # accepted since round 5 (models.py:713-717)
     with pytest.raises(ValueError):
         gsum_amd.ConjugateGaussianProcess().cov(np.zeros((2, 1)))     # df0 = 1 <= 2: covariance does not exist
     t = gsum_amd.TruncationGP(kernel=RBF(1.0), ratio=lambda X: np.ones((len(X), 1, 1)))
