@@ -160,6 +160,10 @@ class CpuContext:
     def desc_array(descs):
         return list(descs)
 
+    @staticmethod
+    def tile_descs(unique, index):
+        return [unique[int(t)] for t in index]
+
     # -- operator level ------------------------------------------------------------------------------
     def kernel_matrix(self, desc, X, Y=None, diag_add=0.0, series=None):
         self.calls["kernel_matrix"] += 1

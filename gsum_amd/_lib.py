@@ -550,6 +550,17 @@ class HipContext:
 
     # -- fused hot path ------------------------------------------------------
     @staticmethod
+    def tile_descs(unique, index):
+        """``[unique[t] for t in index]`` as ONE contiguous ``gsum_kernel_desc[]`` without a Python object per entry: a likelihood surface
+        names each of its ~100 distinct kernels thousands of times (notebook :1457-1459), and joining 8000 x 616 B in Python cost as much
+        as the device call.  The array shares the memory of a numpy gather (kept alive on the result)."""
+        block = np.frombuffer(b"".join(map(bytes, unique)), dtype=np.uint8).reshape(len(unique), C.sizeof(KernelDesc))
+        tiled = np.ascontiguousarray(block[np.asarray(index, dtype=np.intp)])
+        arr = (KernelDesc * tiled.shape[0]).from_buffer(tiled)
+        arr._keep = tiled
+        return arr
+
+    @staticmethod
     def _desc_array(descs):
         """Contiguous ``gsum_kernel_desc[]`` for the C ABI.  An array built earlier (``HipContext.desc_array``) passes through:
         for the fused small-n path the marshalling of thousands of descriptors was more than half of the call."""
