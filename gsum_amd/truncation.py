@@ -237,12 +237,13 @@ class TruncationGP:
         return m_pred
 
     # -- likelihood (models.py:1485-1507) ---------------------------------------------------------------
-    def _coeffs_and_jacobian(self, X, y, orders, ratio_kws):
+    def _coeffs_and_jacobian(self, X, y, orders, ratio_kws, want_coeffs=True):
         ref = self.ref(X)
         ratio = self.ratio(X, **ratio_kws)
         orders = np.asarray(orders)
         orders_mask = ~np.isin(orders, self.excluded)                              # models.py:1495
-        coeffs = coefficients(y=y, ratio=ratio, ref=ref, orders=orders)[:, orders_mask]
+        # (want_coeffs = False: a grid row of mode "reuse" that rescales another row's Gram matrix needs the Jacobian term only)
+        coeffs = coefficients(y=y, ratio=ratio, ref=ref, orders=orders)[:, orders_mask] if want_coeffs else None
         orders_in = orders[orders_mask]
         n = len(orders_in)
         det_factor = np.sum(n * np.log(np.abs(ref)) + np.sum(orders_in) * np.log(np.abs(ratio)))   # :1505
@@ -334,6 +335,14 @@ class TruncationGP:
                 prep[i] = (gp._rhs(Xd, coeffs), det)
             return prep[i]
 
+        def det_for(i):
+            """The Jacobian term of ratio row i alone (the same expression rhs_for evaluates, without the coefficients)."""
+            if i in prep:
+                return prep[i][1]
+            kws = ratio_kws_list[i]
+            kws = kws if isinstance(kws, dict) else {"ratio": kws}
+            return self._coeffs_and_jacobian(Xd, y, orders, kws, want_coeffs=False)[1]
+
         def lml_values(G, sld, svals):
             """Host algebra for a stack of Gram matrices; ``svals[b]`` is the prior scale of entry b (None: the
             process's own prior)."""
@@ -414,7 +423,7 @@ class TruncationGP:
                                 anchor = (q, G, sld)
                         svals = None if scale_vals is None else scale_vals[ss]
                         Gs = np.broadcast_to(G, (len(ss),) + G.shape)
-                        out[i, j, ss] = lml_values(Gs, np.full(len(ss), sld), svals) - rhs_for(i)[1]
+                        out[i, j, ss] = lml_values(Gs, np.full(len(ss), sld), svals) - det_for(i)
                 finally:
                     L.free()
         else:
