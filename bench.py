@@ -693,7 +693,7 @@ def main():
     except Exception as exc:                 # no lab library on this box: the in-situ per-launch figure stands alone
         print(f"[bench] exclusive microbenchmark skipped: {exc}", file=sys.stderr)
 
-    reuse = ell_grid = pred = cfg2 = grad = nb = None
+    reuse = ell_grid = pred = cfg2 = grad = nb = by_order = None
     if rank == 0 and world == 1 and args.extras:
         cfg2 = n2048_leg(ctx)
         nb = notebook_leg()
@@ -732,6 +732,23 @@ def main():
         ctx.set_option("release_scratch", 1)
         pred = predict_leg(ctx, 16384, 2048, reps=5)
         ctx.set_option("release_scratch", 1)
+        # ONE factorisation alone against the order (the stage timer of a single evaluation: kernel build and solve excluded): the dependent
+        # chain of a 256-column step costs ~116 us whatever the order, so the fraction of the fp64 peak grows with n
+        by_order = {}
+        for nn in (2048, 4096, 8192, 16384, 32768):
+            Xn = 0.1 * np.arange(nn)[:, None]
+            Zn = np.concatenate([np.random.RandomState(0).randn(nn, r), np.ones((nn, 1))], axis=1)
+            ctx.set_inputs(Xn, Zn)
+            dn = gsum_amd.describe_kernel(RBF(0.2), 1)
+            best = None
+            for _ in range(3):
+                _, _, info_n = ctx.lml_resident([dn], 1e-10)
+                ms = ctx.timers()["potrf_ms"]
+                best = ms if best is None else min(best, ms)
+            by_order[str(nn)] = {"potrf_ms": best, "tflops": nn ** 3 / 3.0 / (best * 1e-3) / 1e12,
+                                 "frac_of_fp64_mfma_peak": nn ** 3 / 3.0 / (best * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "info": int(info_n[0])}
+            ctx.set_option("release_scratch", 1)
+        ctx.set_inputs(X, Z)
 
     pmc_traffic = pmc_file = pmc_alg = None
     pmc_what = ""
@@ -785,7 +802,8 @@ def main():
                          "single_eval_frac_of_fp64_mfma_peak": chol_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "pipelined_gflops_per_gpu": potrf_flops * K / elapsed / 1e9,
                          "pipelined_frac_of_fp64_mfma_peak": potrf_flops * K / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                         "flops": "n^3/3", "single_eval_ms": stage[1]},
+                         "flops": "n^3/3", "single_eval_ms": stage[1],
+                         "single_eval_by_order": by_order if rank == 0 and world == 1 and args.extras else None},
             "kernel_build": {"gbps_bytes_written": bytes_written / (stage[0] * 1e-3) / 1e9,
                              "frac_of_hbm_peak": bytes_written / (stage[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "bytes_written": "lower-triangle tiles only (4n^2 + 4n*128): what the kernel stores",
