@@ -287,9 +287,10 @@ static int gs_grad_harvest(gsum_ctx* ctx, gs_slot* sl, int P, double* G_out, dou
 
 // n <= GS_GSMALL_MAX: value + gradient pieces of every kernel of the call in ONE launch, one workgroup each (k_grad_small): the reference's own
 // sizes, where a dozen launches and two synchronisations per objective evaluation cost more than the arithmetic.  Measured per objective
-// evaluation through the class (tools/gpu_small_fit_profile.py): n = 8 / 20 / 48 / 64: 202 / 239 / 277 / 311 us against ~340 on the general path;
-// n = 96 / 128: 406 / 486 -- four waves walk the rows of the contractions, so the general path keeps those orders.
-#define GS_GSMALL_MAX 64
+// evaluation through the class (tools/gpu_small_fit_profile.py): n = 8 / 20 / 48 / 64 / 96 / 128: 189 / 194 / 211 / 231 / 276 / 333 us against
+// ~325-340 on the general path (the first form of the kernel walked the contractions' rows with one wave per two rows and lost above n = 64;
+// since the contractions are matrix products the one-block orders are all its).
+#define GS_GSMALL_MAX 128
 static int gs_grad_small(gsum_ctx* ctx, const gsum_kernel_desc* descs, int n_desc, const gsum_grad_param* params, int P, double nugget,
                          double* G_out, double* sld_out, int64_t* info_out, double* trace_out, double* H_out) {
     const int k = ctx->in->k, CH = std::min(512, n_desc);

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce2(const double* part, int ch
 // and its fit() drives L-BFGS with log_marginal_likelihood(theta, eval_gradient=True) (models.py:634-640, 957-958, 1041-1056) -- the
 // general path's dozen launches and two synchronisations cost 250 us per objective evaluation there, this kernel ~60.
 //   k_lml_small's steps (same code: G, sum log diag and info equal the value path's bit for bit), the explicit block inverse from
-//   gs_diag_block, R^-1 = L^-T L^-1 on the matrix cores (gs_tile128), V^T = W^T L^-1, then k_grad_contract's contractions per
-//   hyperparameter, one wave per row: trace_p = tr(R^-1 dR_p), H_p = V^T dR_p V.
+//   gs_diag_block, R^-1 = L^-T L^-1 and V^T = W^T L^-1 on the matrix cores (gs_tile128), then per hyperparameter dR_p entry by entry
+//   (k_grad_contract's formulas), trace_p = tr(R^-1 dR_p) on the way, Q_p = dR_p V on the matrix cores, H_p = V^T Q_p.
 //   scratch per evaluation: A | W^T (16 rows) and V^T (16 rows) in one slot | L^-1 | L^-T | R^-1  (five 128 x 128 slots);
 //   res: 258 doubles as k_finalize;  gres: P x 257 (H_p 16 x 16, then the trace).
 // ------------------------------------------------------------------------------------------------
@@ -278,95 +278,72 @@ __global__ __launch_bounds__(256, 2) void k_grad_small(const double* X, int n, i
     // (rows 16 .. 127 of the A operand are whatever the slot holds: they feed accumulators that are never stored)
     gs_tile128(Vt, 128, Wt, 128, Ut, 128, 16, n16, n16, 0, 1.0, wsd);
     gs_tile128(Rinv, 128, Ut, 128, Ut, 128, n16, n16, n16, 0, 1.0, wsd);
-    // ---- contractions (k_grad_contract's terms, one wave per TWO rows): the points and V^T in LDS, Q_p rows and the row traces beside them
-    double* xs = wsd;                                                  // 128 x GSUM_MAX_D
-    double* Qs = xs + 128 * GSUM_MAX_D;                                // 128 x 16
-    double* trs = Qs + 128 * 16;                                       // 128
-    double* vs = trs + 128;                                            // V^T, 16 x 128
-    static_assert(GS_DIAG_WS >= 128 * GSUM_MAX_D + 128 * 16 + 128 + 16 * 128, "the contractions' LDS");
+    // ---- contractions, as matrix products (round 5, second form: one wave per two rows walked the rows too slowly beyond n = 64):
+    //   dR_p (n16 x n16, kernel-gradient entries on the fly, 256 threads abreast) -> the slot A held;  trace_p = sum_ij R^-1_ij dR_p,ij on the way;
+    //   Q_p = dR_p V on the matrix cores (gs_tile128: A = dR_p, B = V^T);  H_p = V^T Q_p from LDS copies.
+    double* xs = wsd + GS_TILE_LD_DOUBLES;                             // 128 x GSUM_MAX_D, beside the tile's stages
+    double* red = xs + 128 * GSUM_MAX_D;                               // 256
+    static_assert(GS_DIAG_WS >= GS_TILE_LD_DOUBLES + 128 * GSUM_MAX_D + 256, "the contractions' LDS beside the tile's stages");
+    static_assert(GS_TILE_LD_DOUBLES >= 2 * 16 * 128, "Q_p and V^T fit where the tile's stages were");
+    double* dRm = A;                                                   // (L is no longer needed: the block inverse and W^T carry everything)
+    double* Qg = Ut;                                                   // n16 x 16 (L^-T is no longer needed either)
     for (int idx = t; idx < 128 * GSUM_MAX_D; idx += 256) {
         const int r = idx / GSUM_MAX_D, m = idx - r * GSUM_MAX_D;
         xs[idx] = (r < n && m < d) ? X[(int64_t)r * d + m] : 0.0;
     }
-    for (int idx = t; idx < 16 * 128; idx += 256) vs[idx] = (idx & 127) < n16 ? Vt[idx] : 0.0;
     double inv_ls[GSUM_MAX_D];
 #pragma unroll
     for (int m = 0; m < GSUM_MAX_D; ++m) inv_ls[m] = 1.0 / (desc.anisotropic ? desc.length_scale[m < d ? m : 0] : desc.length_scale[0]);
     __syncthreads();
     for (int p = 0; p < P; ++p) {
         const gsum_grad_param pr = params[(int64_t)blockIdx.x * P + p];
-        for (int i0 = 2 * w; i0 < n; i0 += 8) {                        // rows i0, i0 + 1: two independent dependency chains per wave
-            double acc[2][16], tr[2] = {0.0, 0.0};
+        double tr = 0.0;
+        for (int idx = t; idx < n16 * n16; idx += 256) {
+            const int i = idx / n16, j = idx - i * n16;
+            double g = 0.0;
+            if (i < n && j < n) {
+                bool walked = false;
+                if constexpr (TREE) {
+                    if (desc.n_ops > 0) {
+                        (void)gs_tree_eval(desc, xs + i * GSUM_MAX_D, xs + j * GSUM_MAX_D, d, i == j, &pr, &g);
+                        walked = true;
+                    }
+                }
+                if (!walked) {
+                    double s2 = 0.0, dsel = 0.0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) acc[r][c] = 0.0;
-            for (int j = lane; j < n; j += 64) {
-                double g[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int i = i0 + r < n ? i0 + r : i0;             // (an odd n: the second row repeats the first and is not stored)
-                    bool walked = false;
-                    if constexpr (TREE) {
-                        if (desc.n_ops > 0) {
-                            (void)gs_tree_eval(desc, xs + i * GSUM_MAX_D, xs + j * GSUM_MAX_D, d, i == j, &pr, &g[r]);
-                            walked = true;
+                    for (int m = 0; m < GSUM_MAX_D; ++m)
+                        if (m < d) {
+                            const double u = (xs[i * GSUM_MAX_D + m] - xs[j * GSUM_MAX_D + m]) * inv_ls[m];
+                            const double dmm = u * u;
+                            s2 += dmm;
+                            if (m == pr.dim) dsel = dmm;
                         }
-                    }
-                    if (!walked) {
-                        double s = 0.0, dsel = 0.0;
-#pragma unroll
-                        for (int m = 0; m < GSUM_MAX_D; ++m)
-                            if (m < d) {
-                                const double u = (xs[i * GSUM_MAX_D + m] - xs[j * GSUM_MAX_D + m]) * inv_ls[m];
-                                const double dmm = u * u;
-                                s += dmm;
-                                if (m == pr.dim) dsel = dmm;
-                            }
-                        g[r] = gs_kernel_grad(desc, pr, s, pr.code == GSUM_GRAD_LENGTH_ISO ? s : dsel, i == j);
-                    }
-                    if (j <= i) tr[r] = __builtin_fma((j < i ? 2.0 : 1.0) * Rinv[i * 128 + j], g[r], tr[r]);
+                    g = gs_kernel_grad(desc, pr, s2, pr.code == GSUM_GRAD_LENGTH_ISO ? s2 : dsel, i == j);
                 }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double v = vs[c * 128 + j];
-                    acc[0][c] = __builtin_fma(g[0], v, acc[0][c]);
-                    acc[1][c] = __builtin_fma(g[1], v, acc[1][c]);
-                }
+                tr = __builtin_fma(Rinv[i * 128 + j], g, tr);
             }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (i0 + r >= n) break;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    double v = acc[r][c];
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                    acc[r][c] = v;
-                }
-                double tt = tr[r];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) tt += __shfl_xor(tt, off, 64);
-                if (lane < 16) {
-                    double v = acc[r][0];
-#pragma unroll
-                    for (int c = 1; c < 16; ++c) v = (lane == c) ? acc[r][c] : v;
-                    Qs[(i0 + r) * 16 + lane] = v;
-                }
-                if (lane == 0) trs[i0 + r] = tt;
-            }
+            dRm[i * 128 + j] = g;
         }
+        red[t] = tr;
+        __threadfence_block();
         __syncthreads();
+        if (t == 0) {                                                  // the trace: 256 partial sums in index order (deterministic)
+            double ts = 0.0;
+            for (int q = 0; q < 256; ++q) ts += red[q];
+            gout[(int64_t)p * 257 + 256] = ts;
+        }
+        gs_tile128(Qg, 16, dRm, 128, Vt, 128, n16, 16, n16, 0, 1.0, wsd);          // Q_p[i][c] = sum_j dR_p[i][j] V^T[c][j]
         {
-            const int a = t >> 4, b = t & 15;                          // H_p = V^T Q_p, rows in index order (deterministic)
+            double* qs = wsd;                                          // Q_p: n16 x 16;  V^T: 16 x 128 behind it
+            double* vs = wsd + 16 * 128;
+            for (int idx = t; idx < n16 * 16; idx += 256) qs[idx] = Qg[idx];
+            for (int idx = t; idx < 16 * 128; idx += 256) vs[idx] = (idx & 127) < n16 ? Vt[idx] : 0.0;
+            __syncthreads();
+            const int a2 = t >> 4, b2 = t & 15;                        // H_p = V^T Q_p, rows in index order
             double h = 0.0;
-            for (int i = 0; i < n; ++i) h = __builtin_fma(vs[a * 128 + i], Qs[i * 16 + b], h);
+            for (int i = 0; i < n; ++i) h = __builtin_fma(vs[a2 * 128 + i], qs[i * 16 + b2], h);
             gout[(int64_t)p * 257 + t] = h;
-            if (t == 0) {
-                double ts = 0.0;
-                for (int i = 0; i < n; ++i) ts += trs[i];
-                gout[(int64_t)p * 257 + 256] = ts;
-            }
         }
         __syncthreads();
     }

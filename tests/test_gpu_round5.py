@@ -554,9 +554,9 @@ def test_single_gradient_evaluation_forms_are_bit_identical(n, kind):
             lab.set_option(name, 1)
 
 
-@pytest.mark.parametrize("n,d,kind", [(5, 1, "flat"), (20, 1, "flat"), (33, 2, "tree"), (64, 2, "flat"), (64, 1, "tree")])
+@pytest.mark.parametrize("n,d,kind", [(5, 1, "flat"), (20, 1, "flat"), (33, 2, "tree"), (64, 2, "flat"), (64, 1, "tree"), (100, 2, "tree"), (128, 1, "flat")])
 def test_small_gradient_kernel_against_the_general_path(n, d, kind):
-    """k_grad_small (n <= 64: value + gradient pieces of a call in ONE launch, one workgroup per kernel -- the reference's own sizes, where
+    """k_grad_small (n <= 128: value + gradient pieces of a call in ONE launch, one workgroup per kernel -- the reference's own sizes, where
     fit() drives L-BFGS with log_marginal_likelihood(theta, eval_gradient=True): models.py:634-640, 957-958, 1041-1056) against the general
     path (option small_path = 0): G, sum log diag and info bit for bit (the value path's code), traces and H_p to rounding; a call of several
     kernels equals the single calls bit for bit; a matrix that is not positive definite reports its info and zero pieces."""
