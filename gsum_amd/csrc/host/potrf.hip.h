@@ -320,10 +320,6 @@ static int gs_potrf_chain(gsum_ctx* ctx, gsum_mat* m) {
     auto wait1 = [&](hipStream_t st, int kind, int s, unsigned want) {
         hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want, (const unsigned*)nullptr, 0u, fl);
     };
-    auto wait2 = [&](hipStream_t st, int kind, int s, unsigned want, int kind2, int s2, unsigned want2) {
-        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, st, (const unsigned*)(fl + gs_fl(kind, S, s)), want,
-                           (const unsigned*)(fl + gs_fl(kind2, S, s2)), want2, fl);
-    };
     unsigned long long* kst0 = nullptr;          // launch stamps (diagnostics): a (first start, last end) pair per launch, four per step
     if (ctx->chain_stamps) {
         // a launch writes kst[0] (atomicMin) and kst[1] (atomicMax): interleave (start, end) pairs, starts preset to all ones
@@ -520,7 +516,6 @@ static int gs_potrf(gsum_ctx* ctx, gsum_mat* m) {
     // (In a batch the LDS-direct 128x128 tile is 1 % cheaper overall, but then one kernel symbol would serve two
     // roles and rocprofv3's per-kernel average would no longer be the bulk update's.)
     const int ccfg = 1;
-    unsigned long long* stamps = ctx->diag_stamps ? ctx->dstamps : (unsigned long long*)nullptr;
     int prev = -1;                                   // outer step whose bulk update is still in flight
     bool deferred = false;                           // batch mode: the far region still owes the previous panel's update
     for (int k = 0; k < T; k += 2) {

@@ -324,9 +324,7 @@ template <int W, bool FULL>
 __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, double* thr,
                                            double d0, double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
     constexpr int R0 = W, R1 = 7 - W;
-    const int fr = lane & 15, fq = lane >> 4;
     gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
-    const int prow = gs_pair_row(lane);
 
 #pragma unroll
     for (int k = 0; k <= R0; ++k) S0[k] = (gs_d4){0.0, 0.0, 0.0, 0.0};
