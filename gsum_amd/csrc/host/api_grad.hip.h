@@ -297,27 +297,33 @@ static int gs_grad_small(gsum_ctx* ctx, const gsum_kernel_desc* descs, int n_des
     ctx->cur = &ctx->slots[0];
     hipStream_t s = ctx->cur->sm;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t o_desc = 0, o_par = up((size_t)CH * sizeof(gsum_kernel_desc)), o_res = o_par + up((size_t)CH * P * sizeof(gsum_grad_param)),
-                 o_gres = o_res + up((size_t)CH * 258 * 8), o_scr = o_gres + up((size_t)CH * P * 257 * 8);
+    // descriptors and gradient parameters travel in ONE copy, results and gradient pieces come back in ONE (each copy of a pageable buffer is
+    // ~10 us of a ~100-us call): [descs | params] and [res | gres] are contiguous on the device, offsets by the launch's count
+    const size_t in_cap = (size_t)CH * (sizeof(gsum_kernel_desc) + (size_t)P * sizeof(gsum_grad_param));
+    const size_t out_cap = (size_t)CH * (258 + (size_t)P * 257) * 8;
+    const size_t o_in = 0, o_out = up(in_cap), o_scr = o_out + up(out_cap);
     if (gs_reserve(ctx, &ctx->scratch, &ctx->scratch_cap, o_scr + (size_t)CH * GS_GSMALL_SCRATCH * 8)) return -1;
     char* base = (char*)ctx->scratch;
-    const size_t per = (size_t)258 + (size_t)P * 257;
-    if (gs_reserve_pinned(ctx, (size_t)CH * per * 8)) return -1;
-    double* hres = ctx->hbatch;
-    double* hg = hres + (size_t)CH * 258;
+    if (gs_reserve_pinned(ctx, up(in_cap) + out_cap)) return -1;            // (staged inputs | results: two regions, no wait in between)
     for (int lo = 0; lo < n_desc; lo += CH) {
         const int cnt = std::min(CH, n_desc - lo);
-        GS_CHECK(hipMemcpyAsync(base + o_desc, descs + lo, (size_t)cnt * sizeof(gsum_kernel_desc), hipMemcpyHostToDevice, s));
-        GS_CHECK(hipMemcpyAsync(base + o_par, params + (size_t)lo * P, (size_t)cnt * P * sizeof(gsum_grad_param), hipMemcpyHostToDevice, s));
+        const size_t dbytes = (size_t)cnt * sizeof(gsum_kernel_desc), pbytes = (size_t)cnt * P * sizeof(gsum_grad_param);
+        char* stage = (char*)ctx->hbatch;                      // (pinned; the previous launch's copy out of it completed before its results were unpacked)
+        memcpy(stage, descs + lo, dbytes);
+        memcpy(stage + dbytes, params + (size_t)lo * P, pbytes);
+        GS_CHECK(hipMemcpyAsync(base + o_in, stage, dbytes + pbytes, hipMemcpyHostToDevice, s));
         bool tree = false;
         for (int e = 0; e < cnt; ++e) tree = tree || descs[lo + e].n_ops > 0;
+        double* dres = (double*)(base + o_out);
+        double* dgres = dres + (size_t)cnt * 258;
         hipLaunchKernelGGL(tree ? k_grad_small<true> : k_grad_small<false>, dim3(cnt), dim3(256), 0, s, ctx->in->X, (int)ctx->in->n, ctx->in->d,
-                           ctx->in->Z, k, (const gsum_kernel_desc*)(base + o_desc), (const gsum_grad_param*)(base + o_par), P, nugget,
-                           (double*)(base + o_scr), (double*)(base + o_res), (double*)(base + o_gres));
+                           ctx->in->Z, k, (const gsum_kernel_desc*)(base + o_in), (const gsum_grad_param*)(base + o_in + dbytes), P, nugget,
+                           (double*)(base + o_scr), dres, dgres);
         GS_CHECK(hipGetLastError());
-        GS_CHECK(hipMemcpyAsync(hres, base + o_res, (size_t)cnt * 258 * 8, hipMemcpyDeviceToHost, s));
-        GS_CHECK(hipMemcpyAsync(hg, base + o_gres, (size_t)cnt * P * 257 * 8, hipMemcpyDeviceToHost, s));
+        double* hres = (double*)((char*)ctx->hbatch + up(in_cap));
+        GS_CHECK(hipMemcpyAsync(hres, dres, (size_t)cnt * (258 + (size_t)P * 257) * 8, hipMemcpyDeviceToHost, s));
         GS_CHECK(hipStreamSynchronize(s));
+        const double* hg = hres + (size_t)cnt * 258;
         for (int e = 0; e < cnt; ++e) {
             const double* r = hres + (size_t)e * 258;
             const int i = lo + e;
