@@ -84,8 +84,9 @@ def test_underlying_and_sample_y_golden(cpu_backend):
 
 
 @pytest.mark.parametrize("name", T.REFERENCE_TEST_KERNELS)
-def test_reference_interpolation_test(cpu_backend, name):
-    T.test_interpolation_property(name)
+@pytest.mark.parametrize("decomposition", ["cholesky", "eig"])
+def test_reference_interpolation_test(cpu_backend, name, decomposition):
+    T.test_interpolation_property(name, decomposition)
 
 
 def test_notebook_grid_and_optimizer(cpu_backend, notebook_grid):

@@ -372,14 +372,15 @@ def _reference_test_kernel(name):
     }[name]()
 
 
+@pytest.mark.parametrize("decomposition", ["cholesky", "eig"])
 @pytest.mark.parametrize("name", REFERENCE_TEST_KERNELS)
-def test_interpolation_property(name):
-    """The reference's own hot-path test, kernel for kernel (gsum/tests/test.py:63-72, test_cgp_interpolation with
-    decomposition='cholesky'): nugget = 0, default optimiser on (the free-parameter kernels run L-BFGS on the device
+def test_interpolation_property(name, decomposition):
+    """The reference's own hot-path test, kernel for kernel and decomposition for decomposition (gsum/tests/test.py:61-72,
+    test_cgp_interpolation): nugget = 0, default optimiser on (the free-parameter kernels run L-BFGS on the device
     likelihood and its analytic gradient), predict(X_train) == y_train with a vanishing predictive variance."""
     X = np.atleast_2d([1., 3., 5., 6., 7., 8.]).T
     y = (X * np.sin(X)).ravel()
-    gp = gsum_amd.ConjugateGaussianProcess(kernel=_reference_test_kernel(name), nugget=0).fit(X, y)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=_reference_test_kernel(name), nugget=0, decomposition=decomposition).fit(X, y)
     y_pred, y_cov = gp.predict(X, return_cov=True)
     np.testing.assert_almost_equal(y_pred, y)                       # the reference's assert_almost_equal (7 decimals)
     np.testing.assert_almost_equal(np.diag(y_cov), 0.0, decimal=10)
