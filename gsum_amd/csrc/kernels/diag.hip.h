@@ -320,9 +320,15 @@ __device__ __forceinline__ bool gs_d2_step(gs_d4 (&P0)[W + 1], gs_d4 (&P1)[8 - W
 }
 
 // phase 1 of wave W: returns false if a pivot failed (every wave leaves at the same barrier)
-template <int W, bool FULL>
+// PARTIAL (round 5; the one-block kernels k_lml_small / k_grad_small only, FULL tables): only the first `nbv` micro-blocks hold data, the rest of
+// the block is identity padding -- the reference's own orders are 5-20 points, and the factorisation of a 128 x 128 block that is seven eighths
+// identity cost the same 36 us.  Steps 0 .. nbv - 2 run as always (they factor micro-blocks 0 .. nbv - 1); what the skipped steps would leave
+// behind is written directly: zero panel dumps from column nbv - 1 on (the rows below are padding), identity micro-inverses and unit diagonal
+// entries from block nbv on.  The matrix itself already holds the identity there.  Every other caller instantiates PARTIAL = false: the same code as before.
+template <int W, bool FULL, bool PARTIAL = false>
 __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, double* scr, double* Ls, double* Lg, double* thr,
-                                           double d0, double* dbuf, int* fail_sh, int lane, unsigned long long* stamps) {
+                                           double d0, double* dbuf, int* fail_sh, int lane, unsigned long long* stamps, int nbv = 8) {
+    static_assert(!PARTIAL || FULL, "the partial form keeps its tables in LDS");
     constexpr int R0 = W, R1 = 7 - W;
     gs_d4 P0[R0 + 1], P1[R1 + 1], S0[R0 + 1], S1[R1 + 1];
 
@@ -345,15 +351,40 @@ __device__ __forceinline__ bool gs_d2_wave(double* A, int64_t ld, double* Dv, do
         const int f = gs_potf2_16<0>(P0[0], S0[0], A, ld, Dv, thr, dbuf, lane, stamps);
         if (f >= 0 && lane == 0) *fail_sh = f;
     }
-    if (!gs_d2_step<W, 0, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 1, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 2, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 3, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 4, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 5, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 6, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
-    if (!gs_d2_step<W, 7, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;
+#define GS_D2_STEP(J)                                                                                                             \
+    if (!PARTIAL || nbv >= 8 || (J) + 1 < nbv) {              /* (a full block runs every step: step 7's barriers publish block 7) */ \
+        if (!gs_d2_step<W, J, FULL>(P0, P1, S0, S1, A, ld, Dv, scr, Ls, Lg, thr, dbuf, fail_sh, lane, stamps)) return false;      \
+    }
+    GS_D2_STEP(0)
+    GS_D2_STEP(1)
+    GS_D2_STEP(2)
+    GS_D2_STEP(3)
+    GS_D2_STEP(4)
+    GS_D2_STEP(5)
+    GS_D2_STEP(6)
+    GS_D2_STEP(7)
+#undef GS_D2_STEP
     // (the strictly lower micro-blocks went back to the matrix as they were solved, the diagonal ones from the pivot recurrence)
+    if constexpr (PARTIAL) {
+        if (nbv < 8) {
+            __syncthreads();                                  // the last recurrence's D, diagonal entries and failure flag are visible
+            if (*fail_sh >= 0) return false;
+            // what steps nbv - 1 .. 7 would have left: wave W writes for its own two block rows, like the steps do
+            constexpr int R0 = W, R1 = 7 - W;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = half ? R1 : R0;
+                for (int J = (nbv > 1 ? nbv - 1 : 0); J < row; ++J)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) Ls[(GS_LS_SLOT(true, row, J) * 4 + x) * 64 + lane] = 0.0;
+                if (row >= nbv) {
+                    for (int e = lane; e < 16 * GS_DV_STR; e += 64) Dv[row * 16 * GS_DV_STR + e] = (e / GS_DV_STR == e % GS_DV_STR) ? 1.0 : 0.0;
+                    if (lane < 16) dbuf[16 * row + lane] = 1.0;
+                }
+            }
+            __syncthreads();                                  // (a full step ends behind a barrier too: the tables and diagonal entries are visible)
+        }
+    }
     return true;
 }
 
@@ -416,9 +447,9 @@ __device__ __forceinline__ void gs_trtri_block(const double* Ls, const double* D
 #define GS_D2C_DV (8 * 256)
 #define GS_D2C_THR (GS_D2C_DV + 8 * 16 * GS_DV_STR)
 #define GS_D2C_WS (GS_D2C_THR + 128)
-template <bool FULL = true>
+template <bool FULL = true, bool PARTIAL = false>
 __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv, double* Ltab, double* logdet_out,
-                                             const double* diag0, unsigned long long* stamps, double* wsp) {
+                                             const double* diag0, unsigned long long* stamps, double* wsp, int nbv = 8) {
     __shared__ double dbuf[128];
     __shared__ int fail_sh;
     double* Ls = wsp + GS_D2_LS;
@@ -438,10 +469,10 @@ __device__ __forceinline__ int gs_diag_block(double* A, int64_t ld, double* Linv
     if (t < 128) d0 = diag0[t];                         // the thresholds' load goes out ahead of the block's (see gs_d2_wave)
     __builtin_amdgcn_sched_barrier(0);
     bool ok;
-    if (w == 0) ok = gs_d2_wave<0, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else if (w == 1) ok = gs_d2_wave<1, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else if (w == 2) ok = gs_d2_wave<2, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
-    else ok = gs_d2_wave<3, FULL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps);
+    if (w == 0) ok = gs_d2_wave<0, FULL, PARTIAL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps, nbv);
+    else if (w == 1) ok = gs_d2_wave<1, FULL, PARTIAL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps, nbv);
+    else if (w == 2) ok = gs_d2_wave<2, FULL, PARTIAL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps, nbv);
+    else ok = gs_d2_wave<3, FULL, PARTIAL>(A, ld, Dv, scr, Ls, Ltab, thr, d0, dbuf, &fail_sh, lane, stamps, nbv);
     if (!ok) return fail_sh + 1;                       // uniform: every wave read the flag behind the same barrier
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
     if (t < 128) dbuf[t] = log(dbuf[t]);

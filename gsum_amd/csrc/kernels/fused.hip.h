@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     __threadfence_block();
     __syncthreads();
     // ---- Cholesky of the block; its substitution tables stay in wsd
-    const int bad = gs_diag_block(A, 128, (double*)nullptr, (double*)nullptr, &ldet, dg0, nullptr, wsd);
+    // (only the micro-blocks that hold points are factorised: the rest of the block is identity padding, gs_d2_wave<.., PARTIAL>)
+    const int bad = gs_diag_block<true, true>(A, 128, (double*)nullptr, (double*)nullptr, &ldet, dg0, nullptr, wsd, (n + 15) >> 4);
     if (bad) {
         if (t == 0) {
             out[256] = 0.0;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_grad_small(const double* X, int n, i
     else gs_build_tile128_any(A, 128, us, us, etab, etab + 16, 0, 0, n, d, desc, nugget, dg0, w, lane);
     __threadfence_block();
     __syncthreads();
-    const int bad = gs_diag_block(A, 128, Linv, (double*)nullptr, &ldet, dg0, nullptr, wsd);
+    const int bad = gs_diag_block<true, true>(A, 128, Linv, (double*)nullptr, &ldet, dg0, nullptr, wsd, (n + 15) >> 4);
     if (bad) {
         if (t == 0) {
             out[256] = 0.0;

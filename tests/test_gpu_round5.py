@@ -652,3 +652,44 @@ def test_order_32768_property_and_the_refused_orders(ctx):
         ctx.lml_batch([gsum_amd.describe_kernel(RBF(1.0), 1)], big, np.ones((47000, 1)), 1e-10)
     with pytest.raises((ValueError, RuntimeError), match="out of range"):
         ctx.kernel_matrix_dev(gsum_amd.describe_kernel(RBF(1.0), 1), big)
+
+
+def test_partial_diagonal_block_every_count_of_micro_blocks():
+    """The one-block kernels factorise only the micro-blocks that hold points (gs_d2_wave<.., PARTIAL>: the reference's own orders are 5-20 of a
+    128 x 128 block, the rest is identity padding) and write what the skipped steps would have left behind.  Every count of valid micro-blocks,
+    orders on both sides of every boundary: G, sum log diag and info of the one-block path equal the general path's bit for bit (a call of one
+    and a call of several evaluations), the gradient pieces agree to rounding, a pivot that fails in the LAST factorised micro-block is found."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C
+    lab = gsum_amd.lab_context(0)
+    kern = C(1.3) * Matern(0.6, nu=2.5) + WhiteKernel(1e-6)
+    desc, prm = gsum_amd.describe_kernel(kern, 1), gsum_amd.kernels.describe_gradient(kern, 1)
+    try:
+        for n in (1, 2, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 79, 80, 81, 96, 97, 111, 112, 113, 127, 128):
+            rng = np.random.RandomState(n)
+            X = np.sort(rng.rand(n))[:, None] * (0.5 * n + 1.0)
+            Z = np.concatenate([rng.randn(n, 3), np.ones((n, 1))], axis=1)
+            lab.set_option("small_path", 0)
+            want = lab.lml_batch([desc], X, Z, 1e-10)
+            gwant = lab.lml_grad(desc, prm, X, Z, 1e-10)
+            lab.set_option("small_path", 1)
+            got = lab.lml_batch([desc], X, Z, 1e-10)
+            got3 = lab.lml_batch([desc, desc, desc], X, Z, 1e-10)
+            ggot = lab.lml_grad(desc, prm, X, Z, 1e-10)
+            for a, b, c in zip(got, want, got3):
+                assert np.array_equal(a, b) and np.array_equal(np.asarray(c)[2], np.asarray(b)[0]), n
+            assert np.array_equal(ggot[0], gwant[0]) and ggot[1] == gwant[1] and ggot[2] == gwant[2] == 0, n
+            if n > 1:
+                np.testing.assert_allclose(ggot[3], gwant[3], rtol=1e-9, atol=1e-9 * np.abs(gwant[3]).max(), err_msg=str(n))
+                np.testing.assert_allclose(ggot[4], gwant[4], rtol=1e-9, atol=1e-9 * np.abs(gwant[4]).max(), err_msg=str(n))
+        # a duplicated LAST point without jitter: the failing pivot sits in the last factorised micro-block (n = 20: column 19, micro-block 1 of 2)
+        for n in (20, 33):
+            X = np.arange(n, dtype=float)[:, None] * 0.7
+            X[-1] = X[-2]
+            bad = gsum_amd.describe_kernel(C(1.0) * RBF(1.0), 1)
+            info_s = lab.lml_batch([bad], X, np.ones((n, 1)), 0.0)[2]
+            lab.set_option("small_path", 0)
+            info_g = lab.lml_batch([bad], X, np.ones((n, 1)), 0.0)[2]
+            lab.set_option("small_path", 1)
+            assert info_s[0] == info_g[0] == n, (n, info_s, info_g)
+    finally:
+        lab.set_option("small_path", 1)
