@@ -81,7 +81,7 @@ static int gs_check_desc(gsum_ctx* ctx, const gsum_kernel_desc* desc, int d) {
         return 0;
     }
     // a tree: a well-formed postfix program over valid leaves
-    if (desc->n_ops < 0 || desc->n_ops > GSUM_MAX_OPS || desc->n_leaves < 1 || desc->n_leaves > GSUM_MAX_LEAVES) GS_FAIL("kernel tree: bad op / leaf count");
+    if (desc->n_ops < 0 || desc->n_ops > GSUM_MAX_OPS || desc->n_leaves < 0 || desc->n_leaves > GSUM_MAX_LEAVES) GS_FAIL("kernel tree: bad op / leaf count");
     int depth = 0;
     for (int k = 0; k < desc->n_ops; ++k) {
         const int op = desc->op[k];

@@ -203,8 +203,7 @@ def _compile_tree(kernel):
         prog.append(node)
 
     walk(kernel)
-    if counts["leaf"] < 1:
-        raise NotImplementedError(f"kernel {kernel} has no RBF / Matern / RationalQuadratic / ExpSineSquared / DotProduct part")
+    # (a kernel of ConstantKernel / WhiteKernel terms alone -- c 1 1^T + w I -- is a legal scikit-learn kernel and a program without leaves)
     if counts["leaf"] > GSUM_MAX_LEAVES or len(prog) > GSUM_MAX_OPS:
         raise NotImplementedError(f"kernel {kernel} is too large for the device descriptor ({GSUM_MAX_LEAVES} stationary leaves, "
                                   f"{GSUM_MAX_OPS} operations)")

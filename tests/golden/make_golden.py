@@ -752,6 +752,8 @@ TREE_KERNELS = [          # (expression, input dimension): scikit-learn kernels 
     # ... and the one scikit-learn leaf that is not stationary (its diagonal depends on the points)
     ("C(0.001) * DotProduct(sigma_0=2.0) ** 2 + RBF(1.1) + WhiteKernel(1e-3)", 1),
     ("C(0.05) * DotProduct(sigma_0=1.3) * RBF([2.5, 4.0]) + WhiteKernel(1e-2)", 2),
+    # ... and a kernel without any leaf: c 1 1^T + w I
+    ("C(0.5) + WhiteKernel(0.3)", 1),
 ]
 
 

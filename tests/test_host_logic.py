@@ -147,7 +147,9 @@ def test_describe_kernel_flattening():
     np.testing.assert_array_equal(dp.one_arg_diagonal(Xd), (C(0.5) * DotProduct(sigma_0=0.7) ** 2 + RBF(1.0)).diag(Xd))
     with pytest.raises(ValueError):
         dp.one_arg_diagonal()
-    for bad in (Matern(1.0, nu=3.5), WhiteKernel(1.0), C(2.0) ** 2,
+    cw = gsum_amd.describe_kernel(C(0.5) + WhiteKernel(0.1), 1)                  # no leaf at all: c 1 1^T + w I is a legal kernel
+    assert cw.is_tree and cw.n_leaves == 0 and cw.one_arg_diagonal() == 0.6 and gsum_amd.describe_kernel(WhiteKernel(1.0), 1).n_ops == 1
+    for bad in (Matern(1.0, nu=3.5),
                 RBF(1.0) + RBF(2.0) + RBF(3.0) + RBF(4.0) + RBF(5.0)):
         with pytest.raises(NotImplementedError):
             gsum_amd.describe_kernel(bad, 1)
@@ -361,8 +363,8 @@ def test_constant_only_product_terms_are_additive():
     X = np.linspace(0, 1, 5)[:, None]
     K, dK = k(X, eval_gradient=True)
     np.testing.assert_allclose(dK[:, :, 2], 6.0)            # d (c1 c2) / d log c1 = c1 c2 everywhere
-    with pytest.raises(NotImplementedError):
-        gsum_amd.describe_kernel(C(2.0) * C(3.0), 1)
+    cc = gsum_amd.describe_kernel(C(2.0) * C(3.0), 1)         # (a kernel without a leaf is a tree of constants since late round 5)
+    assert cc.is_tree and cc.n_leaves == 0 and cc.one_arg_diagonal() == 6.0
 
 
 def test_importing_the_package_leaves_the_environment_alone():
