@@ -449,6 +449,43 @@ class ConjugateGaussianProcess:
             raise ValueError(f"at most {GSUM_MAX_RHS - 1} curves are supported, got {y.shape[1]}")
         return np.concatenate([y, np.ones((y.shape[0], 1))], axis=1)
 
+    # -- more curves than one device call takes (GSUM_MAX_RHS - 1 = 15) ---------------------------------------------------------------------
+    # The reference takes any number of curves (models.py:602-628, 1026-1035).  Everything its algebra does with the Gram matrix G = Z^T R^-1 Z,
+    # Z = [Y | 1] -- and with the gradient pieces H_p = V^T dR_p V -- uses the curve block only through its TRACE, the SUM of its entries and its
+    # cross terms with the basis column (posterior_from_gram, lml_grad_from_gram, hyper_gradients_from_gram: uniform weights over the curves).  So
+    # the curves go to the device in chunks [<= 13 curves | the sum of ALL curves | 1]: the chunks' diagonals are the curve block's diagonal, the
+    # sum column gives the sum of its entries, and a matrix with those entries on the diagonal, the right total and one constant everywhere else
+    # stands in for it.  Single evaluations (fit, likelihood, gradient, predict); the grid entry points keep the limit.
+    @staticmethod
+    def _many_curves(y):
+        y = np.asarray(y)
+        return y.ndim == 2 and y.shape[1] + 1 > GSUM_MAX_RHS
+
+    @staticmethod
+    def _rhs_chunks(X, y):
+        y = np.asarray(y, dtype=float)
+        n, r = y.shape
+        tail = np.concatenate([y.sum(axis=1)[:, None], np.ones((n, 1))], axis=1)
+        step = GSUM_MAX_RHS - 3
+        for lo in range(0, r, step):
+            idx = np.arange(lo, min(lo + step, r))
+            yield idx, np.concatenate([y[:, idx], tail], axis=1)
+
+    @staticmethod
+    def _stand_in(blocks, ny):
+        """The (ny + 1) x (ny + 1) stand-in for Z^T M Z from the chunks' (m + 2) x (m + 2) matrices of [curves | sum | 1]."""
+        out = np.zeros((ny + 1, ny + 1))
+        total = corner = 0.0
+        for idx, M in blocks:
+            m = len(idx)
+            out[idx, idx] = np.diag(M)[:m]
+            out[idx, ny] = out[ny, idx] = M[:m, m + 1]
+            total, corner = M[m, m], M[m + 1, m + 1]              # (the same in every chunk)
+        off = (total - np.trace(out[:ny, :ny])) / (ny * (ny - 1))
+        out[:ny, :ny] += off * (1.0 - np.eye(ny))
+        out[ny, ny] = corner
+        return out
+
     def _active_kernel(self):
         if getattr(self, 'kernel_', None) is not None:
             return self.kernel_
@@ -501,6 +538,8 @@ class ConjugateGaussianProcess:
             desc = describe_thetas(kernel, [theta], X.shape[1])[0]
         else:
             desc = describe_kernel(kernel, X.shape[1])
+        if self._many_curves(y):
+            return self._lml_many_curves(desc, kernel, theta, eval_gradient, X, np.asarray(y, dtype=float))
         Z = self._rhs(X, y)
         if eval_gradient:                                                            # models.py:957-958, 1041-1056
             params = describe_gradients(kernel, [theta], X.shape[1])[0] if theta is not None else describe_gradient(kernel, X.shape[1])
@@ -515,6 +554,31 @@ class ConjugateGaussianProcess:
             return -np.inf                                                           # models.py:970-972
         lml, _ = self._lml_gram(G[0], sld[0], X.shape[0])
         return lml
+
+    def _lml_many_curves(self, desc, kernel, theta, eval_gradient, X, y):
+        """log_marginal_likelihood for more than GSUM_MAX_RHS - 1 curves: one device call per chunk of curves (see _rhs_chunks)."""
+        ny, ctx = y.shape[1], self._context()
+        params = None
+        if eval_gradient:
+            params = describe_gradients(kernel, [theta], X.shape[1])[0] if theta is not None else describe_gradient(kernel, X.shape[1])
+            if not params:
+                return self.log_marginal_likelihood(theta, X=X, y=y), np.zeros(0)
+        Gb, Hb, sld, trace = [], [], None, None
+        for idx, Zc in self._rhs_chunks(X, y):
+            if eval_gradient:
+                Gc, sld, info, trace, Hc = ctx.lml_grad(desc, params, X, Zc, self.nugget)
+                Hb.append((idx, Hc))
+            else:
+                Gc, slds, infos = ctx.lml_batch([desc], X, Zc, self.nugget)
+                Gc, sld, info = Gc[0], slds[0], infos[0]
+            if info != 0:
+                return (-np.inf, np.zeros(len(params))) if eval_gradient else -np.inf     # models.py:970-972
+            Gb.append((idx, Gc))
+        G = self._stand_in(Gb, ny)
+        if not eval_gradient:
+            return self._lml_gram(G, sld, X.shape[0])[0]
+        H = np.array([self._stand_in([(idx, Hc[p]) for idx, Hc in Hb], ny) for p in range(len(params))])
+        return self._lml_grad_gram(G, sld, trace, H, X.shape[0])
 
     def _lml_gram(self, G, sld, n_points):
         """(log marginal likelihood, posterior dict) of this process from one Gram matrix."""
@@ -557,6 +621,8 @@ class ConjugateGaussianProcess:
         base = self._active_kernel()
         X = np.asarray(self.X_train_ if X is None else X, dtype=float)
         y = self.y_train_ if y is None else y
+        if self._many_curves(y):
+            return [self.log_marginal_likelihood(t, eval_gradient=True, X=X, y=y) for t in thetas]
         Z = self._rhs(X, y)
         thetas = [np.atleast_1d(np.asarray(t, dtype=float)) for t in thetas]
         # descriptors and gradient parameters straight from theta (kernels.describe_thetas): no scikit-learn clone per start
@@ -693,7 +759,8 @@ class ConjugateGaussianProcess:
         self._fit = False
         self._corr = self._corr_L = self._eigh_cache = None
         Xd = np.asarray(self.X_train_, dtype=float)
-        Z = self._rhs(Xd, self.y_train_)
+        many = self._many_curves(self.y_train_)
+        Z = None if many else self._rhs(Xd, self.y_train_)
 
         lml_opt = self._calibrate_kernel()                                  # models.py:707
 
@@ -711,7 +778,15 @@ class ConjugateGaussianProcess:
             self._L_dev.free()
             self._L_dev = None
             raise np.linalg.LinAlgError("Matrix is not positive definite")    # numpy's message; models.py:711
-        G, sld = ctx.forward_gram(self._L_dev, Z)
+        if many:                                  # one forward solve per chunk of curves on the one factor (see _rhs_chunks)
+            y2 = np.asarray(self.y_train_, dtype=float)
+            blocks, sld = [], None
+            for idx, Zc in self._rhs_chunks(Xd, y2):
+                Gc, sld = ctx.forward_gram(self._L_dev, Zc)
+                blocks.append((idx, Gc))
+            G = self._stand_in(blocks, y2.shape[1])
+        else:
+            G, sld = ctx.forward_gram(self._L_dev, Z)
         lml, post = self._lml_gram(G, sld, Xd.shape[0])
         self.log_marginal_likelihood_value_ = lml if lml_opt is None else lml_opt
         self._gram = (G, sld)

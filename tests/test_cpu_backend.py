@@ -130,3 +130,8 @@ def test_predict_var_contract_on_the_cpu_backend():
 
 def test_eig_mode_golden(cpu_backend):
     T.test_eig_mode_golden()
+
+
+@pytest.mark.parametrize("r", [16, 33])
+def test_more_curves_than_one_device_call_takes(cpu_backend, r):
+    T.test_more_curves_than_one_device_call_takes(r)

@@ -1241,3 +1241,51 @@ def test_eig_mode_golden():
         tg = gsum_amd.TruncationGP(kernel=kern, ratio=0.6, ref=2.0, optimizer=None, nugget=case["nugget"], decomposition="eig", **case["priors"])
         tg.fit(X, gsum_amd.partials(y, ratio=0.6, ref=2.0, orders=np.arange(r)), orders=np.arange(r))
         assert tg.log_marginal_likelihood(theta=kern.theta, ratio=0.55) == pytest.approx(case["trunc_lml"], rel=1e-10)
+
+
+@pytest.mark.parametrize("r", [16, 20, 33])
+def test_more_curves_than_one_device_call_takes(r):
+    """The reference takes any number of curves (models.py:602-628, 1026-1035); a device call takes 15.  More go in chunks
+    [<= 13 curves | the sum of all curves | 1] and a stand-in Gram matrix with the curve block's diagonal, the right total and its cross terms
+    with the basis column -- all the conjugate algebra uses of it: likelihood value and gradient of both process classes, fit (optimiser off
+    and on), predict and a truncation process of r orders against the oracle, three prior regimes."""
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    rng = np.random.RandomState(r)
+    n = 60
+    X = np.sort(rng.rand(n))[:, None] * 20
+    Xs = np.linspace(0.5, 19, 7)[:, None]
+    kern = C(1.3) * Matern(0.9, nu=2.5) + WhiteKernel(1e-3)
+    y = 0.3 + np.linalg.cholesky(kern(X) + 1e-8 * np.eye(n)) @ rng.randn(n, r)
+    theta = kern.theta + 0.1
+    for pri in (dict(center=0.2, disp=0.5, df=3, scale=1.3), dict(center=0, disp=0, df=1, scale=1), dict(center=-0.1, disp=1.5, sd=1.1)):
+        for cls, ofn in ((gsum_amd.ConjugateGaussianProcess, orc.cgp_lml_grad), (gsum_amd.ConjugateStudentProcess, orc.csp_lml_grad)):
+            if cls is gsum_amd.ConjugateStudentProcess and "sd" in pri:
+                continue
+            gp = cls(kernel=kern, optimizer=None, **pri)
+            val, grad = gp.log_marginal_likelihood(theta, eval_gradient=True, X=X, y=y)
+            vo, go = ofn(kern, theta, X, y, **pri)
+            # (a likelihood of 33 curves can be a small difference of terms of size n r ~ 2000: relative to the terms, not to their difference)
+            assert val == pytest.approx(vo, rel=1e-11, abs=2e-11 * n * r) and gp.log_marginal_likelihood(theta, X=X, y=y) == pytest.approx(vo, rel=1e-11, abs=2e-11 * n * r)
+            np.testing.assert_allclose(grad, go, rtol=1e-9, atol=1e-9 * np.abs(go).max())
+            both = gp.log_marginal_likelihood_batch([theta, theta + 0.05], X=X, y=y)
+            assert both[0][0] == val and len(both) == 2
+        gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, **pri).fit(X, y)
+        fit = orc.cgp_fit(kern, X, y, **pri)
+        np.testing.assert_allclose(gp.center_, fit["center"], rtol=1e-10, atol=1e-12)
+        assert gp.cov_factor_ == pytest.approx(fit["cov_factor"], rel=1e-10) and gp.df_ == fit["df"]
+        mean, std = gp.predict(Xs, return_std=True)
+        mo, so = orc.cgp_predict(fit, Xs, return_std=True)
+        np.testing.assert_allclose(mean, mo, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(std, so, rtol=1e-8, atol=1e-10)
+    # the default optimiser over the chunked objective finds the generating length scale
+    opt = gsum_amd.ConjugateGaussianProcess(kernel=C(1.3, "fixed") * Matern(0.5, length_scale_bounds=(0.2, 3.0), nu=2.5) + WhiteKernel(1e-3, "fixed"),
+                                            center=0, disp=0, df=1, scale=1).fit(X, y)
+    assert 0.7 < opt.kernel_.k1.k2.length_scale < 1.15
+    # a truncation process of r orders
+    orders = np.arange(r)
+    yp = gsum_amd.partials(y, ratio=0.9, ref=2.0, orders=orders)
+    tg = gsum_amd.TruncationGP(kernel=kern, ratio=0.9, ref=2.0, optimizer=None, center=0.2, disp=0.5, df=3, scale=1.3)
+    tg.fit(X, yp, orders=orders)
+    got = tg.log_marginal_likelihood(theta=kern.theta, ratio=0.85)
+    want = orc.trunc_lml(kern, kern.theta, X, yp, orders, ratio=0.85, ref=2.0, center=0.2, disp=0.5, df=3, scale=1.3)
+    assert got == pytest.approx(want, rel=1e-10)
