@@ -325,7 +325,8 @@ def test_truncation_predict_golden():
 
 
 def test_sixteen_right_hand_sides(ctx):
-    """15 curves + the basis column = GSUM_MAX_RHS; one more is rejected on the host."""
+    """15 curves + the basis column = GSUM_MAX_RHS: the most ONE device call takes; one more goes in chunks (single evaluations, since late
+    round 5: test_more_curves_than_one_device_call_takes) -- the grid entry points still refuse it on the host."""
     from sklearn.gaussian_process.kernels import RBF, WhiteKernel
     rng = np.random.RandomState(5)
     for n in (60, 300):
@@ -342,8 +343,10 @@ def test_sixteen_right_hand_sides(ctx):
         mo, so = orc.cgp_predict(fit, X[:7] + 0.01, return_std=True)
         np.testing.assert_allclose(m, mo, rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(s, so, rtol=1e-7)
+        y16 = rng.randn(n, 16)
+        assert gp.log_marginal_likelihood(theta=kern.theta, X=X, y=y16) == pytest.approx(orc.cgp_lml(kern, kern.theta, X, y16, disp=1.0, df=2), rel=1e-10)
         with pytest.raises(ValueError):
-            gp.log_marginal_likelihood(theta=kern.theta, X=X, y=rng.randn(n, 16))
+            gp._rhs(X, y16)
 
 
 def test_nonpd_behaviour(small_cases):
