@@ -455,7 +455,7 @@ class ConjugateGaussianProcess:
     # cross terms with the basis column (posterior_from_gram, lml_grad_from_gram, hyper_gradients_from_gram: uniform weights over the curves).  So
     # the curves go to the device in chunks [<= 13 curves | the sum of ALL curves | 1]: the chunks' diagonals are the curve block's diagonal, the
     # sum column gives the sum of its entries, and a matrix with those entries on the diagonal, the right total and one constant everywhere else
-    # stands in for it.  Single evaluations (fit, likelihood, gradient, predict); the grid entry points keep the limit.
+    # stands in for it.  Single evaluations (fit, likelihood, gradient, predict) and the truncation classes' surfaces (truncation.py: _grid_chunked).
     @staticmethod
     def _many_curves(y):
         y = np.asarray(y)

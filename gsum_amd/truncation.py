@@ -11,6 +11,7 @@ import warnings
 
 import numpy as np
 
+from ._lib import GSUM_MAX_RHS
 from .conjugate import ConjugateGaussianProcess, ConjugateStudentProcess
 from .kernels import describe_thetas
 from .series import coefficients, geometric_sum
@@ -289,7 +290,7 @@ class TruncationGP:
                 raise ValueError("shard= (one process per GPU) and devices= (one process, several GPUs) exclude each other")
             if gather not in ("host", "rccl"):
                 raise ValueError('gather must be "host" or "rccl"')
-            if mode != "full":
+            if mode != "full" or self._grid_many_curves(orders):
                 return self._grid_over_devices(thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather)
             # mode "full": the surface is ONE call of the library's device group (gsum_group_lml_resident_sets: the flattened points
             # block-partitioned over the devices, one host thread per device inside the library, the optional RCCL gather there too)
@@ -326,6 +327,10 @@ class TruncationGP:
             return shaped(out)
         n_pts = Xd.shape[0]
         prep = {}
+        if self._grid_many_curves(orders):
+            if mode not in ("full", "reuse"):
+                raise ValueError('mode must be "full" or "reuse"')
+            return shaped(self._grid_chunked(out, mine, thetas, ratio_kws_list, scale_vals, Xd, y, orders, mode, ctx))
 
         def rhs_for(i):
             if i not in prep:
@@ -430,6 +435,65 @@ class TruncationGP:
             raise ValueError('mode must be "full" or "reuse"')
         return shaped(out)
 
+
+    def _grid_many_curves(self, orders):
+        orders = np.asarray(self.orders_ if orders is None else orders)
+        return int(np.sum(~np.isin(orders, self.excluded))) + 1 > GSUM_MAX_RHS
+
+    def _grid_chunked(self, out, mine, thetas, ratio_kws_list, scale_vals, Xd, y, orders, mode, ctx):
+        """The surface for more curves than one device call takes (conjugate.py: _rhs_chunks, _stand_in): every (ratio, theta) point
+        gathers its Gram matrix from one device call per chunk of curves -- a full evaluation each in mode "full", a forward solve
+        against the theta's one factor in mode "reuse" -- and the prior scales share it.  Rare (16 or more orders at once); plain."""
+        gp = self.coeffs_process
+        ni, nj, ns = out.shape
+        n_pts = Xd.shape[0]
+        base = gp._active_kernel()
+        todo = {}
+        for flat in mine:
+            i, rest = divmod(int(flat), nj * ns)
+            j, s = divmod(rest, ns)
+            todo.setdefault(j, {}).setdefault(i, []).append(s)
+        descs = dict(zip(todo, describe_thetas(base, [thetas[j] for j in todo], Xd.shape[1])))
+        prep = {}
+
+        def chunks_for(i):
+            if i not in prep:
+                kws = ratio_kws_list[i]
+                kws = kws if isinstance(kws, dict) else {"ratio": kws}
+                coeffs, det = self._coeffs_and_jacobian(Xd, y, orders, kws)
+                prep[i] = (coeffs.shape[1], list(gp._rhs_chunks(Xd, coeffs)), det)
+            return prep[i]
+
+        for j, rows in todo.items():
+            L = None
+            if mode == "reuse":
+                L, info = ctx.factorize(descs[j], Xd, diag_add=gp.nugget)
+            try:
+                for i, ss in rows.items():
+                    ny, chunks, det = chunks_for(i)
+                    blocks, sld, bad = [], 0.0, mode == "reuse" and info != 0
+                    for idx, Zc in chunks:
+                        if bad:
+                            break
+                        if mode == "reuse":
+                            Gc, sld = ctx.forward_gram(L, Zc)
+                        else:
+                            Gc, slds, infos = ctx.lml_batch([descs[j]], Xd, Zc, gp.nugget)
+                            Gc, sld, bad = Gc[0], slds[0], infos[0] != 0
+                        blocks.append((idx, Gc))
+                    if bad:
+                        out[i, j, ss] = -np.inf
+                        continue
+                    Gs = np.broadcast_to(gp._stand_in(blocks, ny), (len(ss), ny + 1, ny + 1))
+                    slds = np.full(len(ss), sld)
+                    if scale_vals is None:
+                        out[i, j, ss] = gp._lml_gram_batch(Gs, slds, n_pts) - det
+                    else:
+                        out[i, j, ss] = gp._lml_gram_batch_sd(Gs, slds, n_pts, scale_vals[ss]) - det
+            finally:
+                if L is not None:
+                    L.free()
+        return out
 
     def _grid_over_devices(self, thetas, ratio_kws_list, scales, X, y, orders, mode, devices, gather):
         if mode not in ("full", "reuse"):

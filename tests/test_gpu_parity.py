@@ -326,7 +326,7 @@ def test_truncation_predict_golden():
 
 def test_sixteen_right_hand_sides(ctx):
     """15 curves + the basis column = GSUM_MAX_RHS: the most ONE device call takes; one more goes in chunks (single evaluations, since late
-    round 5: test_more_curves_than_one_device_call_takes) -- the grid entry points still refuse it on the host."""
+    round 5: test_more_curves_than_one_device_call_takes, the surfaces included)."""
     from sklearn.gaussian_process.kernels import RBF, WhiteKernel
     rng = np.random.RandomState(5)
     for n in (60, 300):
@@ -1292,3 +1292,15 @@ def test_more_curves_than_one_device_call_takes(r):
     got = tg.log_marginal_likelihood(theta=kern.theta, ratio=0.85)
     want = orc.trunc_lml(kern, kern.theta, X, yp, orders, ratio=0.85, ref=2.0, center=0.2, disp=0.5, df=3, scale=1.3)
     assert got == pytest.approx(want, rel=1e-10)
+    # ... and its surfaces: every point the single call's value, both modes, with and without the prior-scale axis, sharded or not
+    thetas, ratios = [kern.theta, kern.theta + 0.2], [0.85, 0.7, 0.95]
+    single = np.array([[tg.log_marginal_likelihood(theta=t, ratio=q) for t in thetas] for q in ratios])
+    for mode in ("full", "reuse"):
+        surf = tg.log_marginal_likelihood_grid(thetas, ratios, mode=mode)
+        np.testing.assert_allclose(surf, single, rtol=1e-10, atol=2e-11 * n * r)
+        halves = [tg.log_marginal_likelihood_grid(thetas, ratios, mode=mode, shard=(k, 2)) for k in range(2)]
+        assert np.array_equal(np.where(np.isnan(halves[0]), halves[1], halves[0]), surf)
+        cube = tg.log_marginal_likelihood_grid(thetas, ratios, scales=[0.8, 1.7], mode=mode)
+        ts = gsum_amd.TruncationGP(kernel=kern, ratio=0.9, ref=2.0, optimizer=None, center=0.2, disp=0.5, sd=1.7).fit(X, yp, orders=orders)
+        assert cube.shape == (3, 2, 2)
+        assert cube[1, 1, 1] == pytest.approx(ts.log_marginal_likelihood(theta=thetas[1], ratio=0.7), rel=1e-10, abs=2e-11 * n * r)
