@@ -267,7 +267,13 @@ class CpuContext:
         if rhs.shape[1] > GSUM_MAX_RHS:
             raise ValueError("k must be 0..GSUM_MAX_RHS")
         out = [self._evaluate(d, X, rhs, nugget)[:3] for d in descs]
-        return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out], dtype=np.int64)
+        return self._stacked(out, rhs.shape[1])
+
+    @staticmethod
+    def _stacked(out, k):
+        """(G, sld, info) of a batch as arrays -- of the right shapes for an empty batch too."""
+        return (np.array([o[0] for o in out], dtype=float).reshape(len(out), k, k), np.array([o[1] for o in out], dtype=float),
+                np.array([o[2] for o in out], dtype=np.int64))
 
     def set_inputs(self, X, rhs):
         self._X, self._Z = np.array(X, dtype=float), np.array(rhs, dtype=float)
@@ -278,7 +284,7 @@ class CpuContext:
 
     def lml_resident_sets(self, descs, set_of, nugget):
         out = [self._evaluate(d, self._X, self._Zsets[int(s)], nugget)[:3] for d, s in zip(descs, set_of)]
-        return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out], dtype=np.int64)
+        return self._stacked(out, self._Zsets.shape[2])
 
     def resident_shape(self):
         if self._X is None:

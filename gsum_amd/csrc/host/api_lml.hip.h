@@ -7,7 +7,8 @@ static int gs_lml_on_sets(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* k
 // set_of (or NULL): the right-hand-side set of every evaluation (gsum_set_inputs_sets)
 static int gs_lml_on(gsum_ctx* ctx, gs_inputs* I, const gsum_kernel_desc* kernels, int32_t n_kernels, double nugget,
                      double* G_out, double* sld_out, int64_t* info_out, const int32_t* set_of = nullptr) {
-    if (!ctx || !kernels || !G_out || !sld_out || !info_out) return -2;
+    if (ctx && n_kernels == 0) return 0;                          // an empty batch is no work, whatever the pointers
+    if (!ctx || !kernels || !G_out || !sld_out || !info_out || n_kernels < 0) return -2;
     if (set_of)
         for (int i = 0; i < n_kernels; ++i)
             if (set_of[i] < 0 || set_of[i] >= I->n_sets) GS_FAIL("set_of: no such right-hand-side set (gsum_set_inputs_sets)");

@@ -135,3 +135,20 @@ def test_eig_mode_golden(cpu_backend):
 @pytest.mark.parametrize("r", [16, 33])
 def test_more_curves_than_one_device_call_takes(cpu_backend, r):
     T.test_more_curves_than_one_device_call_takes(r)
+
+
+def test_an_empty_batch_is_no_work_on_the_cpu_backend():
+    """The same contract as the HIP entry points (tests/test_gpu_round5.py): empty outputs of the right shapes, empty surfaces."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from gsum_amd._cpu import CpuContext
+    rng = np.random.RandomState(0)
+    X = np.sort(rng.rand(30))[:, None] * 9
+    Z = np.concatenate([rng.randn(30, 2), np.ones((30, 1))], axis=1)
+    ctx = CpuContext()
+    G, sld, info = ctx.lml_batch([], X, Z, 1e-10)
+    assert G.shape == (0, 3, 3) and sld.shape == (0,) and info.shape == (0,)
+    gp = gsum_amd.TruncationGP(kernel=RBF(0.5) + WhiteKernel(1e-4), ratio=0.5, ref=1.0, optimizer=None, center=0, disp=0, df=1, scale=1,
+                               backend="cpu")
+    gp.fit(X, gsum_amd.partials(Z[:, :2], ratio=0.5, ref=1.0, orders=np.arange(2)), orders=np.arange(2))
+    assert gp.log_marginal_likelihood_grid([], [0.4, 0.6], mode="full").shape == (2, 0)
+    assert gp.log_marginal_likelihood_grid([gp.coeffs_process.kernel_.theta], [], mode="reuse").shape == (0, 1)

@@ -693,3 +693,25 @@ def test_partial_diagonal_block_every_count_of_micro_blocks():
             assert info_s[0] == info_g[0] == n, (n, info_s, info_g)
     finally:
         lab.set_option("small_path", 1)
+
+
+@pytest.mark.parametrize("n", [5, 300, 1100])
+def test_an_empty_batch_is_no_work(ctx, n):
+    """No evaluations (an empty list of thetas, a rank with no share of a grid): nothing is launched, empty outputs, and the context carries on
+    -- on the one-block path, the one-workgroup-per-evaluation path and the grouped schedule alike."""
+    rng = np.random.RandomState(n)
+    X = np.sort(rng.rand(n))[:, None] * n * 0.3
+    Z = np.concatenate([rng.randn(n, 2), np.ones((n, 1))], axis=1)
+    desc = gsum_amd.describe_kernel(RBF(0.5) + WhiteKernel(1e-4), 1)
+    G, sld, info = ctx.lml_batch([], X, Z, 1e-10)
+    assert G.shape == (0, 3, 3) and sld.shape == (0,) and info.shape == (0,)
+    ctx.set_inputs(X, Z)
+    G, sld, info = ctx.lml_resident([], 1e-10)
+    assert G.shape == (0, 3, 3) and sld.size == 0
+    one = ctx.lml_resident([desc], 1e-10)
+    assert one[2][0] == 0 and np.array_equal(one[0], ctx.lml_batch([desc], X, Z, 1e-10)[0])
+    gp = gsum_amd.TruncationGP(kernel=RBF(0.5) + WhiteKernel(1e-4), ratio=0.5, ref=1.0, optimizer=None, center=0, disp=0, df=1, scale=1)
+    y = gsum_amd.partials(Z[:, :2], ratio=0.5, ref=1.0, orders=np.arange(2))
+    gp.fit(X, y, orders=np.arange(2))
+    assert gp.log_marginal_likelihood_grid([], [0.4, 0.6], mode="full").shape == (2, 0)
+    assert gp.log_marginal_likelihood_grid([gp.coeffs_process.kernel_.theta], [], mode="reuse").shape == (0, 1)
