@@ -22,7 +22,7 @@ LAB_LIB_PATH = os.path.join(_HERE, "libgsum_hip_lab.so")     # the same sources 
 GSUM_MAX_D = 8
 GSUM_MAX_RHS = 16
 GSUM_MAX_LEAVES = 4
-GSUM_MAX_OPS = 16
+GSUM_MAX_OPS = 24
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2, "matern12": 3, "rq": 4, "expsine": 5, "matern_inf": 6, "dot": 7}
 OP_ADD, OP_MUL, OP_LEAF, OP_CONST, OP_WHITE, OP_POW = 1, 2, 16, 32, 64, 128
 
@@ -552,7 +552,7 @@ class HipContext:
     @staticmethod
     def tile_descs(unique, index):
         """``[unique[t] for t in index]`` as ONE contiguous ``gsum_kernel_desc[]`` without a Python object per entry: a likelihood surface
-        names each of its ~100 distinct kernels thousands of times (notebook :1457-1459), and joining 8000 x 616 B in Python cost as much
+        names each of its ~100 distinct kernels thousands of times (notebook :1457-1459), and joining 8000 x 712 B in Python cost as much
         as the device call.  The array shares the memory of a numpy gather (kept alive on the result)."""
         block = np.frombuffer(b"".join(map(bytes, unique)), dtype=np.uint8).reshape(len(unique), C.sizeof(KernelDesc))
         tiled = np.ascontiguousarray(block[np.asarray(index, dtype=np.intp)])

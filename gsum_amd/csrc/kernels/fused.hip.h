@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_small(const double* X, int n, in
     double* us = wsd;                                                   // 78.6 KB of LDS in all, two evaluations per CU
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 616 B of scratch per lane
+    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 712 B of scratch per lane
     double* A = scratch + (int64_t)blockIdx.x * GS_SMALL_SCRATCH;
     double* Wt = A + 128 * 128;                                         // W^T, 16 x 128 row-major (L2-resident)
     double* out = res + (int64_t)blockIdx.x * 258;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_lml_medium(const double* X, int n, i
     __shared__ double ldet_sum;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 616 B of scratch per lane
+    const gsum_kernel_desc& desc = descs[blockIdx.x];      // in place (uniform address, read-only: scalar loads) -- a private copy is 712 B of scratch per lane
     const int np = (n + 127) / 128 * 128, T = np / 128;
     const int64_t ld = GS_LD(np);
     double* A = scratch + (int64_t)blockIdx.x * scratch_stride;

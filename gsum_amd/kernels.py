@@ -7,7 +7,7 @@ The reference calls ``kernel(X)`` / ``kernel(X, Y)`` on arbitrary scikit-learn k
   reference's own tests, notebooks and defaults use; it runs the templated fast kernels and the one-workgroup-per-evaluation paths;
 * tree (round 4) -- any ``Sum`` / ``Product`` / ``Exponentiation`` tree over RBF, Matern(0.5, 1.5, 2.5, inf), RationalQuadratic,
   ExpSineSquared, DotProduct, ConstantKernel and WhiteKernel leaves (``RBF + RBF``, ``C * RBF + C * Matern``, ``ExpSineSquared * RBF``,
-  ``RBF ** 2`` ...): a postfix program in scikit-learn's own evaluation order, at most 4 stationary leaves and 16 operations.
+  ``RBF ** 2`` ...): a postfix program in scikit-learn's own evaluation order, at most 4 stationary leaves and 24 operations.
 
 Other leaves (PairwiseKernel, Matern with another nu: Bessel functions) raise
 ``NotImplementedError`` -- on the 'hip' backend there is deliberately no host fallback.  ``theta`` handling (log-parameters, ordering) is scikit-learn's: leaves left to right, a leaf's

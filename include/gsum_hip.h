@@ -40,7 +40,7 @@ enum { GSUM_RBF = 0, GSUM_MATERN52 = 1, GSUM_MATERN32 = 2, GSUM_MATERN12 = 3,
  * GSUM_OP_CONST + c pushes cval[c], GSUM_OP_WHITE + c pushes cval[c] on that diagonal and 0 elsewhere, ADD / MUL combine two values,
  * GSUM_OP_POW + c raises the top value to the power cval[c] (Exponentiation: the exponent is no hyperparameter). */
 #define GSUM_MAX_LEAVES 4
-#define GSUM_MAX_OPS 16
+#define GSUM_MAX_OPS 24
 enum { GSUM_OP_ADD = 1, GSUM_OP_MUL = 2, GSUM_OP_LEAF = 16, GSUM_OP_CONST = 32, GSUM_OP_WHITE = 64, GSUM_OP_POW = 128 };
 typedef struct {
     int32_t family;                    /* GSUM_RBF ... GSUM_DOT */

@@ -173,8 +173,12 @@ def test_fuzz_kernel_trees_vs_oracle(seed):
         try:
             desc = gsum_amd.describe_kernel(kern, d)
             break
-        except NotImplementedError as exc:                # (a draw beyond the descriptor's 16 operations: the next one)
+        except NotImplementedError as exc:                # (a draw beyond the descriptor's 24 operations: the next one)
             assert "too large" in str(exc)
+    check_tree_kernel(kern, desc, rng, n, d)
+
+
+def check_tree_kernel(kern, desc, rng, n, d):
     X = rng.rand(n, d) * (3.0 + 0.02 * n)
     Xs = rng.rand(11, d) * (3.0 + 0.02 * n)
     ctx = gsum_amd.default_context(0)
@@ -204,3 +208,28 @@ def test_fuzz_kernel_trees_vs_oracle(seed):
     mo, so = orc.cgp_predict(fit, Xs, return_std=True)
     np.testing.assert_allclose(mean, mo, rtol=ptol, atol=ptol * max(1.0, np.abs(mo).max()), err_msg=str(kern))
     np.testing.assert_allclose(std ** 2, so ** 2, rtol=1e-6, atol=ptol * fit["cov_factor"] * max(1.0, scale), err_msg=str(kern))
+
+
+@pytest.mark.parametrize("n", [40, 128, 300, 1100])
+def test_four_scaled_leaves_and_white_noise(n):
+    """The largest sum the descriptor holds: four leaves of four families, each with its ConstantKernel factor, plus WhiteKernel -- 17 operations, ten
+    hyperparameters (the descriptor took 16 operations until late round 5) -- on the one-block, general and one-workgroup paths; and one leaf more is
+    refused on the host with the reason."""
+    from sklearn.gaussian_process.kernels import ConstantKernel as C, Matern, RBF, RationalQuadratic, WhiteKernel
+    rng = np.random.RandomState(n)
+    kern = (C(1.2) * RBF(0.9) + C(0.4) * Matern(1.7, nu=1.5) + C(0.8) * Matern(0.6, nu=2.5) + C(0.3) * RationalQuadratic(length_scale=1.1, alpha=0.8)
+            + WhiteKernel(1e-3))
+    desc = gsum_amd.describe_kernel(kern, 1)
+    assert desc.n_ops == 17 and desc.n_leaves == 4 and len(kern.theta) == 10
+    check_tree_kernel(kern, desc, rng, n, 1)
+    # a surface over it (n = 300, 1100: 12 evaluations take the one-workgroup-per-evaluation path at 300) equals the single calls
+    X = np.sort(rng.rand(n))[:, None] * (3.0 + 0.02 * n)
+    y = drawn(rng, kern, X, 2)
+    gp = gsum_amd.ConjugateGaussianProcess(kernel=kern, optimizer=None, center=0, disp=0, df=1, scale=1)
+    thetas = [kern.theta + 0.02 * j for j in range(12)]
+    batch = gp.log_marginal_likelihood_batch(thetas, X=X, y=y)
+    for j in (0, 5, 11):
+        one = gp.log_marginal_likelihood(thetas[j], eval_gradient=True, X=X, y=y)
+        assert batch[j][0] == one[0] and np.array_equal(batch[j][1], one[1])
+    with pytest.raises(NotImplementedError, match="too large"):
+        gsum_amd.describe_kernel(kern + C(0.1) * RBF(3.0), 1)
