@@ -250,6 +250,31 @@ class TruncationGP:
         det_factor = np.sum(n * np.log(np.abs(ref)) + np.sum(orders_in) * np.log(np.abs(ratio)))   # :1505
         return coeffs, det_factor
 
+    def _rhs_rows(self, X, y, orders, kws_rows):
+        """``_coeffs_and_jacobian`` + ``_rhs`` for several ratio settings at once: ([coefficients | 1] as (rows, n, r + 1), Jacobian terms (rows,)).
+        The same elementwise expressions as helpers.py:71-101 / models.py:1495-1505 over a leading axis -- the notebook's 80 ratio rows cost 80 x a
+        dozen small numpy calls before (2.3 of the grid's 4.4 ms)."""
+        n = np.shape(X)[0]
+        ref = np.broadcast_to(np.atleast_1d(self.ref(X)), (n,))
+        ratios = [np.asarray(self.ratio(X, **kws)) for kws in kws_rows]
+        ratios = np.stack([r if r.shape == (n,) else np.broadcast_to(np.atleast_1d(r), (n,)) for r in ratios])
+        orders = np.asarray(orders)
+        y = np.asarray(y)
+        if y.ndim != 2:
+            raise ValueError("y must be 2d")
+        if len(orders) != y.shape[-1]:
+            raise ValueError("partials and orders must have the same length")
+        mask = ~np.isin(orders, self.excluded)
+        c = np.empty(y.shape, dtype=np.result_type(y, float))
+        c[..., 0] = y[..., 0]
+        c[..., 1:] = np.diff(y, axis=-1)
+        scale = ref[None, :, None] * ratios[:, :, None] ** orders
+        Z = np.ones((len(kws_rows), n, int(mask.sum()) + 1))
+        Z[:, :, :-1] = (c[None] / scale)[:, :, mask]
+        orders_in = orders[mask]
+        dets = np.sum(len(orders_in) * np.log(np.abs(ref))[None, :] + np.sum(orders_in) * np.log(np.abs(ratios)), axis=1)
+        return Z, dets
+
     def log_marginal_likelihood(self, theta, eval_gradient=False, X=None, y=None, orders=None, **ratio_kws):
         X = self.X_train_ if X is None else X
         y = self.y_train_ if y is None else y
@@ -356,7 +381,7 @@ class TruncationGP:
             return gp._lml_gram_batch_sd(G, sld, n_pts, svals)
 
         # one descriptor per theta this rank touches, built in one go and without scikit-learn's per-theta clone
-        js = sorted({int((flat // ns) % nj) for flat in mine})
+        js = np.unique((np.asarray(mine, dtype=np.int64) // ns) % nj).tolist()
         desc_of = dict(zip(js, describe_thetas(base, [thetas[j] for j in js], Xd.shape[1])))
         desc_for = desc_of.__getitem__
 
@@ -373,7 +398,7 @@ class TruncationGP:
             # stay under 1 GiB).  The per-point bookkeeping is numpy's (round 5: 8000 Python iterations and the join of 8000 descriptors
             # were most of the notebook grid's 10.6 ms): the ~100 distinct descriptors are gathered into the call's array in one go.
             row_ids = np.unique(i_a)
-            k_rhs = rhs_for(int(row_ids[0]))[0].shape[1]
+            k_rhs = int(np.sum(~np.isin(np.asarray(orders), self.excluded))) + 1
             max_rows = max(1, int((1 << 30) // max(1, n_pts * k_rhs * 8)))
             js_a = np.asarray(js, dtype=np.int64)
             uniq = [desc_of[j] for j in js]
@@ -381,10 +406,12 @@ class TruncationGP:
             for lo in range(0, len(row_ids), max_rows):
                 chunk = row_ids[lo:lo + max_rows]
                 sel = np.nonzero((i_a >= chunk[0]) & (i_a <= chunk[-1]))[0]              # (ascending rows: a chunk is a range)
-                ctx.set_inputs_sets(Xd, np.stack([rhs_for(int(i))[0] for i in chunk]))
+                kws_rows = [ratio_kws_list[int(i)] for i in chunk]
+                Zs, dets = self._rhs_rows(Xd, y, orders, [kws if isinstance(kws, dict) else {"ratio": kws} for kws in kws_rows])
+                ctx.set_inputs_sets(Xd, Zs)
                 set_of = np.searchsorted(chunk, i_a[sel])
                 descs = tile(uniq, np.searchsorted(js_a, j_a[sel]))
-                dets = np.array([rhs_for(int(i))[1] for i in chunk])[set_of]
+                dets = dets[set_of]
                 G, sld, info = ctx.lml_resident_sets(descs, set_of, gp.nugget)
                 svals = None if scale_vals is None else scale_vals[s_a[sel]]
                 vals = np.where(info != 0, -np.inf, lml_values(G, sld, svals) - dets)
